@@ -1,0 +1,231 @@
+/*
+ * ortk.h — C-ABI of libortk.so: the MI355X (gfx950) HIP implementation of the Object Relation
+ * Transformer hot path of jiahuei/sparse-image-captioning.
+ *
+ * Boundary rules:
+ *   - plain C: raw DEVICE pointers, sizes, a hipStream_t passed as void*; no torch / C++ types;
+ *   - caller owns every buffer (outputs and workspace are caller-allocated; sizes via *_bytes queries);
+ *   - no hidden allocation, no host synchronisation, no global mutable state: every call only enqueues
+ *     kernels on `stream` (thread-safe per stream, hipGraph-capturable);
+ *   - return 0 on success, a negative ORTK_E* code on bad arguments, a positive hipError_t if a launch failed.
+ *
+ * The reference is 100 % Python/PyTorch, so there is no native FFI to mirror; each entry point cites the
+ * reference Python function whose arithmetic it replaces (paths relative to the reference repo root).
+ * All floating-point tensors are fp32 in memory.  `precision` selects the MFMA operand type of the dense
+ * projections only: 0 = fp32 MFMA (bit-faithful parity mode), 1 = bf16 MFMA with fp32 accumulation.
+ */
+#ifndef ORTK_H
+#define ORTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORTK_VERSION 1
+#define ORTK_EINVAL (-1)   /* bad argument / unsupported shape */
+#define ORTK_ENOSPC (-2)   /* workspace too small */
+#define ORTK_ENOSYS (-3)   /* option not implemented (e.g. ACORT weight sharing) */
+
+typedef void* ortk_stream;  /* hipStream_t */
+
+int ortk_version(void);
+/* 1 if a gfx950 device is visible, else 0 (never throws). */
+int ortk_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model geometry — the fields models/transformer.py:418-437 reads from `config`.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ortk_config {
+    int32_t d_model, d_ff, n_layers, n_heads;
+    int32_t vocab, feat, seq_len;              /* vocab_size, att_feat_size, max_seq_length          */
+    int32_t pad_id, bos_id, eos_id, unk_id;
+    int32_t box_trig;                          /* !no_box_trigonometric_embedding (only 1 supported) */
+    int32_t precision;                         /* 0 fp32 MFMA, 1 bf16 MFMA                           */
+    float   drop_src, drop;                    /* att_embed dropout; every other dropout (0.1 | 0.1/3)*/
+} ortk_config;
+
+/* ------------------------------------------------------------------------------------------------
+ * Parameter arena.  All parameters live in ONE flat fp32 buffer (gradients, Adam moments and — for the
+ * `_prune` variant — mask logits use mirrors with identical offsets).  Q/K/V weights of a layer are
+ * adjacent (one N=3d GEMM), the cross-attention K/V weights of ALL decoder layers are adjacent (one
+ * GEMM per batch of images), the 8 WG geometry vectors of a layer form one (8,64) block.
+ * Entry names are the reference state_dict keys.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ortk_arena_numel(const ortk_config* cfg);               /* trainable floats (size of grad / Adam mirrors) */
+int64_t ortk_arena_numel_with_buffers(const ortk_config* cfg);  /* + the `pe` buffer stored behind them           */
+int32_t ortk_arena_entries(const ortk_config* cfg);
+/* name_buf >= 128 bytes; shape[4]; kind: 0 = parameter, 1 = parameter that the `_prune` variant masks (>= 2-D),
+ * 2 = buffer (model.tgt_embed.1.pe, transformer.py:365-376: filled by the host, never trained). */
+int ortk_arena_entry(const ortk_config* cfg, int32_t index, char* name_buf, int64_t* offset,
+                     int64_t* numel, int32_t* ndim, int64_t* shape, int32_t* kind);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-path entry points (the native executor).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ortk_batch {
+    const float*   att_feats;   /* (B, S, feat)   zero padded                       collate.py:119-169 */
+    const float*   boxes;       /* (B, S, 4)      relative x0,y0,x1,y1                                  */
+    const float*   att_masks;   /* (B, S)         1 = valid region                                      */
+    const int64_t* seqs;        /* (R, seq_stride) token ids; columns 0..T-1 are decoder inputs,        */
+    int64_t        seq_stride;  /*                 columns 1..T the targets (T = teacher-forced steps)  */
+    const float*   tok_weight;  /* (R, T) per-target weight: XE -> masks[:,1:]; SCST -> mask*reward     */
+    int32_t B, S, R, T;         /* R = B * captions-per-image                                           */
+} ortk_batch;
+
+size_t ortk_train_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T);
+
+/* Teacher-forced forward (RelationTransformerModel._forward, models/relation_transformer.py:368-372).
+ * Activations stay in `ws` for a following backward.  If logp_out != NULL the (R,T,ldv) log-probs are
+ * written there (ldv >= vocab, multiple of 4).  `train` != 0 enables dropout keyed by `seed`. */
+int ortk_forward(const ortk_config* cfg, const float* params, const ortk_batch* batch, void* ws, size_t ws_bytes,
+                 float* logp_out, int64_t ldv, int32_t train, uint64_t seed, ortk_stream stream);
+
+/* Fused criterion on the logits left in `ws` by ortk_forward:
+ *   loss = -sum_{r,t} logp[r,t,target]*tok_weight[r,t] / norm      (LanguageModelCriterion losses.py:36-43,
+ *   RewardCriterion losses.py:15-29), norm = *norm_dev (device scalar, e.g. sum of the 0/1 mask).
+ * Writes the scalar loss to *loss_dev and leaves dLoss/dlogits in `ws`. */
+int ortk_loss(const ortk_config* cfg, const ortk_batch* batch, void* ws, size_t ws_bytes,
+              const float* norm_dev, float* loss_dev, ortk_stream stream);
+
+/* Alternative to ortk_loss for an external criterion: dlogp (R,T,ldv) -> dLoss/dlogits in `ws`. */
+int ortk_loss_external(const ortk_config* cfg, const ortk_batch* batch, void* ws, size_t ws_bytes,
+                       const float* logp, const float* dlogp, int64_t ldv, ortk_stream stream);
+
+/* Backward through decoder, encoder, geometry bias and att_embed; ACCUMULATES into `grads` (arena mirror). */
+int ortk_backward(const ortk_config* cfg, const float* params, float* grads, const ortk_batch* batch,
+                  void* ws, size_t ws_bytes, int32_t train, uint64_t seed, ortk_stream stream);
+
+/* Cached-attention decoding: CachedTransformerBase._generate_captions (models/transformer.py:471-561)
+ * + CaptionModel.batch_beam_search (models/caption_model.py:30-226, group_size 1). */
+typedef struct ortk_decode_opts {
+    int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
+    int32_t num_random_sample;
+    float   temperature;
+    int32_t decoding_constraint;  /* forbid repeating the previous token */
+    int32_t length_penalty;       /* 0 none, 1 "wu_<alpha>", 2 "avg_<alpha>"   utils/model_utils.py:121-146 */
+    double  length_alpha;
+    uint64_t seed;                /* multinomial: Gumbel-max over counter-based uniforms */
+} ortk_decode_opts;
+
+size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, const ortk_decode_opts* o);
+/* seq_out (B,K,seq_len) int64, logprob_out (B,K,seq_len) fp32, score_out (B,K) fp32 or NULL; K = beam | samples | 1. */
+int ortk_decode(const ortk_config* cfg, const float* params, const float* att_feats, const float* boxes,
+                const float* att_masks, int32_t B, int32_t S, const ortk_decode_opts* o, void* ws, size_t ws_bytes,
+                int64_t* seq_out, float* logprob_out, float* score_out, ortk_stream stream);
+
+/* Encoder only (EncoderDecoder.encode, relation_transformer.py:69-70): memory_out (B,S,d).
+ * Workspace: ortk_decode_workspace_bytes(cfg, B, S, {beam_size = 1}). */
+int ortk_encode(const ortk_config* cfg, const float* params, const float* att_feats, const float* boxes,
+                const float* att_masks, int32_t B, int32_t S, void* ws, size_t ws_bytes, float* memory_out,
+                ortk_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator-level entry points (each is also what the executor calls; exported for parity tests).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* C = epilogue(op(A) * op(B)).  Replaces torch.nn.functional.linear and its autograd
+ * (transformer.py:238,280,324-325,412; relation_transformer.py:168-176,191,331-333).
+ *   transA = 0: A is (M,K) row-major, lda;   1: A is stored (K,M) row-major.
+ *   transB = 0: B is (N,K) row-major (a torch Linear weight), ldb;   1: B is stored (K,N) row-major.
+ *   v = acc + bias[n]; relu; v *= rowscale[m]; dropout(p, seed, index m*N+n); v *= (gate[m,n]>0)*gate_scale;
+ *   v += resid[m,n];  then C = v, or C += v (atomically, K split over `splitk` workgroups) if accumulate. */
+typedef struct ortk_gemm_args {
+    const float* A; const float* B; float* C;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K, transA, transB;
+    const float* bias; const float* rowscale; const float* resid; int64_t ldr;
+    const float* gate; int64_t ldg; float gate_scale;
+    int32_t relu; float drop_p; uint32_t drop_seed;
+    int32_t accumulate, splitk, precision;
+} ortk_gemm_args;
+int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
+
+/* LayerNorm of transformer.py:338-341: a*(x-mean)/(std_unbiased+eps)+b.  stats (rows,2) = {mean, std}. */
+int ortk_layernorm_fwd(const float* x, const float* a, const float* b, float* y, float* stats,
+                       int64_t rows, int32_t d, float eps, ortk_stream stream);
+/* dx = dLN/dx (+ dres if non-NULL); da, db accumulate (+=). */
+int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
+                       float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, ortk_stream stream);
+
+/* Geometry bias of BoxMultiHeadedAttention (relation_transformer.py:196-256,177-183,286):
+ * out[l,b,h,i,j] = log(max(relu(WG[l,h].e_ij + bG[l,h]), 1e-6)).  wg[l]/bg[l] are per-layer device pointers
+ * laid out (h,64)/(h).  dim_mat = the 8 fp32 wavelengths 1/1000^(k/8) as torch computes them. */
+int ortk_box_logbias_fwd(const float* boxes, const float* const* wg, const float* const* bg, const float* dim_mat,
+                         float* out, int32_t L, int32_t B, int32_t S, int32_t H, ortk_stream stream);
+/* dscore (L,B,H,S,S) -> dwg[l] (H,64) += , dbg[l] (H) += . */
+int ortk_box_logbias_bwd(const float* boxes, const float* const* wg, const float* const* bg, const float* dim_mat,
+                         const float* dscore, float* const* dwg, float* const* dbg,
+                         int32_t L, int32_t B, int32_t S, int32_t H, ortk_stream stream);
+/* The 64-d embedding itself, (B,S,S,64) — test/diagnostic only. */
+int ortk_box_embedding(const float* boxes, const float* dim_mat, float* out, int32_t B, int32_t S, ortk_stream stream);
+
+/* Scaled-dot-product attention over small tiles held in LDS (transformer.py:285-295, relation_transformer.py:258-293).
+ * nkv key/value groups of Lk keys; each group serves Lq consecutive query rows.
+ *   score = q.k/sqrt(dk); masked_fill(-1e9) where kmask[g,j]==0 or (causal and j > i % causal_period);
+ *   score += bias[g,h,i,j];  P = softmax;  O = dropout(P) V.
+ * Q/K/V/O are row matrices with H*dk head-concatenated columns and their own leading dimensions.
+ * kv_index (optional, (nkv,Lk) int32) gives the physical K/V row of key j of group g (beam ancestry). */
+typedef struct ortk_attn_args {
+    const float* q; const float* k; const float* v; float* o;
+    int64_t ldq, ldk, ldv, ldo;
+    const float* kmask; const float* bias; const int32_t* kv_index;
+    int64_t kv_group_stride;        /* K/V rows between consecutive groups when kv_index == NULL (0 = Lk) */
+    float* p;                       /* (nkv,H,Lq,Lk) probabilities, saved for backward (may be NULL in fwd) */
+    int32_t nkv, H, Lq, Lk, dk, causal_period;
+    float drop_p; uint32_t drop_seed;
+    /* backward only */
+    const float* d_o; float* dq; float* d_k; float* dv; float* dscore;  /* dscore (nkv,H,Lq,Lk) or NULL */
+    int64_t lddo, lddq, lddk, lddv;
+} ortk_attn_args;
+int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
+int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);
+
+/* InputEmbedding + PositionalEncoding (transformer.py:383-401): out[r*T+t] = lut[tok]*sqrt(d) + pe[t0+t], dropout.
+ * Also emits keymask[r*T+t] = (tok != pad). */
+int ortk_embed_fwd(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out, float* keymask,
+                   int64_t R, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p, uint32_t seed, ortk_stream stream);
+int ortk_embed_bwd(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut,
+                   int64_t R, int32_t T, int32_t d, float drop_p, uint32_t seed, ortk_stream stream);
+
+/* In-place log_softmax over the first V columns of (rows, ld) (OutputEmbedding, transformer.py:412-413);
+ * logits are first multiplied by `scale` (1/temperature). */
+int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, float scale, ortk_stream stream);
+/* Fused cross-entropy on logits (rows, ld): loss_dev += -sum logp[target]*w/norm; logits <- dLoss/dlogits. */
+int ortk_xent_fwd_bwd(float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
+                      const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, ortk_stream stream);
+/* log_softmax backward: dlogits = dlogp - exp(logp) * sum_v dlogp, written over (rows, ld_out). */
+int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, float* dlogits, int64_t ld_out,
+                         int64_t rows, int32_t V, ortk_stream stream);
+
+/* out[n] += sum_m x[m,n] (bias gradients). */
+int ortk_colsum(const float* x, int64_t ld, float* out, int64_t M, int32_t N, ortk_stream stream);
+/* y = gate > 0 ? x*scale : 0 — backward of relu (+dropout) given the saved forward output. */
+int ortk_gate_apply(const float* x, const float* gate, float* y, int64_t n, float scale, ortk_stream stream);
+/* y = x * keep(seed,i)/(1-p) — backward of a residual-branch dropout. */
+int ortk_dropout_apply(const float* x, float* y, int64_t n, float p, uint32_t seed, ortk_stream stream);
+int ortk_fill(float* x, int64_t n, float value, ortk_stream stream);
+int ortk_sum(const float* x, int64_t n, float* out_dev, ortk_stream stream);  /* *out_dev = sum(x) */
+
+/* clip_grad_value_ + Adam (utils/optim.py:116-126,187-191; torch.optim.Adam update rule).
+ * bc1 = 1-beta1^t, bc2 = 1-beta2^t computed by the host in double precision. */
+int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float clip, float bc1, float bc2, ortk_stream stream);
+
+/* MaskMixin.get_masked_weight over the whole arena (pruning/masked_layer.py:84-110, pruning/sampler.py):
+ *   mode 0: s = round(sigmoid(m))  (supermask, eval)      mode 1: s = bernoulli(sigmoid(m)) (supermask, train)
+ *   mode 2: s = m                  (binary masks: magnitude / SNIP / mask_freeze)
+ * w_eff = s * w.  Backward (straight-through, sampler.py:10-34): dw = dw_eff*s; dm += dw_eff*w*sigmoid'(m)
+ * (mode 2: dm += dw_eff*w, used by SNIP only; dm may be NULL). */
+int ortk_mask_apply(const float* w, const float* m, float* w_eff, int64_t n, int32_t mode, uint32_t seed, ortk_stream stream);
+int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw, float* dm, int64_t n, int32_t mode,
+                  uint32_t seed, ortk_stream stream);
+/* count_dev[0] += number of kept entries (round(sigmoid(m)) for mode 0/1, m != 0 for mode 2) in m[0..n). */
+int ortk_mask_count(const float* m, int64_t n, int32_t mode, float* count_dev, ortk_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORTK_H */

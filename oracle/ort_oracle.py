@@ -401,11 +401,6 @@ def is_mask(name: str) -> bool:
     return name.endswith("_pruning_mask")
 
 
-def round_sigmoid(m: Tensor) -> Tensor:
-    """pruning/sampler.py:27-34,57-66: torch.round is round-half-to-even (logit 0 -> pruned)."""
-    return torch.round(torch.sigmoid(m))
-
-
 class _STE(torch.autograd.Function):
     """Straight-through sample (pruning/sampler.py:10-34): forward = given sample, backward = identity."""
 
@@ -416,6 +411,13 @@ class _STE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, None
+
+
+def round_sigmoid(m: Tensor) -> Tensor:
+    """pruning/sampler.py:27-34,57-66: torch.round is round-half-to-even (logit 0 -> pruned); the backward is
+    straight-through over the real sigmoid derivative, so the sparsity loss DOES reach the mask logits."""
+    probs = torch.sigmoid(m)
+    return _STE.apply(probs, torch.round(probs.detach()))
 
 
 def effective_params(P: Dict[str, Tensor], mask_type: str, training: bool = False,
@@ -437,7 +439,7 @@ def effective_params(P: Dict[str, Tensor], mask_type: str, training: bool = Fals
         m = P[mname]
         if mask_type == "supermask":
             probs = torch.sigmoid(m)
-            s = _STE.apply(probs, samples[mname] if training else torch.round(probs))
+            s = _STE.apply(probs, samples[mname] if training else torch.round(probs.detach()))
         else:
             s = m
         out[name] = s * w
@@ -456,7 +458,7 @@ def mask_sparsities(P, mask_type: str, names: Optional[Sequence[str]] = None):
 
 
 def sparsity_loss(P, target: float, weight: float, step: int, max_step: int) -> Tensor:
-    """``compute_sparsity_loss`` (pruning/prune.py:228-269) — value only carries no gradient (round)."""
+    """``compute_sparsity_loss`` (pruning/prune.py:228-269)."""
     total, _, _, _ = mask_sparsities(P, "supermask")
     loss = torch.abs(target - total)
     s = 1.0 + torch.cos(torch.tensor(min(1.0, step / max_step) * math.pi))

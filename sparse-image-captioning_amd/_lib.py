@@ -1,0 +1,161 @@
+"""ctypes binding of libortk.so (the C-ABI declared in include/ortk.h).
+
+The HIP library is the product: there is NO Python / PyTorch fallback for any op.  ``lib()`` raises
+``OrtkUnavailable`` loudly when the shared object is missing, and every device entry point refuses to run
+without a gfx950 GPU.  PyTorch is used only for device memory (``tensor.data_ptr()``), the current HIP stream
+and ``torch.distributed``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libortk.so")
+
+
+class OrtkUnavailable(RuntimeError):
+    pass
+
+
+class OrtkError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("d_ff", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
+                ("vocab", C.c_int32), ("feat", C.c_int32), ("seq_len", C.c_int32),
+                ("pad_id", C.c_int32), ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("unk_id", C.c_int32),
+                ("box_trig", C.c_int32), ("precision", C.c_int32), ("drop_src", C.c_float), ("drop", C.c_float)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("att_feats", C.c_void_p), ("boxes", C.c_void_p), ("att_masks", C.c_void_p), ("seqs", C.c_void_p),
+                ("seq_stride", C.c_int64), ("tok_weight", C.c_void_p),
+                ("B", C.c_int32), ("S", C.c_int32), ("R", C.c_int32), ("T", C.c_int32)]
+
+
+class DecodeOpts(C.Structure):
+    _fields_ = [("beam_size", C.c_int32), ("num_random_sample", C.c_int32), ("temperature", C.c_float),
+                ("decoding_constraint", C.c_int32), ("length_penalty", C.c_int32), ("length_alpha", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("transA", C.c_int32), ("transB", C.c_int32),
+                ("bias", C.c_void_p), ("rowscale", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64),
+                ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_scale", C.c_float),
+                ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("accumulate", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+                ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
+                ("kmask", C.c_void_p), ("bias", C.c_void_p), ("kv_index", C.c_void_p), ("kv_group_stride", C.c_int64),
+                ("p", C.c_void_p),
+                ("nkv", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("dk", C.c_int32),
+                ("causal_period", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("d_o", C.c_void_p), ("dq", C.c_void_p), ("d_k", C.c_void_p), ("dv", C.c_void_p), ("dscore", C.c_void_p),
+                ("lddo", C.c_int64), ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64)]
+
+
+_P, _I32, _I64, _F, _U32, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t
+_CFG = C.POINTER(Config)
+
+# name -> (restype, argtypes); kept in sync with include/ortk.h by tests/test_lib_host.py
+SIGNATURES = {
+    "ortk_version": (_I32, []),
+    "ortk_device_ok": (_I32, []),
+    "ortk_arena_numel": (_I64, [_CFG]),
+    "ortk_arena_numel_with_buffers": (_I64, [_CFG]),
+    "ortk_arena_entries": (_I32, [_CFG]),
+    "ortk_arena_entry": (_I32, [_CFG, _I32, C.c_char_p, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I32),
+                               C.POINTER(_I64), C.POINTER(_I32)]),
+    "ortk_train_workspace_bytes": (_SZ, [_CFG, _I32, _I32, _I32, _I32]),
+    "ortk_forward": (_I32, [_CFG, _P, C.POINTER(Batch), _P, _SZ, _P, _I64, _I32, _U64, _P]),
+    "ortk_loss": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _P]),
+    "ortk_loss_external": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _I64, _P]),
+    "ortk_backward": (_I32, [_CFG, _P, _P, C.POINTER(Batch), _P, _SZ, _I32, _U64, _P]),
+    "ortk_decode_workspace_bytes": (_SZ, [_CFG, _I32, _I32, C.POINTER(DecodeOpts)]),
+    "ortk_decode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, C.POINTER(DecodeOpts), _P, _SZ, _P, _P, _P, _P]),
+    "ortk_encode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P, _P]),
+    "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),
+    "ortk_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
+    "ortk_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
+    "ortk_box_logbias_fwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, _I32, _I32, _I32, _I32, _P]),
+    "ortk_box_logbias_bwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, C.POINTER(_P), C.POINTER(_P),
+                                   _I32, _I32, _I32, _I32, _P]),
+    "ortk_box_embedding": (_I32, [_P, C.POINTER(_F), _P, _I32, _I32, _P]),
+    "ortk_attention_fwd": (_I32, [C.POINTER(AttnArgs), _P]),
+    "ortk_attention_bwd": (_I32, [C.POINTER(AttnArgs), _P]),
+    "ortk_embed_fwd": (_I32, [_P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _F, _U32, _P]),
+    "ortk_embed_bwd": (_I32, [_P, _I64, _P, _P, _I64, _I32, _I32, _F, _U32, _P]),
+    "ortk_log_softmax": (_I32, [_P, _I64, _I32, _I64, _F, _P]),
+    "ortk_xent_fwd_bwd": (_I32, [_P, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I64, _P]),
+    "ortk_log_softmax_bwd": (_I32, [_P, _P, _I64, _P, _I64, _I64, _I32, _P]),
+    "ortk_colsum": (_I32, [_P, _I64, _P, _I64, _I32, _P]),
+    "ortk_gate_apply": (_I32, [_P, _P, _P, _I64, _F, _P]),
+    "ortk_dropout_apply": (_I32, [_P, _P, _I64, _F, _U32, _P]),
+    "ortk_fill": (_I32, [_P, _I64, _F, _P]),
+    "ortk_sum": (_I32, [_P, _I64, _P, _P]),
+    "ortk_adam_clip": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "ortk_mask_apply": (_I32, [_P, _P, _P, _I64, _I32, _U32, _P]),
+    "ortk_mask_bwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _U32, _P]),
+    "ortk_mask_count": (_I32, [_P, _I64, _I32, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises OrtkUnavailable if libortk.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OrtkUnavailable(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C sparse-image-captioning_amd/csrc`).  There is no CPU / PyTorch fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def require_gpu():
+    """Fail loudly unless a gfx950 device is usable."""
+    if not torch.cuda.is_available():
+        raise OrtkUnavailable("no HIP device visible: the ORT hot path runs only on MI355X (gfx950); no CPU fallback")
+    if not lib().ortk_device_ok():
+        raise OrtkUnavailable("the visible device is not gfx950; libortk.so carries gfx950 code objects only")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libortk takes device pointers only"
+    return C.c_void_p(t.data_ptr())
+
+
+def check(code, what):
+    if code != 0:
+        names = {-1: "ORTK_EINVAL (bad argument / unsupported shape)", -2: "ORTK_ENOSPC (workspace too small)",
+                 -3: "ORTK_ENOSYS (option not implemented)"}
+        raise OrtkError(f"{what} failed: {names.get(code, 'hipError ' + str(code))}")
+
+
+def f32c(t):
+    """contiguous fp32 CUDA tensor (no copy when already so)"""
+    assert t.is_cuda
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,56 @@
+// Shared device/host helpers for libortk (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ortk.h"
+
+#define ORTK_WAVE 64
+
+#define ORTK_CHECK_LAUNCH()                         \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+static inline hipStream_t ortk_s(ortk_stream s) { return (hipStream_t)s; }
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG: one 32-bit mix per element.  The oracle carries the same function
+// (oracle/ort_oracle.py: gumbel_from_hash) so that sampled decodes are reproducible token for token.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ static inline uint32_t ortk_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+// uniform in (0,1) with 24 random bits
+__host__ __device__ static inline float ortk_u01(uint32_t h) { return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// dropout keep decision for element `idx` of the tensor keyed by `seed`
+__device__ static inline bool ortk_keep(uint32_t seed, uint64_t idx, float p) {
+    uint32_t h = ortk_mix32((uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x85EBCA77u + seed);
+    return ortk_u01(h) >= p;
+}
+__host__ static inline uint32_t ortk_subseed(uint64_t seed, uint32_t op) {
+    return ortk_mix32((uint32_t)seed ^ ortk_mix32((uint32_t)(seed >> 32) + 0x632BE5ABu) ^ (op * 0x9E3779B1u + 0x7F4A7C15u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes, DPP/shuffle based)
+// ---------------------------------------------------------------------------------------------
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ static inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int64_t ortk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t ortk_align(int64_t a, int64_t b) { return ortk_cdiv(a, b) * b; }

@@ -1,0 +1,325 @@
+// ortk_decode.hip — on-device bookkeeping of greedy / multinomial / beam-search decoding.
+//
+// Replaces the host loops of CaptionModel.batch_beam_search (models/caption_model.py:56-111,151-226) and of
+// CachedTransformerBase._generate_captions (models/transformer.py:507-561).  The reference does, per step, a full
+// sort of b*V candidates per image, a Python loop over images x beams with two .item() syncs each, a torch.cat of
+// the (N,b,t,V) log-prob history and an index_select of all 24 cache tensors.  Here:
+//   * one workgroup per image selects the b best of b*V candidates (per-thread top lists -> LDS -> b rounds of
+//     block arg-max), in descending order like the sort;
+//   * histories are (N*b, L) token / token-log-prob tables re-ordered by parent (ping-pong buffers);
+//   * the self-attention KV cache is NEVER moved: each beam carries a table of the physical cache rows of its
+//     ancestors (kvidx), re-threaded by parent pointer each step; cross-attention K/V exist once per image;
+//   * finished hypotheses go to a per-image list; the final stable top-b by (length-penalised) score runs on
+//     device too.  No host synchronisation anywhere in the 18 steps.
+#include "ortk_internal.h"
+
+namespace ortk {
+namespace {
+
+__global__ void kv_append_kernel(const float* __restrict__ qkv, float* __restrict__ ck, float* __restrict__ cv, int64_t rows,
+                                 int d, int row_mult, int tmax, int t) {
+    const int64_t n = rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / d;
+        const int c = (int)(i - r * d);
+        const int64_t dst = ((r * row_mult) * tmax + t) * d + c;
+        ck[dst] = qkv[r * 3 * d + d + c];
+        cv[dst] = qkv[r * 3 * d + 2 * d + c];
+    }
+}
+
+__global__ void fill_i64_kernel(int64_t* p, int64_t n, int64_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+__global__ void kvidx_init_kernel(int32_t* p, int64_t rows, int row_mult, int tmax) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256)
+        p[i] = (int32_t)(i * row_mult * tmax);
+}
+
+// ------------------------------------------------------------------------------------------------ beam step
+constexpr int MAXB = 8;   // beams kept per thread (>= beam size)
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__device__ __forceinline__ double length_pen(int kind, double alpha, int len, double p) {
+    if (kind == 1) return p / (pow(5.0 + (double)len, alpha) / pow(6.0, alpha));   // utils/model_utils.py:134-140
+    if (kind == 2) return p / (double)len;                                         // utils/model_utils.py:143-146
+    return p;
+}
+
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logp, int t) {
+    __shared__ float sv[256 * MAXB];
+    __shared__ int si[256 * MAXB];
+    __shared__ float red_v[4];
+    __shared__ int red_i[4], red_pos[4];
+    __shared__ float win_v[MAXB];
+    __shared__ int win_i[MAXB];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = st.b, V = st.V, L = st.L;
+    const int nq = t == 0 ? 1 : b;
+    const int cur = t & 1, nxt = cur ^ 1;
+
+    float bv[MAXB];
+    int bi[MAXB];
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k) { bv[k] = -INFINITY; bi[k] = 0x7FFFFFFF; }
+    for (int q = 0; q < nq; ++q) {
+        const int64_t srow = t == 0 ? img : (int64_t)img * b + q;
+        const float* lp = logp + srow * st.ldv;
+        const float cum = t == 0 ? 0.f : st.cum[(int64_t)img * b + q];
+        const int prev = (st.decoding_constraint && t > 0) ? st.seq[cur][((int64_t)img * b + q) * L + t - 1] : -1;
+        for (int v = tid; v < V; v += 256) {
+            if (v == prev) continue;
+            float cv = cum + lp[v];
+            int ci = q * V + v;
+            if (better(cv, ci, bv[MAXB - 1], bi[MAXB - 1])) {
+#pragma unroll
+                for (int k = 0; k < MAXB; ++k) {
+                    if (better(cv, ci, bv[k], bi[k])) {
+                        const float tv = bv[k]; const int ti = bi[k];
+                        bv[k] = cv; bi[k] = ci; cv = tv; ci = ti;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k) { sv[tid * MAXB + k] = bv[k]; si[tid * MAXB + k] = bi[k]; }
+    __syncthreads();
+    // b rounds of block-wide arg-max over the 256*MAXB staged candidates (each thread scans its own MAXB)
+    for (int r = 0; r < b; ++r) {
+        float mv = -INFINITY; int mi = 0x7FFFFFFF, mp = -1;
+#pragma unroll
+        for (int k = 0; k < MAXB; ++k) {
+            const float v = sv[tid * MAXB + k]; const int i = si[tid * MAXB + k];
+            if (better(v, i, mv, mi)) { mv = v; mi = i; mp = tid * MAXB + k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(mv, o, 64); const int oi = __shfl_xor(mi, o, 64); const int op = __shfl_xor(mp, o, 64);
+            if (better(ov, oi, mv, mi)) { mv = ov; mi = oi; mp = op; }
+        }
+        if (lane == 0) { red_v[wave] = mv; red_i[wave] = mi; red_pos[wave] = mp; }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = red_v[0]; int fi = red_i[0], fp = red_pos[0];
+            for (int w = 1; w < 4; ++w)
+                if (better(red_v[w], red_i[w], fv, fi)) { fv = red_v[w]; fi = red_i[w]; fp = red_pos[w]; }
+            win_v[r] = fv; win_i[r] = fi;
+            if (fp >= 0) sv[fp] = -INFINITY, si[fp] = 0x7FFFFFFF;
+        }
+        __syncthreads();
+    }
+    // histories, ancestry table, next tokens: thread q handles new beam q
+    if (tid < b) {
+        const int q = tid;
+        const int ix = win_i[q];
+        const int parent = ix / V, tok = ix - parent * V;
+        const int64_t nrow = (int64_t)img * b + q, prow = (int64_t)img * b + parent;
+        const int64_t srow = t == 0 ? img : prow;
+        for (int u = 0; u < t; ++u) {
+            st.seq[nxt][nrow * L + u] = st.seq[cur][prow * L + u];
+            st.tok_lp[nxt][nrow * L + u] = st.tok_lp[cur][prow * L + u];
+        }
+        st.seq[nxt][nrow * L + t] = tok;
+        st.tok_lp[nxt][nrow * L + t] = logp[srow * st.ldv + tok];
+        st.it[nrow] = tok;
+        // keys of the next pass: ancestors' cache rows, then this beam's own slot at time t+1
+        const int32_t* src = st.kvidx[cur] + srow * (t + 1);
+        int32_t* dst = st.kvidx[nxt] + nrow * (t + 2);
+        for (int u = 0; u <= t; ++u) dst[u] = src[u];
+        dst[t + 1] = (int32_t)(nrow * st.tmax + t + 1);
+    }
+    __syncthreads();
+    // finished hypotheses (sequential per image: insertion order matters for the final stable sort)
+    if (tid == 0) {
+        int cnt = st.done_cnt[img];
+        const int cap = b * L;
+        for (int q = 0; q < b; ++q) {
+            const int64_t nrow = (int64_t)img * b + q;
+            const int tok = st.seq[nxt][nrow * L + t];
+            float cum = win_v[q];
+            const bool end = tok == st.eos || t == L - 1;
+            if (end) {
+                if (cnt < cap) {
+                    const int64_t base = ((int64_t)img * cap + cnt);
+                    for (int u = 0; u <= t; ++u) {
+                        st.done_seq[base * L + u] = st.seq[nxt][nrow * L + u];
+                        st.done_lp[base * L + u] = st.tok_lp[nxt][nrow * L + u];
+                    }
+                    st.done_len[base] = t + 1;
+                    st.done_p[base] = length_pen(st.length_penalty, st.length_alpha, t + 1, (double)cum);
+                    ++cnt;
+                }
+                cum -= 1000.f;
+            }
+            st.cum[nrow] = cum;
+        }
+        st.done_cnt[img] = cnt;
+    }
+}
+
+// stable top-b of each image's finished list by score (descending; earlier insertion wins ties)
+__global__ __launch_bounds__(64) void beam_finalize_kernel(BeamState st, int64_t* __restrict__ seq_out, float* __restrict__ lp_out,
+                                                           float* __restrict__ score_out) {
+    __shared__ unsigned char taken[MAXB * 64];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int b = st.b, L = st.L, cap = b * L;
+    const int cnt = st.done_cnt[img];
+    for (int i = lane; i < cap; i += 64) taken[i] = 0;
+    __syncthreads();
+    for (int r = 0; r < b; ++r) {
+        double best = -INFINITY; int bi = 0x7FFFFFFF;
+        for (int i = lane; i < cnt; i += 64)
+            if (!taken[i]) {
+                const double p = st.done_p[(int64_t)img * cap + i];
+                if (p > best || (p == best && i < bi)) { best = p; bi = i; }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double op = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (op > best || (op == best && oi < bi)) { best = op; bi = oi; }
+        }
+        const int64_t orow = (int64_t)img * b + r;
+        if (bi != 0x7FFFFFFF) {
+            const int64_t base = (int64_t)img * cap + bi;
+            const int len = st.done_len[base];
+            for (int u = lane; u < L; u += 64) {
+                seq_out[orow * L + u] = u < len ? (int64_t)st.done_seq[base * L + u] : 0;
+                lp_out[orow * L + u] = u < len ? st.done_lp[base * L + u] : 0.f;
+            }
+            if (lane == 0) { taken[bi] = 1; if (score_out) score_out[orow] = (float)best; }
+        } else {
+            for (int u = lane; u < L; u += 64) { seq_out[orow * L + u] = 0; lp_out[orow * L + u] = 0.f; }
+            if (lane == 0 && score_out) score_out[orow] = 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ greedy / multinomial
+__global__ void sample_init_kernel(SampleState st, int bos) {
+    const int64_t n = (int64_t)st.rows * st.L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { st.seq[i] = 0; st.lp[i] = 0.f; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < st.rows; i += (int64_t)gridDim.x * 256) {
+        st.it[i] = bos; st.unfinished[i] = bos != st.eos;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.last_step[0] = -1;
+}
+
+__device__ __forceinline__ float gumbel(uint64_t seed, int t, int row, int v) {
+    // identical to oracle/ort_oracle.py: gumbel_from_hash
+    uint32_t x = (uint32_t)row * 0x9E3779B1u + (uint32_t)v * 0x85EBCA77u + (uint32_t)(t + 1) * 0xC2B2AE3Du + (uint32_t)seed * 0x27D4EB2Fu;
+    const float u = ortk_u01(ortk_mix32(x));
+    return -logf(-logf(u));
+}
+
+__global__ __launch_bounds__(256) void sample_step_kernel(SampleState st, const float* __restrict__ logp, int t) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lp = logp + (int64_t)row * st.ldv;
+    const int prev = (st.decoding_constraint && t > 0) ? (int)st.seq[(int64_t)row * st.L + t - 1] : -1;
+    float mv = -INFINITY; int mi = 0x7FFFFFFF;
+    for (int v = tid; v < st.V; v += 256) {
+        if (v == prev) continue;
+        float x = lp[v];
+        if (st.sample) x = x / st.temperature + gumbel(st.seed, t, row, v);
+        if (better(x, v, mv, mi)) { mv = x; mi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mv, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (better(ov, oi, mv, mi)) { mv = ov; mi = oi; }
+    }
+    if (lane == 0) { red_v[wave] = mv; red_i[wave] = mi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w], red_i[w], mv, mi)) { mv = red_v[w]; mi = red_i[w]; }
+        const int unf = st.unfinished[row];
+        st.it[row] = mi;
+        st.seq[(int64_t)row * st.L + t] = unf ? mi : 0;      // seq[:, t] = it * unfinished   (transformer.py:546)
+        st.lp[(int64_t)row * st.L + t] = lp[mi];             // NOT masked after EOS          (transformer.py:548)
+        const int now = unf && (mi != st.eos);
+        st.unfinished[row] = now;
+        // the reference leaves the loop at the first step where no row is unfinished (transformer.py:550-551)
+        if (unf && !now) atomicMax(st.last_step, t);
+        if (now && t == st.L - 1) atomicMax(st.last_step, t);
+    }
+}
+
+__global__ void sample_finalize_kernel(SampleState st) {
+    const int last = st.last_step[0];
+    const int64_t n = (int64_t)st.rows * st.L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i % st.L);
+        if (t > last) { st.lp[i] = 0.f; st.seq[i] = 0; }
+    }
+}
+
+inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ortk_cdiv(n, 256), 2048)); }
+
+}  // namespace
+
+int kv_append(const float* qkv, float* ck, float* cv, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax, int32_t t,
+              hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(kv_append_kernel, dim3(ew_grid(rows * d)), dim3(256), 0, s, qkv, ck, cv, rows, d, row_mult, tmax, t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, n, v);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, n, v);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int kvidx_init(int32_t* kvidx, int64_t rows, int32_t row_mult, int32_t tmax, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(kvidx_init_kernel, dim3(ew_grid(rows)), dim3(256), 0, s, kvidx, rows, row_mult, tmax);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s) {
+    if (st.b < 1 || st.b > MAXB) return ORTK_EINVAL;
+    if (st.B == 0) return 0;
+    hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int beam_finalize(const BeamState& st, int64_t* seq_out, float* lp_out, float* score_out, hipStream_t s) {
+    if (st.b < 1 || st.b > MAXB || st.b * st.L > MAXB * 64) return ORTK_EINVAL;
+    if (st.B == 0) return 0;
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3((unsigned)st.B), dim3(64), 0, s, st, seq_out, lp_out, score_out);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int sample_init(const SampleState& st, int32_t bos, hipStream_t s) {
+    hipLaunchKernelGGL(sample_init_kernel, dim3(ew_grid((int64_t)st.rows * st.L)), dim3(256), 0, s, st, bos);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s) {
+    if (st.rows == 0) return 0;
+    hipLaunchKernelGGL(sample_step_kernel, dim3((unsigned)st.rows), dim3(256), 0, s, st, logp, t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int sample_finalize(const SampleState& st, hipStream_t s) {
+    if (st.rows == 0) return 0;
+    hipLaunchKernelGGL(sample_finalize_kernel, dim3(ew_grid((int64_t)st.rows * st.L)), dim3(256), 0, s, st);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace ortk

@@ -1,0 +1,256 @@
+// ortk_embed_loss.hip — token embedding, generator log-softmax, fused cross-entropy, small reductions.
+//
+// Replaces InputEmbedding + PositionalEncoding (models/transformer.py:383-401), OutputEmbedding's log_softmax
+// (transformer.py:412-413) and LanguageModelCriterion / RewardCriterion (utils/losses.py:15-43).
+#include "ortk_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(128) void embed_fwd_kernel(const int64_t* __restrict__ seq, int64_t seq_stride,
+                                                        const float* __restrict__ lut, const float* __restrict__ pe,
+                                                        float* __restrict__ out, float* __restrict__ keymask, int T, int t0,
+                                                        int d, int pad_id, float scale, float drop_p, uint32_t seed) {
+    const int64_t row = blockIdx.x;           // r*T + t
+    const int64_t r = row / T;
+    const int t = (int)(row - r * T);
+    const int64_t tok = seq[r * seq_stride + t];
+    if (keymask && threadIdx.x == 0) keymask[row] = tok != pad_id ? 1.f : 0.f;
+    const float* e = lut + tok * d;
+    const float* p = pe + (int64_t)(t0 + t) * d;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int c = threadIdx.x; c < d; c += 128) {
+        float v = e[c] * scale + p[c];
+        if (drop_p > 0.f) v = ortk_keep(seed, (uint64_t)row * d + c, drop_p) ? v * inv_keep : 0.f;
+        out[row * d + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const int64_t* __restrict__ seq, int64_t seq_stride,
+                                                        const float* __restrict__ dout, float* __restrict__ dlut, int T,
+                                                        int d, float scale, float drop_p, uint32_t seed) {
+    const int64_t row = blockIdx.x;
+    const int64_t r = row / T;
+    const int t = (int)(row - r * T);
+    const int64_t tok = seq[r * seq_stride + t];
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int c = threadIdx.x; c < d; c += 128) {
+        float g = dout[row * d + c];
+        if (drop_p > 0.f) g = ortk_keep(seed, (uint64_t)row * d + c, drop_p) ? g * inv_keep : 0.f;
+        atomicAdd(&dlut[tok * d + c], g * scale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- block reductions
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sh[w]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------- log-softmax / CE
+__global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x, int V, int64_t ld, float scale) {
+    __shared__ float sh[4];
+    float* row = x + (int64_t)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, row[c] * scale);
+    mx = block_max(mx, sh);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) s += expf(row[c] * scale - mx);
+    s = block_sum(s, sh);
+    const float lse = logf(s);
+    for (int c = threadIdx.x; c < V; c += 256) row[c] = (row[c] * scale - mx) - lse;
+}
+
+__global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                   int64_t target_stride, int T, const float* __restrict__ weight,
+                                                   const float* __restrict__ norm_dev, float* __restrict__ loss_dev, int V,
+                                                   int64_t ld) {
+    __shared__ float sh[4];
+    const int64_t r = blockIdx.x;
+    float* row = logits + r * ld;
+    const int64_t tgt = targets[(r / T) * target_stride + (r % T)];
+    const float w = weight[r] / norm_dev[0];
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, row[c]);
+    mx = block_max(mx, sh);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) s += expf(row[c] - mx);
+    s = block_sum(s, sh);
+    const float lse = logf(s);
+    if (threadIdx.x == 0 && w != 0.f) atomicAdd(loss_dev, -((row[tgt] - mx) - lse) * w);
+    __syncthreads();
+    for (int c = threadIdx.x; c < (int)ld; c += 256) {
+        float g = 0.f;
+        if (c < V && w != 0.f) g = (expf((row[c] - mx) - lse) - (c == tgt ? 1.f : 0.f)) * w;
+        row[c] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp,
+                                                              int64_t ld_in, float* __restrict__ dlogits, int64_t ld_out, int V) {
+    __shared__ float sh[4];
+    const int64_t r = blockIdx.x;
+    const float* lp = logp + r * ld_in;
+    const float* dl = dlogp + r * ld_in;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) s += dl[c];
+    s = block_sum(s, sh);
+    float* o = dlogits + r * ld_out;
+    for (int c = threadIdx.x; c < (int)ld_out; c += 256) o[c] = c < V ? dl[c] - expf(lp[c]) * s : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------- misc
+// column sums: each workgroup covers 64 columns x ROWS rows; lanes walk columns (coalesced), waves walk rows.
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, float* __restrict__ out,
+                                                     int64_t M, int N) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    float acc = 0.f;
+    if (c < N)
+        for (int64_t r = r0 + wave; r < min(M, r0 + CS_ROWS); r += 4) acc += x[r * ld + c];
+    sh[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < N) atomicAdd(&out[c], sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                            float p, uint32_t seed) {
+    const float inv_keep = 1.f / (1.f - p);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = ortk_keep(seed, (uint64_t)i, p) ? x[i] * inv_keep : 0.f;
+}
+
+__global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                         float* __restrict__ y, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = gate[i] > 0.f ? x[i] * scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
+}
+
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+inline unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>(ortk_cdiv(n, 256), 2048); }
+
+}  // namespace
+
+extern "C" int ortk_embed_fwd(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out,
+                              float* keymask, int64_t R, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p,
+                              uint32_t seed, ortk_stream stream) {
+    if (!seq || !lut || !pe || !out || R < 0 || T < 1 || d < 1) return ORTK_EINVAL;
+    if (R == 0) return 0;
+    const float scale = (float)sqrt((double)d);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)(R * T)), dim3(128), 0, ortk_s(stream), seq, seq_stride, lut, pe, out,
+                       keymask, T, t0, d, pad_id, scale, drop_p, seed);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_embed_bwd(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut, int64_t R, int32_t T,
+                              int32_t d, float drop_p, uint32_t seed, ortk_stream stream) {
+    if (!seq || !dout || !dlut || R < 0 || T < 1 || d < 1) return ORTK_EINVAL;
+    if (R == 0) return 0;
+    const float scale = (float)sqrt((double)d);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(R * T)), dim3(128), 0, ortk_s(stream), seq, seq_stride, dout, dlut, T, d,
+                       scale, drop_p, seed);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, float scale, ortk_stream stream) {
+    if (!x || rows < 0 || V < 1 || ld < V) return ORTK_EINVAL;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), x, V, ld, scale);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_xent_fwd_bwd(float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
+                                 const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, ortk_stream stream) {
+    if (!logits || !targets || !weight || !norm_dev || !loss_dev || rows < 0 || V < 1 || ld < V || T < 1) return ORTK_EINVAL;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logits, targets, target_stride, T, weight,
+                       norm_dev, loss_dev, V, ld);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, float* dlogits, int64_t ld_out,
+                                    int64_t rows, int32_t V, ortk_stream stream) {
+    if (!logp || !dlogp || !dlogits || rows < 0 || V < 1 || ld_in < V || ld_out < V) return ORTK_EINVAL;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logp, dlogp, ld_in, dlogits,
+                       ld_out, V);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_colsum(const float* x, int64_t ld, float* out, int64_t M, int32_t N, ortk_stream stream) {
+    if (!x || !out || M < 0 || N < 0) return ORTK_EINVAL;
+    if (M == 0 || N == 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ortk_cdiv(N, 64), (unsigned)ortk_cdiv(M, CS_ROWS)), dim3(256), 0,
+                       ortk_s(stream), x, ld, out, M, N);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_dropout_apply(const float* x, float* y, int64_t n, float p, uint32_t seed, ortk_stream stream) {
+    if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, y, n, p, seed);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_gate_apply(const float* x, const float* gate, float* y, int64_t n, float scale, ortk_stream stream) {
+    if (!x || !gate || !y || n < 0) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gate_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, gate, y, n, scale);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_fill(float* x, int64_t n, float value, ortk_stream stream) {
+    if (!x || n < 0) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, n, value);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_sum(const float* x, int64_t n, float* out_dev, ortk_stream stream) {
+    if (!x || !out_dev || n < 0) return ORTK_EINVAL;
+    if (int e = ortk_fill(out_dev, 1, 0.f, stream)) return e;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sum_kernel, dim3((unsigned)std::min<int64_t>(ortk_cdiv(n, 256), 256)), dim3(256), 0, ortk_s(stream), x, n,
+                       out_dev);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,329 @@
+// ortk_gemm.hip — MFMA GEMM with fused epilogues for every dense projection of the ORT path.
+//
+// Replaces torch.nn.functional.linear + its autograd in the reference
+// (models/transformer.py:238,280,324-325,412; models/relation_transformer.py:168-176,191,331-333).
+//
+// One kernel template covers the three operand layouts the path needs, all on row-major fp32 storage:
+//   forward   Y  = X  W^T   : A (M,K)        , B = W  (N,K)  -> transA=0, transB=0
+//   dgrad     dX = dY W     : A (M,K'=N_out) , B = W  stored (K',N') -> transA=0, transB=1
+//   wgrad     dW = dY^T X   : A = dY stored (K'=rows, M'=N_out), B = X stored (K', N'=K_in) -> transA=1, transB=1
+//
+// Tiling (gfx950, wave64): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 =
+// 4x4 MFMA 16x16 tiles; K is consumed 16 (fp32) or 32 (bf16) at a time through a double-buffered LDS image
+// that is ALWAYS k-major ([k][m] / [k][n]); only the global->LDS staging differs per layout, so the fragment
+// reads are identical for all three.  The MFMA is issued "swapped" (B-tile as the A operand) so that each lane
+// ends up with 4 consecutive n for one m: epilogue loads/stores are float4 along the contiguous C dimension.
+//
+// Workgroup ids are remapped so that the blocks resident on one XCD (ids b, b+8, ...) walk CONSECUTIVE tiles
+// (n fastest): they share the A panel in that XCD's L2 instead of fetching it 8 times.
+#include "ortk_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int PITCH = 128 + 16;  // floats; 144 % 32 == 16 -> the two k-rows a 32-lane half reads hit disjoint banks
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // bijective for any nwg: XCD x (= bid % 8) gets a contiguous chunk of logical ids
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float4 ld4(const float* __restrict__ base, int64_t ld, int row, int col, int nrows, int ncols,
+                                      bool vec) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows && col < ncols) {
+        const float* p = base + (int64_t)row * ld + col;
+        if (vec && col + 3 < ncols) {
+            r = *reinterpret_cast<const float4*>(p);
+        } else {
+            r.x = p[0];
+            if (col + 1 < ncols) r.y = p[1];
+            if (col + 2 < ncols) r.z = p[2];
+            if (col + 3 < ncols) r.w = p[3];
+        }
+    }
+    return r;
+}
+
+struct Epi {
+    float* C; int64_t ldc;
+    const float* bias; const float* rowscale; const float* resid; int64_t ldr;
+    const float* gate; int64_t ldg; float gate_scale;
+    int relu; float drop_p; uint32_t drop_seed; int accumulate; bool first_split;
+    int M, N;
+};
+
+__device__ __forceinline__ void epilogue4(const Epi& e, int m, int n0, f32x4 acc) {
+    if (m >= e.M || n0 >= e.N) return;
+    const float rs = e.rowscale ? e.rowscale[m] : 1.f;
+    const float inv_keep = e.drop_p > 0.f ? 1.f / (1.f - e.drop_p) : 1.f;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r;
+        float x = acc[r];
+        if (n < e.N) {
+            // bias / residual are added once: by the first K-split when accumulating
+            if (e.bias && e.first_split) x += e.bias[n];
+            if (e.relu) x = fmaxf(x, 0.f);
+            x *= rs;
+            if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, (uint64_t)m * (uint64_t)e.N + n, e.drop_p) ? x * inv_keep : 0.f;
+            if (e.gate) x = e.gate[(int64_t)m * e.ldg + n] > 0.f ? x * e.gate_scale : 0.f;
+            if (e.resid && e.first_split) x += e.resid[(int64_t)m * e.ldr + n];
+        }
+        v[r] = x;
+    }
+    float* c = e.C + (int64_t)m * e.ldc + n0;
+    if (e.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + r < e.N) atomicAdd(c + r, v[r]);
+    } else if (n0 + 3 < e.N && ((e.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0)) {
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + r < e.N) c[r] = v[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 MFMA
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    constexpr int BK = 16;
+    __shared__ __attribute__((aligned(16))) float sA[2][BK][PITCH];
+    __shared__ __attribute__((aligned(16))) float sB[2][BK][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks = rest / tilesM;
+    const int mb = mt * BM, nb = nt * BN;
+    const int k_begin = ks * kchunk;
+    const int k_end = min(p.K, k_begin + kchunk);
+
+    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = tid + 256 * u;
+            if (!TA) ra[u] = ld4(p.A, p.lda, mb + (f >> 2), k0 + 4 * (f & 3), p.M, k_end, vecA);
+            else     ra[u] = ld4(p.A, p.lda, k0 + (f >> 5), mb + 4 * (f & 31), k_end, p.M, vecA);
+            if (!TB) rb[u] = ld4(p.B, p.ldb, nb + (f >> 2), k0 + 4 * (f & 3), p.N, k_end, vecB);
+            else     rb[u] = ld4(p.B, p.ldb, k0 + (f >> 5), nb + 4 * (f & 31), k_end, p.N, vecB);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = tid + 256 * u;
+            if (!TA) {
+                const int m = f >> 2, k = 4 * (f & 3);
+                sA[buf][k + 0][m] = ra[u].x; sA[buf][k + 1][m] = ra[u].y;
+                sA[buf][k + 2][m] = ra[u].z; sA[buf][k + 3][m] = ra[u].w;
+            } else {
+                *reinterpret_cast<float4*>(&sA[buf][f >> 5][4 * (f & 31)]) = ra[u];
+            }
+            if (!TB) {
+                const int n = f >> 2, k = 4 * (f & 3);
+                sB[buf][k + 0][n] = rb[u].x; sB[buf][k + 1][n] = rb[u].y;
+                sB[buf][k + 2][n] = rb[u].z; sB[buf][k + 3][n] = rb[u].w;
+            } else {
+                *reinterpret_cast<float4*>(&sB[buf][f >> 5][4 * (f & 31)]) = rb[u];
+            }
+        }
+    };
+
+    int buf = 0;
+    if (k_begin < k_end) {
+        gload(k_begin);
+        sstore(0);
+    }
+    __syncthreads();
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool has_next = k0 + BK < k_end;
+        if (has_next) gload(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[buf][4 * kk + lk][wm * 64 + 16 * i + lr];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sB[buf][4 * kk + lk][wn * 64 + 16 * j + lr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    Epi e{p.C, p.ldc, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_scale,
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            epilogue4(e, mb + wm * 64 + 16 * i + lr, nb + wn * 64 + 16 * j + 4 * lk, acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 MFMA
+// Same tiling; operands are converted fp32 -> bf16 while staging, LDS image [k][m] bf16 (k-major, BK = 32),
+// fragments (8 consecutive k for one m) are gathered with the hardware transposing read ds_read_b64_tr_b16.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int PITCH16 = 128 + 16;  // bf16 elements per k-row (288 B): 4 consecutive k-rows land on disjoint banks
+
+__device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (bf16x4 __attribute__((address_space(3)))*)(p));
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    constexpr int BK = 32;
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][BK][PITCH16];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][BK][PITCH16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks = rest / tilesM;
+    const int mb = mt * BM, nb = nt * BN;
+    const int k_begin = ks * kchunk;
+    const int k_end = min(p.K, k_begin + kchunk);
+    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // tile = 128 x 32 fp32 = 1024 float4 -> 4 per thread per operand
+    float4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 256 * u;
+            if (!TA) ra[u] = ld4(p.A, p.lda, mb + (f >> 3), k0 + 4 * (f & 7), p.M, k_end, vecA);
+            else     ra[u] = ld4(p.A, p.lda, k0 + (f >> 5), mb + 4 * (f & 31), k_end, p.M, vecA);
+            if (!TB) rb[u] = ld4(p.B, p.ldb, nb + (f >> 3), k0 + 4 * (f & 7), p.N, k_end, vecB);
+            else     rb[u] = ld4(p.B, p.ldb, k0 + (f >> 5), nb + 4 * (f & 31), k_end, p.N, vecB);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 256 * u;
+            if (!TA) {
+                const int m = f >> 3, k = 4 * (f & 7);
+                sA[buf][k + 0][m] = (__bf16)ra[u].x; sA[buf][k + 1][m] = (__bf16)ra[u].y;
+                sA[buf][k + 2][m] = (__bf16)ra[u].z; sA[buf][k + 3][m] = (__bf16)ra[u].w;
+            } else {
+                bf16x4 t = {(__bf16)ra[u].x, (__bf16)ra[u].y, (__bf16)ra[u].z, (__bf16)ra[u].w};
+                *reinterpret_cast<bf16x4*>(&sA[buf][f >> 5][4 * (f & 31)]) = t;
+            }
+            if (!TB) {
+                const int n = f >> 3, k = 4 * (f & 7);
+                sB[buf][k + 0][n] = (__bf16)rb[u].x; sB[buf][k + 1][n] = (__bf16)rb[u].y;
+                sB[buf][k + 2][n] = (__bf16)rb[u].z; sB[buf][k + 3][n] = (__bf16)rb[u].w;
+            } else {
+                bf16x4 t = {(__bf16)rb[u].x, (__bf16)rb[u].y, (__bf16)rb[u].z, (__bf16)rb[u].w};
+                *reinterpret_cast<bf16x4*>(&sB[buf][f >> 5][4 * (f & 31)]) = t;
+            }
+        }
+    };
+
+    int buf = 0;
+    if (k_begin < k_end) {
+        gload(k_begin);
+        sstore(0);
+    }
+    __syncthreads();
+    const int lr = lane & 15, lg = lane >> 4;
+    // transposing read: lane 4q+p of a 16-lane group supplies &img[k0 + q][c0 + 4p]; it receives column (lane&15)
+    // of the 4 rows k0..k0+3.  Group g reads k = 8g..8g+3 then 8g+4..8g+7 -> the 8-element MFMA fragment.
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool has_next = k0 + BK < k_end;
+        if (has_next) gload(k0 + BK);
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __bf16* base = &sA[buf][8 * lg + tq][wm * 64 + 16 * i + 4 * tp];
+            bf16x4 lo = tr_read(base), hi = tr_read(base + 4 * PITCH16);
+            a[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16* base = &sB[buf][8 * lg + tq][wn * 64 + 16 * j + 4 * tp];
+            bf16x4 lo = tr_read(base), hi = tr_read(base + 4 * PITCH16);
+            b[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        if (has_next) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    (void)lr;
+    Epi e{p.C, p.ldc, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_scale,
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            epilogue4(e, mb + wm * 64 + 16 * i + (lane & 15), nb + wn * 64 + 16 * j + 4 * lg, acc[i][j]);
+}
+
+}  // namespace
+
+extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
+    if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return ORTK_EINVAL;
+    if (a->M == 0 || a->N == 0) return 0;
+    ortk_gemm_args p = *a;
+    const int tilesM = (int)ortk_cdiv(p.M, BM), tilesN = (int)ortk_cdiv(p.N, BN);
+    const int bk = p.precision ? 32 : 16;
+    int splitk = p.accumulate ? (p.splitk > 0 ? p.splitk : 1) : 1;
+    int kchunk = bk;
+    if (p.K <= 0) {
+        splitk = 1;  // empty reduction: C = epilogue(0), bias / residual still applied
+    } else {
+        const int ksteps = (int)ortk_cdiv(p.K, bk);
+        if (splitk > ksteps) splitk = ksteps;
+        kchunk = (int)ortk_cdiv(ksteps, splitk) * bk;
+        splitk = (int)ortk_cdiv(p.K, kchunk);
+    }
+    if (p.transA && !p.transB) return ORTK_EINVAL;  // not needed by the path
+    dim3 grid((unsigned)(tilesM * tilesN * splitk)), block(256);
+    hipStream_t s = ortk_s(stream);
+    const int key = (p.precision ? 4 : 0) | (p.transA ? 2 : 0) | (p.transB ? 1 : 0);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+        case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+        case 3: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+        case 5: hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+        case 7: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+        default: return ORTK_EINVAL;
+    }
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}

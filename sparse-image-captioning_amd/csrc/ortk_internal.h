@@ -1,0 +1,54 @@
+// Internal (non-ABI) launchers shared between the decode kernels and the executor.
+#pragma once
+#include "ortk_common.h"
+
+namespace ortk {
+
+// copy the new token's K and V (columns d..3d of the packed QKV row) into the self-attention cache
+int kv_append(const float* qkv, float* cache_k, float* cache_v, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax,
+              int32_t t, hipStream_t s);
+
+struct BeamState {
+    int32_t B, b, L, V, eos;
+    int64_t ldv;
+    // ping-pong histories, (B*b, L)
+    int32_t* seq[2];
+    float* tok_lp[2];
+    float* cum;               // (B*b)
+    int64_t* it;              // (B*b) tokens fed to the next decoder pass
+    int32_t* kvidx[2];        // (B*b, t+1) physical cache rows of every ancestor key
+    // finished hypotheses, capacity b*L per image
+    int32_t* done_seq;        // (B, b*L, L)
+    float* done_lp;           // (B, b*L, L)
+    double* done_p;           // (B, b*L)   (penalised score; double like the reference's python floats)
+    int32_t* done_len;        // (B, b*L)
+    int32_t* done_cnt;        // (B)
+    int32_t decoding_constraint, length_penalty;
+    double length_alpha;
+    int32_t tmax;             // cache time capacity
+};
+int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s);
+int beam_finalize(const BeamState& st, int64_t* seq_out, float* lp_out, float* score_out, hipStream_t s);
+
+struct SampleState {
+    int32_t rows, L, V, eos;
+    int64_t ldv;
+    int64_t* it;              // (rows) next tokens
+    int64_t* seq;             // (rows, L)   output
+    float* lp;                // (rows, L)   output
+    int32_t* unfinished;      // (rows)
+    int32_t* last_step;       // (1) max over rows of the step at which the row finished
+    int32_t decoding_constraint, sample;
+    float temperature;
+    uint64_t seed;
+};
+int sample_init(const SampleState& st, int32_t bos, hipStream_t s);
+int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s);
+int sample_finalize(const SampleState& st, hipStream_t s);
+
+int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
+int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
+// kvidx[g*1 + 0] = g*row_mult*tmax  (index table for the first decoder pass)
+int kvidx_init(int32_t* kvidx, int64_t rows, int32_t row_mult, int32_t tmax, hipStream_t s);
+
+}  // namespace ortk

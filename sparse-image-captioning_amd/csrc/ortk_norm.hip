@@ -1,0 +1,191 @@
+// ortk_norm.hip — the reference's non-standard LayerNorm (models/transformer.py:329-341):
+//     y = a_2 * (x - mean) / (std_unbiased + eps) + b_2
+// One wave (64 lanes) per row, reductions by wavefront shuffles; a row of d <= 2048 floats stays in registers
+// (statically indexed, so nothing spills to scratch): lane l owns columns {4l..4l+3} + 256*it (vector form)
+// or l + 64*it (scalar form for d % 4 != 0 or unaligned rows).
+#include "ortk_common.h"
+
+namespace {
+
+// NREG = floats per lane: 8 covers d <= 512 (the model width), 32 covers d <= 2048.
+
+template <bool VEC, int NREG> struct Cols {
+    static constexpr int W = VEC ? 4 : 1;           // consecutive columns per iteration
+    static constexpr int NIT = NREG / W;            // iterations
+    static __device__ __forceinline__ int col(int lane, int it) { return VEC ? lane * 4 + 256 * it : lane + 64 * it; }
+};
+
+template <bool VEC, int NREG>
+__device__ __forceinline__ void load_row(const float* __restrict__ x, int d, int lane, float (&v)[NREG]) {
+    using C = Cols<VEC, NREG>;
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+        const int c = C::col(lane, it);
+        if (VEC) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < d) t = *reinterpret_cast<const float4*>(x + c);
+            v[it * 4] = t.x; v[it * 4 + 1] = t.y; v[it * 4 + 2] = t.z; v[it * 4 + 3] = t.w;
+        } else {
+            v[it] = c < d ? x[c] : 0.f;
+        }
+    }
+}
+
+template <bool VEC, int NREG>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     float* __restrict__ stats, int64_t rows, int d, float eps) {
+    using C = Cols<VEC, NREG>;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NREG];
+    load_row<VEC, NREG>(x + row * d, d, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) s += v[i];  // out-of-range slots hold 0
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it)
+#pragma unroll
+        for (int u = 0; u < C::W; ++u)
+            if (C::col(lane, it) + u < d) { const float t = v[it * C::W + u] - mean; q += t * t; }
+    const float sd = sqrtf(wave_sum(q) / (float)(d - 1));
+    const float rinv = 1.f / (sd + eps);
+    if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = sd; }
+    float* yr = y + row * d;
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+        const int c = C::col(lane, it);
+        if (c < d) {
+            if (VEC) {
+                const float4 aa = *reinterpret_cast<const float4*>(a + c), bb = *reinterpret_cast<const float4*>(b + c);
+                float4 o;
+                o.x = aa.x * (v[it * 4] - mean) * rinv + bb.x;
+                o.y = aa.y * (v[it * 4 + 1] - mean) * rinv + bb.y;
+                o.z = aa.z * (v[it * 4 + 2] - mean) * rinv + bb.z;
+                o.w = aa.w * (v[it * 4 + 3] - mean) * rinv + bb.w;
+                *reinterpret_cast<float4*>(yr + c) = o;
+            } else {
+                yr[c] = a[c] * (v[it] - mean) * rinv + b[c];
+            }
+        }
+    }
+}
+
+// Backward.  With xc = x - mean, r = 1/(sd+eps), g = dy*a, n = d:
+//   dx = r*(g - mean(g)) - r^2 * sum(g*xc) * xc / ((n-1)*sd)      [+ dres]
+//   da += sum_rows dy*xc*r ; db += sum_rows dy
+// Each workgroup walks LN_ROWS_PER_BLOCK rows (4 waves, round-robin); every lane owns fixed columns, so the
+// per-column partial sums stay in registers and are combined through LDS + one atomicAdd per column per block.
+constexpr int LN_ROWS_PER_BLOCK = 64;
+
+template <bool VEC, int NREG>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ a, const float* __restrict__ stats,
+                                                     const float* __restrict__ dres, float* __restrict__ dx,
+                                                     float* __restrict__ da, float* __restrict__ db, int64_t rows, int d,
+                                                     float eps) {
+    using C = Cols<VEC, NREG>;
+    extern __shared__ float red[];  // [2][d] partial da / db
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < 2 * d; c += 256) red[c] = 0.f;
+    __syncthreads();
+    float pa[NREG], pb[NREG], av[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
+    load_row<VEC, NREG>(a, d, lane, av);
+    const int64_t r0 = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK;
+    for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 4) {
+        const int64_t row = r0 + rr;
+        if (row >= rows) break;
+        float xv[NREG], gv[NREG];
+        load_row<VEC, NREG>(x + row * d, d, lane, xv);
+        load_row<VEC, NREG>(dy + row * d, d, lane, gv);
+        const float mean = stats[row * 2], sd = stats[row * 2 + 1];
+        const float r = 1.f / (sd + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int it = 0; it < C::NIT; ++it)
+#pragma unroll
+            for (int u = 0; u < C::W; ++u) {
+                const int i = it * C::W + u;
+                const bool in = C::col(lane, it) + u < d;
+                const float xc = in ? xv[i] - mean : 0.f, dyv = gv[i];
+                pa[i] += dyv * xc * r; pb[i] += dyv;
+                const float g = dyv * av[i];
+                xv[i] = xc; gv[i] = g; sg += g; sgx += g * xc;
+            }
+        sg = wave_sum(sg); sgx = wave_sum(sgx);
+        const float mg = sg / (float)d;
+        const float coef = r * r * sgx / ((float)(d - 1) * sd);
+        float* dxr = dx + row * d;
+        const float* res = dres ? dres + row * d : nullptr;
+#pragma unroll
+        for (int it = 0; it < C::NIT; ++it) {
+            const int c = C::col(lane, it);
+            if (c < d) {
+                if (VEC) {
+                    float4 o;
+                    o.x = r * (gv[it * 4] - mg) - coef * xv[it * 4];
+                    o.y = r * (gv[it * 4 + 1] - mg) - coef * xv[it * 4 + 1];
+                    o.z = r * (gv[it * 4 + 2] - mg) - coef * xv[it * 4 + 2];
+                    o.w = r * (gv[it * 4 + 3] - mg) - coef * xv[it * 4 + 3];
+                    if (res) { const float4 t = *reinterpret_cast<const float4*>(res + c); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+                    *reinterpret_cast<float4*>(dxr + c) = o;
+                } else {
+                    float o = r * (gv[it] - mg) - coef * xv[it];
+                    if (res) o += res[c];
+                    dxr[c] = o;
+                }
+            }
+        }
+    }
+    // combine the 4 waves' column partials
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it)
+#pragma unroll
+        for (int u = 0; u < C::W; ++u) {
+            const int c = C::col(lane, it) + u;
+            if (c < d) { atomicAdd(&red[c], pa[it * C::W + u]); atomicAdd(&red[d + c], pb[it * C::W + u]); }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        atomicAdd(&da[c], red[c]);
+        atomicAdd(&db[c], red[d + c]);
+    }
+}
+
+inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int ortk_layernorm_fwd(const float* x, const float* a, const float* b, float* y, float* stats, int64_t rows,
+                                  int32_t d, float eps, ortk_stream stream) {
+    if (!x || !a || !b || !y || d < 2 || d > 2048 || rows < 0) return ORTK_EINVAL;
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)ortk_cdiv(rows, 4)), block(256);
+    const bool vec = d % 4 == 0 && al16(x) && al16(y) && al16(a) && al16(b);
+#define LN_F(V, N) hipLaunchKernelGGL((ln_fwd_kernel<V, N>), grid, block, 0, ortk_s(stream), x, a, b, y, stats, rows, d, eps)
+    if (d <= 512) { if (vec) LN_F(true, 8); else LN_F(false, 8); }
+    else          { if (vec) LN_F(true, 32); else LN_F(false, 32); }
+#undef LN_F
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
+                                  float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, ortk_stream stream) {
+    if (!dy || !x || !a || !stats || !dx || !da || !db || d < 2 || d > 2048 || rows < 0) return ORTK_EINVAL;
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)ortk_cdiv(rows, LN_ROWS_PER_BLOCK)), block(256);
+    const size_t shm = 2 * (size_t)d * sizeof(float);
+    const bool vec = d % 4 == 0 && al16(dy) && al16(x) && al16(a) && al16(dres) && al16(dx);
+#define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps)
+    if (d <= 512) { if (vec) LN_B(true, 8); else LN_B(false, 8); }
+    else          { if (vec) LN_B(true, 32); else LN_B(false, 32); }
+#undef LN_B
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}

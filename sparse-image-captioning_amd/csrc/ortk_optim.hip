@@ -1,0 +1,128 @@
+// ortk_optim.hip — arena-wide elementwise passes: fused clip+Adam and the pruning-mask algebra.
+//
+// All parameters live in one flat arena (include/ortk.h), so each of these is ONE launch over 55 M (or 111 M)
+// contiguous floats, float4-vectorised and HBM-bound, instead of one small kernel per tensor:
+//   * clip_grad_value_ + Adam  (utils/optim.py:116-126,187-191; torch.optim.Adam's rule, no amsgrad / weight decay)
+//   * MaskMixin.get_masked_weight for all 147 masked tensors (pruning/masked_layer.py:84-110) and the
+//     straight-through backward of pruning/sampler.py:10-66.
+#include "ortk_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n, float step_size, float b1, float b2,
+                                                        float eps, float clip, float sqrt_bc2) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float gc = fminf(fmaxf(G[u], -clip), clip);
+            M[u] = M[u] + (gc - M[u]) * (1.f - b1);           // exp_avg.lerp_(grad, 1 - beta1)
+            V[u] = V[u] * b2 + gc * gc * (1.f - b2);
+            const float denom = sqrtf(V[u]) / sqrt_bc2 + eps;
+            P[u] = P[u] - step_size * (M[u] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gc = fminf(fmaxf(g[i], -clip), clip);
+        const float mi = m[i] + (gc - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + gc * gc * (1.f - b2);
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// sample of element i under `mode`
+__device__ __forceinline__ float mask_sample(float m, int mode, uint32_t seed, uint64_t i) {
+    if (mode == 2) return m;
+    const float pr = sigmoidf_(m);
+    if (mode == 0) return rintf(pr);  // round-half-to-even like torch.round (logit 0 -> 0.5 -> 0)
+    const uint32_t h = ortk_mix32((uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32) * 0x85EBCA77u + seed);
+    return ortk_u01(h) < pr ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void mask_apply_kernel(const float* __restrict__ w, const float* __restrict__ m,
+                                                         float* __restrict__ we, int64_t n, int mode, uint32_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        we[i] = mask_sample(m[i], mode, seed, (uint64_t)i) * w[i];
+}
+
+__global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__ dwe, const float* __restrict__ w,
+                                                       const float* __restrict__ m, float* __restrict__ dw, float* __restrict__ dm,
+                                                       int64_t n, int mode, uint32_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float g = dwe[i], mi = m[i];
+        const float s = mask_sample(mi, mode, seed, (uint64_t)i);
+        if (dm) {
+            float ds = g * w[i];                       // d/ds of (s*w)
+            if (mode != 2) { const float pr = sigmoidf_(mi); ds *= pr * (1.f - pr); }
+            dm[i] += ds;
+        }
+        dw[i] = g * s;                                  // may alias dwe
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_count_kernel(const float* __restrict__ m, int64_t n, int mode, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float c = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        c += mode == 2 ? (m[i] != 0.f ? 1.f : 0.f) : rintf(sigmoidf_(m[i]));
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+inline unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>(ortk_cdiv(n, 256), 4096); }
+
+}  // namespace
+
+extern "C" int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float clip, float bc1, float bc2, ortk_stream stream) {
+    if (!p || !g || !m || !v || n < 0 || bc1 <= 0.f || bc2 <= 0.f) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!(al(p) && al(g) && al(m) && al(v))) return ORTK_EINVAL;
+    const float step_size = lr / bc1;
+    const float sqrt_bc2 = (float)sqrt((double)bc2);
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ortk_s(stream), p, g, m, v, n, step_size, beta1,
+                       beta2, eps, clip, sqrt_bc2);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_mask_apply(const float* w, const float* m, float* w_eff, int64_t n, int32_t mode, uint32_t seed,
+                               ortk_stream stream) {
+    if (!w || !m || !w_eff || n < 0 || mode < 0 || mode > 2) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), w, m, w_eff, n, mode, seed);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw, float* dm, int64_t n, int32_t mode,
+                             uint32_t seed, ortk_stream stream) {
+    if (!dw_eff || !w || !m || !dw || n < 0 || mode < 0 || mode > 2) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), dw_eff, w, m, dw, dm, n, mode, seed);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_mask_count(const float* m, int64_t n, int32_t mode, float* count_dev, ortk_stream stream) {
+    if (!m || !count_dev || n < 0 || mode < 0 || mode > 2) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)std::min<int64_t>(ortk_cdiv(n, 256), 1024)), dim3(256), 0,
+                       ortk_s(stream), m, n, mode, count_dev);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}

@@ -228,6 +228,10 @@ def main():
     g3["eval/loss_total"] = np.float32(loss.item())
     for n, p in pmodel.named_parameters():
         g3["eval/grad/" + n] = (p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32))
+    pmodel.zero_grad()
+    pmodel.compute_sparsity_loss(0.9, 30.0, 50, 100).backward()
+    for n in ("att_embed.0.weight_pruning_mask", "model.decoder.layers.1.feed_forward.w_1.weight_pruning_mask"):
+        g3["sploss_grad/" + n] = dict(pmodel.named_parameters())[n].grad.numpy().copy()
 
     # train mode with injected Bernoulli draws: u depends on the SHAPE of the probability tensor only
     def u_for_shape(shape):

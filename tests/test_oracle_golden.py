@@ -170,6 +170,13 @@ def test_prune_eval_forward_stats_and_grads(g3):
     loss.backward()
     for n, p in P.items():
         close(p.grad if p.grad is not None else torch.zeros_like(p), g3["eval/grad/" + n], 5e-5)
+    # the sparsity loss alone: straight-through Round over sigmoid (tiny values -> relative check)
+    for p in P.values():
+        p.grad = None
+    O.sparsity_loss(P, 0.9, 30.0, 50, 100).backward()
+    for k, v in g3.items():
+        if k.startswith("sploss_grad/"):
+            np.testing.assert_allclose(P[k[len("sploss_grad/"):]].grad.numpy(), v, rtol=1e-4, atol=1e-12)
 
 
 def test_prune_train_injected_bernoulli(g3):
