@@ -218,10 +218,11 @@ int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, floa
  *   mode 0: s = round(sigmoid(m))  (supermask, eval)      mode 1: s = bernoulli(sigmoid(m)) (supermask, train)
  *   mode 2: s = m                  (binary masks: magnitude / SNIP / mask_freeze)
  * w_eff = s * w.  Backward (straight-through, sampler.py:10-34): dw = dw_eff*s; dm += dw_eff*w*sigmoid'(m)
- * (mode 2: dm += dw_eff*w, used by SNIP only; dm may be NULL). */
+ * (mode 2: dm += dw_eff*w, used by SNIP only; dm may be NULL).  extra_coef_dev (device scalar or NULL) is added to
+ * dLoss/ds of every element before the sigmoid derivative: the gradient of compute_sparsity_loss (prune.py:228-269). */
 int ortk_mask_apply(const float* w, const float* m, float* w_eff, int64_t n, int32_t mode, uint32_t seed, ortk_stream stream);
 int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw, float* dm, int64_t n, int32_t mode,
-                  uint32_t seed, ortk_stream stream);
+                  uint32_t seed, const float* extra_coef_dev, ortk_stream stream);
 /* count_dev[0] += number of kept entries (round(sigmoid(m)) for mode 0/1, m != 0 for mode 2) in m[0..n). */
 int ortk_mask_count(const float* m, int64_t n, int32_t mode, float* count_dev, ortk_stream stream);
 

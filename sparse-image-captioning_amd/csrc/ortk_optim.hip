@@ -58,12 +58,15 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__ dwe, const float* __restrict__ w,
                                                        const float* __restrict__ m, float* __restrict__ dw, float* __restrict__ dm,
-                                                       int64_t n, int mode, uint32_t seed) {
+                                                       int64_t n, int mode, uint32_t seed,
+                                                       const float* __restrict__ extra_coef) {
+    // extra_coef[0] = d(sparsity loss)/d(sample), the same for every mask element (pruning/prune.py:228-269)
+    const float ec = extra_coef ? extra_coef[0] : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float g = dwe[i], mi = m[i];
         const float s = mask_sample(mi, mode, seed, (uint64_t)i);
         if (dm) {
-            float ds = g * w[i];                       // d/ds of (s*w)
+            float ds = g * w[i] + ec;                  // d/ds of (s*w) + sparsity-loss term
             if (mode != 2) { const float pr = sigmoidf_(mi); ds *= pr * (1.f - pr); }
             dm[i] += ds;
         }
@@ -110,10 +113,10 @@ extern "C" int ortk_mask_apply(const float* w, const float* m, float* w_eff, int
 }
 
 extern "C" int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw, float* dm, int64_t n, int32_t mode,
-                             uint32_t seed, ortk_stream stream) {
+                             uint32_t seed, const float* extra_coef_dev, ortk_stream stream) {
     if (!dw_eff || !w || !m || !dw || n < 0 || mode < 0 || mode > 2) return ORTK_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), dw_eff, w, m, dw, dm, n, mode, seed);
+    hipLaunchKernelGGL(mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), dw_eff, w, m, dw, dm, n, mode, seed, extra_coef_dev);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,448 @@
+"""Object Relation Transformer on MI355X — host-side mirror of the reference's
+``sparse_caption/models/relation_transformer.py:297-426`` (+ ``caption_model.py:24-28``,
+``transformer.py:417-561``).  All arithmetic happens in libortk.so; this class owns
+
+* the flat fp32 parameter arena (every ``nn.Parameter`` is a view into it, with the reference's state_dict key
+  names, so ``state_dict()`` / ``load_state_dict(strict=True)`` are interchangeable with the reference),
+* the drop-in call contract: ``model(att_feats, boxes, seqs, att_masks)`` -> log-probs ``(R, T, V)`` that
+  participate in torch autograd, ``model(..., mode="sample", opt=...)`` -> ``(seq, seq_logprobs)``.
+"""
+import ctypes as C
+import math
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import register_model
+from .. import _lib as L
+
+
+class _Node(nn.Module):
+    """Structural placeholder so that parameter paths equal the reference's module paths."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("structural node: compute happens in RelationTransformerModel")
+
+
+class ObjectRelationBatchLayout:
+    """Documents the batch dict the model consumes (reference ``data/collate.py:119-169,202-216``); the data
+    side (feature files, tokenizer) is out of scope, so this is NOT a collate function."""
+    KEYS = ("att_feats", "att_masks", "boxes", "seqs", "masks")
+
+    @staticmethod
+    def add_argparse_args(parser):
+        parser.add_argument("--seq_per_img", type=int, default=5)
+        parser.add_argument("--max_seq_length", type=int, default=18)
+
+
+def make_ccfg(config, precision, drop, train_drop_src=None):
+    c = L.Config()
+    c.d_model, c.d_ff = int(config.d_model), int(config.dim_feedforward)
+    c.n_layers, c.n_heads = int(config.num_layers), int(config.num_heads)
+    c.vocab, c.feat, c.seq_len = int(config.vocab_size), int(config.att_feat_size), int(config.max_seq_length)
+    c.pad_id, c.bos_id, c.eos_id, c.unk_id = (int(config.pad_token_id), int(config.bos_token_id),
+                                              int(config.eos_token_id), int(config.unk_token_id))
+    c.box_trig = 0 if config.no_box_trigonometric_embedding else 1
+    c.precision = int(precision)
+    c.drop_src = float(config.drop_prob_src if train_drop_src is None else train_drop_src)
+    c.drop = float(drop)
+    return c
+
+
+def arena_entries(ccfg):
+    lib = L.lib()
+    n = lib.ortk_arena_entries(C.byref(ccfg))
+    if n < 0:
+        raise L.OrtkError("unsupported model geometry (see ortk_model.hip: check_cfg)")
+    out = []
+    name = C.create_string_buffer(128)
+    off, numel, ndim, kind = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+    shape = (C.c_int64 * 4)()
+    for i in range(n):
+        L.check(lib.ortk_arena_entry(C.byref(ccfg), i, name, C.byref(off), C.byref(numel), C.byref(ndim), shape,
+                                     C.byref(kind)), "ortk_arena_entry")
+        out.append(dict(name=name.value.decode(), offset=off.value, numel=numel.value,
+                        shape=tuple(shape[j] for j in range(ndim.value)), kind=kind.value))
+    return out
+
+
+class _ForwardFn(torch.autograd.Function):
+    """Teacher-forced log-probs with the backward routed through ortk_backward."""
+
+    @staticmethod
+    def forward(ctx, model, batch, train, seed, *params):
+        logp, ws = model._run_forward(batch, train, seed, want_logp=True, cache_ws=False)
+        ctx.model_ref = weakref.ref(model)
+        ctx.batch, ctx.ws, ctx.train, ctx.seed = batch, ws, train, seed
+        ctx.save_for_backward(logp)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        model = ctx.model_ref()
+        (logp,) = ctx.saved_tensors
+        grads = model._run_backward_external(ctx.batch, ctx.ws, logp, dlogp.contiguous(), ctx.train, ctx.seed)
+        ctx.ws = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class CaptionModelBase(nn.Module):
+    """``CaptionModel.forward`` mode dispatch (caption_model.py:24-28)."""
+
+    def forward(self, *args, **kwargs):
+        mode = kwargs.pop("mode", "forward")
+        return getattr(self, "_" + mode)(*args, **kwargs)
+
+
+@register_model("relation_transformer")
+class RelationTransformerModel(CaptionModelBase):
+    COLLATE_FN = ObjectRelationBatchLayout
+    DROPOUT = 0.1          # make_model(dropout=0.1), relation_transformer.py:306
+    MASKED = False
+
+    def __init__(self, config, precision=None):
+        super().__init__()
+        self.config = config
+        for k in ("share_att_encoder", "share_att_decoder", "share_layer_encoder", "share_layer_decoder"):
+            if config.get(k, None) if hasattr(config, "get") else getattr(config, k, None):
+                raise NotImplementedError(f"`{k}` (ACORT weight sharing) is not implemented in the HIP path yet")
+        # attributes the callers read (transformer.py:418-437; utils/training.py:253)
+        self.d_model, self.dim_feedforward = config.d_model, config.dim_feedforward
+        self.num_layers, self.num_heads = config.num_layers, config.num_heads
+        self.drop_prob_src = config.drop_prob_src
+        self.seq_length = config.max_seq_length
+        self.att_feat_size, self.vocab_size = config.att_feat_size, config.vocab_size
+        self.eos_idx, self.bos_idx = config.eos_token_id, config.bos_token_id
+        self.unk_idx, self.pad_idx = config.unk_token_id, config.pad_token_id
+        self.box_trigonometric_embedding = not config.no_box_trigonometric_embedding
+        assert self.num_layers > 0, "num_layers should be greater than 0"
+        if precision is None:
+            precision = config.get("ortk_precision", 0) if hasattr(config, "get") else 0
+        self.precision = {"fp32": 0, "f32": 0, "bf16": 1}.get(precision, precision)
+        self._ccfg = make_ccfg(config, self.precision, self.DROPOUT)
+        self._entries = arena_entries(self._ccfg)
+        lib = L.lib()
+        self._n_train = lib.ortk_arena_numel(C.byref(self._ccfg))
+        self._n_all = lib.ortk_arena_numel_with_buffers(C.byref(self._ccfg))
+        self._flat = torch.zeros(self._n_all)
+        self._params = {}
+        self._build_tree()
+        self._bind()
+        self.reset_parameters()
+        self._ws_cache = {}
+        self._seed_counter = 0
+        self.done_beams = None
+
+    # ------------------------------------------------------------------ arena plumbing
+    def _extra_param_specs(self, entry):
+        """(suffix, arena_attr) of additional per-entry parameters (the `_prune` variant adds masks)."""
+        return []
+
+    def _build_tree(self):
+        for e in self._entries:
+            parts = e["name"].split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            if e["kind"] == 2:
+                node.register_buffer(parts[-1], torch.empty(0))
+                self._params[e["name"]] = (node, parts[-1], None)
+            else:
+                par = nn.Parameter(torch.empty(0))
+                node.register_parameter(parts[-1], par)
+                self._params[e["name"]] = (node, parts[-1], par)
+                for suffix, _ in self._extra_param_specs(e):
+                    mp = nn.Parameter(torch.empty(0))
+                    node.register_parameter(parts[-1] + suffix, mp)
+                    self._params[e["name"] + suffix] = (node, parts[-1] + suffix, mp)
+
+    def _arenas(self):
+        return {"": "_flat"}
+
+    def _bind(self):
+        """(Re)point every Parameter / buffer at its slice of the flat arenas."""
+        for e in self._entries:
+            node, leaf, par = self._params[e["name"]]
+            view = self._flat[e["offset"]:e["offset"] + e["numel"]].view(e["shape"])
+            if par is None:
+                node._buffers[leaf] = view
+            else:
+                par.data = view
+                for suffix, attr in self._extra_param_specs(e):
+                    arena = getattr(self, attr, None)
+                    if arena is None:
+                        continue
+                    self._params[e["name"] + suffix][2].data = arena[e["offset"]:e["offset"] + e["numel"]].view(e["shape"])
+
+    def _apply(self, fn, recurse=True):
+        for attr in self._arenas().values():
+            if getattr(self, attr, None) is None:
+                continue
+            t = fn(getattr(self, attr))
+            if t.dtype != torch.float32:
+                raise TypeError("the ORT arena is fp32; choose bf16 MFMA with precision='bf16', not .half()/.bfloat16()")
+            setattr(self, attr, t)
+        self._bind()
+        self._ws_cache = {}
+        for par in self.parameters():
+            if par.grad is not None:
+                par.grad = fn(par.grad)
+        return self
+
+    def named_weight_entries(self):
+        return [e for e in self._entries if e["kind"] != 2]
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        """Same distributions as the reference: xavier-uniform on every >=2-D tensor under ``model.``
+        (relation_transformer.py:336-338), torch defaults elsewhere (nn.Linear for att_embed and all biases,
+        ones/zeros for LayerNorm), ``pe`` built in fp32 like transformer.py:369-374."""
+        for e in self._entries:
+            node, leaf, par = self._params[e["name"]]
+            name, shape = e["name"], e["shape"]
+            t = node._buffers[leaf] if par is None else par.data
+            if e["kind"] == 2:
+                d = shape[-1]
+                position = torch.arange(0, shape[1]).unsqueeze(1).float()
+                div_term = torch.exp(torch.arange(0, d, 2).float() * -(math.log(10000.0) / d))
+                t[0, :, 0::2] = torch.sin(position * div_term)
+                t[0, :, 1::2] = torch.cos(position * div_term)
+            elif name.endswith(".a_2"):
+                t.fill_(1.0)
+            elif name.endswith(".b_2"):
+                t.zero_()
+            elif len(shape) >= 2:
+                if name.startswith("model."):
+                    nn.init.xavier_uniform_(t)
+                else:
+                    nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            else:  # Linear bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                wshape = self._shape_of(name[:-len("bias")] + "weight")
+                bound = 1.0 / math.sqrt(wshape[1]) if wshape is not None and wshape[1] > 0 else 0.0
+                t.uniform_(-bound, bound)
+
+    def _shape_of(self, name):
+        for e in self._entries:
+            if e["name"] == name:
+                return e["shape"]
+        return None
+
+    # ------------------------------------------------------------------ helpers
+    def _eff_params_ptr(self, train, seed):
+        """Device pointer of the arena the kernels read (the `_prune` variant materialises s*W first)."""
+        return L.ptr(self._flat)
+
+    def _next_seed(self):
+        self._seed_counter += 1
+        return (torch.initial_seed() * 1000003 + self._seed_counter) & 0xFFFFFFFFFFFFFFFF or 1
+
+    def _workspace(self, key, nbytes, cache):
+        if cache and key in self._ws_cache and self._ws_cache[key].numel() >= nbytes:
+            return self._ws_cache[key]
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._flat.device)
+        if cache:
+            self._ws_cache[key] = ws
+        return ws
+
+    @staticmethod
+    def clip_att(att_feats, att_masks, boxes):
+        """relation_transformer.py:398-405 (boxes are cut to the same length; collate pads all three alike)."""
+        if att_masks is not None:
+            max_len = int(att_masks.long().sum(1).max())
+            att_feats, att_masks = att_feats[:, :max_len], att_masks[:, :max_len]
+            boxes = boxes[:, :max_len]
+        return att_feats, att_masks, boxes
+
+    def _prepare(self, att_feats, boxes, att_masks):
+        L.require_gpu()
+        assert att_feats.is_cuda and boxes.is_cuda, "inputs must live on the MI355X (no CPU path)"
+        att_feats, att_masks, boxes = self.clip_att(att_feats, att_masks, boxes)
+        if att_masks is None:
+            att_masks = att_feats.new_ones(att_feats.shape[:2])
+        assert att_feats.size(-1) == self.att_feat_size and boxes.size(-1) == 4
+        return L.f32c(att_feats), L.f32c(boxes), L.f32c(att_masks)
+
+    def _make_batch(self, att_feats, boxes, att_masks, seqs=None, tok_weight=None):
+        b = L.Batch()
+        keep = [att_feats, boxes, att_masks]
+        b.att_feats, b.boxes, b.att_masks = att_feats.data_ptr(), boxes.data_ptr(), att_masks.data_ptr()
+        b.B, b.S = att_feats.shape[0], att_feats.shape[1]
+        if seqs is not None:
+            assert seqs.dtype == torch.long and seqs.is_cuda
+            seqs = seqs.contiguous()
+            assert seqs.size(0) % b.B == 0, "caption rows must be a multiple of the image count"
+            b.seqs, b.seq_stride = seqs.data_ptr(), seqs.size(1)
+            b.R, b.T = seqs.size(0), seqs.size(1) - 1
+            keep.append(seqs)
+            if tok_weight is not None:
+                tok_weight = L.f32c(tok_weight)
+                assert tok_weight.shape == (b.R, b.T)
+                b.tok_weight = tok_weight.data_ptr()
+                keep.append(tok_weight)
+        b._keep = keep
+        return b
+
+    # ------------------------------------------------------------------ teacher forcing
+    def _run_forward(self, batch, train, seed, want_logp, cache_ws):
+        lib = L.lib()
+        nbytes = lib.ortk_train_workspace_bytes(C.byref(self._ccfg), batch.B, batch.S, batch.R, batch.T)
+        ws = self._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, cache_ws)
+        logp, ldv = None, 0
+        if want_logp:
+            ldv = (self.vocab_size + 3) // 4 * 4
+            logp = torch.empty(batch.R, batch.T, ldv, device=self._flat.device)
+        L.check(lib.ortk_forward(C.byref(self._ccfg), self._eff_params_ptr(train, seed), C.byref(batch), L.ptr(ws),
+                                 ws.numel(), L.ptr(logp), ldv, int(train), seed, L.stream_ptr()), "ortk_forward")
+        return logp, ws
+
+    def _grad_views(self, gflat):
+        out = []
+        for e in self.named_weight_entries():
+            out.append(gflat[e["offset"]:e["offset"] + e["numel"]].view(e["shape"]))
+        return out
+
+    def _param_list(self):
+        return [self._params[e["name"]][2] for e in self.named_weight_entries()]
+
+    def _run_backward_external(self, batch, ws, logp, dlogp, train, seed):
+        lib = L.lib()
+        L.check(lib.ortk_loss_external(C.byref(self._ccfg), C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(logp),
+                                       L.ptr(dlogp), logp.size(-1), L.stream_ptr()), "ortk_loss_external")
+        gflat = torch.zeros(self._n_train, device=self._flat.device)
+        L.check(lib.ortk_backward(C.byref(self._ccfg), self._eff_params_ptr(train, seed), L.ptr(gflat), C.byref(batch),
+                                  L.ptr(ws), ws.numel(), int(train), seed, L.stream_ptr()), "ortk_backward")
+        return self._finish_grads(gflat, train, seed)
+
+    def _finish_grads(self, gflat, train, seed):
+        return self._grad_views(gflat)
+
+    def _forward(self, att_feats, boxes, seqs, att_masks=None, **kwargs):
+        """``_forward`` (relation_transformer.py:368-372): log-probs (R, T, V), T = seqs.size(1) - 1."""
+        att_feats, boxes, att_masks = self._prepare(att_feats, boxes, att_masks)
+        batch = self._make_batch(att_feats, boxes, att_masks, seqs)
+        train = bool(self.training)
+        seed = self._next_seed() if train else 0
+        params = self._param_list()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            logp = _ForwardFn.apply(self, batch, train, seed, *params)
+        else:
+            logp, _ = self._run_forward(batch, train, seed, want_logp=True, cache_ws=True)
+        return logp[..., :self.vocab_size]
+
+    # ------------------------------------------------------------------ decoding
+    @staticmethod
+    def _parse_length_penalty(s):
+        if not s:
+            return 0, 0.0
+        kind, alpha = s.split("_")
+        return {"wu": 1, "avg": 2}[kind], float(alpha)
+
+    @torch.no_grad()
+    def _decode(self, att_feats, boxes, att_masks, opt):
+        lib = L.lib()
+        o = L.DecodeOpts()
+        o.num_random_sample = int(opt.get("num_random_sample", 0))
+        o.beam_size = int(opt.get("beam_size", 1))
+        o.temperature = float(opt.get("temperature", 1.0))
+        o.decoding_constraint = int(opt.get("decoding_constraint", 0))
+        o.length_penalty, o.length_alpha = self._parse_length_penalty(opt.get("length_penalty", ""))
+        o.seed = int(opt.get("seed", self._next_seed())) & 0xFFFFFFFF
+        for k in ("group_size",):
+            if int(opt.get(k, 1)) != 1:
+                raise NotImplementedError("diverse beam groups (group_size > 1) are not implemented in the HIP path")
+        if o.num_random_sample > 0:
+            assert o.beam_size < 1, f"Beam size must be < 1, saw {o.beam_size}"      # transformer.py:509
+            K = o.num_random_sample
+        else:
+            assert o.beam_size >= 1, f"Beam size must be >= 1, saw {o.beam_size}"    # transformer.py:514
+            assert o.beam_size <= self.vocab_size                                    # transformer.py:482
+            K = o.beam_size
+        B, S = att_feats.shape[:2]
+        nbytes = lib.ortk_decode_workspace_bytes(C.byref(self._ccfg), B, S, C.byref(o))
+        if nbytes == 0:
+            raise L.OrtkError("unsupported decode options")
+        ws = self._workspace(("decode", B, S, K, o.beam_size > 1), nbytes, True)
+        dev = self._flat.device
+        seq = torch.empty(B, K, self.seq_length, dtype=torch.long, device=dev)
+        lp = torch.empty(B, K, self.seq_length, device=dev)
+        score = torch.empty(B, K, device=dev)
+        L.check(lib.ortk_decode(C.byref(self._ccfg), self._eff_params_ptr(False, 0), L.ptr(att_feats), L.ptr(boxes),
+                                L.ptr(att_masks), B, S, C.byref(o), L.ptr(ws), ws.numel(), L.ptr(seq), L.ptr(lp),
+                                L.ptr(score), L.stream_ptr()), "ortk_decode")
+        return seq, lp, score
+
+    def _sample(self, att_feats, boxes, att_masks=None, opt=None, **kwargs):
+        """``_sample`` (relation_transformer.py:390-396) + ``_generate_captions`` (transformer.py:471-561).
+
+        Returns ``seq (N,K,L)`` int64 and ``seq_logprobs (N,K,L)``.  Under autograd with
+        ``num_random_sample > 0`` (the SCST rollout, utils/training.py:224-237) the tokens are drawn without a
+        graph and their log-probs are recomputed by ONE differentiable teacher-forced pass — identical values
+        (SURVEY.md §9.3), far cheaper backward than the reference's 18-step incremental graph.
+        """
+        opt = {} if opt is None else opt
+        feats, bxs, masks = self._prepare(att_feats, boxes, att_masks)
+        seq, lp, score = self._decode(feats, bxs, masks, opt)
+        self._last_decode = (seq, lp, score, int(opt.get("beam_size", 1)))
+        self.done_beams = None
+        ns = int(opt.get("num_random_sample", 0))
+        params = self._param_list()
+        if ns > 0 and torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            rows = seq.view(-1, self.seq_length)
+            tf_in = torch.cat([rows.new_full((rows.size(0), 1), self.bos_idx), rows], 1)
+            logp = self._forward(feats, bxs, tf_in, masks)                     # (N*ns, L, V), differentiable
+            tok_lp = logp.gather(2, rows.unsqueeze(2)).squeeze(2).view_as(lp)
+            lp = torch.where(seq != self.pad_idx, tok_lp, lp)
+        return seq, lp
+
+    @property
+    def beams(self):
+        """Lazy equivalent of the reference's ``done_beams`` (caption_model.py:221-226): per image a list of
+        ``{"seq", "logps" (per-token), "p"}`` — built on first access (host sync)."""
+        if self.done_beams is None and getattr(self, "_last_decode", None) is not None:
+            seq, lp, score, beam = self._last_decode
+            out = []
+            for n in range(seq.size(0)):
+                cur = []
+                for k in range(seq.size(1)):
+                    ln = int((seq[n, k] != 0).sum())
+                    cur.append({"seq": seq[n, k, :ln], "logps": lp[n, k, :ln], "p": float(score[n, k])})
+                out.append(cur)
+            self.done_beams = out
+        return self.done_beams
+
+    def get_logprobs_state(self, it, memory, mask, state):
+        raise NotImplementedError(
+            "the per-step host API (relation_transformer.py:374-387) is replaced by the fused on-device decode loop "
+            "(ortk_decode); use mode='sample'")
+
+    @torch.no_grad()
+    def encode(self, att_feats, boxes, att_masks=None):
+        """Encoder memory (B, S, d) — ``model.encode`` (relation_transformer.py:69-70) incl. feature prep."""
+        lib = L.lib()
+        feats, bxs, masks = self._prepare(att_feats, boxes, att_masks)
+        B, S = feats.shape[:2]
+        o = L.DecodeOpts()
+        o.beam_size, o.temperature = 1, 1.0
+        ws = self._workspace(("decode", B, S, 1, False), lib.ortk_decode_workspace_bytes(C.byref(self._ccfg), B, S, C.byref(o)), True)
+        mem = torch.empty(B, S, self.d_model, device=self._flat.device)
+        L.check(lib.ortk_encode(C.byref(self._ccfg), self._eff_params_ptr(False, 0), L.ptr(feats), L.ptr(bxs), L.ptr(masks),
+                                B, S, L.ptr(ws), ws.numel(), L.ptr(mem), L.stream_ptr()), "ortk_encode")
+        return mem
+
+    @staticmethod
+    def add_argparse_args(parser):
+        """Model flags of transformer.py:563-614 and relation_transformer.py:414-426."""
+        ObjectRelationBatchLayout.add_argparse_args(parser)
+        parser.add_argument("--d_model", type=int, default=512)
+        parser.add_argument("--dim_feedforward", type=int, default=2048)
+        parser.add_argument("--num_layers", type=int, default=6)
+        parser.add_argument("--num_heads", type=int, default=8)
+        parser.add_argument("--drop_prob_src", type=float, default=0.5)
+        parser.add_argument("--att_feat_size", type=int, default=2048)
+        for k in ("share_att_encoder", "share_att_decoder", "share_layer_encoder", "share_layer_decoder"):
+            parser.add_argument("--" + k, default=None)
+        parser.add_argument("--no_box_trigonometric_embedding", action="store_true")
+        parser.add_argument("--ortk_precision", type=str, default="fp32", choices=("fp32", "bf16"))

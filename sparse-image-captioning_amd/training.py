@@ -1,0 +1,152 @@
+"""Native training harness — the counterpart of the step bodies in the reference's
+``scripts/train_transformer.py:65-81`` and ``scripts/train_n_prune_transformer.py:132-168`` and of
+``TrainingModule.compute_scst_loss`` (``utils/training.py:202-255``):
+
+    zero_grad -> forward -> criterion -> backward -> clip_grad_value_(0.1) -> Adam(lr = Noam)       [one step]
+
+Everything between the batch and the updated parameters is HIP on flat arenas: ``ortk_forward`` (activations kept
+in the workspace), the fused criterion ``ortk_loss`` (log-probs are never materialised), ``ortk_backward`` into
+the flat gradient arena, ONE RCCL all-reduce of that arena when ``torch.distributed`` is initialised (one process
+per GPU, minibatch split by image; loss normalised by the GLOBAL mask sum), and ``ortk_adam_clip``.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .pruning import prune
+
+
+def noam_rate(step, d_model, factor, warmup):
+    """utils/optim.py:46-49."""
+    return factor * (d_model ** (-0.5) * min(step ** (-0.5), step * warmup ** (-1.5)))
+
+
+class NativeTrainer:
+    def __init__(self, model, noamopt_factor=1.0, noamopt_warmup=20000, grad_clip=0.1, betas=(0.9, 0.98), eps=1e-9,
+                 prune_supermask_lr=100.0, mask_eps=1e-2, sparsity_target=None, sparsity_weight=None, max_train_step=1):
+        L.require_gpu()
+        self.model = model
+        self.dev = model._flat.device
+        assert self.dev.type == "cuda", "move the model to the GPU first"
+        self.factor, self.warmup, self.clip, self.betas, self.eps = noamopt_factor, noamopt_warmup, grad_clip, betas, eps
+        n = model._n_train
+        self.grads = torch.zeros(n, device=self.dev)
+        self.m = torch.zeros(n, device=self.dev)
+        self.v = torch.zeros(n, device=self.dev)
+        self.step_count = 0
+        self.loss_dev = torch.zeros(1, device=self.dev)
+        self.norm_dev = torch.zeros(1, device=self.dev)
+        self.masked = getattr(model, "MASKED", False)
+        if self.masked:
+            self.train_masks = model._supermask
+            self.mask_lr, self.mask_eps = prune_supermask_lr, mask_eps
+            if self.train_masks:
+                self.dm = torch.zeros(n, device=self.dev)
+                self.mm = torch.zeros(n, device=self.dev)
+                self.mv = torch.zeros(n, device=self.dev)
+            self.sparsity_target = sparsity_target
+            # scripts/train_n_prune_transformer.py:306-312: weight = max(5, 1.5 / (1 - target)) unless given
+            self.sparsity_weight = sparsity_weight if (sparsity_weight is not None and sparsity_weight >= 0) else (
+                max(5.0, 1.5 / (1.0 - sparsity_target)) if sparsity_target is not None else 0.0)
+            self.max_train_step = max_train_step
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    # ------------------------------------------------------------------ pieces
+    def _batch(self, data, tok_weight):
+        m = self.model
+        feats, boxes, masks = m._prepare(data["att_feats"], data["boxes"], data.get("att_masks"))
+        return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight)
+
+    def _fwd_bwd(self, batch, norm, train=True):
+        """forward + fused criterion + backward into self.grads; returns the device loss scalar."""
+        m, lib = self.model, L.lib()
+        seed = m._next_seed() if train else 0
+        nbytes = lib.ortk_train_workspace_bytes(C.byref(m._ccfg), batch.B, batch.S, batch.R, batch.T)
+        ws = m._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, True)
+        pptr = m._eff_params_ptr(train, seed)
+        L.check(lib.ortk_forward(C.byref(m._ccfg), pptr, C.byref(batch), L.ptr(ws), ws.numel(), None, 0, int(train), seed,
+                                 L.stream_ptr()), "ortk_forward")
+        L.check(lib.ortk_loss(C.byref(m._ccfg), C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(norm), L.ptr(self.loss_dev),
+                              L.stream_ptr()), "ortk_loss")
+        L.check(lib.ortk_backward(C.byref(m._ccfg), pptr, L.ptr(self.grads), C.byref(batch), L.ptr(ws), ws.numel(), int(train),
+                                  seed, L.stream_ptr()), "ortk_backward")
+        return seed
+
+    def _allreduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.grads)          # RCCL over xGMI: one flat 222 MB bucket (SUM; loss is pre-normalised)
+            if self.masked and self.train_masks:
+                dist.all_reduce(self.dm)
+
+    def _adam(self, p, g, m, v, lr, eps):
+        t = self.step_count
+        b1, b2 = self.betas
+        L.check(L.lib().ortk_adam_clip(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, self.clip,
+                                       1.0 - b1 ** t, 1.0 - b2 ** t, L.stream_ptr()), "ortk_adam_clip")
+
+    def rate(self):
+        return noam_rate(max(self.step_count, 1), self.model.d_model, self.factor, self.warmup)
+
+    # ------------------------------------------------------------------ steps
+    def xe_step(self, data, train=True):
+        """One XE step on ``data`` = {att_feats, boxes, att_masks, seqs, masks}; returns the loss (device scalar).
+        Loss = LanguageModelCriterion(model(**data), seqs[:,1:], masks[:,1:]) (train_transformer.py:70)."""
+        tok_w = data["masks"][:, 1:].contiguous().float()
+        return self._step(data, tok_w, tok_w, train)
+
+    def scst_step(self, data, reward_fn, num_samples=5, baseline="greedy", train=True):
+        """SCST step (utils/training.py:202-255): greedy baseline + `num_samples` multinomial rollouts (no graph,
+        cached attention), rewards from ``reward_fn(sample_seq (N,ns,L), greedy_seq (N,1,L) | None) -> (N*ns,)``,
+        then ONE teacher-forced pass over [BOS, sample] with per-token weight mask*reward (RewardCriterion)."""
+        m = self.model
+        was_training = m.training
+        greedy = None
+        if baseline == "greedy":
+            m.eval()
+            greedy, _ = m(att_feats=data["att_feats"], boxes=data["boxes"], att_masks=data.get("att_masks"), mode="sample")
+        m.train(was_training)
+        with torch.no_grad():
+            seq, _ = m(att_feats=data["att_feats"], boxes=data["boxes"], att_masks=data.get("att_masks"), mode="sample",
+                       opt={"num_random_sample": num_samples, "beam_size": 0})
+        reward = reward_fn(seq, greedy).to(self.dev).float().reshape(-1)
+        rows = seq.view(-1, seq.size(-1))
+        mask = (rows != m.pad_idx).float()
+        tf = dict(data)
+        tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
+        loss = self._step(tf, mask * reward[:, None], mask, train)
+        return loss, reward, seq, greedy
+
+    def _step(self, data, tok_weight, norm_mask, train):
+        m = self.model
+        self.step_count += 1
+        self.grads.zero_()
+        L.check(L.lib().ortk_sum(L.ptr(norm_mask.contiguous()), norm_mask.numel(), L.ptr(self.norm_dev), L.stream_ptr()), "ortk_sum")
+        if self.world > 1:
+            dist.all_reduce(self.norm_dev)       # LanguageModelCriterion semantics over the GLOBAL batch
+        batch = self._batch(data, tok_weight)
+        seed = self._fwd_bwd(batch, self.norm_dev, train)
+        loss = self.loss_dev.clone()
+        lr = self.rate()
+        if self.masked:
+            coef = None
+            if self.train_masks:
+                self.dm.zero_()
+                if self.sparsity_target is not None:
+                    sl = m.compute_sparsity_loss(self.sparsity_target, self.sparsity_weight, self.step_count - 1,
+                                                 self.max_train_step)
+                    loss = loss + sl
+                    coef, m._sparsity_coef = m._sparsity_coef, None
+                    if self.world > 1:
+                        coef = coef / self.world     # identical on every rank; the all-reduce below sums it back
+            L.check(L.lib().ortk_mask_bwd(L.ptr(self.grads), L.ptr(m._flat), L.ptr(m._mask_flat), L.ptr(self.grads),
+                                          L.ptr(self.dm) if self.train_masks else None, m._n_train, m._mode(train),
+                                          m._mask_seed(seed), L.ptr(coef), L.stream_ptr()), "ortk_mask_bwd")
+        self._allreduce()
+        self._adam(m._flat[:m._n_train], self.grads, self.m, self.v, lr, self.eps)
+        if self.masked and self.train_masks:
+            # second param group of train_n_prune_transformer.py:67-82: lr = prune_supermask_lr (not Noam), eps 1e-2
+            self._adam(m._mask_flat, self.dm, self.mm, self.mv, self.mask_lr, self.mask_eps)
+        return loss
