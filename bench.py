@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the ORT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Default workload = BASELINE.json configs[1]: ORT dense, bf16 MFMA, 256 images x 5 captions x 36 regions x 2048-d per
+GPU, teacher-forcing XE.  One "step" = zero_grad -> forward (dropout on) -> fused criterion -> backward ->
+(RCCL all-reduce of the flat gradient arena when N > 1) -> clip + Adam(Noam): the step body of the reference's
+scripts/train_transformer.py:65-81.  Inputs are synthetic and resident in HBM before the timed
+region.  metric = captions/sec = N * B * 5 / step_time  (the reference's "ex/sec", train_transformer.py:85-91).
+
+Other workloads (same JSON contract):  --workload decode|sparse_decode|sparse_xe|scst
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work, SURVEY.md §8(d): dense XE 6.354 GFLOP forward per image (5 captions), x3 for fwd+bwd
+GFLOP_FWD_PER_IMAGE = 6.354
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, Chip-level parameters)
+PEAK_F32_TFLOPS = 157.3        # fp32 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(B, S, F, V, spi, seq_len, seed, device):
+    """Synthetic ObjectRelationCollate batch: ReLU-like features (~30 % zeros), relative boxes,
+    all-valid regions, BOS + 8..16 uniform tokens + EOS + PAD."""
+    rs = np.random.RandomState(seed)
+    att = (rs.gamma(0.5, 2.3, size=(B, S, F)) * (rs.uniform(size=(B, S, F)) < 0.7)).astype(np.float32)
+    x0, y0 = rs.uniform(0, 0.7, (B, S)), rs.uniform(0, 0.7, (B, S))
+    w, h = rs.uniform(0.03, 0.6, (B, S)), rs.uniform(0.03, 0.6, (B, S))
+    boxes = np.stack([x0, y0, np.minimum(x0 + w, 1), np.minimum(y0 + h, 1)], -1).astype(np.float32)
+    R = B * spi
+    seqs = np.zeros((R, seq_len), np.int64)
+    masks = np.zeros((R, seq_len), np.float32)
+    lens = rs.randint(8, 17, size=R)
+    for r in range(R):
+        L = int(min(lens[r], seq_len - 2))
+        seqs[r, 0] = 2
+        seqs[r, 1:1 + L] = rs.randint(4, V, size=L)
+        seqs[r, 1 + L] = 3
+        masks[r, :L + 2] = 1
+    t = lambda a: torch.from_numpy(a).to(device)
+    return dict(att_feats=t(att), boxes=t(boxes), att_masks=torch.ones(B, S, device=device), seqs=t(seqs), masks=t(masks))
+
+
+def cpu_baseline(workload, cfg_dict, seconds=15.0):
+    """The oracle (parity-pinned CPU restatement of the reference path, torch CPU fp32) timed on this host's cores
+    on a bounded sample of the same workload: 16 images x 5 captions per step (decode: 16 images, beam 5)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import helpers as H
+    from oracle import ort_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OCfg(**{k: v for k, v in cfg_dict.items() if not k.startswith("prune")})
+    P = H.torch_state(H.dense_param_shapes(cfg_dict), 8888, requires_grad=True)
+    B = 16
+    b = synth_batch(B, 36, cfg.att_feat_size, cfg.vocab_size, 5, cfg.max_seq_length, 1, "cpu")
+    state = {}
+    n, t0 = 0, None
+    t_start = time.time()
+    while True:
+        if workload in ("xe", "sparse_xe", "scst"):
+            for p in P.values():
+                p.grad = None
+            logp = O.forward_logp(P, cfg, b["att_feats"], b["boxes"], b["seqs"], b["att_masks"])
+            loss = O.xe_loss(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+            loss.backward()
+            with torch.no_grad():
+                O.adam_clip_step(P, {k: p.grad for k, p in P.items()}, state, 1e-4)
+            units = B * 5
+        else:
+            with torch.no_grad():
+                O.beam_search({k: v.detach() for k, v in P.items()}, cfg, b["att_feats"], b["boxes"], b["att_masks"], 5)
+            units = B
+        if t0 is None:          # first iteration = warm-up
+            t0 = time.time()
+            continue
+        n += 1
+        if time.time() - t0 > seconds or time.time() - t_start > 3 * seconds:
+            break
+    dt = (time.time() - t0) / max(n, 1)
+    return {"value": round(units / dt, 2), "unit": "captions/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of {B} images ({'5 captions each, fwd+bwd+Adam' if units != B else 'beam-5 decode'}), "
+                      f"oracle/ort_oracle.py on torch CPU fp32, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="xe", choices=("xe", "sparse_xe", "scst", "decode", "sparse_decode"))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 256; decode 1024)")
+    ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import sparse_image_captioning_amd as pkg
+    from sparse_image_captioning_amd.utils.config import ort_config
+    from sparse_image_captioning_amd.training import NativeTrainer
+    L = pkg._lib
+    L.require_gpu()
+
+    decode = args.workload in ("decode", "sparse_decode")
+    sparse = args.workload.startswith("sparse")
+    B = args.batch or (1024 if decode else 256)
+    spi, S = 5, 36
+    # ORT pruning / SCST commands use drop_prob_src 0.1 (resources/commands_pruning.sh:240,265); dense XE default 0.5
+    config = ort_config(drop_prob_src=0.5, prune_type="supermask")
+    torch.manual_seed(8888)     # identical weights (and dropout / mask streams) on every rank
+    name = "relation_transformer_prune" if args.workload == "sparse_xe" else "relation_transformer"
+    model = pkg.get_model(name)(config, precision=args.precision)
+    if sparse:
+        with torch.no_grad():
+            if args.workload == "sparse_xe":    # mask logits with round(sigmoid(m)) ~ Bernoulli(0.05): 95 % sparse
+                for _, m in model.all_pruning_masks():
+                    m.copy_(torch.where(torch.rand_like(m) < 0.05, torch.full_like(m, 3.0), torch.full_like(m, -3.0)))
+            else:                                # decode: dense class on densified 95 %-pruned weights (eval_model.py:64-88)
+                for n_, p in model.named_parameters():
+                    if p.dim() >= 2:
+                        p.mul_((torch.rand_like(p) < 0.05).float())
+    model = model.to(dev)
+    batch = synth_batch(B, S, config.att_feat_size, config.vocab_size, spi, config.max_seq_length, 1000 + rank, dev)
+
+    if decode:
+        model.eval()
+        opt = {"beam_size": 5}
+
+        def step():
+            model(att_feats=batch["att_feats"], boxes=batch["boxes"], att_masks=batch["att_masks"], opt=opt, mode="sample")
+        units_per_step = B
+    elif args.workload == "scst":
+        model.train()
+        tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000)
+        rw = torch.randn(B * 5, device=dev)
+
+        def step():
+            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy")
+        units_per_step = B * 5
+    else:
+        model.train()
+        tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000,
+                           sparsity_target=0.95 if args.workload == "sparse_xe" else None, max_train_step=100000)
+
+        def step():
+            tr.xe_step(batch)
+        units_per_step = B * spi
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * units_per_step / (elapsed / args.steps)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the forward-layout MFMA GEMM (X W^T), measured live with HIP events
+        # around every launch of one extra (untimed) step, on the launch stream.
+        lib = L.lib()
+        key = (4 if args.precision == "bf16" else 0)
+        lib.ortk_prof_enable(1)
+        step()
+        torch.cuda.synchronize()
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        per_key = {}
+        for k in (key, key + 1, key + 3):
+            lib.ortk_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl))
+            per_key[k] = (n.value, ms.value, fl.value)
+        lib.ortk_prof_enable(0)
+        n0, ms0, fl0 = per_key[key]
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+        tot_ms = sum(v[1] for v in per_key.values())
+        tot_fl = sum(v[2] for v in per_key.values())
+        roofline = {"bound": "mfma", "kernel": f"gemm_{args.precision}_kernel<false,false> (forward X*W^T)",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
+                    "algorithmic_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3),
+                    "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
+                                         "ms_per_step": round(tot_ms, 3)},
+                    "traffic": None}
+        if not decode:
+            step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3 * (0.05 if sparse else 1.0)
+            roofline["whole_step"] = {"algorithmic_tflop": round(step_tflop, 3),
+                                      "achieved_tflops": round(step_tflop / (ms_per_step * 1e-3), 2),
+                                      "frac_of_peak": round(step_tflop / (ms_per_step * 1e-3) / peak, 4)}
+        cfgname = {"xe": "ORT dense, batch 256 images x 5 captions, teacher-forcing XE fwd+bwd+Adam (BASELINE configs[1])",
+                   "sparse_xe": "ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; masked dense GEMM)",
+                   "scst": "ORT dense SCST: greedy + 5 multinomial rollouts + teacher-forced update (BASELINE configs[3])",
+                   "decode": "ORT dense, cached-KV beam-5 decode, 1024 images",
+                   "sparse_decode": "ORT 95% sparse (densified), cached-KV beam-5 decode, 1024 images (BASELINE configs[4])"}[args.workload]
+        out = {"metric": "captions/sec", "value": round(value, 1), "unit": "captions/sec", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+               "config": {"workload": cfgname, "images_per_gpu": B, "regions": S, "captions_per_image": spi,
+                          "parallelism": f"dp{world}" if world > 1 else "single",
+                          "storage": "fp32 activations/weights, bf16 MFMA operands" if args.precision == "bf16" else "fp32"},
+               "roofline": roofline}
+        if not args.no_cpu_baseline and world == 1:
+            from sparse_image_captioning_amd.utils.config import ORT_DEFAULTS
+            out["cpu_baseline"] = cpu_baseline(args.workload, dict(ORT_DEFAULTS))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

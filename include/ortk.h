@@ -142,6 +142,10 @@ typedef struct ortk_gemm_args {
     int32_t accumulate, splitk, precision;
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
+/* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its
+ * launch stream, summed per kernel instance key = precision*4 + transA*2 + transB.  collect() synchronises. */
+int ortk_prof_enable(int32_t on);
+int ortk_prof_collect(int32_t key, int64_t* launches, double* total_ms, double* total_flops);
 
 /* LayerNorm of transformer.py:338-341: a*(x-mean)/(std_unbiased+eps)+b.  stats (rows,2) = {mean, std}. */
 int ortk_layernorm_fwd(const float* x, const float* a, const float* b, float* y, float* stats,

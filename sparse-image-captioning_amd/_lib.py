@@ -83,6 +83,8 @@ SIGNATURES = {
     "ortk_decode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, C.POINTER(DecodeOpts), _P, _SZ, _P, _P, _P, _P]),
     "ortk_encode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P, _P]),
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),
+    "ortk_prof_enable": (_I32, [_I32]),
+    "ortk_prof_collect": (_I32, [_I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ortk_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "ortk_box_logbias_fwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, _I32, _I32, _I32, _I32, _P]),

@@ -16,6 +16,7 @@
 //
 // Workgroup ids are remapped so that the blocks resident on one XCD (ids b, b+8, ...) walk CONSECUTIVE tiles
 // (n fastest): they share the A panel in that XCD's L2 instead of fetching it 8 times.
+#include <vector>
 #include "ortk_common.h"
 
 namespace {
@@ -295,6 +296,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ profiling hook
+// Opt-in, measurement only (bench.py's roofline leg): HIP events around every GEMM launch on the launch stream,
+// accumulated per kernel instance (precision, transA, transB).  Disabled by default; the timed region of bench.py
+// never runs with it on.  This is the only process-global state in the library.
+namespace {
+struct ProfRec { hipEvent_t a, b; int key; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec>* g_prof = nullptr;
+}  // namespace
+
+extern "C" int ortk_prof_enable(int32_t on) {
+    if (!g_prof) g_prof = new std::vector<ProfRec>();
+    for (auto& r : *g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof->clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+// key = precision*4 + transA*2 + transB.  Waits for the recorded events (host sync: measurement only).
+extern "C" int ortk_prof_collect(int32_t key, int64_t* launches, double* total_ms, double* total_flops) {
+    if (!g_prof || !launches || !total_ms || !total_flops) return ORTK_EINVAL;
+    *launches = 0; *total_ms = 0; *total_flops = 0;
+    for (auto& r : *g_prof) {
+        if (r.key != key) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return ORTK_EINVAL;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return ORTK_EINVAL;
+        *launches += 1; *total_ms += ms; *total_flops += r.flops;
+    }
+    return 0;
+}
+
 extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return ORTK_EINVAL;
     if (a->M == 0 || a->N == 0) return 0;
@@ -315,6 +347,12 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     dim3 grid((unsigned)(tilesM * tilesN * splitk)), block(256);
     hipStream_t s = ortk_s(stream);
     const int key = (p.precision ? 4 : 0) | (p.transA ? 2 : 0) | (p.transB ? 1 : 0);
+    ProfRec rec{};
+    if (g_prof_on) {
+        if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return ORTK_EINVAL;
+        rec.key = key; rec.flops = 2.0 * p.M * p.N * p.K;
+        (void)hipEventRecord(rec.a, s);
+    }
     switch (key) {
         case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
         case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
@@ -324,6 +362,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         case 7: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
         default: return ORTK_EINVAL;
     }
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof->push_back(rec); }
     ORTK_CHECK_LAUNCH();
     return 0;
 }

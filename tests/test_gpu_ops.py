@@ -19,8 +19,18 @@ def L():
     return P._lib
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.cuda().contiguous()
+    """Copy to the GPU and keep the tensor alive: the C-ABI takes raw pointers and launches asynchronously, so a
+    temporary that dies right after `.data_ptr()` could be recycled by the caching allocator under the kernel."""
+    d = t.cuda().contiguous()
+    _KEEP.append(d)
+    if len(_KEEP) > 512:
+        torch.cuda.synchronize()
+        del _KEEP[:256]
+    return d
 
 
 def rnd(*shape, seed=0, scale=1.0):
