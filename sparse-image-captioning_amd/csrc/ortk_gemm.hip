@@ -182,28 +182,72 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 MFMA
-// Same tiling; operands are converted fp32 -> bf16 while staging, LDS image [k][m] bf16 (k-major, BK = 32),
-// fragments (8 consecutive k for one m) are gathered with the hardware transposing read ds_read_b64_tr_b16.
+// Same 128x128 tiling, K consumed 64 at a time (32 MFMA 16x16x32 per wave between barriers).  Operands are fp32 in
+// memory and are converted to bf16 while staging.  The LDS image of an operand follows its GLOBAL layout so that the
+// staging writes are always 8-byte vector stores:
+//   * k-contiguous operand (activations X, weights W as (N,K)):  image [m][k], pitch 72 bf16;  the 8-element MFMA
+//     fragment (8 consecutive k of one row) is one ds_read_b128;
+//   * k-major operand (dY^T / X for wgrad, W for dgrad):           image [k][m], pitch 136 bf16;  the fragment is
+//     gathered by two hardware-transposing reads (ds_read_b64_tr_b16).
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-constexpr int PITCH16 = 128 + 16;  // bf16 elements per k-row (288 B): 4 consecutive k-rows land on disjoint banks
+constexpr int BK16 = 64;
+constexpr int PITCH_MK = BK16 + 8;     // [m][k] image: 144 B rows (16-B aligned, rows spread over banks)
+constexpr int PITCH_KM = 128 + 8;      // [k][m] image: 272 B rows (8-B aligned for the transposing read)
+constexpr int IMG_ELEMS = 128 * PITCH_MK > BK16 * PITCH_KM ? 128 * PITCH_MK : BK16 * PITCH_KM;
 
 __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        (bf16x4 __attribute__((address_space(3)))*)(p));
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x4 cvt4(const float4& v) {
+    return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+
+// stage one 128 x 64 operand tile: global fp32 -> registers (8 float4 per thread)
+template <bool T>
+__device__ __forceinline__ void g2r(float4 (&r)[8], const float* __restrict__ base, int64_t ld, int tile0, int k0, int nmn, int k_end,
+                                    bool vec, int tid) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int f = tid + 256 * u;
+        if (!T) r[u] = ld4(base, ld, tile0 + (f >> 4), k0 + 4 * (f & 15), nmn, k_end, vec);
+        else    r[u] = ld4(base, ld, k0 + (f >> 5), tile0 + 4 * (f & 31), k_end, nmn, vec);
+    }
+}
+template <bool T>
+__device__ __forceinline__ void r2s(const float4 (&r)[8], __bf16* img, int tid) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int f = tid + 256 * u;
+        if (!T) *reinterpret_cast<bf16x4*>(img + (f >> 4) * PITCH_MK + 4 * (f & 15)) = cvt4(r[u]);
+        else    *reinterpret_cast<bf16x4*>(img + (f >> 5) * PITCH_KM + 4 * (f & 31)) = cvt4(r[u]);
+    }
+}
+// fragment of 16 rows starting at m0 for k-sub-step ks (32 wide)
+template <bool T>
+__device__ __forceinline__ bf16x8 frag(const __bf16* img, int m0, int ks, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    if (!T) {
+        return *reinterpret_cast<const bf16x8*>(img + (m0 + lr) * PITCH_MK + ks * 32 + 8 * lg);
+    } else {
+        // lane 4q+p of a 16-lane group supplies &img[k0 + q][m0 + 4p]; it receives column (lane & 15) of 4 k-rows
+        const __bf16* p = img + (ks * 32 + 8 * lg + (lr >> 2)) * PITCH_KM + m0 + 4 * (lane & 3);
+        const bf16x4 lo = tr_read(p), hi = tr_read(p + 4 * PITCH_KM);
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
 }
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
-    constexpr int BK = 32;
-    __shared__ __attribute__((aligned(16))) __bf16 sA[2][BK][PITCH16];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[2][BK][PITCH16];
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    auto sA = [&](int b_) { return smem16 + (size_t)b_ * 2 * IMG_ELEMS; };
+    auto sB = [&](int b_) { return smem16 + (size_t)b_ * 2 * IMG_ELEMS + IMG_ELEMS; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks = rest / tilesM;
+    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks_ = rest / tilesM;
     const int mb = mt * BM, nb = nt * BN;
-    const int k_begin = ks * kchunk;
+    const int k_begin = ks_ * kchunk;
     const int k_end = min(p.K, k_begin + kchunk);
     const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
     const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
@@ -214,85 +258,50 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // tile = 128 x 32 fp32 = 1024 float4 -> 4 per thread per operand
-    float4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = tid + 256 * u;
-            if (!TA) ra[u] = ld4(p.A, p.lda, mb + (f >> 3), k0 + 4 * (f & 7), p.M, k_end, vecA);
-            else     ra[u] = ld4(p.A, p.lda, k0 + (f >> 5), mb + 4 * (f & 31), k_end, p.M, vecA);
-            if (!TB) rb[u] = ld4(p.B, p.ldb, nb + (f >> 3), k0 + 4 * (f & 7), p.N, k_end, vecB);
-            else     rb[u] = ld4(p.B, p.ldb, k0 + (f >> 5), nb + 4 * (f & 31), k_end, p.N, vecB);
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = tid + 256 * u;
-            if (!TA) {
-                const int m = f >> 3, k = 4 * (f & 7);
-                sA[buf][k + 0][m] = (__bf16)ra[u].x; sA[buf][k + 1][m] = (__bf16)ra[u].y;
-                sA[buf][k + 2][m] = (__bf16)ra[u].z; sA[buf][k + 3][m] = (__bf16)ra[u].w;
-            } else {
-                bf16x4 t = {(__bf16)ra[u].x, (__bf16)ra[u].y, (__bf16)ra[u].z, (__bf16)ra[u].w};
-                *reinterpret_cast<bf16x4*>(&sA[buf][f >> 5][4 * (f & 31)]) = t;
-            }
-            if (!TB) {
-                const int n = f >> 3, k = 4 * (f & 7);
-                sB[buf][k + 0][n] = (__bf16)rb[u].x; sB[buf][k + 1][n] = (__bf16)rb[u].y;
-                sB[buf][k + 2][n] = (__bf16)rb[u].z; sB[buf][k + 3][n] = (__bf16)rb[u].w;
-            } else {
-                bf16x4 t = {(__bf16)rb[u].x, (__bf16)rb[u].y, (__bf16)rb[u].z, (__bf16)rb[u].w};
-                *reinterpret_cast<bf16x4*>(&sB[buf][f >> 5][4 * (f & 31)]) = t;
-            }
-        }
-    };
-
+    float4 ra[8], rb[8];
     int buf = 0;
     if (k_begin < k_end) {
-        gload(k_begin);
-        sstore(0);
+        g2r<TA>(ra, p.A, p.lda, mb, k_begin, p.M, k_end, vecA, tid);
+        g2r<TB>(rb, p.B, p.ldb, nb, k_begin, p.N, k_end, vecB, tid);
+        r2s<TA>(ra, sA(0), tid);
+        r2s<TB>(rb, sB(0), tid);
     }
     __syncthreads();
-    const int lr = lane & 15, lg = lane >> 4;
-    // transposing read: lane 4q+p of a 16-lane group supplies &img[k0 + q][c0 + 4p]; it receives column (lane&15)
-    // of the 4 rows k0..k0+3.  Group g reads k = 8g..8g+3 then 8g+4..8g+7 -> the 8-element MFMA fragment.
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        const bool has_next = k0 + BK < k_end;
-        if (has_next) gload(k0 + BK);
-        bf16x8 a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const __bf16* base = &sA[buf][8 * lg + tq][wm * 64 + 16 * i + 4 * tp];
-            bf16x4 lo = tr_read(base), hi = tr_read(base + 4 * PITCH16);
-            a[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int k0 = k_begin; k0 < k_end; k0 += BK16) {
+        const bool has_next = k0 + BK16 < k_end;
+        if (has_next) {
+            g2r<TA>(ra, p.A, p.lda, mb, k0 + BK16, p.M, k_end, vecA, tid);
+            g2r<TB>(rb, p.B, p.ldb, nb, k0 + BK16, p.N, k_end, vecB, tid);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16* base = &sB[buf][8 * lg + tq][wn * 64 + 16 * j + 4 * tp];
-            bf16x4 lo = tr_read(base), hi = tr_read(base + 4 * PITCH16);
-            b[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag<TA>(sA(buf), wm * 64 + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = frag<TB>(sB(buf), wn * 64 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-        if (has_next) sstore(buf ^ 1);
+        if (has_next) {
+            r2s<TA>(ra, sA(buf ^ 1), tid);
+            r2s<TB>(rb, sB(buf ^ 1), tid);
+        }
         __syncthreads();
         buf ^= 1;
     }
-    (void)lr;
     Epi e{p.C, p.ldc, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            epilogue4(e, mb + wm * 64 + 16 * i + (lane & 15), nb + wn * 64 + 16 * j + 4 * lg, acc[i][j]);
+            epilogue4(e, mb + wm * 64 + 16 * i + (lane & 15), nb + wn * 64 + 16 * j + 4 * (lane >> 4), acc[i][j]);
 }
+constexpr size_t BF16_LDS_BYTES = (size_t)4 * IMG_ELEMS * sizeof(__bf16);
 
 }  // namespace
 
@@ -332,7 +341,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     if (a->M == 0 || a->N == 0) return 0;
     ortk_gemm_args p = *a;
     const int tilesM = (int)ortk_cdiv(p.M, BM), tilesN = (int)ortk_cdiv(p.N, BN);
-    const int bk = p.precision ? 32 : 16;
+    const int bk = p.precision ? BK16 : 16;
     int splitk = p.accumulate ? (p.splitk > 0 ? p.splitk : 1) : 1;
     int kchunk = bk;
     if (p.K <= 0) {
@@ -347,6 +356,13 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     dim3 grid((unsigned)(tilesM * tilesN * splitk)), block(256);
     hipStream_t s = ortk_s(stream);
     const int key = (p.precision ? 4 : 0) | (p.transA ? 2 : 0) | (p.transB ? 1 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
+        attr_set = true;
+    }
     ProfRec rec{};
     if (g_prof_on) {
         if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return ORTK_EINVAL;
@@ -357,9 +373,9 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
         case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
         case 3: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
-        case 7: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk); break;
+        case 5: hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk); break;
+        case 7: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk); break;
         default: return ORTK_EINVAL;
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof->push_back(rec); }
