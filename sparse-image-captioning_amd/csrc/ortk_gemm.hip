@@ -55,37 +55,75 @@ struct Epi {
     int M, N;
 };
 
-__device__ __forceinline__ void epilogue4(const Epi& e, int m, int n0, f32x4 acc) {
-    if (m >= e.M || n0 >= e.N) return;
-    const float rs = e.rowscale ? e.rowscale[m] : 1.f;
+// 4 consecutive elements of a row vector / matrix row, zero beyond N
+__device__ __forceinline__ float4 ldrow4(const float* __restrict__ p, int n0, int N, bool vec) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && n0 + 3 < N) return *reinterpret_cast<const float4*>(p);
+    if (n0 < N) r.x = p[0];
+    if (n0 + 1 < N) r.y = p[1];
+    if (n0 + 2 < N) r.z = p[2];
+    if (n0 + 3 < N) r.w = p[3];
+    return r;
+}
+
+// Epilogue of one wave's 64x64 sub-tile: acc[i][j] holds C[m = mrow0 + 16 i][n = ncol0 + 16 j + 0..3].
+// Bias is loaded once per j; residual / gate rows are fetched as float4 for all four j of a row BEFORE any of that
+// row's stores (independent loads in flight together instead of 16 load->store chains per thread).
+__device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0, f32x4 (&acc)[4][4]) {
+    const bool first = e.first_split;
+    const bool vec_b = e.bias && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0);
+    const bool vec_r = e.resid && ((e.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.resid) & 15) == 0);
+    const bool vec_g = e.gate && ((e.ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.gate) & 15) == 0);
+    const bool vec_c = ((e.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0);
     const float inv_keep = e.drop_p > 0.f ? 1.f / (1.f - e.drop_p) : 1.f;
-    float v[4];
+    float4 bias4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = n0 + r;
-        float x = acc[r];
-        if (n < e.N) {
-            // bias / residual are added once: by the first K-split when accumulating
-            if (e.bias && e.first_split) x += e.bias[n];
-            if (e.relu) x = fmaxf(x, 0.f);
-            x *= rs;
-            if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, (uint64_t)m * (uint64_t)e.N + n, e.drop_p) ? x * inv_keep : 0.f;
-            if (e.gate) x = e.gate[(int64_t)m * e.ldg + n] > 0.f ? x * e.gate_scale : 0.f;
-            if (e.resid && e.first_split) x += e.resid[(int64_t)m * e.ldr + n];
-        }
-        v[r] = x;
+    for (int j = 0; j < 4; ++j) {
+        const int n0 = ncol0 + 16 * j;
+        bias4[j] = (e.bias && first && n0 < e.N) ? ldrow4(e.bias + n0, n0, e.N, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float* c = e.C + (int64_t)m * e.ldc + n0;
-    if (e.accumulate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n0 + r < e.N) atomicAdd(c + r, v[r]);
-    } else if (n0 + 3 < e.N && ((e.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0)) {
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
+    for (int i = 0; i < 4; ++i) {
+        const int m = mrow0 + 16 * i;
+        if (m >= e.M) continue;
+        const float rs = e.rowscale ? e.rowscale[m] : 1.f;
+        float4 res[4], gat[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n0 + r < e.N) c[r] = v[r];
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = ncol0 + 16 * j;
+            res[j] = (e.resid && first && n0 < e.N) ? ldrow4(e.resid + (int64_t)m * e.ldr + n0, n0, e.N, vec_r) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gat[j] = (e.gate && n0 < e.N) ? ldrow4(e.gate + (int64_t)m * e.ldg + n0, n0, e.N, vec_g) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = ncol0 + 16 * j;
+            if (n0 >= e.N) continue;
+            const float bb[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
+            const float rr[4] = {res[j].x, res[j].y, res[j].z, res[j].w};
+            const float gg[4] = {gat[j].x, gat[j].y, gat[j].z, gat[j].w};
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] + bb[r];
+                if (e.relu) x = fmaxf(x, 0.f);
+                x *= rs;
+                if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, (uint64_t)m * (uint64_t)e.N + (n0 + r), e.drop_p) ? x * inv_keep : 0.f;
+                if (e.gate) x = gg[r] > 0.f ? x * e.gate_scale : 0.f;
+                v[r] = x + rr[r];
+            }
+            float* c = e.C + (int64_t)m * e.ldc + n0;
+            if (e.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < e.N) atomicAdd(c + r, v[r]);
+            } else if (vec_c && n0 + 3 < e.N) {
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < e.N) c[r] = v[r];
+            }
+        }
     }
 }
 
@@ -112,15 +150,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const bool fullA = vecA && mb + BM <= p.M, fullB = vecB && nb + BN <= p.N;   // workgroup-uniform
     float4 ra[2], rb[2];
     auto gload = [&](int k0) {
+        const bool kfull = k0 + BK <= k_end;
+        if (fullA && kfull) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int f = tid + 256 * u;
-            if (!TA) ra[u] = ld4(p.A, p.lda, mb + (f >> 2), k0 + 4 * (f & 3), p.M, k_end, vecA);
-            else     ra[u] = ld4(p.A, p.lda, k0 + (f >> 5), mb + 4 * (f & 31), k_end, p.M, vecA);
-            if (!TB) rb[u] = ld4(p.B, p.ldb, nb + (f >> 2), k0 + 4 * (f & 3), p.N, k_end, vecB);
-            else     rb[u] = ld4(p.B, p.ldb, k0 + (f >> 5), nb + 4 * (f & 31), k_end, p.N, vecB);
+            for (int u = 0; u < 2; ++u) {
+                const int f = tid + 256 * u;
+                ra[u] = *reinterpret_cast<const float4*>(!TA ? p.A + (int64_t)(mb + (f >> 2)) * p.lda + k0 + 4 * (f & 3)
+                                                             : p.A + (int64_t)(k0 + (f >> 5)) * p.lda + mb + 4 * (f & 31));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = tid + 256 * u;
+                if (!TA) ra[u] = ld4(p.A, p.lda, mb + (f >> 2), k0 + 4 * (f & 3), p.M, k_end, vecA);
+                else     ra[u] = ld4(p.A, p.lda, k0 + (f >> 5), mb + 4 * (f & 31), k_end, p.M, vecA);
+            }
+        }
+        if (fullB && kfull) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = tid + 256 * u;
+                rb[u] = *reinterpret_cast<const float4*>(!TB ? p.B + (int64_t)(nb + (f >> 2)) * p.ldb + k0 + 4 * (f & 3)
+                                                             : p.B + (int64_t)(k0 + (f >> 5)) * p.ldb + nb + 4 * (f & 31));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = tid + 256 * u;
+                if (!TB) rb[u] = ld4(p.B, p.ldb, nb + (f >> 2), k0 + 4 * (f & 3), p.N, k_end, vecB);
+                else     rb[u] = ld4(p.B, p.ldb, k0 + (f >> 5), nb + 4 * (f & 31), k_end, p.N, vecB);
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -174,11 +236,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
 
     Epi e{p.C, p.ldc, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            epilogue4(e, mb + wm * 64 + 16 * i + lr, nb + wn * 64 + 16 * j + 4 * lk, acc[i][j]);
+    epilogue_tile(e, mb + wm * 64 + lr, nb + wn * 64 + 4 * lk, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 MFMA
@@ -203,15 +261,28 @@ __device__ __forceinline__ bf16x4 cvt4(const float4& v) {
     return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
 }
 
-// stage one 128 x 64 operand tile: global fp32 -> registers (8 float4 per thread)
+// stage one 128 x 64 operand tile: global fp32 -> registers (8 float4 per thread).
+// `fast` (workgroup-uniform): the whole tile is in bounds and 16-B aligned -> 8 unconditional, independent
+// global_load_dwordx4 that stay in flight together.  (Per-load bounds branches made hipcc drain vmcnt at every
+// join: 16 serialized memory round trips per K-step, ~4 % MFMA utilisation in the first profile.)
 template <bool T>
 __device__ __forceinline__ void g2r(float4 (&r)[8], const float* __restrict__ base, int64_t ld, int tile0, int k0, int nmn, int k_end,
-                                    bool vec, int tid) {
+                                    bool vec, bool fast, int tid) {
+    if (fast) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int f = tid + 256 * u;
-        if (!T) r[u] = ld4(base, ld, tile0 + (f >> 4), k0 + 4 * (f & 15), nmn, k_end, vec);
-        else    r[u] = ld4(base, ld, k0 + (f >> 5), tile0 + 4 * (f & 31), k_end, nmn, vec);
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u;
+            const float* p = !T ? base + (int64_t)(tile0 + (f >> 4)) * ld + k0 + 4 * (f & 15)
+                                : base + (int64_t)(k0 + (f >> 5)) * ld + tile0 + 4 * (f & 31);
+            r[u] = *reinterpret_cast<const float4*>(p);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u;
+            if (!T) r[u] = ld4(base, ld, tile0 + (f >> 4), k0 + 4 * (f & 15), nmn, k_end, vec);
+            else    r[u] = ld4(base, ld, k0 + (f >> 5), tile0 + 4 * (f & 31), k_end, nmn, vec);
+        }
     }
 }
 template <bool T>
@@ -258,11 +329,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const bool fullA = vecA && mb + BM <= p.M, fullB = vecB && nb + BN <= p.N;   // workgroup-uniform
     float4 ra[8], rb[8];
     int buf = 0;
     if (k_begin < k_end) {
-        g2r<TA>(ra, p.A, p.lda, mb, k_begin, p.M, k_end, vecA, tid);
-        g2r<TB>(rb, p.B, p.ldb, nb, k_begin, p.N, k_end, vecB, tid);
+        const bool kfull = k_begin + BK16 <= k_end;
+        g2r<TA>(ra, p.A, p.lda, mb, k_begin, p.M, k_end, vecA, fullA && kfull, tid);
+        g2r<TB>(rb, p.B, p.ldb, nb, k_begin, p.N, k_end, vecB, fullB && kfull, tid);
         r2s<TA>(ra, sA(0), tid);
         r2s<TB>(rb, sB(0), tid);
     }
@@ -270,8 +343,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
     for (int k0 = k_begin; k0 < k_end; k0 += BK16) {
         const bool has_next = k0 + BK16 < k_end;
         if (has_next) {
-            g2r<TA>(ra, p.A, p.lda, mb, k0 + BK16, p.M, k_end, vecA, tid);
-            g2r<TB>(rb, p.B, p.ldb, nb, k0 + BK16, p.N, k_end, vecB, tid);
+            const bool kfull = k0 + 2 * BK16 <= k_end;
+            g2r<TA>(ra, p.A, p.lda, mb, k0 + BK16, p.M, k_end, vecA, fullA && kfull, tid);
+            g2r<TB>(rb, p.B, p.ldb, nb, k0 + BK16, p.N, k_end, vecB, fullB && kfull, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -295,11 +369,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
     }
     Epi e{p.C, p.ldc, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            epilogue4(e, mb + wm * 64 + 16 * i + (lane & 15), nb + wn * 64 + 16 * j + 4 * (lane >> 4), acc[i][j]);
+    epilogue_tile(e, mb + wm * 64 + (lane & 15), nb + wn * 64 + 4 * (lane >> 4), acc);
 }
 constexpr size_t BF16_LDS_BYTES = (size_t)4 * IMG_ELEMS * sizeof(__bf16);
 

@@ -1,0 +1,55 @@
+"""Data-parallel helpers (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on MI355X,
+"gloo" in the CPU tests).  The ORT path shards by IMAGE: a rank keeps B/N images with all their caption rows.
+Only two exchanges exist on the data path:
+  * the scalar normaliser (sum of the 0/1 token mask) so that every rank divides by the GLOBAL count, as
+    LanguageModelCriterion / RewardCriterion do on the full batch (utils/losses.py:15-43);
+  * ONE all-reduce (SUM) of the flat gradient arena (222 MB fp32 dense; + mask-logit gradients for supermasks).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_batch(data, r=None, n=None):
+    """Rank r's slice of a collated batch: images [r*B/n, (r+1)*B/n) and their caption rows (rows of `seqs` /
+    `masks` are grouped by image: row = image*seq_per_img + k, data/collate.py:133-150)."""
+    r = rank() if r is None else r
+    n = world() if n is None else n
+    B = data["att_feats"].size(0)
+    assert B % n == 0, f"batch of {B} images does not split over {n} ranks"
+    per = B // n
+    out = {}
+    spi = data["seqs"].size(0) // B if "seqs" in data and data["seqs"] is not None else 0
+    for k, v in data.items():
+        if not torch.is_tensor(v):
+            out[k] = v[r * per:(r + 1) * per] if isinstance(v, (list, tuple)) and len(v) == B else v
+        elif k in ("seqs", "masks"):
+            out[k] = v[r * per * spi:(r + 1) * per * spi]
+        elif v.size(0) == B:
+            out[k] = v[r * per:(r + 1) * per]
+        else:
+            out[k] = v
+    return out
+
+
+def reduce_scalar_sum(t):
+    """In-place SUM over ranks of a (1,) tensor (the loss normaliser)."""
+    if world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def allreduce_arena(*arenas):
+    """In-place SUM of flat gradient arenas; one collective per arena (each is one contiguous bucket)."""
+    if world() > 1:
+        for a in arenas:
+            if a is not None:
+                dist.all_reduce(a, op=dist.ReduceOp.SUM)
+    return arenas

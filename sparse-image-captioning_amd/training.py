@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import parallel
 from .pruning import prune
 
 
@@ -52,7 +53,7 @@ class NativeTrainer:
             self.sparsity_weight = sparsity_weight if (sparsity_weight is not None and sparsity_weight >= 0) else (
                 max(5.0, 1.5 / (1.0 - sparsity_target)) if sparsity_target is not None else 0.0)
             self.max_train_step = max_train_step
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world = parallel.world()
 
     # ------------------------------------------------------------------ pieces
     def _batch(self, data, tok_weight):
@@ -76,10 +77,8 @@ class NativeTrainer:
         return seed
 
     def _allreduce(self):
-        if self.world > 1:
-            dist.all_reduce(self.grads)          # RCCL over xGMI: one flat 222 MB bucket (SUM; loss is pre-normalised)
-            if self.masked and self.train_masks:
-                dist.all_reduce(self.dm)
+        # RCCL over xGMI: one flat 222 MB bucket (SUM; every rank's loss is already divided by the GLOBAL norm)
+        parallel.allreduce_arena(self.grads, self.dm if (self.masked and self.train_masks) else None)
 
     def _adam(self, p, g, m, v, lr, eps):
         t = self.step_count
@@ -124,8 +123,7 @@ class NativeTrainer:
         self.step_count += 1
         self.grads.zero_()
         L.check(L.lib().ortk_sum(L.ptr(norm_mask.contiguous()), norm_mask.numel(), L.ptr(self.norm_dev), L.stream_ptr()), "ortk_sum")
-        if self.world > 1:
-            dist.all_reduce(self.norm_dev)       # LanguageModelCriterion semantics over the GLOBAL batch
+        parallel.reduce_scalar_sum(self.norm_dev)   # LanguageModelCriterion semantics over the GLOBAL batch
         batch = self._batch(data, tok_weight)
         seed = self._fwd_bwd(batch, self.norm_dev, train)
         loss = self.loss_dev.clone()
