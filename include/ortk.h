@@ -133,13 +133,14 @@ int ortk_encode(const ortk_config* cfg, const float* params, const float* att_fe
  *   v = acc + bias[n]; relu; v *= rowscale[m]; dropout(p, seed, index m*N+n); v *= (gate[m,n]>0)*gate_scale;
  *   v += resid[m,n];  then C = v, or C += v (atomically, K split over `splitk` workgroups) if accumulate. */
 typedef struct ortk_gemm_args {
-    const float* A; const float* B; float* C;
+    const void* A; const void* B; void* C;
     int64_t lda, ldb, ldc;
     int32_t M, N, K, transA, transB;
     const float* bias; const float* rowscale; const float* resid; int64_t ldr;
-    const float* gate; int64_t ldg; float gate_scale;
+    const void* gate; int64_t ldg; float gate_scale;
     int32_t relu; float drop_p; uint32_t drop_seed;
     int32_t accumulate, splitk, precision;
+    int32_t a_dtype, b_dtype, c_dtype, gate_dtype;   /* storage type of A / B / C / gate: 0 = fp32, 1 = bf16 (precision 1 only) */
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its
@@ -148,7 +149,7 @@ int ortk_prof_enable(int32_t on);
 int ortk_prof_collect(int32_t key, int64_t* launches, double* total_ms, double* total_flops);
 
 /* LayerNorm of transformer.py:338-341: a*(x-mean)/(std_unbiased+eps)+b.  stats (rows,2) = {mean, std}. */
-int ortk_layernorm_fwd(const float* x, const float* a, const float* b, float* y, float* stats,
+int ortk_layernorm_fwd(const float* x, const float* a, const float* b, void* y, int32_t y_dtype, float* stats,
                        int64_t rows, int32_t d, float eps, ortk_stream stream);
 /* dx = dLN/dx (+ dres if non-NULL); da, db accumulate (+=). */
 int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
@@ -173,7 +174,7 @@ int ortk_box_embedding(const float* boxes, const float* dim_mat, float* out, int
  * Q/K/V/O are row matrices with H*dk head-concatenated columns and their own leading dimensions.
  * kv_index (optional, (nkv,Lk) int32) gives the physical K/V row of key j of group g (beam ancestry). */
 typedef struct ortk_attn_args {
-    const float* q; const float* k; const float* v; float* o;
+    const float* q; const float* k; const float* v; void* o;
     int64_t ldq, ldk, ldv, ldo;
     const float* kmask; const float* bias; const int32_t* kv_index;
     int64_t kv_group_stride;        /* K/V rows between consecutive groups when kv_index == NULL (0 = Lk) */
@@ -181,8 +182,9 @@ typedef struct ortk_attn_args {
     int32_t nkv, H, Lq, Lk, dk, causal_period;
     float drop_p; uint32_t drop_seed;
     /* backward only */
-    const float* d_o; float* dq; float* d_k; float* dv; float* dscore;  /* dscore (nkv,H,Lq,Lk) or NULL */
+    const float* d_o; void* dq; void* d_k; void* dv; float* dscore;  /* dscore (nkv,H,Lq,Lk) or NULL */
     int64_t lddo, lddq, lddk, lddv;
+    int32_t o_dtype, dqkv_dtype;    /* storage type of O (fwd) and of dQ/dK/dV (bwd): 0 = fp32, 1 = bf16 */
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);
@@ -197,19 +199,23 @@ int ortk_embed_bwd(const int64_t* seq, int64_t seq_stride, const float* dout, fl
 /* In-place log_softmax over the first V columns of (rows, ld) (OutputEmbedding, transformer.py:412-413);
  * logits are first multiplied by `scale` (1/temperature). */
 int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, float scale, ortk_stream stream);
-/* Fused cross-entropy on logits (rows, ld): loss_dev += -sum logp[target]*w/norm; logits <- dLoss/dlogits. */
-int ortk_xent_fwd_bwd(float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
-                      const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, ortk_stream stream);
+/* Fused cross-entropy on logits (rows, ld): loss_dev += -sum logp[target]*w/norm; dlogits (rows, ld_dl; fp32 or bf16;
+ * may alias logits when fp32 with ld_dl == ld) <- dLoss/dlogits, zero in the pad columns. */
+int ortk_xent_fwd_bwd(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
+                      const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld,
+                      void* dlogits, int32_t dl_dtype, int64_t ld_dl, ortk_stream stream);
 /* log_softmax backward: dlogits = dlogp - exp(logp) * sum_v dlogp, written over (rows, ld_out). */
-int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, float* dlogits, int64_t ld_out,
-                         int64_t rows, int32_t V, ortk_stream stream);
+int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, void* dlogits, int32_t dl_dtype,
+                         int64_t ld_out, int64_t rows, int32_t V, ortk_stream stream);
 
 /* out[n] += sum_m x[m,n] (bias gradients). */
-int ortk_colsum(const float* x, int64_t ld, float* out, int64_t M, int32_t N, ortk_stream stream);
+int ortk_colsum(const void* x, int32_t x_dtype, int64_t ld, float* out, int64_t M, int32_t N, ortk_stream stream);
 /* y = gate > 0 ? x*scale : 0 — backward of relu (+dropout) given the saved forward output. */
-int ortk_gate_apply(const float* x, const float* gate, float* y, int64_t n, float scale, ortk_stream stream);
+int ortk_gate_apply(const float* x, const float* gate, void* y, int32_t y_dtype, int64_t n, float scale, ortk_stream stream);
 /* y = x * keep(seed,i)/(1-p) — backward of a residual-branch dropout. */
-int ortk_dropout_apply(const float* x, float* y, int64_t n, float p, uint32_t seed, ortk_stream stream);
+int ortk_dropout_apply(const float* x, void* y, int32_t y_dtype, int64_t n, float p, uint32_t seed, ortk_stream stream);
+/* fp32 -> bf16 copy (the working copy of the weight arena in precision 1). */
+int ortk_cast_bf16(const float* x, void* y, int64_t n, ortk_stream stream);
 int ortk_fill(float* x, int64_t n, float value, ortk_stream stream);
 int ortk_sum(const float* x, int64_t n, float* out_dev, ortk_stream stream);  /* *out_dev = sum(x) */
 

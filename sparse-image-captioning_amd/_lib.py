@@ -48,7 +48,8 @@ class GemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("rowscale", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64),
                 ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_scale", C.c_float),
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("accumulate", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32)]
+                ("accumulate", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32),
+                ("a_dtype", C.c_int32), ("b_dtype", C.c_int32), ("c_dtype", C.c_int32), ("gate_dtype", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -59,7 +60,8 @@ class AttnArgs(C.Structure):
                 ("nkv", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("dk", C.c_int32),
                 ("causal_period", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
                 ("d_o", C.c_void_p), ("dq", C.c_void_p), ("d_k", C.c_void_p), ("dv", C.c_void_p), ("dscore", C.c_void_p),
-                ("lddo", C.c_int64), ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64)]
+                ("lddo", C.c_int64), ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64),
+                ("o_dtype", C.c_int32), ("dqkv_dtype", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _U32, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t
@@ -85,7 +87,7 @@ SIGNATURES = {
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),
     "ortk_prof_enable": (_I32, [_I32]),
     "ortk_prof_collect": (_I32, [_I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "ortk_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
+    "ortk_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "ortk_box_logbias_fwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, _I32, _I32, _I32, _I32, _P]),
     "ortk_box_logbias_bwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, C.POINTER(_P), C.POINTER(_P),
@@ -96,11 +98,12 @@ SIGNATURES = {
     "ortk_embed_fwd": (_I32, [_P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _F, _U32, _P]),
     "ortk_embed_bwd": (_I32, [_P, _I64, _P, _P, _I64, _I32, _I32, _F, _U32, _P]),
     "ortk_log_softmax": (_I32, [_P, _I64, _I32, _I64, _F, _P]),
-    "ortk_xent_fwd_bwd": (_I32, [_P, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I64, _P]),
-    "ortk_log_softmax_bwd": (_I32, [_P, _P, _I64, _P, _I64, _I64, _I32, _P]),
-    "ortk_colsum": (_I32, [_P, _I64, _P, _I64, _I32, _P]),
-    "ortk_gate_apply": (_I32, [_P, _P, _P, _I64, _F, _P]),
-    "ortk_dropout_apply": (_I32, [_P, _P, _I64, _F, _U32, _P]),
+    "ortk_xent_fwd_bwd": (_I32, [_P, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I64, _P, _I32, _I64, _P]),
+    "ortk_log_softmax_bwd": (_I32, [_P, _P, _I64, _P, _I32, _I64, _I64, _I32, _P]),
+    "ortk_colsum": (_I32, [_P, _I32, _I64, _P, _I64, _I32, _P]),
+    "ortk_gate_apply": (_I32, [_P, _P, _P, _I32, _I64, _F, _P]),
+    "ortk_dropout_apply": (_I32, [_P, _P, _I32, _I64, _F, _U32, _P]),
+    "ortk_cast_bf16": (_I32, [_P, _P, _I64, _P]),
     "ortk_fill": (_I32, [_P, _I64, _F, _P]),
     "ortk_sum": (_I32, [_P, _I64, _P, _P]),
     "ortk_adam_clip": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P]),

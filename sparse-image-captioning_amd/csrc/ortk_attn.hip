@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ortk_attn_args a) {
         if (lane < a.dk) {
             float o = 0.f;
             for (int j = 0; j < a.Lk; ++j) o += t.p[wave][j] * t.v[j][lane];
-            a.o[qrow * a.ldo + h * a.dk + lane] = o;
+            st_elem(a.o, qrow * a.ldo + h * a.dk + lane, a.o_dtype, o);
         }
         wave_sync();
     }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_bwd_reg_kernel(ortk_attn_args a) {
                 accv[j] += pdj * gv;
             }
         }
-        if (lane < dk) a.dq[qrow * a.lddq + h * dk + lane] = dq;
+        if (lane < dk) st_elem(a.dq, qrow * a.lddq + h * dk + lane, a.dqkv_dtype, dq);
     }
     // sum the 4 waves' partials: one wave at a time adds its registers into the LDS tiles
     for (int w = 0; w < 4; ++w) {
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(256) void attn_bwd_reg_kernel(ortk_attn_args a) {
     for (int idx = tid; idx < Lk * dk; idx += 256) {
         const int j = idx / dk, dd = idx - j * dk;
         const int64_t row = (int64_t)g * Lk + j;
-        a.d_k[row * a.lddk + h * dk + dd] = sdK[j][dd];
-        a.dv[row * a.lddv + h * dk + dd] = sdV[j][dd];
+        st_elem(a.d_k, row * a.lddk + h * dk + dd, a.dqkv_dtype, sdK[j][dd]);
+        st_elem(a.dv, row * a.lddv + h * dk + dd, a.dqkv_dtype, sdV[j][dd]);
     }
 }
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ortk_attn_args a) {
                 atomicAdd(&t.dk[j][lane], dsj * qv);
                 atomicAdd(&t.dv[j][lane], pdj * gv);
             }
-            a.dq[qrow * a.lddq + h * a.dk + lane] = dq;
+            st_elem(a.dq, qrow * a.lddq + h * a.dk + lane, a.dqkv_dtype, dq);
         }
         wave_sync();
     }
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ortk_attn_args a) {
     for (int idx = tid; idx < a.Lk * a.dk; idx += 256) {
         const int j = idx / a.dk, dd = idx - j * a.dk;
         const int64_t row = (int64_t)g * a.Lk + j;
-        a.d_k[row * a.lddk + h * a.dk + dd] = t.dk[j][dd];
-        a.dv[row * a.lddv + h * a.dk + dd] = t.dv[j][dd];
+        st_elem(a.d_k, row * a.lddk + h * a.dk + dd, a.dqkv_dtype, t.dk[j][dd]);
+        st_elem(a.dv, row * a.lddv + h * a.dk + dd, a.dqkv_dtype, t.dv[j][dd]);
     }
 }
 

@@ -15,6 +15,42 @@
 static inline hipStream_t ortk_s(ortk_stream s) { return (hipStream_t)s; }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// ---------------------------------------------------------------------------------------------
+// Element types of activation buffers.  All arithmetic is fp32; in the mixed-precision mode (precision = 1) the
+// tensors that only feed MFMA operands are STORED as bf16 (halves their HBM / L2 traffic); ORTK_F32 everywhere
+// in the fp32 parity mode.
+// ---------------------------------------------------------------------------------------------
+enum : int { ORTK_F32 = 0, ORTK_BF16 = 1 };
+static inline size_t ortk_esize(int dt) { return dt == ORTK_BF16 ? 2 : 4; }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int DT = ORTK_F32; };
+template <> struct Elem<__bf16> { static constexpr int DT = ORTK_BF16; };
+
+__device__ __forceinline__ float ld_elem(const void* p, int64_t i, int dt) {
+    return dt == ORTK_BF16 ? (float)reinterpret_cast<const __bf16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_elem(void* p, int64_t i, int dt, float v) {
+    if (dt == ORTK_BF16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v; else reinterpret_cast<float*>(p)[i] = v;
+}
+// 4 consecutive elements (16-B / 8-B aligned) as float4
+__device__ __forceinline__ float4 ld_elem4(const void* p, int64_t i, int dt) {
+    if (dt == ORTK_BF16) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p) + i);
+        return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ void st_elem4(void* p, int64_t i, int dt, float4 v) {
+    if (dt == ORTK_BF16) {
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = v;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG: one 32-bit mix per element.  The oracle carries the same function

@@ -77,13 +77,13 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x,
     for (int c = threadIdx.x; c < V; c += 256) row[c] = (row[c] * scale - mx) - lse;
 }
 
-__global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets,
+__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                    int64_t target_stride, int T, const float* __restrict__ weight,
                                                    const float* __restrict__ norm_dev, float* __restrict__ loss_dev, int V,
-                                                   int64_t ld) {
+                                                   int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl) {
     __shared__ float sh[4];
     const int64_t r = blockIdx.x;
-    float* row = logits + r * ld;
+    const float* row = logits + r * ld;
     const int64_t tgt = targets[(r / T) * target_stride + (r % T)];
     const float w = weight[r] / norm_dev[0];
     float mx = -INFINITY;
@@ -95,15 +95,16 @@ __global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, c
     const float lse = logf(s);
     if (threadIdx.x == 0 && w != 0.f) atomicAdd(loss_dev, -((row[tgt] - mx) - lse) * w);
     __syncthreads();
-    for (int c = threadIdx.x; c < (int)ld; c += 256) {
+    // dlogits may alias logits (fp32, same ld): every element is read before it is overwritten by the same thread
+    for (int c = threadIdx.x; c < (int)ld_dl; c += 256) {
         float g = 0.f;
         if (c < V && w != 0.f) g = (expf((row[c] - mx) - lse) - (c == tgt ? 1.f : 0.f)) * w;
-        row[c] = g;
+        st_elem(dlogits, r * ld_dl + c, dl_dt, g);
     }
 }
 
 __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp,
-                                                              int64_t ld_in, float* __restrict__ dlogits, int64_t ld_out, int V) {
+                                                              int64_t ld_in, void* __restrict__ dlogits, int dl_dt, int64_t ld_out, int V) {
     __shared__ float sh[4];
     const int64_t r = blockIdx.x;
     const float* lp = logp + r * ld_in;
@@ -111,14 +112,13 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
     float s = 0.f;
     for (int c = threadIdx.x; c < V; c += 256) s += dl[c];
     s = block_sum(s, sh);
-    float* o = dlogits + r * ld_out;
-    for (int c = threadIdx.x; c < (int)ld_out; c += 256) o[c] = c < V ? dl[c] - expf(lp[c]) * s : 0.f;
+    for (int c = threadIdx.x; c < (int)ld_out; c += 256) st_elem(dlogits, r * ld_out + c, dl_dt, c < V ? dl[c] - expf(lp[c]) * s : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------- misc
 // column sums: each workgroup covers 64 columns x ROWS rows; lanes walk columns (coalesced), waves walk rows.
 constexpr int CS_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, float* __restrict__ out,
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int x_dt, int64_t ld, float* __restrict__ out,
                                                      int64_t M, int N) {
     __shared__ float sh[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,23 +126,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
     float acc = 0.f;
     if (c < N)
-        for (int64_t r = r0 + wave; r < min(M, r0 + CS_ROWS); r += 4) acc += x[r * ld + c];
+        for (int64_t r = r0 + wave; r < min(M, r0 + CS_ROWS); r += 4) acc += ld_elem(x, r * ld + c, x_dt);
     sh[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && c < N) atomicAdd(&out[c], sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
 }
 
-__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, void* __restrict__ y, int y_dt, int64_t n,
                                                             float p, uint32_t seed) {
     const float inv_keep = 1.f / (1.f - p);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        y[i] = ortk_keep(seed, (uint64_t)i, p) ? x[i] * inv_keep : 0.f;
+        st_elem(y, i, y_dt, (p > 0.f && !ortk_keep(seed, (uint64_t)i, p)) ? 0.f : x[i] * inv_keep);
 }
 
 __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ x, const float* __restrict__ gate,
-                                                         float* __restrict__ y, int64_t n, float scale) {
+                                                         void* __restrict__ y, int y_dt, int64_t n, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        y[i] = gate[i] > 0.f ? x[i] * scale : 0.f;
+        st_elem(y, i, y_dt, gate[i] > 0.f ? x[i] * scale : 0.f);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<bf16x4*>(y)[i] = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (__bf16)x[i];
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, int64_t n, float v) {
@@ -192,47 +201,60 @@ extern "C" int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, f
     return 0;
 }
 
-extern "C" int ortk_xent_fwd_bwd(float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
-                                 const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, ortk_stream stream) {
-    if (!logits || !targets || !weight || !norm_dev || !loss_dev || rows < 0 || V < 1 || ld < V || T < 1) return ORTK_EINVAL;
+extern "C" int ortk_xent_fwd_bwd(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
+                                 const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, void* dlogits,
+                                 int32_t dl_dtype, int64_t ld_dl, ortk_stream stream) {
+    if (!logits || !targets || !weight || !norm_dev || !loss_dev || !dlogits || rows < 0 || V < 1 || ld < V || ld_dl < V || T < 1)
+        return ORTK_EINVAL;
+    if (dl_dtype != ORTK_F32 && dl_dtype != ORTK_BF16) return ORTK_EINVAL;
+    if ((const void*)dlogits == (const void*)logits && (dl_dtype != ORTK_F32 || ld_dl != ld)) return ORTK_EINVAL;
     if (rows == 0) return 0;
     hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logits, targets, target_stride, T, weight,
-                       norm_dev, loss_dev, V, ld);
+                       norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, float* dlogits, int64_t ld_out,
-                                    int64_t rows, int32_t V, ortk_stream stream) {
+extern "C" int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, void* dlogits, int32_t dl_dtype,
+                                    int64_t ld_out, int64_t rows, int32_t V, ortk_stream stream) {
     if (!logp || !dlogp || !dlogits || rows < 0 || V < 1 || ld_in < V || ld_out < V) return ORTK_EINVAL;
+    if (dl_dtype != ORTK_F32 && dl_dtype != ORTK_BF16) return ORTK_EINVAL;
     if (rows == 0) return 0;
     hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logp, dlogp, ld_in, dlogits,
-                       ld_out, V);
+                       (int)dl_dtype, ld_out, V);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int ortk_colsum(const float* x, int64_t ld, float* out, int64_t M, int32_t N, ortk_stream stream) {
-    if (!x || !out || M < 0 || N < 0) return ORTK_EINVAL;
+extern "C" int ortk_colsum(const void* x, int32_t x_dtype, int64_t ld, float* out, int64_t M, int32_t N, ortk_stream stream) {
+    if (!x || !out || M < 0 || N < 0 || (x_dtype != ORTK_F32 && x_dtype != ORTK_BF16)) return ORTK_EINVAL;
     if (M == 0 || N == 0) return 0;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ortk_cdiv(N, 64), (unsigned)ortk_cdiv(M, CS_ROWS)), dim3(256), 0,
-                       ortk_s(stream), x, ld, out, M, N);
+                       ortk_s(stream), x, (int)x_dtype, ld, out, M, N);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int ortk_dropout_apply(const float* x, float* y, int64_t n, float p, uint32_t seed, ortk_stream stream) {
-    if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return ORTK_EINVAL;
+extern "C" int ortk_dropout_apply(const float* x, void* y, int32_t y_dtype, int64_t n, float p, uint32_t seed, ortk_stream stream) {
+    if (!x || !y || n < 0 || p < 0.f || p >= 1.f || (y_dtype != ORTK_F32 && y_dtype != ORTK_BF16)) return ORTK_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, y, n, p, seed);
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, y, (int)y_dtype, n, p, seed);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int ortk_gate_apply(const float* x, const float* gate, float* y, int64_t n, float scale, ortk_stream stream) {
-    if (!x || !gate || !y || n < 0) return ORTK_EINVAL;
+extern "C" int ortk_gate_apply(const float* x, const float* gate, void* y, int32_t y_dtype, int64_t n, float scale, ortk_stream stream) {
+    if (!x || !gate || !y || n < 0 || (y_dtype != ORTK_F32 && y_dtype != ORTK_BF16)) return ORTK_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(gate_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, gate, y, n, scale);
+    hipLaunchKernelGGL(gate_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, gate, y, (int)y_dtype, n, scale);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_cast_bf16(const float* x, void* y, int64_t n, ortk_stream stream) {
+    if (!x || !y || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ortk_s(stream), x, reinterpret_cast<__bf16*>(y), n);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -48,9 +48,9 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ base, int64_t ld
 }
 
 struct Epi {
-    float* C; int64_t ldc;
+    void* C; int64_t ldc; int c_dt;
     const float* bias; const float* rowscale; const float* resid; int64_t ldr;
-    const float* gate; int64_t ldg; float gate_scale;
+    const void* gate; int64_t ldg; int g_dt; float gate_scale;
     int relu; float drop_p; uint32_t drop_seed; int accumulate; bool first_split;
     int M, N;
 };
@@ -69,35 +69,47 @@ __device__ __forceinline__ float4 ldrow4(const float* __restrict__ p, int n0, in
 // Epilogue of one wave's 64x64 sub-tile: acc[i][j] holds C[m = mrow0 + 16 i][n = ncol0 + 16 j + 0..3].
 // Bias is loaded once per j; residual / gate rows are fetched as float4 for all four j of a row BEFORE any of that
 // row's stores (independent loads in flight together instead of 16 load->store chains per thread).
+template <bool FAST>
 __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0, f32x4 (&acc)[4][4]) {
     const bool first = e.first_split;
-    const bool vec_b = e.bias && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0);
-    const bool vec_r = e.resid && ((e.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.resid) & 15) == 0);
-    const bool vec_g = e.gate && ((e.ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.gate) & 15) == 0);
-    const bool vec_c = ((e.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0);
+    // FAST: the launcher has verified full tiles and vector alignment of every pointer -> no bounds / alignment tests
+    const bool vec_b = FAST || (e.bias && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0));
+    const bool vec_r = FAST || (e.resid && ((e.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.resid) & 15) == 0));
+    const bool vec_g = FAST || (e.gate && ((e.ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.gate) & 15) == 0));
+    const bool vec_c = FAST || (((e.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0));
+    const int EN = FAST ? 0x7FFFFFFF : e.N, EM = FAST ? 0x7FFFFFFF : e.M;   // bounds the compiler can fold away
+    const bool c16 = e.c_dt == ORTK_BF16, g16 = e.g_dt == ORTK_BF16;
     const float inv_keep = e.drop_p > 0.f ? 1.f / (1.f - e.drop_p) : 1.f;
     float4 bias4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n0 = ncol0 + 16 * j;
-        bias4[j] = (e.bias && first && n0 < e.N) ? ldrow4(e.bias + n0, n0, e.N, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bias4[j] = (e.bias && first && n0 < EN) ? ldrow4(e.bias + n0, n0, EN, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = mrow0 + 16 * i;
-        if (m >= e.M) continue;
+        if (m >= EM) continue;
         const float rs = e.rowscale ? e.rowscale[m] : 1.f;
         float4 res[4], gat[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n0 = ncol0 + 16 * j;
-            res[j] = (e.resid && first && n0 < e.N) ? ldrow4(e.resid + (int64_t)m * e.ldr + n0, n0, e.N, vec_r) : make_float4(0.f, 0.f, 0.f, 0.f);
-            gat[j] = (e.gate && n0 < e.N) ? ldrow4(e.gate + (int64_t)m * e.ldg + n0, n0, e.N, vec_g) : make_float4(1.f, 1.f, 1.f, 1.f);
+            res[j] = (e.resid && first && n0 < EN) ? ldrow4(e.resid + (int64_t)m * e.ldr + n0, n0, EN, vec_r) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gat[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (e.gate && n0 < EN) {
+                if (!g16) gat[j] = ldrow4(reinterpret_cast<const float*>(e.gate) + (int64_t)m * e.ldg + n0, n0, EN, vec_g);
+                else if (vec_g && n0 + 3 < EN) gat[j] = ld_elem4(e.gate, (int64_t)m * e.ldg + n0, ORTK_BF16);
+                else {
+                    float* gp = &gat[j].x;
+                    for (int r = 0; r < 4; ++r) if (n0 + r < EN) gp[r] = ld_elem(e.gate, (int64_t)m * e.ldg + n0 + r, ORTK_BF16);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n0 = ncol0 + 16 * j;
-            if (n0 >= e.N) continue;
+            if (n0 >= EN) continue;
             const float bb[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
             const float rr[4] = {res[j].x, res[j].y, res[j].z, res[j].w};
             const float gg[4] = {gat[j].x, gat[j].y, gat[j].z, gat[j].w};
@@ -111,18 +123,20 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
                 if (e.gate) x = gg[r] > 0.f ? x * e.gate_scale : 0.f;
                 v[r] = x + rr[r];
             }
-            float* c = e.C + (int64_t)m * e.ldc + n0;
-            if (e.accumulate) {
+            const int64_t ci = (int64_t)m * e.ldc + n0;
+            if (e.accumulate) {      // always fp32 (gradient arena)
+                float* c = reinterpret_cast<float*>(e.C) + ci;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (n0 + r < e.N) atomicAdd(c + r, v[r]);
-            } else if (vec_c && n0 + 3 < e.N) {
-                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (n0 + r < EN) atomicAdd(c + r, v[r]);
+            } else if (vec_c && n0 + 3 < EN) {
+                st_elem4(e.C, ci, e.c_dt, make_float4(v[0], v[1], v[2], v[3]));   // 16-B (fp32) or 8-B (bf16) store
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (n0 + r < e.N) c[r] = v[r];
+                    if (n0 + r < EN) st_elem(e.C, ci + r, e.c_dt, v[r]);
             }
+            (void)c16;
         }
     }
 }
@@ -150,6 +164,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const float* Af = reinterpret_cast<const float*>(p.A);
+    const float* Bf = reinterpret_cast<const float*>(p.B);
     const bool fullA = vecA && mb + BM <= p.M, fullB = vecB && nb + BN <= p.N;   // workgroup-uniform
     float4 ra[2], rb[2];
     auto gload = [&](int k0) {
@@ -158,30 +174,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int f = tid + 256 * u;
-                ra[u] = *reinterpret_cast<const float4*>(!TA ? p.A + (int64_t)(mb + (f >> 2)) * p.lda + k0 + 4 * (f & 3)
-                                                             : p.A + (int64_t)(k0 + (f >> 5)) * p.lda + mb + 4 * (f & 31));
+                ra[u] = *reinterpret_cast<const float4*>(!TA ? Af + (int64_t)(mb + (f >> 2)) * p.lda + k0 + 4 * (f & 3)
+                                                             : Af + (int64_t)(k0 + (f >> 5)) * p.lda + mb + 4 * (f & 31));
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int f = tid + 256 * u;
-                if (!TA) ra[u] = ld4(p.A, p.lda, mb + (f >> 2), k0 + 4 * (f & 3), p.M, k_end, vecA);
-                else     ra[u] = ld4(p.A, p.lda, k0 + (f >> 5), mb + 4 * (f & 31), k_end, p.M, vecA);
+                if (!TA) ra[u] = ld4(Af, p.lda, mb + (f >> 2), k0 + 4 * (f & 3), p.M, k_end, vecA);
+                else     ra[u] = ld4(Af, p.lda, k0 + (f >> 5), mb + 4 * (f & 31), k_end, p.M, vecA);
             }
         }
         if (fullB && kfull) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int f = tid + 256 * u;
-                rb[u] = *reinterpret_cast<const float4*>(!TB ? p.B + (int64_t)(nb + (f >> 2)) * p.ldb + k0 + 4 * (f & 3)
-                                                             : p.B + (int64_t)(k0 + (f >> 5)) * p.ldb + nb + 4 * (f & 31));
+                rb[u] = *reinterpret_cast<const float4*>(!TB ? Bf + (int64_t)(nb + (f >> 2)) * p.ldb + k0 + 4 * (f & 3)
+                                                             : Bf + (int64_t)(k0 + (f >> 5)) * p.ldb + nb + 4 * (f & 31));
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int f = tid + 256 * u;
-                if (!TB) rb[u] = ld4(p.B, p.ldb, nb + (f >> 2), k0 + 4 * (f & 3), p.N, k_end, vecB);
-                else     rb[u] = ld4(p.B, p.ldb, k0 + (f >> 5), nb + 4 * (f & 31), k_end, p.N, vecB);
+                if (!TB) rb[u] = ld4(Bf, p.ldb, nb + (f >> 2), k0 + 4 * (f & 3), p.N, k_end, vecB);
+                else     rb[u] = ld4(Bf, p.ldb, k0 + (f >> 5), nb + 4 * (f & 31), k_end, p.N, vecB);
             }
         }
     };
@@ -234,66 +250,103 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
         buf ^= 1;
     }
 
-    Epi e{p.C, p.ldc, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_scale,
+    Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N};
-    epilogue_tile(e, mb + wm * 64 + lr, nb + wn * 64 + 4 * lk, acc);
+    epilogue_tile<false>(e, mb + wm * 64 + lr, nb + wn * 64 + 4 * lk, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 MFMA
-// Same 128x128 tiling, K consumed 64 at a time (32 MFMA 16x16x32 per wave between barriers).  Operands are fp32 in
-// memory and are converted to bf16 while staging.  The LDS image of an operand follows its GLOBAL layout so that the
-// staging writes are always 8-byte vector stores:
+// Same 128x128 tiling, K consumed 64 at a time (32 MFMA 16x16x32 per wave between barriers).  Each operand is
+// either fp32 or bf16 in memory (template ET); fp32 is converted while staging, bf16 is moved as 16-byte chunks.
+// The LDS image of an operand follows its GLOBAL layout so that the staging writes are vector stores:
 //   * k-contiguous operand (activations X, weights W as (N,K)):  image [m][k], pitch 72 bf16;  the 8-element MFMA
 //     fragment (8 consecutive k of one row) is one ds_read_b128;
 //   * k-major operand (dY^T / X for wgrad, W for dgrad):           image [k][m], pitch 136 bf16;  the fragment is
 //     gathered by two hardware-transposing reads (ds_read_b64_tr_b16).
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 constexpr int BK16 = 64;
 constexpr int PITCH_MK = BK16 + 8;     // [m][k] image: 144 B rows (16-B aligned, rows spread over banks)
-constexpr int PITCH_KM = 128 + 8;      // [k][m] image: 272 B rows (8-B aligned for the transposing read)
+constexpr int PITCH_KM = 128 + 8;      // [k][m] image: 272 B rows (16-B aligned; 8-B aligned for the transposing read)
 constexpr int IMG_ELEMS = 128 * PITCH_MK > BK16 * PITCH_KM ? 128 * PITCH_MK : BK16 * PITCH_KM;
 
 __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
 }
-__device__ __forceinline__ bf16x4 cvt4(const float4& v) {
-    return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+
+// One 128 x 64 operand tile in flight: global -> registers (16-byte chunks) -> LDS image (bf16).
+// The staged chunks live in a plain local array that is only ever indexed with unrolled constants and never has its
+// address taken: a first version kept them in a struct member and read them through reinterpret_cast — hipcc then put
+// the array in SCRATCH and waited for every load right after issuing it (scratch_store + vmcnt), which serialised the
+// whole prefetch.
+template <typename ET> struct ChunkT;
+// native LLVM vector types (HIP's float4 / uint4 are structs around unions, which defeated SROA for the bf16 case)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <> struct ChunkT<float> { typedef f32x4 type; };
+template <> struct ChunkT<__bf16> { typedef u32x4 type; };
+
+template <bool T, typename ET> struct StageCfg {
+    static constexpr int EPC = 16 / (int)sizeof(ET);                 // elements per chunk: 4 (fp32) | 8 (bf16)
+    static constexpr int NCH = 128 * BK16 / EPC / 256;               // chunks per thread:   8        | 4
+    static constexpr int CPR = (T ? 128 : BK16) / EPC;               // chunks per storage row
+    static constexpr int PITCH = T ? PITCH_KM : PITCH_MK;
+    typedef typename ChunkT<ET>::type chunk_t;
+};
+
+template <typename ET> __device__ __forceinline__ typename ChunkT<ET>::type guarded_chunk(const ET* base, int64_t ld, int grow, int gcol, int nrows, int ncols);
+template <> __device__ __forceinline__ f32x4 guarded_chunk<float>(const float* base, int64_t ld, int grow, int gcol, int nrows, int ncols) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (grow < nrows) {
+        const float* p = base + (int64_t)grow * ld + gcol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (gcol + q < ncols) v[q] = p[q];
+    }
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 guarded_chunk<__bf16>(const __bf16* base, int64_t ld, int grow, int gcol, int nrows, int ncols) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (grow < nrows) {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + (int64_t)grow * ld + gcol;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (gcol + q < ncols) v[q >> 1] |= (unsigned int)p[q] << (16 * (q & 1));
+    }
+    return v;
 }
 
-// stage one 128 x 64 operand tile: global fp32 -> registers (8 float4 per thread).
-// `fast` (workgroup-uniform): the whole tile is in bounds and 16-B aligned -> 8 unconditional, independent
-// global_load_dwordx4 that stay in flight together.  (Per-load bounds branches made hipcc drain vmcnt at every
-// join: 16 serialized memory round trips per K-step, ~4 % MFMA utilisation in the first profile.)
-template <bool T>
-__device__ __forceinline__ void g2r(float4 (&r)[8], const float* __restrict__ base, int64_t ld, int tile0, int k0, int nmn, int k_end,
-                                    bool vec, bool fast, int tid) {
-    if (fast) {
+template <bool T, typename ET, bool FAST, typename CT, int N>
+__device__ __forceinline__ void stage_load(CT (&r)[N], const ET* __restrict__ base,
+                                           int64_t ld, int tile0, int k0, int nmn, int k_end, bool fast, int tid) {
+    typedef StageCfg<T, ET> S;
+    typedef CT chunk_t;
+    static_assert(N == S::NCH, "chunk array size");
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int f = tid + 256 * u;
-            const float* p = !T ? base + (int64_t)(tile0 + (f >> 4)) * ld + k0 + 4 * (f & 15)
-                                : base + (int64_t)(k0 + (f >> 5)) * ld + tile0 + 4 * (f & 31);
-            r[u] = *reinterpret_cast<const float4*>(p);
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int f = tid + 256 * u;
-            if (!T) r[u] = ld4(base, ld, tile0 + (f >> 4), k0 + 4 * (f & 15), nmn, k_end, vec);
-            else    r[u] = ld4(base, ld, k0 + (f >> 5), tile0 + 4 * (f & 31), k_end, nmn, vec);
-        }
-    }
-}
-template <bool T>
-__device__ __forceinline__ void r2s(const float4 (&r)[8], __bf16* img, int tid) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < S::NCH; ++u) {
         const int f = tid + 256 * u;
-        if (!T) *reinterpret_cast<bf16x4*>(img + (f >> 4) * PITCH_MK + 4 * (f & 15)) = cvt4(r[u]);
-        else    *reinterpret_cast<bf16x4*>(img + (f >> 5) * PITCH_KM + 4 * (f & 31)) = cvt4(r[u]);
+        const int srow = f / S::CPR, scol = (f % S::CPR) * S::EPC;   // storage row / first column of the chunk
+        const int grow = (T ? k0 : tile0) + srow, gcol = (T ? tile0 : k0) + scol;
+        if (FAST || fast) {
+            r[u] = *reinterpret_cast<const chunk_t*>(base + (int64_t)grow * ld + gcol);
+        } else {
+            const int nrows = T ? k_end : nmn, ncols = T ? nmn : k_end;
+            r[u] = guarded_chunk<ET>(base, ld, grow, gcol, nrows, ncols);
+        }
     }
 }
+__device__ __forceinline__ void lds_put(__bf16* dst, f32x4 v) {
+    *reinterpret_cast<bf16x4*>(dst) = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+__device__ __forceinline__ void lds_put(__bf16* dst, u32x4 v) { *reinterpret_cast<u32x4*>(dst) = v; }
+
+template <bool T, typename ET, typename CT, int N>
+__device__ __forceinline__ void stage_store(const CT (&r)[N], __bf16* img, int tid) {
+    typedef StageCfg<T, ET> S;
+    static_assert(N == S::NCH, "chunk array size");
+#pragma unroll
+    for (int u = 0; u < S::NCH; ++u) {
+        const int f = tid + 256 * u;
+        lds_put(img + (f / S::CPR) * S::PITCH + (f % S::CPR) * S::EPC, r[u]);
+    }
+}
+
 // fragment of 16 rows starting at m0 for k-sub-step ks (32 wide)
 template <bool T>
 __device__ __forceinline__ bf16x8 frag(const __bf16* img, int m0, int ks, int lane) {
@@ -308,7 +361,9 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* img, int m0, int ks, int la
     }
 }
 
-template <bool TA, bool TB>
+// FAST = every tile is full (M % 128 == N % 128 == 0, K-chunks multiples of 64) and every pointer is vector-aligned:
+// the launcher checks this, and the kernel then contains no bounds test at all (the guarded variant is 10x the code).
+template <bool TA, bool TB, typename AT, typename BT, bool FAST>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     auto sA = [&](int b_) { return smem16 + (size_t)b_ * 2 * IMG_ELEMS; };
@@ -320,8 +375,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
     const int mb = mt * BM, nb = nt * BN;
     const int k_begin = ks_ * kchunk;
     const int k_end = min(p.K, k_begin + kchunk);
-    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+    const AT* Ap = reinterpret_cast<const AT*>(p.A);
+    const BT* Bp = reinterpret_cast<const BT*>(p.B);
+    const bool vecA = ((p.lda * sizeof(AT)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    const bool vecB = ((p.ldb * sizeof(BT)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+    const bool fullA = vecA && mb + BM <= p.M, fullB = vecB && nb + BN <= p.N;   // workgroup-uniform
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -329,23 +387,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bool fullA = vecA && mb + BM <= p.M, fullB = vecB && nb + BN <= p.N;   // workgroup-uniform
-    float4 ra[8], rb[8];
+    typename StageCfg<TA, AT>::chunk_t ra[StageCfg<TA, AT>::NCH];
+    typename StageCfg<TB, BT>::chunk_t rb[StageCfg<TB, BT>::NCH];
     int buf = 0;
     if (k_begin < k_end) {
         const bool kfull = k_begin + BK16 <= k_end;
-        g2r<TA>(ra, p.A, p.lda, mb, k_begin, p.M, k_end, vecA, fullA && kfull, tid);
-        g2r<TB>(rb, p.B, p.ldb, nb, k_begin, p.N, k_end, vecB, fullB && kfull, tid);
-        r2s<TA>(ra, sA(0), tid);
-        r2s<TB>(rb, sB(0), tid);
+        stage_load<TA, AT, FAST>(ra, Ap, p.lda, mb, k_begin, p.M, k_end, fullA && kfull, tid);
+        stage_load<TB, BT, FAST>(rb, Bp, p.ldb, nb, k_begin, p.N, k_end, fullB && kfull, tid);
+        stage_store<TA, AT>(ra, sA(0), tid);
+        stage_store<TB, BT>(rb, sB(0), tid);
     }
     __syncthreads();
     for (int k0 = k_begin; k0 < k_end; k0 += BK16) {
         const bool has_next = k0 + BK16 < k_end;
         if (has_next) {
             const bool kfull = k0 + 2 * BK16 <= k_end;
-            g2r<TA>(ra, p.A, p.lda, mb, k0 + BK16, p.M, k_end, vecA, fullA && kfull, tid);
-            g2r<TB>(rb, p.B, p.ldb, nb, k0 + BK16, p.N, k_end, vecB, fullB && kfull, tid);
+            stage_load<TA, AT, FAST>(ra, Ap, p.lda, mb, k0 + BK16, p.M, k_end, fullA && kfull, tid);
+            stage_load<TB, BT, FAST>(rb, Bp, p.ldb, nb, k0 + BK16, p.N, k_end, fullB && kfull, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -361,17 +419,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         if (has_next) {
-            r2s<TA>(ra, sA(buf ^ 1), tid);
-            r2s<TB>(rb, sB(buf ^ 1), tid);
+            stage_store<TA, AT>(ra, sA(buf ^ 1), tid);
+            stage_store<TB, BT>(rb, sB(buf ^ 1), tid);
         }
         __syncthreads();
         buf ^= 1;
     }
-    Epi e{p.C, p.ldc, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_scale,
+    Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
-    epilogue_tile(e, mb + wm * 64 + (lane & 15), nb + wn * 64 + 4 * (lane >> 4), acc);
+    epilogue_tile<FAST>(e, mb + wm * 64 + (lane & 15), nb + wn * 64 + 4 * (lane >> 4), acc);
 }
 constexpr size_t BF16_LDS_BYTES = (size_t)4 * IMG_ELEMS * sizeof(__bf16);
+
+typedef void (*gemm16_fn)(ortk_gemm_args, int, int, int);
+template <bool TA, bool TB, bool FAST> gemm16_fn pick16t(int adt, int bdt) {
+    if (adt == ORTK_F32 && bdt == ORTK_F32) return gemm_bf16_kernel<TA, TB, float, float, FAST>;
+    if (adt == ORTK_F32 && bdt == ORTK_BF16) return gemm_bf16_kernel<TA, TB, float, __bf16, FAST>;
+    if (adt == ORTK_BF16 && bdt == ORTK_F32) return gemm_bf16_kernel<TA, TB, __bf16, float, FAST>;
+    return gemm_bf16_kernel<TA, TB, __bf16, __bf16, FAST>;
+}
+template <bool TA, bool TB> gemm16_fn pick16(int adt, int bdt, bool fast) {
+    return fast ? pick16t<TA, TB, true>(adt, bdt) : pick16t<TA, TB, false>(adt, bdt);
+}
 
 }  // namespace
 
@@ -410,6 +479,11 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return ORTK_EINVAL;
     if (a->M == 0 || a->N == 0) return 0;
     ortk_gemm_args p = *a;
+    auto dt_ok = [](int d) { return d == ORTK_F32 || d == ORTK_BF16; };
+    if (!dt_ok(p.a_dtype) || !dt_ok(p.b_dtype) || !dt_ok(p.c_dtype) || !dt_ok(p.gate_dtype)) return ORTK_EINVAL;
+    if (!p.precision && (p.a_dtype || p.b_dtype)) return ORTK_EINVAL;   // fp32 MFMA path takes fp32 operands only
+    if (p.accumulate && p.c_dtype) return ORTK_EINVAL;                   // accumulation targets the fp32 gradient arena
+    if (p.transA && !p.transB) return ORTK_EINVAL;                       // layout not needed by the path
     const int tilesM = (int)ortk_cdiv(p.M, BM), tilesN = (int)ortk_cdiv(p.N, BN);
     const int bk = p.precision ? BK16 : 16;
     int splitk = p.accumulate ? (p.splitk > 0 ? p.splitk : 1) : 1;
@@ -422,31 +496,41 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         kchunk = (int)ortk_cdiv(ksteps, splitk) * bk;
         splitk = (int)ortk_cdiv(p.K, kchunk);
     }
-    if (p.transA && !p.transB) return ORTK_EINVAL;  // not needed by the path
     dim3 grid((unsigned)(tilesM * tilesN * splitk)), block(256);
     hipStream_t s = ortk_s(stream);
     const int key = (p.precision ? 4 : 0) | (p.transA ? 2 : 0) | (p.transB ? 1 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
-        attr_set = true;
-    }
     ProfRec rec{};
     if (g_prof_on) {
         if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return ORTK_EINVAL;
         rec.key = key; rec.flops = 2.0 * p.M * p.N * p.K;
         (void)hipEventRecord(rec.a, s);
     }
-    switch (key) {
-        case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
-        case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
-        case 3: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk); break;
-        case 7: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk); break;
-        default: return ORTK_EINVAL;
+    if (!p.precision) {
+        switch (key) {
+            case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+            case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+            case 3: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
+            default: return ORTK_EINVAL;
+        }
+    } else {
+        auto al = [](const void* q, size_t a_) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) % a_) == 0; };
+        const size_t ea = ortk_esize(p.a_dtype), eb = ortk_esize(p.b_dtype), ec = ortk_esize(p.c_dtype), eg = ortk_esize(p.gate_dtype);
+        const bool fast = p.M % BM == 0 && p.N % BN == 0 && p.K > 0 && p.K % BK16 == 0 && kchunk % BK16 == 0 &&
+                          al(p.A, 16) && al(p.B, 16) && (p.lda * ea) % 16 == 0 && (p.ldb * eb) % 16 == 0 &&
+                          al(p.C, 4 * ec) && (p.ldc % 4) == 0 && al(p.bias, 16) && al(p.resid, 16) && (p.ldr % 4) == 0 &&
+                          al(p.gate, 4 * eg) && (p.ldg % 4) == 0;
+        gemm16_fn fn = key == 4 ? pick16<false, false>(p.a_dtype, p.b_dtype, fast)
+                     : key == 5 ? pick16<false, true>(p.a_dtype, p.b_dtype, fast)
+                                : pick16<true, true>(p.a_dtype, p.b_dtype, fast);
+        // > 64 KB of dynamic LDS needs the attribute once per kernel instance
+        static gemm16_fn seen[32]; static int nseen = 0;
+        bool known = false;
+        for (int i = 0; i < nseen; ++i) known |= seen[i] == fn;
+        if (!known) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
+            if (nseen < 32) seen[nseen++] = fn;
+        }
+        hipLaunchKernelGGL(fn, grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk);
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof->push_back(rec); }
     ORTK_CHECK_LAUNCH();

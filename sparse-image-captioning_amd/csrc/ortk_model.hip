@@ -123,28 +123,32 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
 // ------------------------------------------------------------------------------------------------ workspace
 struct Bump {
     char* base; size_t off;
-    template <typename T> T* take(int64_t n) {
+    template <typename T> T* take(int64_t n) { return reinterpret_cast<T*>(take_bytes((size_t)n * sizeof(T))); }
+    void* take_bytes(size_t bytes) {
         off = (off + 255) & ~(size_t)255;
-        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-        off += (size_t)n * sizeof(T);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
         return p;
     }
 };
 
+// Buffers marked (A) hold MFMA operands only: bf16 in mixed precision (cfg.precision = 1), fp32 otherwise.
 struct EncBuf {   // per encoder layer
-    float *y1, *qkv, *P, *o, *xm, *y2, *h, *xout, *st1, *st2;
+    void *y1 /*A*/; float* qkv; float* P; void* o /*A*/; float* xm; void* y2 /*A*/; void* h /*A*/; float* xout; float *st1, *st2;
 };
 struct DecBuf {   // per decoder layer
-    float *y1, *qkv, *Ps, *o1, *xm1, *y2, *qc, *Pc, *o2, *xm2, *y3, *h, *xout, *st1, *st2, *st3;
+    void* y1 /*A*/; float* qkv; float* Ps; void* o1 /*A*/; float* xm1; void* y2 /*A*/; float* qc; float* Pc; void* o2 /*A*/;
+    float* xm2; void* y3 /*A*/; void* h /*A*/; float* xout; float *st1, *st2, *st3;
 };
 struct TrainWS {
-    int64_t Me, Md, ldv;
-    float *x0, *logbias, *dscore, *mem, *st_mem;
+    int64_t Me, Md, ldv; int adt;
+    void* w16;                              // bf16 working copy of the weight arena (mixed precision)
+    float *x0, *logbias, *dscore; void* mem /*A*/; float* st_mem;
     EncBuf enc[MAXLAYERS];
-    float *dx0, *keymask, *ckv, *dec_out, *st_out, *logits;
+    float *dx0, *keymask, *ckv; void* dec_out /*A*/; float *st_out, *logits; void* dlogits /*A; aliases logits in fp32*/;
     DecBuf dec[MAXLAYERS];
     // backward temporaries
-    float *ga, *gb, *gt, *gy, *gqkv, *gh, *gkv, *scalar;
+    float *ga, *gb, *gy; void *gt /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
     size_t bytes;
 };
 
@@ -152,34 +156,40 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers;
     const int64_t Me = (int64_t)B * S, Md = (int64_t)R * T, Mx = Me > Md ? Me : Md;
     const int64_t spi = B > 0 ? R / B : 1;
-    w.Me = Me; w.Md = Md; w.ldv = ortk_align(c.vocab, 4);
+    w.Me = Me; w.Md = Md; w.ldv = ortk_align(c.vocab, 8);
+    w.adt = c.precision ? ORTK_BF16 : ORTK_F32;
+    const size_t es = ortk_esize(w.adt);
     Bump b{reinterpret_cast<char*>(base), 0};
+    auto act = [&](int64_t n) { return b.take_bytes((size_t)n * es); };
+    Offsets o; build_layout(c, o, nullptr);
+    w.w16 = c.precision ? b.take_bytes((size_t)o.total * 2) : nullptr;
     w.x0 = b.take<float>(Me * d);
     w.logbias = b.take<float>(L * B * H * S * S);
     w.dscore = b.take<float>(L * B * H * S * S);
     for (int l = 0; l < L; ++l) {
         EncBuf& e = w.enc[l];
-        e.y1 = b.take<float>(Me * d); e.qkv = b.take<float>(Me * 3 * d); e.P = b.take<float>((int64_t)B * H * S * S);
-        e.o = b.take<float>(Me * d); e.xm = b.take<float>(Me * d); e.y2 = b.take<float>(Me * d);
-        e.h = b.take<float>(Me * ff); e.xout = b.take<float>(Me * d);
+        e.y1 = act(Me * d); e.qkv = b.take<float>(Me * 3 * d); e.P = b.take<float>((int64_t)B * H * S * S);
+        e.o = act(Me * d); e.xm = b.take<float>(Me * d); e.y2 = act(Me * d);
+        e.h = act(Me * ff); e.xout = b.take<float>(Me * d);
         e.st1 = b.take<float>(Me * 2); e.st2 = b.take<float>(Me * 2);
     }
-    w.mem = b.take<float>(Me * d); w.st_mem = b.take<float>(Me * 2);
+    w.mem = act(Me * d); w.st_mem = b.take<float>(Me * 2);
     w.dx0 = b.take<float>(Md * d); w.keymask = b.take<float>(Md);
     w.ckv = b.take<float>(Me * L * 2 * d);
     for (int l = 0; l < L; ++l) {
         DecBuf& e = w.dec[l];
-        e.y1 = b.take<float>(Md * d); e.qkv = b.take<float>(Md * 3 * d); e.Ps = b.take<float>((int64_t)R * H * T * T);
-        e.o1 = b.take<float>(Md * d); e.xm1 = b.take<float>(Md * d); e.y2 = b.take<float>(Md * d);
+        e.y1 = act(Md * d); e.qkv = b.take<float>(Md * 3 * d); e.Ps = b.take<float>((int64_t)R * H * T * T);
+        e.o1 = act(Md * d); e.xm1 = b.take<float>(Md * d); e.y2 = act(Md * d);
         e.qc = b.take<float>(Md * d); e.Pc = b.take<float>((int64_t)B * H * spi * T * S);
-        e.o2 = b.take<float>(Md * d); e.xm2 = b.take<float>(Md * d); e.y3 = b.take<float>(Md * d);
-        e.h = b.take<float>(Md * ff); e.xout = b.take<float>(Md * d);
+        e.o2 = act(Md * d); e.xm2 = b.take<float>(Md * d); e.y3 = act(Md * d);
+        e.h = act(Md * ff); e.xout = b.take<float>(Md * d);
         e.st1 = b.take<float>(Md * 2); e.st2 = b.take<float>(Md * 2); e.st3 = b.take<float>(Md * 2);
     }
-    w.dec_out = b.take<float>(Md * d); w.st_out = b.take<float>(Md * 2);
+    w.dec_out = act(Md * d); w.st_out = b.take<float>(Md * 2);
     w.logits = b.take<float>(Md * w.ldv);
-    w.ga = b.take<float>(Mx * d); w.gb = b.take<float>(Mx * d); w.gt = b.take<float>(Mx * d); w.gy = b.take<float>(Mx * d);
-    w.gqkv = b.take<float>(Mx * 3 * d); w.gh = b.take<float>(Mx * ff); w.gkv = b.take<float>(Me * L * 2 * d);
+    w.dlogits = c.precision ? act(Md * w.ldv) : (void*)w.logits;
+    w.ga = b.take<float>(Mx * d); w.gb = b.take<float>(Mx * d); w.gy = b.take<float>(Mx * d);
+    w.gt = act(Mx * d); w.gqkv = act(Mx * 3 * d); w.gh = act(Mx * ff); w.gkv = act(Me * L * 2 * d);
     w.scalar = b.take<float>(64);
     w.bytes = (b.off + 255) & ~(size_t)255;
 }
@@ -189,54 +199,68 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
 
 struct Ctx {
     const ortk_config* cfg; hipStream_t s; int prec; uint64_t seed; bool train;
+    const float* P;          // fp32 parameter arena (biases, LayerNorm, embeddings, and weights in fp32 mode)
+    const void* W16;         // bf16 weight arena (mixed precision) or nullptr
+    int adt;                 // dtype of (A) buffers
     float p_drop() const { return train ? cfg->drop : 0.f; }
     float p_src() const { return train ? cfg->drop_src : 0.f; }
     uint32_t sub(uint32_t op) const { return ortk_subseed(seed, op); }
+    const void* W(int64_t off) const {
+        return prec ? (const void*)(reinterpret_cast<const __bf16*>(W16) + off) : (const void*)(P + off);
+    }
+    int wdt() const { return prec ? ORTK_BF16 : ORTK_F32; }
 };
+static inline void* off_elems(void* p, int64_t n, int dt) { return reinterpret_cast<char*>(p) + (size_t)n * ortk_esize(dt); }
+static inline const void* off_elems(const void* p, int64_t n, int dt) { return reinterpret_cast<const char*>(p) + (size_t)n * ortk_esize(dt); }
 
-// Y = epi(X W^T): forward projection
-static int fwd_gemm(const Ctx& c, const float* X, int64_t ldx, const float* W, const float* bias, float* Y, int64_t ldy,
+// Y = epi(X W^T): forward projection (W = weight at arena offset woff, (N,K) row-major)
+static int fwd_gemm(const Ctx& c, const void* X, int xdt, int64_t ldx, int64_t woff, const float* bias, void* Y, int ydt, int64_t ldy,
                     int64_t M, int N, int K, bool relu = false, float drop = 0.f, uint32_t seed = 0, const float* resid = nullptr,
                     int64_t ldr = 0, const float* rowscale = nullptr) {
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
-    a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Y; a.ldc = ldy; a.M = (int)M; a.N = N; a.K = K;
+    a.A = X; a.a_dtype = xdt; a.lda = ldx; a.B = c.W(woff); a.b_dtype = c.wdt(); a.ldb = K; a.C = Y; a.c_dtype = ydt; a.ldc = ldy;
+    a.M = (int)M; a.N = N; a.K = K;
     a.bias = bias; a.relu = relu; a.drop_p = drop; a.drop_seed = seed; a.resid = resid; a.ldr = ldr; a.rowscale = rowscale;
     a.precision = c.prec;
     return ortk_gemm(&a, (ortk_stream)c.s);
 }
 // dX = dY W   (W stored (N_out, K_in)); optional ReLU/dropout gate
-static int dgrad_gemm(const Ctx& c, const float* dY, int64_t lddy, const float* W, float* dX, int64_t lddx, int64_t M, int Nout,
-                      int Kin, const float* gate = nullptr, int64_t ldg = 0, float gate_scale = 1.f) {
+static int dgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, int64_t woff, void* dX, int dxdt, int64_t lddx, int64_t M,
+                      int Nout, int Kin, const void* gate = nullptr, int gdt = 0, int64_t ldg = 0, float gate_scale = 1.f) {
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
-    a.A = dY; a.lda = lddy; a.B = W; a.ldb = Kin; a.transB = 1; a.C = dX; a.ldc = lddx; a.M = (int)M; a.N = Kin; a.K = Nout;
-    a.gate = gate; a.ldg = ldg; a.gate_scale = gate_scale; a.precision = c.prec;
+    a.A = dY; a.a_dtype = dydt; a.lda = lddy; a.B = c.W(woff); a.b_dtype = c.wdt(); a.ldb = Kin; a.transB = 1;
+    a.C = dX; a.c_dtype = dxdt; a.ldc = lddx; a.M = (int)M; a.N = Kin; a.K = Nout;
+    a.gate = gate; a.gate_dtype = gdt; a.ldg = ldg; a.gate_scale = gate_scale; a.precision = c.prec;
     return ortk_gemm(&a, (ortk_stream)c.s);
 }
 // dW += dY^T X ; db += colsum(dY)
-static int wgrad_gemm(const Ctx& c, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, float* db, int64_t M,
-                      int Nout, int Kin) {
+static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, const void* X, int xdt, int64_t ldx, float* dW, float* db,
+                      int64_t M, int Nout, int Kin) {
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
-    a.A = dY; a.lda = lddy; a.transA = 1; a.B = X; a.ldb = ldx; a.transB = 1; a.C = dW; a.ldc = Kin;
+    a.A = dY; a.a_dtype = dydt; a.lda = lddy; a.transA = 1; a.B = X; a.b_dtype = xdt; a.ldb = ldx; a.transB = 1; a.C = dW; a.ldc = Kin;
     a.M = Nout; a.N = Kin; a.K = (int)M; a.accumulate = 1; a.precision = c.prec;
     const int64_t tiles = ortk_cdiv(Nout, 128) * ortk_cdiv(Kin, 128);
     int64_t sk = ortk_cdiv(768, tiles);
     const int64_t max_sk = std::max<int64_t>(1, M / 256);
     a.splitk = (int)std::max<int64_t>(1, std::min(sk, max_sk));
     TRY(ortk_gemm(&a, (ortk_stream)c.s));
-    if (db) TRY(ortk_colsum(dY, lddy, db, M, Nout, (ortk_stream)c.s));
+    if (db) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)c.s));
     return 0;
 }
-static int ln_fwd(const Ctx& c, const float* x, const float* P, int64_t a, int64_t b, float* y, float* st, int64_t rows) {
-    return ortk_layernorm_fwd(x, P + a, P + b, y, st, rows, c.cfg->d_model, 1e-6f, (ortk_stream)c.s);
+static int ln_fwd(const Ctx& c, const float* x, int64_t a, int64_t b, void* y, int ydt, float* st, int64_t rows) {
+    return ortk_layernorm_fwd(x, c.P + a, c.P + b, y, ydt, st, rows, c.cfg->d_model, 1e-6f, (ortk_stream)c.s);
 }
-static int ln_bwd(const Ctx& c, const float* dy, const float* x, const float* P, float* G, int64_t a, int64_t b, const float* st,
+static int ln_bwd(const Ctx& c, const float* dy, const float* x, float* G, int64_t a, int64_t b, const float* st,
                   const float* dres, float* dx, int64_t rows) {
-    return ortk_layernorm_bwd(dy, x, P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, (ortk_stream)c.s);
+    return ortk_layernorm_bwd(dy, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, (ortk_stream)c.s);
 }
-// gradient through a residual-branch dropout: returns the buffer holding dx * keep/(1-p)
-static int drop_bwd(const Ctx& c, const float* dx, float* tmp, int64_t n, uint32_t op, const float** out) {
-    if (c.p_drop() > 0.f) { TRY(ortk_dropout_apply(dx, tmp, n, c.p_drop(), c.sub(op), (ortk_stream)c.s)); *out = tmp; }
-    else *out = dx;
+// gradient through a residual-branch dropout: the buffer (and its dtype) holding dx * keep/(1-p).
+// Mixed precision always goes through `tmp` (it also performs the fp32 -> bf16 conversion of the GEMM operand).
+static int drop_bwd(const Ctx& c, const float* dx, void* tmp, int64_t n, uint32_t op, const void** out, int* out_dt) {
+    if (c.p_drop() > 0.f || c.adt == ORTK_BF16) {
+        TRY(ortk_dropout_apply(dx, tmp, c.adt, n, c.p_drop(), c.sub(op), (ortk_stream)c.s));
+        *out = tmp; *out_dt = c.adt;
+    } else { *out = dx; *out_dt = ORTK_F32; }
     return 0;
 }
 
@@ -258,37 +282,39 @@ enum Op : uint32_t { OP_SRC = 1, OP_EMB = 2, OP_ENC = 16, OP_DEC = 16 + 16 * MAX
 static inline uint32_t eop(int l, int k) { return OP_ENC + 16 * l + k; }
 static inline uint32_t dop(int l, int k) { return OP_DEC + 16 * l + k; }
 
-struct EncPtrs { float *y1, *qkv, *P, *o, *xm, *y2, *h, *xout, *st1, *st2; };
+struct EncPtrs { void* y1; float* qkv; float* P; void* o; float* xm; void* y2; void* h; float* xout; float *st1, *st2; };
 
-// encoder stack; `bufs[l]` may alias between layers when nothing has to be kept for a backward pass
-static int encoder_forward(const Ctx& c, const Offsets& o, const float* P, const float* feats, const float* boxes,
-                           const float* masks, int B, int S, float* x0, float* logbias, const EncPtrs* bufs, float* mem,
-                           float* st_mem) {
+// encoder stack; `bufs[l]` may alias between layers when nothing has to be kept for a backward pass.
+// `mem` receives the final LayerNorm in dtype `mem_dt`.
+static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, const float* boxes, const float* masks, int B, int S,
+                           float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem) {
     const ortk_config& cfg = *c.cfg;
-    const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H;
+    const float* P = c.P;
+    const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H, A = c.adt;
     const int64_t Me = (int64_t)B * S;
     // att_embed: relu(Linear) on valid regions, zeros elsewhere, dropout (relation_transformer.py:331-333,349-350)
-    TRY(fwd_gemm(c, feats, cfg.feat, P + o.att_w, P + o.att_b, x0, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC), nullptr, 0, masks));
+    TRY(fwd_gemm(c, feats, ORTK_F32, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
+                 nullptr, 0, masks));
     const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS];
     for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; }
     TRY(ortk_box_logbias_fwd(boxes, wg, bg, dim_mat(), logbias, L, B, S, H, (ortk_stream)c.s));
     const float* x = x0;
     for (int l = 0; l < L; ++l) {
         const EncOff& e = o.enc[l]; const EncPtrs& b = bufs[l];
-        TRY(ln_fwd(c, x, P, e.n0a, e.n0b, b.y1, b.st1, Me));
-        TRY(fwd_gemm(c, b.y1, d, P + e.wqkv, P + e.bqkv, b.qkv, 3 * d, Me, 3 * d, d));
+        TRY(ln_fwd(c, x, e.n0a, e.n0b, b.y1, A, b.st1, Me));
+        TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Me, 3 * d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.ldo = d;
+        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
         a.kmask = masks; a.bias = logbias + (int64_t)l * B * H * S * S; a.p = b.P;
         a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         TRY(ortk_attention_fwd(&a, (ortk_stream)c.s));
-        TRY(fwd_gemm(c, b.o, d, P + e.wo, P + e.bo, b.xm, d, Me, d, d, false, c.p_drop(), c.sub(eop(l, 1)), x, d));
-        TRY(ln_fwd(c, b.xm, P, e.n1a, e.n1b, b.y2, b.st2, Me));
-        TRY(fwd_gemm(c, b.y2, d, P + e.w1, P + e.b1, b.h, ff, Me, ff, d, true, c.p_drop(), c.sub(eop(l, 2))));
-        TRY(fwd_gemm(c, b.h, ff, P + e.w2, P + e.b2, b.xout, d, Me, d, ff, false, c.p_drop(), c.sub(eop(l, 3)), b.xm, d));
+        TRY(fwd_gemm(c, b.o, A, d, e.wo, P + e.bo, b.xm, ORTK_F32, d, Me, d, d, false, c.p_drop(), c.sub(eop(l, 1)), x, d));
+        TRY(ln_fwd(c, b.xm, e.n1a, e.n1b, b.y2, A, b.st2, Me));
+        TRY(fwd_gemm(c, b.y2, A, d, e.w1, P + e.b1, b.h, A, ff, Me, ff, d, true, c.p_drop(), c.sub(eop(l, 2))));
+        TRY(fwd_gemm(c, b.h, A, ff, e.w2, P + e.b2, b.xout, ORTK_F32, d, Me, d, ff, false, c.p_drop(), c.sub(eop(l, 3)), b.xm, d));
         x = b.xout;
     }
-    TRY(ln_fwd(c, x, P, o.enc_na, o.enc_nb, mem, st_mem, Me));
+    TRY(ln_fwd(c, x, o.enc_na, o.enc_nb, mem, mem_dt, st_mem, Me));
     return 0;
 }
 
@@ -297,6 +323,12 @@ static void enc_ptrs_from_ws(const TrainWS& w, int L, EncPtrs* out) {
         const EncBuf& e = w.enc[l];
         out[l] = EncPtrs{e.y1, e.qkv, e.P, e.o, e.xm, e.y2, e.h, e.xout, e.st1, e.st2};
     }
+}
+
+// bf16 working copy of the trainable arena (weights are the B operand of every forward / dgrad GEMM)
+static int make_w16(const ortk_config* cfg, const Offsets& o, const float* params, void* w16, ortk_stream stream) {
+    if (!cfg->precision) return 0;
+    return ortk_cast_bf16(params, w16, o.total, stream);
 }
 
 }  // namespace ortk
@@ -370,47 +402,48 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     if (logp_out && (ldv_out < cfg->vocab)) return ORTK_EINVAL;
-    Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0};
+    TRY(make_w16(cfg, o, params, w.w16, stream));
+    Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
     const float* P = params;
-    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab;
+    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const int64_t Me = w.Me, Md = w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
-    TRY(encoder_forward(c, o, P, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, w.st_mem));
+    TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem));
     // decoder
     TRY(ortk_embed_fwd(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, R, T, 0, d, cfg->pad_id, c.p_drop(),
                        c.sub(OP_EMB), stream));
-    TRY(fwd_gemm(c, w.mem, d, P + o.ckv_w, P + o.ckv_b, w.ckv, (int64_t)L * 2 * d, Me, L * 2 * d, d));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, (int64_t)L * 2 * d, Me, L * 2 * d, d));
     const float* x = w.dx0;
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
-        TRY(ln_fwd(c, x, P, e.n0a, e.n0b, b.y1, b.st1, Md));
-        TRY(fwd_gemm(c, b.y1, d, P + e.wqkv, P + e.bqkv, b.qkv, 3 * d, Md, 3 * d, d));
+        TRY(ln_fwd(c, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
+        TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Md, 3 * d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.ldo = d;
+        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
         a.kmask = w.keymask; a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.causal_period = T;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
         TRY(ortk_attention_fwd(&a, stream));
-        TRY(fwd_gemm(c, b.o1, d, P + e.wo, P + e.bo, b.xm1, d, Md, d, d, false, c.p_drop(), c.sub(dop(l, 1)), x, d));
-        TRY(ln_fwd(c, b.xm1, P, e.n1a, e.n1b, b.y2, b.st2, Md));
-        TRY(fwd_gemm(c, b.y2, d, P + e.cqw, P + e.cqb, b.qc, d, Md, d, d));
+        TRY(fwd_gemm(c, b.o1, A, d, e.wo, P + e.bo, b.xm1, ORTK_F32, d, Md, d, d, false, c.p_drop(), c.sub(dop(l, 1)), x, d));
+        TRY(ln_fwd(c, b.xm1, e.n1a, e.n1b, b.y2, A, b.st2, Md));
+        TRY(fwd_gemm(c, b.y2, A, d, e.cqw, P + e.cqb, b.qc, ORTK_F32, d, Md, d, d));
         std::memset(&a, 0, sizeof(a));
         a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
-        a.o = b.o2; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
+        a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         TRY(ortk_attention_fwd(&a, stream));
-        TRY(fwd_gemm(c, b.o2, d, P + e.cow, P + e.cob, b.xm2, d, Md, d, d, false, c.p_drop(), c.sub(dop(l, 3)), b.xm1, d));
-        TRY(ln_fwd(c, b.xm2, P, e.n2a, e.n2b, b.y3, b.st3, Md));
-        TRY(fwd_gemm(c, b.y3, d, P + e.w1, P + e.b1, b.h, ff, Md, ff, d, true, c.p_drop(), c.sub(dop(l, 4))));
-        TRY(fwd_gemm(c, b.h, ff, P + e.w2, P + e.b2, b.xout, d, Md, d, ff, false, c.p_drop(), c.sub(dop(l, 5)), b.xm2, d));
+        TRY(fwd_gemm(c, b.o2, A, d, e.cow, P + e.cob, b.xm2, ORTK_F32, d, Md, d, d, false, c.p_drop(), c.sub(dop(l, 3)), b.xm1, d));
+        TRY(ln_fwd(c, b.xm2, e.n2a, e.n2b, b.y3, A, b.st3, Md));
+        TRY(fwd_gemm(c, b.y3, A, d, e.w1, P + e.b1, b.h, A, ff, Md, ff, d, true, c.p_drop(), c.sub(dop(l, 4))));
+        TRY(fwd_gemm(c, b.h, A, ff, e.w2, P + e.b2, b.xout, ORTK_F32, d, Md, d, ff, false, c.p_drop(), c.sub(dop(l, 5)), b.xm2, d));
         x = b.xout;
     }
-    TRY(ln_fwd(c, x, P, o.dec_na, o.dec_nb, w.dec_out, w.st_out, Md));
+    TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.dec_out, A, w.st_out, Md));
     if (logp_out) {
-        TRY(fwd_gemm(c, w.dec_out, d, P + o.gen_w, P + o.gen_b, logp_out, ldv_out, Md, V, d));
+        TRY(fwd_gemm(c, w.dec_out, A, d, o.gen_w, P + o.gen_b, logp_out, ORTK_F32, ldv_out, Md, V, d));
         TRY(ortk_log_softmax(logp_out, Md, V, ldv_out, 1.f, stream));
     } else {
-        TRY(fwd_gemm(c, w.dec_out, d, P + o.gen_w, P + o.gen_b, w.logits, w.ldv, Md, V, d));
+        TRY(fwd_gemm(c, w.dec_out, A, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, Md, V, d));
     }
     return 0;
 }
@@ -424,7 +457,7 @@ extern "C" int ortk_loss(const ortk_config* cfg, const ortk_batch* bt, void* ws,
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     TRY(ortk_fill(loss_dev, 1, 0.f, stream));
     return ortk_xent_fwd_bwd(w.logits, bt->seqs + 1, bt->seq_stride, bt->T, bt->tok_weight, norm_dev, loss_dev, w.Md, cfg->vocab,
-                             w.ldv, stream);
+                             w.ldv, w.dlogits, w.adt, w.ldv, stream);
 }
 
 extern "C" int ortk_loss_external(const ortk_config* cfg, const ortk_batch* bt, void* ws, size_t ws_bytes, const float* logp,
@@ -434,10 +467,8 @@ extern "C" int ortk_loss_external(const ortk_config* cfg, const ortk_batch* bt, 
     if (!ws || !logp || !dlogp || ldv < cfg->vocab) return ORTK_EINVAL;
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
-    return ortk_log_softmax_bwd(logp, dlogp, ldv, w.logits, w.ldv, w.Md, cfg->vocab, stream);
+    return ortk_log_softmax_bwd(logp, dlogp, ldv, w.dlogits, w.adt, w.ldv, w.Md, cfg->vocab, stream);
 }
-
-extern "C" int ortk_gate_apply(const float* x, const float* gate, float* y, int64_t n, float scale, ortk_stream stream);
 
 extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float* grads, const ortk_batch* bt, void* ws,
                              size_t ws_bytes, int32_t train, uint64_t seed, ortk_stream stream) {
@@ -447,96 +478,100 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
     Offsets o; build_layout(*cfg, o, nullptr);
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
-    Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0};   // must match the forward's (train, seed)
-    const float* P = params; float* G = grads;
-    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab;
+    // (train, seed) must match the forward's; the bf16 weight copy made by the forward is still in the workspace
+    Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
+    float* G = grads;
+    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const int64_t Me = w.Me, Md = w.Md;
     const float inv_keep = c.p_drop() > 0.f ? 1.f / (1.f - c.p_drop()) : 1.f;
 
     // generator
-    TRY(wgrad_gemm(c, w.logits, w.ldv, w.dec_out, d, G + o.gen_w, G + o.gen_b, Md, V, d));
-    TRY(dgrad_gemm(c, w.logits, w.ldv, P + o.gen_w, w.gy, d, Md, V, d));
+    TRY(wgrad_gemm(c, w.dlogits, A, w.ldv, w.dec_out, A, d, G + o.gen_w, G + o.gen_b, Md, V, d));
+    TRY(dgrad_gemm(c, w.dlogits, A, w.ldv, o.gen_w, w.gy, ORTK_F32, d, Md, V, d));
     float* dx = w.ga; float* dx2 = w.gb;
-    TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, P, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md));
-    TRY(ortk_fill(w.gkv, Me * L * 2 * d, 0.f, stream));
+    TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md));
     for (int l = L - 1; l >= 0; --l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         const float* xin = l == 0 ? w.dx0 : w.dec[l - 1].xout;
-        const float* dt;
+        const void* dt; int dtt;
         // feed-forward sublayer
-        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 5), &dt));
-        TRY(wgrad_gemm(c, dt, d, b.h, ff, G + e.w2, G + e.b2, Md, d, ff));
-        TRY(dgrad_gemm(c, dt, d, P + e.w2, w.gh, ff, Md, d, ff, b.h, ff, inv_keep));
-        TRY(wgrad_gemm(c, w.gh, ff, b.y3, d, G + e.w1, G + e.b1, Md, ff, d));
-        TRY(dgrad_gemm(c, w.gh, ff, P + e.w1, w.gy, d, Md, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm2, P, G, e.n2a, e.n2b, b.st3, dx, dx2, Md));
+        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 5), &dt, &dtt));
+        TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Md, d, ff));
+        TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Md, d, ff, b.h, A, ff, inv_keep));
+        TRY(wgrad_gemm(c, w.gh, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
+        TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Md, ff, d));
+        TRY(ln_bwd(c, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, Md));
         // cross-attention sublayer
-        TRY(drop_bwd(c, dx2, w.gt, Md * d, dop(l, 3), &dt));
-        TRY(wgrad_gemm(c, dt, d, b.o2, d, G + e.cow, G + e.cob, Md, d, d));
-        TRY(dgrad_gemm(c, dt, d, P + e.cow, w.gy, d, Md, d, d));
+        TRY(drop_bwd(c, dx2, w.gt, Md * d, dop(l, 3), &dt, &dtt));
+        TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
+        TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
         a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
         a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
-        a.d_o = w.gy; a.lddo = d; a.dq = w.gt; a.lddq = d;
-        a.d_k = w.gkv + (int64_t)l * 2 * d; a.dv = w.gkv + (int64_t)l * 2 * d + d; a.lddk = a.lddv = (int64_t)L * 2 * d;
+        a.d_o = w.gy; a.lddo = d; a.dq = w.gt; a.lddq = d; a.dqkv_dtype = A;
+        a.d_k = off_elems(w.gkv, (int64_t)l * 2 * d, A); a.dv = off_elems(w.gkv, (int64_t)l * 2 * d + d, A);
+        a.lddk = a.lddv = (int64_t)L * 2 * d;
         TRY(ortk_attention_bwd(&a, stream));
-        TRY(wgrad_gemm(c, w.gt, d, b.y2, d, G + e.cqw, G + e.cqb, Md, d, d));
-        TRY(dgrad_gemm(c, w.gt, d, P + e.cqw, w.gy, d, Md, d, d));
-        TRY(ln_bwd(c, w.gy, b.xm1, P, G, e.n1a, e.n1b, b.st2, dx2, dx, Md));
+        TRY(wgrad_gemm(c, w.gt, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
+        TRY(dgrad_gemm(c, w.gt, A, d, e.cqw, w.gy, ORTK_F32, d, Md, d, d));
+        TRY(ln_bwd(c, w.gy, b.xm1, G, e.n1a, e.n1b, b.st2, dx2, dx, Md));
         // self-attention sublayer
-        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 1), &dt));
-        TRY(wgrad_gemm(c, dt, d, b.o1, d, G + e.wo, G + e.bo, Md, d, d));
-        TRY(dgrad_gemm(c, dt, d, P + e.wo, w.gy, d, Md, d, d));
+        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 1), &dt, &dtt));
+        TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
+        TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Md, d, d));
         std::memset(&a, 0, sizeof(a));
         a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
-        a.d_o = w.gy; a.lddo = d; a.dq = w.gqkv; a.d_k = w.gqkv + d; a.dv = w.gqkv + 2 * d; a.lddq = a.lddk = a.lddv = 3 * d;
+        a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
+        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, d, A); a.dv = off_elems(w.gqkv, 2 * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         TRY(ortk_attention_bwd(&a, stream));
-        TRY(wgrad_gemm(c, w.gqkv, 3 * d, b.y1, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
-        TRY(dgrad_gemm(c, w.gqkv, 3 * d, P + e.wqkv, w.gy, d, Md, 3 * d, d));
-        TRY(ln_bwd(c, w.gy, xin, P, G, e.n0a, e.n0b, b.st1, dx, dx2, Md));
+        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
+        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, 3 * d, d));
+        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md));
         std::swap(dx, dx2);
     }
     TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), stream));
     // cross-attention K/V projections of all layers, and the gradient of the encoder memory
-    TRY(wgrad_gemm(c, w.gkv, (int64_t)L * 2 * d, w.mem, d, G + o.ckv_w, G + o.ckv_b, Me, L * 2 * d, d));
-    TRY(dgrad_gemm(c, w.gkv, (int64_t)L * 2 * d, P + o.ckv_w, w.gy, d, Me, L * 2 * d, d));
+    TRY(wgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, L * 2 * d, d));
+    TRY(dgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, o.ckv_w, w.gy, ORTK_F32, d, Me, L * 2 * d, d));
     // encoder
     dx = w.ga; dx2 = w.gb;
-    TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, P, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me));
+    TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me));
     for (int l = L - 1; l >= 0; --l) {
         const EncOff& e = o.enc[l]; const EncBuf& b = w.enc[l];
         const float* xin = l == 0 ? w.x0 : w.enc[l - 1].xout;
-        const float* dt;
-        TRY(drop_bwd(c, dx, w.gt, Me * d, eop(l, 3), &dt));
-        TRY(wgrad_gemm(c, dt, d, b.h, ff, G + e.w2, G + e.b2, Me, d, ff));
-        TRY(dgrad_gemm(c, dt, d, P + e.w2, w.gh, ff, Me, d, ff, b.h, ff, inv_keep));
-        TRY(wgrad_gemm(c, w.gh, ff, b.y2, d, G + e.w1, G + e.b1, Me, ff, d));
-        TRY(dgrad_gemm(c, w.gh, ff, P + e.w1, w.gy, d, Me, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm, P, G, e.n1a, e.n1b, b.st2, dx, dx2, Me));
-        TRY(drop_bwd(c, dx2, w.gt, Me * d, eop(l, 1), &dt));
-        TRY(wgrad_gemm(c, dt, d, b.o, d, G + e.wo, G + e.bo, Me, d, d));
-        TRY(dgrad_gemm(c, dt, d, P + e.wo, w.gy, d, Me, d, d));
+        const void* dt; int dtt;
+        TRY(drop_bwd(c, dx, w.gt, Me * d, eop(l, 3), &dt, &dtt));
+        TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Me, d, ff));
+        TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Me, d, ff, b.h, A, ff, inv_keep));
+        TRY(wgrad_gemm(c, w.gh, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
+        TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Me, ff, d));
+        TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me));
+        TRY(drop_bwd(c, dx2, w.gt, Me * d, eop(l, 1), &dt, &dtt));
+        TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
+        TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Me, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
         a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
-        a.d_o = w.gy; a.lddo = d; a.dq = w.gqkv; a.d_k = w.gqkv + d; a.dv = w.gqkv + 2 * d; a.lddq = a.lddk = a.lddv = 3 * d;
+        a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
+        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, d, A); a.dv = off_elems(w.gqkv, 2 * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         a.dscore = w.dscore + (int64_t)l * B * H * S * S;
         TRY(ortk_attention_bwd(&a, stream));
-        TRY(wgrad_gemm(c, w.gqkv, 3 * d, b.y1, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
-        TRY(dgrad_gemm(c, w.gqkv, 3 * d, P + e.wqkv, w.gy, d, Me, 3 * d, d));
-        TRY(ln_bwd(c, w.gy, xin, P, G, e.n0a, e.n0b, b.st1, dx2, dx, Me));
+        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
+        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, 3 * d, d));
+        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me));
     }
     // geometry bias weights
     {
+        const float* P = params;
         const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS]; float* dwg[MAXLAYERS]; float* dbg[MAXLAYERS];
         for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; dwg[l] = G + o.enc[l].wg; dbg[l] = G + o.enc[l].bg; }
         TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, dim_mat(), w.dscore, dwg, dbg, L, B, S, H, stream));
     }
     // att_embed: x0 = dropout(relu(.) * mask)  ->  d(pre-activation) = dx * [x0 > 0] / (1 - p_src)
-    TRY(ortk_gate_apply(dx, w.x0, w.gt, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));
-    TRY(wgrad_gemm(c, w.gt, d, bt->att_feats, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
+    TRY(ortk_gate_apply(dx, w.x0, w.gt, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));
+    TRY(wgrad_gemm(c, w.gt, A, d, bt->att_feats, ORTK_F32, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
     return 0;
 }
 
@@ -554,29 +589,35 @@ extern "C" int ortk_encode(const ortk_config* cfg, const float* params, const fl
 // ================================================================================================ decoding
 namespace ortk {
 struct DecodeWS {
-    int64_t ldv;
-    float *x0, *logbias, *mem, *st, *ckv;
+    int64_t ldv; int adt;
+    void* w16;
+    float *x0, *logbias; void* mem /*A*/; float *st, *ckv;
     EncPtrs enc;                       // one set of encoder buffers, reused by every layer
-    float *xa, *xb, *y, *qkv, *o, *q, *h, *logits;
+    float *xa, *xb; void* y /*A*/; float* qkv; void* o /*A*/; float* q; void* h /*A*/; float* logits;
     float *cache_k[MAXLAYERS], *cache_v[MAXLAYERS];
-    int64_t* it; int64_t* seq64; float* lp; int32_t *unfinished, *last_step;
+    int64_t* it; int32_t *unfinished, *last_step;
     int32_t *bseq[2], *kvidx[2], *done_seq, *done_len, *done_cnt; float *blp[2], *cum, *done_lp; double* done_p;
     size_t bytes;
 };
 static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
     const int64_t Me = (int64_t)B * S, rows = (int64_t)B * K;
-    w.ldv = ortk_align(c.vocab, 4);
+    w.ldv = ortk_align(c.vocab, 8);
+    w.adt = c.precision ? ORTK_BF16 : ORTK_F32;
+    const size_t es = ortk_esize(w.adt);
     Bump b{reinterpret_cast<char*>(base), 0};
+    auto act = [&](int64_t n) { return b.take_bytes((size_t)n * es); };
+    Offsets o; build_layout(c, o, nullptr);
+    w.w16 = c.precision ? b.take_bytes((size_t)o.total * 2) : nullptr;
     w.x0 = b.take<float>(Me * d); w.logbias = b.take<float>(L * B * H * S * S);
-    w.enc.y1 = b.take<float>(Me * d); w.enc.qkv = b.take<float>(Me * 3 * d); w.enc.P = nullptr; w.enc.o = b.take<float>(Me * d);
-    w.enc.xm = b.take<float>(Me * d); w.enc.y2 = b.take<float>(Me * d); w.enc.h = b.take<float>(Me * ff);
-    w.enc.xout = b.take<float>(Me * d); w.enc.st1 = b.take<float>(Me * 2); w.enc.st2 = w.enc.st1;
-    w.mem = b.take<float>(Me * d); w.st = b.take<float>(std::max(Me, rows) * 2);
+    w.enc.y1 = act(Me * d); w.enc.qkv = b.take<float>(Me * 3 * d); w.enc.P = nullptr; w.enc.o = act(Me * d);
+    w.enc.xm = b.take<float>(Me * d); w.enc.y2 = act(Me * d); w.enc.h = act(Me * ff);
+    w.enc.xout = w.x0; w.enc.st1 = b.take<float>(Me * 2); w.enc.st2 = w.enc.st1;
+    w.mem = b.take_bytes((size_t)Me * d * 4); w.st = b.take<float>(std::max(Me, rows) * 2);
     w.ckv = b.take<float>(Me * L * 2 * d);
-    w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = b.take<float>(rows * d);
-    w.qkv = b.take<float>(rows * 3 * d); w.o = b.take<float>(rows * d); w.q = b.take<float>(rows * d);
-    w.h = b.take<float>(rows * ff); w.logits = b.take<float>(rows * w.ldv);
+    w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = act(rows * d);
+    w.qkv = b.take<float>(rows * 3 * d); w.o = act(rows * d); w.q = b.take<float>(rows * d);
+    w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take<float>(rows * T * d); w.cache_v[l] = b.take<float>(rows * T * d); }
     w.it = b.take<int64_t>(rows);
     if (beam) {
@@ -597,10 +638,11 @@ static int encode_impl(const ortk_config* cfg, const float* params, const float*
     Offsets o; build_layout(*cfg, o, nullptr);
     DecodeWS w; carve_decode(*cfg, B, S, 1, false, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
-    Ctx c{cfg, ortk_s(stream), cfg->precision, 0, false};
+    TRY(make_w16(cfg, o, params, w.w16, stream));
+    Ctx c{cfg, ortk_s(stream), cfg->precision, 0, false, params, w.w16, w.adt};
     EncPtrs ep[MAXLAYERS];
-    for (int l = 0; l < cfg->n_layers; ++l) { ep[l] = w.enc; ep[l].xout = w.x0; }
-    return encoder_forward(c, o, params, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, memory_out, w.st);
+    for (int l = 0; l < cfg->n_layers; ++l) ep[l] = w.enc;
+    return encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, memory_out, ORTK_F32, w.st);
 }
 
 static int decode_K(const ortk_decode_opts* o) {
@@ -631,16 +673,17 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     hipStream_t s = ortk_s(stream);
-    Ctx c{cfg, s, cfg->precision, 0, false};
+    TRY(make_w16(cfg, o, params, w.w16, stream));
+    Ctx c{cfg, s, cfg->precision, 0, false, params, w.w16, w.adt};
     const float* P = params;
-    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, T = cfg->seq_len;
+    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, T = cfg->seq_len, A = w.adt;
     const int64_t Me = (int64_t)B * S;
     // No activations are kept: every encoder layer reuses one buffer set, and the residual stream is updated in
     // place (x is dead once xm = x + attn(...) exists, so the FFN sublayer writes its output back over x).
     EncPtrs ep[MAXLAYERS];
-    for (int l = 0; l < L; ++l) { ep[l] = w.enc; ep[l].xout = w.x0; }
-    TRY(encoder_forward(c, o, P, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, w.st));
-    TRY(fwd_gemm(c, w.mem, d, P + o.ckv_w, P + o.ckv_b, w.ckv, (int64_t)L * 2 * d, Me, L * 2 * d, d));
+    for (int l = 0; l < L; ++l) ep[l] = w.enc;
+    TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, (int64_t)L * 2 * d, Me, L * 2 * d, d));
 
     const int64_t rows_full = (int64_t)B * K;
     BeamState bs; std::memset(&bs, 0, sizeof(bs));
@@ -671,31 +714,31 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         float* x = w.xa; float* xn = w.xb;
         for (int l = 0; l < L; ++l) {
             const DecOff& e = o.dec[l];
-            TRY(ln_fwd(c, x, P, e.n0a, e.n0b, w.y, w.st, rows));
-            TRY(fwd_gemm(c, w.y, d, P + e.wqkv, P + e.bqkv, w.qkv, 3 * d, rows, 3 * d, d));
+            TRY(ln_fwd(c, x, e.n0a, e.n0b, w.y, A, w.st, rows));
+            TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, 3 * d, d));
             TRY(kv_append(w.qkv, w.cache_k[l], w.cache_v[l], rows, d, row_mult, T, t, s));
             ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-            a.q = w.qkv; a.ldq = 3 * d; a.k = w.cache_k[l]; a.v = w.cache_v[l]; a.ldk = a.ldv = d; a.o = w.o; a.ldo = d;
+            a.q = w.qkv; a.ldq = 3 * d; a.k = w.cache_k[l]; a.v = w.cache_v[l]; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
             a.nkv = (int)rows; a.H = H; a.Lq = 1; a.Lk = t + 1; a.dk = dk;
             if (beam) a.kv_index = w.kvidx[t & 1]; else a.kv_group_stride = T;
             TRY(ortk_attention_fwd(&a, stream));
-            TRY(fwd_gemm(c, w.o, d, P + e.wo, P + e.bo, xn, d, rows, d, d, false, 0.f, 0, x, d));
+            TRY(fwd_gemm(c, w.o, A, d, e.wo, P + e.bo, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
             std::swap(x, xn);
-            TRY(ln_fwd(c, x, P, e.n1a, e.n1b, w.y, w.st, rows));
-            TRY(fwd_gemm(c, w.y, d, P + e.cqw, P + e.cqb, w.q, d, rows, d, d));
+            TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
+            TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
             std::memset(&a, 0, sizeof(a));
             a.q = w.q; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
-            a.o = w.o; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
+            a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
             TRY(ortk_attention_fwd(&a, stream));
-            TRY(fwd_gemm(c, w.o, d, P + e.cow, P + e.cob, xn, d, rows, d, d, false, 0.f, 0, x, d));
+            TRY(fwd_gemm(c, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
             std::swap(x, xn);
-            TRY(ln_fwd(c, x, P, e.n2a, e.n2b, w.y, w.st, rows));
-            TRY(fwd_gemm(c, w.y, d, P + e.w1, P + e.b1, w.h, ff, rows, ff, d, true));
-            TRY(fwd_gemm(c, w.h, ff, P + e.w2, P + e.b2, xn, d, rows, d, ff, false, 0.f, 0, x, d));
+            TRY(ln_fwd(c, x, e.n2a, e.n2b, w.y, A, w.st, rows));
+            TRY(fwd_gemm(c, w.y, A, d, e.w1, P + e.b1, w.h, A, ff, rows, ff, d, true));
+            TRY(fwd_gemm(c, w.h, A, ff, e.w2, P + e.b2, xn, ORTK_F32, d, rows, d, ff, false, 0.f, 0, x, d));
             std::swap(x, xn);
         }
-        TRY(ln_fwd(c, x, P, o.dec_na, o.dec_nb, w.y, w.st, rows));
-        TRY(fwd_gemm(c, w.y, d, P + o.gen_w, P + o.gen_b, w.logits, w.ldv, rows, V, d));
+        TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.y, A, w.st, rows));
+        TRY(fwd_gemm(c, w.y, A, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, V, d));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.
         const float scale = (beam && t > 0) ? 1.f / op->temperature : 1.f;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ x, int d, int
 
 template <bool VEC, int NREG>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
-                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     const float* __restrict__ b, void* __restrict__ y, int y_dt,
                                                      float* __restrict__ stats, int64_t rows, int d, float eps) {
     using C = Cols<VEC, NREG>;
     const int lane = threadIdx.x & 63;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float sd = sqrtf(wave_sum(q) / (float)(d - 1));
     const float rinv = 1.f / (sd + eps);
     if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = sd; }
-    float* yr = y + row * d;
+    const int64_t yoff = row * d;
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
         const int c = C::col(lane, it);
@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 o.y = aa.y * (v[it * 4 + 1] - mean) * rinv + bb.y;
                 o.z = aa.z * (v[it * 4 + 2] - mean) * rinv + bb.z;
                 o.w = aa.w * (v[it * 4 + 3] - mean) * rinv + bb.w;
-                *reinterpret_cast<float4*>(yr + c) = o;
+                st_elem4(y, yoff + c, y_dt, o);
             } else {
-                yr[c] = a[c] * (v[it] - mean) * rinv + b[c];
+                st_elem(y, yoff + c, y_dt, a[c] * (v[it] - mean) * rinv + b[c]);
             }
         }
     }
@@ -161,13 +161,13 @@ inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintp
 
 }  // namespace
 
-extern "C" int ortk_layernorm_fwd(const float* x, const float* a, const float* b, float* y, float* stats, int64_t rows,
-                                  int32_t d, float eps, ortk_stream stream) {
-    if (!x || !a || !b || !y || d < 2 || d > 2048 || rows < 0) return ORTK_EINVAL;
+extern "C" int ortk_layernorm_fwd(const float* x, const float* a, const float* b, void* y, int32_t y_dtype, float* stats,
+                                  int64_t rows, int32_t d, float eps, ortk_stream stream) {
+    if (!x || !a || !b || !y || d < 2 || d > 2048 || rows < 0 || (y_dtype != ORTK_F32 && y_dtype != ORTK_BF16)) return ORTK_EINVAL;
     if (rows == 0) return 0;
     dim3 grid((unsigned)ortk_cdiv(rows, 4)), block(256);
     const bool vec = d % 4 == 0 && al16(x) && al16(y) && al16(a) && al16(b);
-#define LN_F(V, N) hipLaunchKernelGGL((ln_fwd_kernel<V, N>), grid, block, 0, ortk_s(stream), x, a, b, y, stats, rows, d, eps)
+#define LN_F(V, N) hipLaunchKernelGGL((ln_fwd_kernel<V, N>), grid, block, 0, ortk_s(stream), x, a, b, y, (int)y_dtype, stats, rows, d, eps)
     if (d <= 512) { if (vec) LN_F(true, 8); else LN_F(false, 8); }
     else          { if (vec) LN_F(true, 32); else LN_F(false, 32); }
 #undef LN_F

@@ -109,7 +109,7 @@ def test_layernorm_fwd_bwd(L, rows, d):
     ref.backward(dy)
     y = torch.empty(rows, d, device="cuda"); st = torch.empty(rows, 2, device="cuda")
     xd, ad, bd = dev(x), dev(a), dev(b)
-    L.check(L.lib().ortk_layernorm_fwd(L.ptr(xd), L.ptr(ad), L.ptr(bd), L.ptr(y), L.ptr(st), rows, d, 1e-6, L.stream_ptr()), "ln")
+    L.check(L.lib().ortk_layernorm_fwd(L.ptr(xd), L.ptr(ad), L.ptr(bd), L.ptr(y), 0, L.ptr(st), rows, d, 1e-6, L.stream_ptr()), "ln")
     torch.testing.assert_close(y.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
     dx = torch.empty(rows, d, device="cuda"); da = torch.zeros(d, device="cuda"); db = torch.zeros(d, device="cuda")
     L.check(L.lib().ortk_layernorm_bwd(L.ptr(dev(dy)), L.ptr(xd), L.ptr(ad), L.ptr(st), L.ptr(dev(dres)), L.ptr(dx), L.ptr(da),
@@ -266,7 +266,7 @@ def test_embed_xent_softmax_colsum(L):
     seqd = dev(seq)  # keep alive
     loss = torch.zeros(1, device="cuda"); ld_dev = dev(logits)
     L.check(L.lib().ortk_xent_fwd_bwd(L.ptr(ld_dev), C.c_void_p(seqd.data_ptr() + 8), T + 1, T, L.ptr(wd), L.ptr(nd), L.ptr(loss),
-                                      R * T, V, ld, L.stream_ptr()), "xent")
+                                      R * T, V, ld, L.ptr(ld_dev), 0, ld, L.stream_ptr()), "xent")
     assert abs(loss.item() - ref_loss.item()) < 1e-5 * max(1, abs(ref_loss.item()))
     torch.testing.assert_close(ld_dev.cpu()[:, :V], lg.grad, rtol=1e-4, atol=1e-7)
     assert float(ld_dev[:, V:].abs().max()) == 0.0
@@ -278,11 +278,11 @@ def test_embed_xent_softmax_colsum(L):
     dlp = rnd(R * T, V, seed=5)
     lg2 = logits[:, :V].clone().requires_grad_(); torch.log_softmax(lg2, -1).backward(dlp)
     outg = torch.empty(R * T, ld, device="cuda")
-    L.check(L.lib().ortk_log_softmax_bwd(L.ptr(dev(lpd)), L.ptr(dev(dlp)), V, L.ptr(outg), ld, R * T, V, L.stream_ptr()), "lsm_bwd")
+    L.check(L.lib().ortk_log_softmax_bwd(L.ptr(dev(lpd)), L.ptr(dev(dlp)), V, L.ptr(outg), 0, ld, R * T, V, L.stream_ptr()), "lsm_bwd")
     torch.testing.assert_close(outg.cpu()[:, :V], lg2.grad, rtol=1e-4, atol=1e-5)
     # column sums
     X = rnd(1000, 77, seed=6); acc = dev(torch.ones(77))
-    L.check(L.lib().ortk_colsum(L.ptr(dev(X)), 77, L.ptr(acc), 1000, 77, L.stream_ptr()), "colsum")
+    L.check(L.lib().ortk_colsum(L.ptr(dev(X)), 0, 77, L.ptr(acc), 1000, 77, L.stream_ptr()), "colsum")
     torch.testing.assert_close(acc.cpu(), 1 + X.sum(0), rtol=1e-4, atol=1e-4)
 
 
@@ -321,3 +321,41 @@ def test_adam_clip_and_masks(L):
     L.check(L.lib().ortk_mask_bwd(L.ptr(dev(torch.ones(n))), L.ptr(dev(torch.ones(n))), L.ptr(dev(m2)), L.ptr(dw), None, n, 1, 99, None,
                                   L.stream_ptr()), "mask_bwd")
     assert torch.equal(dw, we)
+
+
+def test_bf16_storage_paths(L):
+    """Mixed-precision storage: bf16 A / B operands, bf16 C, bf16 LN / attention / dropout outputs vs fp32 math."""
+    M, N, K = 300, 200, 192
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    A16, B16 = dev(A).bfloat16(), dev(B).bfloat16()
+    ref = A16.float().cpu() @ B16.float().cpu().t()
+    sc = ref.abs().max().item()
+    for (a_t, adt), (b_t, bdt) in [((A16, 1), (B16, 1)), ((dev(A), 0), (B16, 1)), ((A16, 1), (dev(B), 0))]:
+        out = gemm(L, a_t, b_t, M, N, K, 0, 0, 1, a_dtype=adt, b_dtype=bdt)
+        assert (out.cpu() - ref).abs().max().item() < 2e-2 * sc
+    # k-major (wgrad / dgrad) layouts with bf16 operands
+    At16, Bt16 = dev(A.t().contiguous()).bfloat16(), dev(B.t().contiguous()).bfloat16()
+    out = gemm(L, At16, Bt16, M, N, K, 1, 1, 1, a_dtype=1, b_dtype=1)
+    assert (out.cpu() - ref).abs().max().item() < 2e-2 * sc
+    out = gemm(L, A16, Bt16, M, N, K, 0, 1, 1, a_dtype=1, b_dtype=1)
+    assert (out.cpu() - ref).abs().max().item() < 2e-2 * sc
+    # bf16 C + bf16 gate
+    gate = dev(rnd(M, N, seed=3)).bfloat16()
+    C16 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    gemm(L, A16, B16, M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1, C=C16, c_dtype=1, gate=gate, gate_dtype=1, gate_scale=2.0)
+    refg = ref * (gate.float().cpu() > 0) * 2.0
+    assert (C16.float().cpu() - refg).abs().max().item() < 3e-2 * sc
+    # LayerNorm with bf16 output, dropout / gate / cast helpers
+    rows, d = 77, 512
+    x, a, b = rnd(rows, d, seed=4), 1 + 0.1 * rnd(d, seed=5), 0.1 * rnd(d, seed=6)
+    y16 = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16); st = torch.empty(rows, 2, device="cuda")
+    L.check(L.lib().ortk_layernorm_fwd(L.ptr(dev(x)), L.ptr(dev(a)), L.ptr(dev(b)), L.ptr(y16), 1, L.ptr(st), rows, d, 1e-6, L.stream_ptr()), "ln16")
+    torch.testing.assert_close(y16.float().cpu(), O.layer_norm(x, a, b), rtol=1e-2, atol=1e-2)
+    xx = dev(rnd(1000, seed=7)); o16 = torch.empty(1000, device="cuda", dtype=torch.bfloat16)
+    L.check(L.lib().ortk_dropout_apply(L.ptr(xx), L.ptr(o16), 1, 1000, 0.0, 0, L.stream_ptr()), "drop16")
+    torch.testing.assert_close(o16.float(), xx.bfloat16().float())
+    L.check(L.lib().ortk_cast_bf16(L.ptr(xx), L.ptr(o16), 1000, L.stream_ptr()), "cast")
+    assert torch.equal(o16, xx.bfloat16())
+    acc = torch.zeros(200, device="cuda")
+    L.check(L.lib().ortk_colsum(L.ptr(C16), 1, N, L.ptr(acc), M, N, L.stream_ptr()), "colsum16")
+    torch.testing.assert_close(acc.cpu(), C16.float().cpu().sum(0), rtol=1e-3, atol=1e-2)
