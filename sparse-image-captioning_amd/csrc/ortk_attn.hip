@@ -138,91 +138,93 @@ __device__ __forceinline__ TilesB carve_bwd(float* base, int Lk) {
 // dK = dS^T Q / sqrt(dk), dV = Pdrop^T dO.  dscore (optional) receives dS — the gradient of the additive
 // geometry bias (and of the pre-softmax scores).
 //
-// Fast form (Lk <= 64): lane = key for the score-side math, lane = feature for the dQ / dK / dV side.  Per-key scalars
-// (dS_j, Pdrop_j) and per-feature scalars (dO_d) are broadcast with v_readlane (constant lane index -> SGPR operand,
-// no LDS traffic), and each wave keeps its partial dK[j][lane], dV[j][lane] for ALL keys in registers across the
-// query rows it walks; the 4 waves' partials are summed through LDS once at the end.  (The first version used
-// ds_add_f32 atomics per (key, feature, query): 53 % of the whole training step in the round-1 profile.)
+// Fast form (Lk <= 64): ONE WAVE owns one (K/V group, head) pair — no workgroup barrier, no cross-wave reduction.
+// lane = key for the score-side math, lane = feature for the dQ / dK / dV side.  The wave keeps dK[j][lane] and
+// dV[j][lane] for ALL keys of its group in registers while it walks the group's query rows and writes them once
+// at the end (256-B coalesced rows).  Per-row scalars cross lanes through a 3 x 64-float LDS scratch line
+// (broadcast reads).  K and V of the pair sit in the wave's own LDS slice (pitch dk+1).
+// History: v1 accumulated dK/dV with ds_add_f32 atomics (53 % of the training step); v2 used one workgroup per pair
+// with a 4-phase LDS reduction (10 ms/step, mostly barriers and idle waves on 17-row tiles).
 template <int LKMAX>
-__global__ __launch_bounds__(256) void attn_bwd_reg_kernel(ortk_attn_args a) {
+__global__ __launch_bounds__(256) void attn_bwd_wave_kernel(ortk_attn_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem_b[];
-    float (*sK)[KP] = reinterpret_cast<float (*)[KP]>(smem_b);
-    float (*sV)[KP] = reinterpret_cast<float (*)[KP]>(smem_b + (size_t)a.Lk * KP);
-    float (*sdK)[KP] = reinterpret_cast<float (*)[KP]>(smem_b + (size_t)2 * a.Lk * KP);
-    float (*sdV)[KP] = reinterpret_cast<float (*)[KP]>(smem_b + (size_t)3 * a.Lk * KP);
-    const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.nkv * a.H) return;                 // whole wave exits; no barriers below
+    const int g = pair / a.H, h = pair - g * a.H;
     const int Lk = a.Lk, dk = a.dk;
-    for (int idx = tid; idx < Lk * dk; idx += 256) {
-        const int j = idx / dk, dd = idx - j * dk;
+    const size_t per_wave = (size_t)2 * Lk * KP + 3 * 64;
+    float* base = smem_b + wave * per_wave;
+    float (*sK)[KP] = reinterpret_cast<float (*)[KP]>(base);
+    float (*sV)[KP] = reinterpret_cast<float (*)[KP]>(base + (size_t)Lk * KP);
+    float* sgo = base + (size_t)2 * Lk * KP;         // dO row       (lane = feature)
+    float* sds = sgo + 64;                           // dS / sqrt(dk) (lane = key)
+    float* spd = sds + 64;                           // dropped P     (lane = key)
+    for (int idx = lane; idx < Lk * KP; idx += 64) {
+        const int j = idx / KP, dd = idx - j * KP;
         const int64_t row = (int64_t)g * Lk + j;
-        sK[j][dd] = a.k[row * a.ldk + h * dk + dd];
-        sV[j][dd] = a.v[row * a.ldv + h * dk + dd];
-        sdK[j][dd] = 0.f;
-        sdV[j][dd] = 0.f;
+        const bool in = dd < dk;
+        sK[j][dd] = in ? a.k[row * a.ldk + h * dk + dd] : 0.f;
+        sV[j][dd] = in ? a.v[row * a.ldv + h * dk + dd] : 0.f;
     }
-    __syncthreads();
+    wave_sync();
     const float scale = sqrtf((float)dk);
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     float acck[LKMAX], accv[LKMAX];
 #pragma unroll
     for (int j = 0; j < LKMAX; ++j) { acck[j] = 0.f; accv[j] = 0.f; }
-    for (int i = wave; i < a.Lq; i += 4) {
+    const int jl = lane < Lk ? lane : 0, dl = lane < dk ? lane : 0;
+    for (int i = 0; i < a.Lq; ++i) {
         const int64_t qrow = (int64_t)g * a.Lq + i;
         float qv = 0.f, gv = 0.f;                      // lane = feature
         if (lane < dk) {
             qv = a.q[qrow * a.ldq + h * dk + lane];
             gv = a.d_o[qrow * a.lddo + h * dk + lane];
         }
+        sgo[lane] = gv;
         const int64_t pbase = (((int64_t)g * a.H + h) * a.Lq + i) * Lk;
-        // lane = key: dP_j = sum_d dO_d V[j][d]
-        float p = 0.f, dp = 0.f, pd = 0.f;
-        {
-            float acc = 0.f;
-            const int j = lane < Lk ? lane : 0;
-#pragma unroll
-            for (int dd = 0; dd < MAXD; ++dd)
-                if (dd < dk) acc += bcast(gv, dd) * sV[j][dd];
-            if (lane < Lk) {
-                p = a.p[pbase + lane];
-                const bool keep = a.drop_p > 0.f ? ortk_keep(a.drop_seed, (uint64_t)(pbase + lane), a.drop_p) : true;
-                dp = keep ? acc * inv_keep : 0.f;
-                pd = keep ? p * inv_keep : 0.f;
-            }
+        float p = 0.f;
+        bool keep = true;
+        if (lane < Lk) {
+            p = a.p[pbase + lane];
+            if (a.drop_p > 0.f) keep = ortk_keep(a.drop_seed, (uint64_t)(pbase + lane), a.drop_p);
         }
+        wave_sync();
+        // lane = key: dP_j = sum_d dO_d V[j][d]   (pad features hold zeros)
+        float acc = 0.f;
+#pragma unroll 8
+        for (int dd = 0; dd < MAXD; ++dd) acc += sgo[dd] * sV[jl][dd];
+        const float dp = (lane < Lk && keep) ? acc * inv_keep : 0.f;
+        const float pd = (lane < Lk && keep) ? p * inv_keep : 0.f;
         const float dot = wave_sum(p * dp);
         const float ds = p * (dp - dot);
         if (a.dscore && lane < Lk) a.dscore[pbase + lane] = ds;
-        const float dsq = ds / scale;
+        sds[lane] = ds / scale;
+        spd[lane] = pd;
+        wave_sync();
         // lane = feature: dQ_d = sum_j dS_j K[j][d];  dK[j][d] += dS_j q_d;  dV[j][d] += Pd_j dO_d
         float dq = 0.f;
-        const int dl = lane < dk ? lane : 0;
 #pragma unroll
         for (int j = 0; j < LKMAX; ++j) {
             if (j < Lk) {
-                const float dsj = bcast(dsq, j);
-                const float pdj = bcast(pd, j);
+                const float dsj = sds[j], pdj = spd[j];
                 dq += dsj * sK[j][dl];
                 acck[j] += dsj * qv;
                 accv[j] += pdj * gv;
             }
         }
         if (lane < dk) st_elem(a.dq, qrow * a.lddq + h * dk + lane, a.dqkv_dtype, dq);
+        wave_sync();
     }
-    // sum the 4 waves' partials: one wave at a time adds its registers into the LDS tiles
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w && lane < dk) {
+    if (lane < dk) {
 #pragma unroll
-            for (int j = 0; j < LKMAX; ++j)
-                if (j < Lk) { sdK[j][lane] += acck[j]; sdV[j][lane] += accv[j]; }
+        for (int j = 0; j < LKMAX; ++j) {
+            if (j < Lk) {
+                const int64_t row = (int64_t)g * Lk + j;
+                st_elem(a.d_k, row * a.lddk + h * dk + lane, a.dqkv_dtype, acck[j]);
+                st_elem(a.dv, row * a.lddv + h * dk + lane, a.dqkv_dtype, accv[j]);
+            }
         }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < Lk * dk; idx += 256) {
-        const int j = idx / dk, dd = idx - j * dk;
-        const int64_t row = (int64_t)g * Lk + j;
-        st_elem(a.d_k, row * a.lddk + h * dk + dd, a.dqkv_dtype, sdK[j][dd]);
-        st_elem(a.dv, row * a.lddv + h * dk + dd, a.dqkv_dtype, sdV[j][dd]);
     }
 }
 
@@ -331,18 +333,23 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)bwd_lds_bytes(MAXK));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_reg_kernel<64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * 64 * KP));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wave_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * (2 * 64 * KP + 192)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wave_kernel<48>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * (2 * 48 * KP + 192)));
         attr_set = true;
     }
-    const dim3 grid((unsigned)(a->nkv * a->H)), block(256);
-    const size_t reg_lds = sizeof(float) * 4 * (size_t)a->Lk * KP;
+    const int pairs = a->nkv * a->H;
+    const dim3 wgrid((unsigned)ortk_cdiv(pairs, 4)), block(256);
+    const size_t wave_lds = sizeof(float) * 4 * ((size_t)2 * a->Lk * KP + 192);
     if (a->Lk <= 32)
-        hipLaunchKernelGGL(attn_bwd_reg_kernel<32>, grid, block, reg_lds, ortk_s(stream), *a);
+        hipLaunchKernelGGL(attn_bwd_wave_kernel<32>, wgrid, block, wave_lds, ortk_s(stream), *a);
+    else if (a->Lk <= 48)
+        hipLaunchKernelGGL(attn_bwd_wave_kernel<48>, wgrid, block, wave_lds, ortk_s(stream), *a);
     else if (a->Lk <= 64)
-        hipLaunchKernelGGL(attn_bwd_reg_kernel<64>, grid, block, reg_lds, ortk_s(stream), *a);
+        hipLaunchKernelGGL(attn_bwd_wave_kernel<64>, wgrid, block, wave_lds, ortk_s(stream), *a);
     else
-        hipLaunchKernelGGL(attn_bwd_kernel, grid, block, bwd_lds_bytes(a->Lk), ortk_s(stream), *a);
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)pairs), block, bwd_lds_bytes(a->Lk), ortk_s(stream), *a);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -292,7 +292,7 @@ class RelationTransformerModel(CaptionModelBase):
         ws = self._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, cache_ws)
         logp, ldv = None, 0
         if want_logp:
-            ldv = (self.vocab_size + 3) // 4 * 4
+            ldv = (self.vocab_size + 127) // 128 * 128      # padded vocabulary: full GEMM tiles (pad log-probs unused)
             logp = torch.empty(batch.R, batch.T, ldv, device=self._flat.device)
         L.check(lib.ortk_forward(C.byref(self._ccfg), self._eff_params_ptr(train, seed), C.byref(batch), L.ptr(ws),
                                  ws.numel(), L.ptr(logp), ldv, int(train), seed, L.stream_ptr()), "ortk_forward")
