@@ -141,6 +141,7 @@ typedef struct ortk_gemm_args {
     int32_t relu; float drop_p; uint32_t drop_seed;
     int32_t accumulate, splitk, precision;
     int32_t a_dtype, b_dtype, c_dtype, gate_dtype;   /* storage type of A / B / C / gate: 0 = fp32, 1 = bf16 (precision 1 only) */
+    float* colsum;   /* optional, transA && precision 1: colsum[m] += sum_k A[k,m] (bias gradient fused into the wgrad GEMM) */
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its

@@ -49,7 +49,8 @@ class GemmArgs(C.Structure):
                 ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_scale", C.c_float),
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
                 ("accumulate", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32),
-                ("a_dtype", C.c_int32), ("b_dtype", C.c_int32), ("c_dtype", C.c_int32), ("gate_dtype", C.c_int32)]
+                ("a_dtype", C.c_int32), ("b_dtype", C.c_int32), ("c_dtype", C.c_int32), ("gate_dtype", C.c_int32),
+                ("colsum", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):

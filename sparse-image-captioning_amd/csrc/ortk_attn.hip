@@ -113,6 +113,66 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ortk_attn_args a) {
     }
 }
 
+// Forward, fast form (Lk <= 64): one wave per (K/V group, head) pair, no workgroup barrier (see the backward below).
+__global__ __launch_bounds__(256) void attn_fwd_wave_kernel(ortk_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.nkv * a.H) return;
+    const int g = pair / a.H, h = pair - g * a.H;
+    const int Lk = a.Lk, dk = a.dk;
+    const size_t per_wave = (size_t)2 * Lk * KP + 2 * 64;
+    float* base = smem_f + wave * per_wave;
+    float (*sK)[KP] = reinterpret_cast<float (*)[KP]>(base);
+    float (*sV)[KP] = reinterpret_cast<float (*)[KP]>(base + (size_t)Lk * KP);
+    float* sq = base + (size_t)2 * Lk * KP;
+    float* sp = sq + 64;
+    for (int idx = lane; idx < Lk * KP; idx += 64) {
+        const int j = idx / KP, dd = idx - j * KP;
+        const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j]
+                                       : (int64_t)g * (a.kv_group_stride > 0 ? a.kv_group_stride : Lk) + j;
+        const bool in = dd < dk;
+        sK[j][dd] = in ? a.k[row * a.ldk + h * dk + dd] : 0.f;
+        sV[j][dd] = in ? a.v[row * a.ldv + h * dk + dd] : 0.f;
+    }
+    const float kmask = (lane < Lk && a.kmask) ? a.kmask[(int64_t)g * Lk + lane] : 1.f;
+    const float scale = sqrtf((float)dk);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int jl = lane < Lk ? lane : 0, dl = lane < dk ? lane : 0;
+    wave_sync();
+    for (int i = 0; i < a.Lq; ++i) {
+        const int64_t qrow = (int64_t)g * a.Lq + i;
+        sq[lane] = lane < dk ? a.q[qrow * a.ldq + h * dk + lane] : 0.f;
+        const int qpos = a.causal_period > 0 ? i % a.causal_period : 0;
+        const int64_t pbase = (((int64_t)g * a.H + h) * a.Lq + i) * Lk;
+        wave_sync();
+        float acc = 0.f;
+#pragma unroll 8
+        for (int dd = 0; dd < MAXD; ++dd) acc += sq[dd] * sK[jl][dd];
+        float sc = -INFINITY;
+        if (lane < Lk) {
+            acc = acc / scale;
+            if (kmask == 0.f || (a.causal_period > 0 && lane > qpos)) acc = -1e9f;
+            if (a.bias) acc = a.bias[pbase + lane] + acc;
+            sc = acc;
+        }
+        const float mx = wave_max(sc);
+        const float e = lane < Lk ? expf(sc - mx) : 0.f;
+        const float sum = wave_sum(e);
+        float p = e / sum;
+        if (lane < Lk) {
+            if (a.p) a.p[pbase + lane] = p;
+            if (a.drop_p > 0.f) p = ortk_keep(a.drop_seed, (uint64_t)(pbase + lane), a.drop_p) ? p * inv_keep : 0.f;
+        }
+        sp[lane] = lane < Lk ? p : 0.f;
+        wave_sync();
+        float o = 0.f;
+        for (int j = 0; j < Lk; ++j) o += sp[j] * sV[j][dl];
+        if (lane < dk) st_elem(a.o, qrow * a.ldo + h * dk + lane, a.o_dtype, o);
+        wave_sync();
+    }
+}
+
 struct TilesB {
     float (*k)[KP]; float (*v)[KP]; float (*dk)[KP]; float (*dv)[KP];   // [Lk][KP] each
     float (*q)[MAXD]; float (*go)[MAXD];                                // [4][MAXD]
@@ -318,9 +378,17 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)fwd_lds_bytes(MAXK));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * 4 * (2 * 64 * KP + 128)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(a->nkv * a->H)), dim3(256), fwd_lds_bytes(a->Lk), ortk_s(stream), *a);
+    if (a->Lk <= 64) {
+        const int pairs = a->nkv * a->H;
+        hipLaunchKernelGGL(attn_fwd_wave_kernel, dim3((unsigned)ortk_cdiv(pairs, 4)), dim3(256),
+                           sizeof(float) * 4 * ((size_t)2 * a->Lk * KP + 128), ortk_s(stream), *a);
+    } else {
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(a->nkv * a->H)), dim3(256), fwd_lds_bytes(a->Lk), ortk_s(stream), *a);
+    }
     ORTK_CHECK_LAUNCH();
     return 0;
 }

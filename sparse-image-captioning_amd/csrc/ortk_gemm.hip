@@ -336,14 +336,26 @@ __device__ __forceinline__ void lds_put(__bf16* dst, f32x4 v) {
 }
 __device__ __forceinline__ void lds_put(__bf16* dst, u32x4 v) { *reinterpret_cast<u32x4*>(dst) = v; }
 
-template <bool T, typename ET, typename CT, int N>
-__device__ __forceinline__ void stage_store(const CT (&r)[N], __bf16* img, int tid) {
+__device__ __forceinline__ void chunk_add(float (&cs)[8], f32x4 v) { cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3]; }
+__device__ __forceinline__ void chunk_add(float (&cs)[8], u32x4 v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        cs[2 * q] += __uint_as_float(v[q] << 16);              // low  bf16 of the dword
+        cs[2 * q + 1] += __uint_as_float(v[q] & 0xFFFF0000u);   // high bf16
+    }
+}
+
+// CS: also accumulate, per thread, the sums over k of the chunk's columns (bias gradient fused into wgrad: for the
+// k-major A operand every chunk of a thread covers the SAME columns, tid % CPR).
+template <bool T, typename ET, bool CS, typename CT, int N>
+__device__ __forceinline__ void stage_store(const CT (&r)[N], __bf16* img, int tid, float (&cs)[8]) {
     typedef StageCfg<T, ET> S;
     static_assert(N == S::NCH, "chunk array size");
 #pragma unroll
     for (int u = 0; u < S::NCH; ++u) {
         const int f = tid + 256 * u;
         lds_put(img + (f / S::CPR) * S::PITCH + (f % S::CPR) * S::EPC, r[u]);
+        if (CS) chunk_add(cs, r[u]);
     }
 }
 
@@ -389,13 +401,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
 
     typename StageCfg<TA, AT>::chunk_t ra[StageCfg<TA, AT>::NCH];
     typename StageCfg<TB, BT>::chunk_t rb[StageCfg<TB, BT>::NCH];
+    // fused bias gradient (wgrad layout only): column sums of A, taken by the workgroups of the first N-tile
+    const bool do_cs = TA && p.colsum != nullptr && nt == 0;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cs_unused[8];
     int buf = 0;
     if (k_begin < k_end) {
         const bool kfull = k_begin + BK16 <= k_end;
         stage_load<TA, AT, FAST>(ra, Ap, p.lda, mb, k_begin, p.M, k_end, fullA && kfull, tid);
         stage_load<TB, BT, FAST>(rb, Bp, p.ldb, nb, k_begin, p.N, k_end, fullB && kfull, tid);
-        stage_store<TA, AT>(ra, sA(0), tid);
-        stage_store<TB, BT>(rb, sB(0), tid);
+        if (do_cs) stage_store<TA, AT, TA>(ra, sA(0), tid, cs); else stage_store<TA, AT, false>(ra, sA(0), tid, cs_unused);
+        stage_store<TB, BT, false>(rb, sB(0), tid, cs_unused);
     }
     __syncthreads();
     for (int k0 = k_begin; k0 < k_end; k0 += BK16) {
@@ -419,11 +434,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         if (has_next) {
-            stage_store<TA, AT>(ra, sA(buf ^ 1), tid);
-            stage_store<TB, BT>(rb, sB(buf ^ 1), tid);
+            if (do_cs) stage_store<TA, AT, TA>(ra, sA(buf ^ 1), tid, cs); else stage_store<TA, AT, false>(ra, sA(buf ^ 1), tid, cs_unused);
+            stage_store<TB, BT, false>(rb, sB(buf ^ 1), tid, cs_unused);
         }
         __syncthreads();
         buf ^= 1;
+    }
+    if (TA && do_cs) {
+        // combine the 256 / CPR threads that own the same columns (the LDS images are free: the K loop ended with a barrier)
+        typedef StageCfg<TA, AT> S;
+        float* red = reinterpret_cast<float*>(smem16);
+#pragma unroll
+        for (int q = 0; q < S::EPC; ++q) red[tid * S::EPC + q] = cs[q];
+        __syncthreads();
+        if (tid < BM && (FAST || mb + tid < p.M)) {
+            const int c = tid / S::EPC, eidx = tid % S::EPC;
+            float sum = 0.f;
+            for (int rr = 0; rr < 256 / S::CPR; ++rr) sum += red[(rr * S::CPR + c) * S::EPC + eidx];
+            atomicAdd(p.colsum + mb + tid, sum);
+        }
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
@@ -484,6 +513,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     if (!p.precision && (p.a_dtype || p.b_dtype)) return ORTK_EINVAL;   // fp32 MFMA path takes fp32 operands only
     if (p.accumulate && p.c_dtype) return ORTK_EINVAL;                   // accumulation targets the fp32 gradient arena
     if (p.transA && !p.transB) return ORTK_EINVAL;                       // layout not needed by the path
+    if (p.colsum && !(p.precision && p.transA)) return ORTK_EINVAL;      // fused column sums: bf16-MFMA wgrad layout only
     const int tilesM = (int)ortk_cdiv(p.M, BM), tilesN = (int)ortk_cdiv(p.N, BN);
     const int bk = p.precision ? BK16 : 16;
     int splitk = p.accumulate ? (p.splitk > 0 ? p.splitk : 1) : 1;

@@ -249,8 +249,9 @@ static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, cons
     const int64_t sk = (320 + tiles / 2) / tiles;
     const int64_t max_sk = std::max<int64_t>(1, M / 512);
     a.splitk = (int)std::max<int64_t>(1, std::min(sk, max_sk));
+    if (c.prec) a.colsum = db;             // bias gradient fused into the wgrad kernel (bf16-MFMA path)
     TRY(ortk_gemm(&a, (ortk_stream)c.s));
-    if (db) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)c.s));
+    if (db && !c.prec) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)c.s));
     return 0;
 }
 static int ln_fwd(const Ctx& c, const float* x, int64_t a, int64_t b, void* y, int ydt, float* st, int64_t rows) {

@@ -337,6 +337,15 @@ def test_bf16_storage_paths(L):
     At16, Bt16 = dev(A.t().contiguous()).bfloat16(), dev(B.t().contiguous()).bfloat16()
     out = gemm(L, At16, Bt16, M, N, K, 1, 1, 1, a_dtype=1, b_dtype=1)
     assert (out.cpu() - ref).abs().max().item() < 2e-2 * sc
+    # fused column sums (bias gradient) in the wgrad layout: guarded shape, full-tile shape with split-K, fp32 A
+    for (m_, n_, k_, adt_) in ((M, N, K, 1), (256, 128, 1024, 1), (256, 128, 1024, 0)):
+        A_ = rnd(k_, m_, seed=21); B_ = rnd(k_, n_, seed=22)
+        Ad = dev(A_).bfloat16() if adt_ else dev(A_); Bd = dev(B_).bfloat16()
+        csum = torch.ones(m_, device="cuda"); Cacc = torch.zeros(m_, n_, device="cuda")
+        gemm(L, Ad, Bd, m_, n_, k_, 1, 1, 1, a_dtype=adt_, b_dtype=1, C=Cacc, accumulate=1, splitk=4, colsum=csum)
+        torch.testing.assert_close(csum.cpu(), 1 + Ad.float().cpu().sum(0), rtol=1e-3, atol=1e-2)
+        refc = Ad.float().cpu().t() @ Bd.float().cpu()
+        assert (Cacc.cpu() - refc).abs().max().item() < 2e-2 * refc.abs().max().item()
     out = gemm(L, A16, Bt16, M, N, K, 0, 1, 1, a_dtype=1, b_dtype=1)
     assert (out.cpu() - ref).abs().max().item() < 2e-2 * sc
     # bf16 C + bf16 gate
