@@ -267,6 +267,7 @@ constexpr int BK16 = 64;
 constexpr int PITCH_MK = BK16 + 8;     // [m][k] image: 144 B rows (16-B aligned, rows spread over banks)
 constexpr int PITCH_KM = 128 + 8;      // [k][m] image: 272 B rows (16-B aligned; 8-B aligned for the transposing read)
 constexpr int IMG_ELEMS = 128 * PITCH_MK > BK16 * PITCH_KM ? 128 * PITCH_MK : BK16 * PITCH_KM;
+constexpr size_t BF16_LDS_BYTES_C = (size_t)4 * IMG_ELEMS * 2;   // 2 stages x (A + B) images of bf16
 
 __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
@@ -373,6 +374,76 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* img, int m0, int ks, int la
     }
 }
 
+// Epilogue through LDS (bf16-MFMA kernels): the 128x128 fp32 tile is first laid out row-major in the (now free)
+// staging LDS, then written out one full 512-byte row segment per half-wave — coalesced float4 / bf16x4 stores and
+// float4 residual / gate loads — or, when accumulating (wgrad split-K), as 256 contiguous bytes per atomic
+// wave-instruction.  The register-layout epilogue issued atomics that touched 16 rows x 4 scattered dwords per
+// instruction: the 17x-slow access shape (MI355X_MICROARCH.md, Global float atomics); a 2048x512x21760 wgrad with
+// 48 K-splits took 554 us, of which ~400 us were atomics.
+constexpr int CP = 128 + 4;   // fp32 row pitch of the staged C tile (528 B: 16-B aligned)
+template <bool FAST>
+__device__ __forceinline__ void epilogue_staged(const Epi& e, float* sC, int mb, int nb, int wm, int wn, int lane, int wave,
+                                                f32x4 (&acc)[4][4]) {
+    {   // registers -> LDS (lane holds 4 consecutive n of row m)
+        const int mr = wm * 64 + (lane & 15), nc = wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(sC + (mr + 16 * i) * CP + nc + 16 * j) = acc[i][j];
+    }
+    __syncthreads();
+    const int EN = FAST ? 0x7FFFFFFF : e.N, EM = FAST ? 0x7FFFFFFF : e.M;
+    const bool first = e.first_split;
+    if (e.accumulate) {
+        // 64 lanes = 64 consecutive columns of one row: 256 contiguous bytes per atomic instruction
+        for (int it = 0; it < 64; ++it) {
+            const int r = it * 2 + (wave >> 1), c = (wave & 1) * 64 + lane;
+            const int m = mb + r, n = nb + c;
+            if (m < EM && n < EN) atomicAdd(reinterpret_cast<float*>(e.C) + (int64_t)m * e.ldc + n, sC[r * CP + c]);
+        }
+        return;
+    }
+    const bool vec_r = FAST || (e.resid && ((e.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.resid) & 15) == 0));
+    const bool vec_g = FAST || (e.gate && ((e.ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.gate) & 15) == 0));
+    const bool vec_c = FAST || (((e.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0));
+    const bool vec_b = FAST || (e.bias && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0));
+    const float inv_keep = e.drop_p > 0.f ? 1.f / (1.f - e.drop_p) : 1.f;
+    const int c4 = (lane & 31) * 4, n0 = nb + c4;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.bias && first && n0 < EN) b4 = ldrow4(e.bias + n0, n0, EN, vec_b);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int r = it * 8 + wave * 2 + (lane >> 5);
+        const int m = mb + r;
+        if (m >= EM || n0 >= EN) continue;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + r * CP + c4);
+        const float rs = e.rowscale ? e.rowscale[m] : 1.f;
+        float4 res = make_float4(0.f, 0.f, 0.f, 0.f), gat = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (e.resid && first) res = ldrow4(e.resid + (int64_t)m * e.ldr + n0, n0, EN, vec_r);
+        if (e.gate) {
+            if (e.g_dt == ORTK_F32) gat = ldrow4(reinterpret_cast<const float*>(e.gate) + (int64_t)m * e.ldg + n0, n0, EN, vec_g);
+            else if (vec_g && n0 + 3 < EN) gat = ld_elem4(e.gate, (int64_t)m * e.ldg + n0, ORTK_BF16);
+            else { float* gp = &gat.x; for (int q = 0; q < 4; ++q) if (n0 + q < EN) gp[q] = ld_elem(e.gate, (int64_t)m * e.ldg + n0 + q, ORTK_BF16); }
+        }
+        const float rr[4] = {res.x, res.y, res.z, res.w}, gg[4] = {gat.x, gat.y, gat.z, gat.w};
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = a4[q] + bb[q];
+            if (e.relu) x = fmaxf(x, 0.f);
+            x *= rs;
+            if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, (uint64_t)m * (uint64_t)e.N + (n0 + q), e.drop_p) ? x * inv_keep : 0.f;
+            if (e.gate) x = gg[q] > 0.f ? x * e.gate_scale : 0.f;
+            v[q] = x + rr[q];
+        }
+        const int64_t ci = (int64_t)m * e.ldc + n0;
+        if (vec_c && n0 + 3 < EN) st_elem4(e.C, ci, e.c_dt, make_float4(v[0], v[1], v[2], v[3]));
+        else for (int q = 0; q < 4; ++q) if (n0 + q < EN) st_elem(e.C, ci + q, e.c_dt, v[q]);
+    }
+}
+
 // FAST = every tile is full (M % 128 == N % 128 == 0, K-chunks multiples of 64) and every pointer is vector-aligned:
 // the launcher checks this, and the kernel then contains no bounds test at all (the guarded variant is 10x the code).
 template <bool TA, bool TB, typename AT, typename BT, bool FAST>
@@ -456,7 +527,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
-    epilogue_tile<FAST>(e, mb + wm * 64 + (lane & 15), nb + wn * 64 + 4 * (lane >> 4), acc);
+    if (TA && do_cs) __syncthreads();     // the column-sum scratch shares the LDS with the staged C tile
+    static_assert(128 * CP * sizeof(float) <= BF16_LDS_BYTES_C, "staged C tile must fit the staging LDS");
+    // plain stores are faster straight from the accumulator layout (64-B segments, no LDS round trip: 491 vs 436 TF
+    // on 21760x2048x512); atomics need the contiguous 256-B shape that only the staged form provides
+    if (p.accumulate) epilogue_staged<FAST>(e, reinterpret_cast<float*>(smem16), mb, nb, wm, wn, lane, wave, acc);
+    else epilogue_tile<FAST>(e, mb + wm * 64 + (lane & 15), nb + wn * 64 + 4 * (lane >> 4), acc);
 }
 constexpr size_t BF16_LDS_BYTES = (size_t)4 * IMG_ELEMS * sizeof(__bf16);
 

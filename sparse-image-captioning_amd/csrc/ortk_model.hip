@@ -243,10 +243,11 @@ static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, cons
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
     a.A = dY; a.a_dtype = dydt; a.lda = lddy; a.transA = 1; a.B = X; a.b_dtype = xdt; a.ldb = ldx; a.transB = 1; a.C = dW; a.ldc = Kin;
     a.M = Nout; a.N = Kin; a.K = (int)M; a.accumulate = 1; a.precision = c.prec;
-    // K (= rows of the batch) is split so that ~1 workgroup per CU exists; more splits only add atomic traffic
-    // (measured: 512x512x21760 runs 2.4x faster with 8 splits than with 48)
+    // K (= rows of the batch) is split over workgroups that accumulate with 256-B-contiguous atomics.  Tuned on the
+    // path's shapes (scratch/wgrad_bench.py): ~384 workgroups (1.5 per CU) for the small outputs, 3 splits for the
+    // 10112x512 generator (632 tiles alone leave a 23 % tail), never fewer than 8 K-steps per workgroup.
     const int64_t tiles = ortk_cdiv(Nout, 128) * ortk_cdiv(Kin, 128);
-    const int64_t sk = (320 + tiles / 2) / tiles;
+    int64_t sk = tiles >= 256 ? (M >= 16384 ? 3 : 1) : (384 + tiles / 2) / tiles;
     const int64_t max_sk = std::max<int64_t>(1, M / 512);
     a.splitk = (int)std::max<int64_t>(1, std::min(sk, max_sk));
     if (c.prec) a.colsum = db;             // bias gradient fused into the wgrad kernel (bf16-MFMA path)
