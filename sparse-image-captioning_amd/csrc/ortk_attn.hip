@@ -11,6 +11,7 @@
 // cross attention that is all captions of one image (5 x 17 rows), so the encoder memory's K/V are read once
 // per image instead of once per caption (the reference repeats them, relation_transformer.py:63-66), and in
 // the backward dK/dV of an image are complete inside one workgroup (no atomics to global memory).
+#include <cstdlib>
 #include "ortk_common.h"
 
 namespace {
@@ -170,6 +171,285 @@ __global__ __launch_bounds__(256) void attn_fwd_wave_kernel(ortk_attn_args a) {
         for (int j = 0; j < Lk; ++j) o += sp[j] * sV[j][dl];
         if (lane < dk) st_elem(a.o, qrow * a.ldo + h * dk + lane, a.o_dtype, o);
         wave_sync();
+    }
+}
+
+// ================================================================================================ MFMA attention
+// fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, so the parity mode keeps its numerics) for the four small
+// products of a (K/V group, head) pair.  The per-lane-FMA kernels above are LDS-bandwidth bound (one ds_read_b32 per
+// multiply-add: 160 us for the 10 240 17x17 decoder tiles); an MFMA consumes two LDS dwords per lane for 16 FMAs.
+// One workgroup per pair, one wave per 16-row query tile.  LDS pitches: operands read as [row = M/N index][k]
+// use a pitch = 4 (mod 32) dwords, operands read as [k][n] use a pitch = 16 (mod 32): both conflict-free.
+constexpr int PK_ = 66, PN_ = 80;   // 66 = 2 (mod 32): 16 rows x 2 k-lanes of a half-wave hit 32 distinct banks
+static int attn_impl() { static int v = -1; if (v < 0) { const char* e = getenv("ORTK_ATTN_IMPL"); v = e ? atoi(e) : 0; } return v; }
+typedef __attribute__((ext_vector_type(4))) float f4;
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, int Lkp, int DKP) {
+    extern __shared__ __attribute__((aligned(16))) float smem_m[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
+    const int Lk = a.Lk, dk = a.dk, Lq = a.Lq;
+    float* sK = smem_m;                         // [Lkp][PK_]  rows = key,  k = feature
+    float* sV = sK + Lkp * PK_;                 // [Lkp][PN_]  rows = key (k of P.V), n = feature
+    float* sMask = sV + Lkp * PN_;              // [64]
+    float* sQ = sMask + 64 + wave * (16 * PK_ * 2);   // [16][PK_]
+    float* sP = sQ + 16 * PK_;                  // [16][PK_]   rows = query, k = key
+    for (int idx = tid; idx < Lkp * DKP; idx += blockDim.x) {
+        const int j = idx / DKP, dd = idx - j * DKP;
+        float kv = 0.f, vv = 0.f;
+        if (j < Lk && dd < dk) {
+            const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j]
+                                           : (int64_t)g * (a.kv_group_stride > 0 ? a.kv_group_stride : Lk) + j;
+            kv = a.k[row * a.ldk + h * dk + dd];
+            vv = a.v[row * a.ldv + h * dk + dd];
+        }
+        sK[j * PK_ + dd] = kv;
+        sV[j * PN_ + dd] = vv;
+    }
+    if (tid < 64) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
+    __syncthreads();
+    const float scale = sqrtf((float)dk);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int njt = Lkp >> 4, ndt = DKP >> 4, nit = (Lq + 15) >> 4;
+    for (int it = wave; it < nit; it += nw) {
+        const int i0 = it * 16;
+        for (int idx = lane; idx < 16 * DKP; idx += 64) {
+            const int r = idx / DKP, dd = idx - r * DKP;
+            const int i = i0 + r;
+            sQ[r * PK_ + dd] = (i < Lq && dd < dk) ? a.q[((int64_t)g * Lq + i) * a.ldq + h * dk + dd] : 0.f;
+        }
+        wave_sync();
+        // S = Q K^T : D[i = 4*lq + r][j = 16*jt + lr]
+        f4 sacc[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            sacc[jt] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (jt < njt) {
+                for (int kk = 0; kk < DKP / 4; ++kk) {
+                    const float av = sQ[lr * PK_ + 4 * kk + lq];
+                    const float bv = sK[(16 * jt + lr) * PK_ + 4 * kk + lq];
+                    sacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, sacc[jt], 0, 0, 0);
+                }
+            }
+        }
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt < njt) {
+                const int j = 16 * jt + lr;
+                const float mk = sMask[j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 4 * lq + r;
+                    float x = sacc[jt][r] / scale;
+                    const int qpos = a.causal_period > 0 ? i % a.causal_period : 0;
+                    if (mk == 0.f || (a.causal_period > 0 && j > qpos)) x = -1e9f;
+                    if (mk < 0.f) x = -INFINITY;                                   // padded key: not part of the row
+                    else if (a.bias && i < Lq) x = a.bias[(((int64_t)g * a.H + h) * Lq + i) * Lk + j] + x;
+                    sacc[jt][r] = x;
+                    mx[r] = fmaxf(mx[r], x);
+                }
+            }
+        }
+        float sum[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mx[r] = group16_max(mx[r]); sum[r] = 0.f; }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt < njt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = expf(sacc[jt][r] - mx[r]); sacc[jt][r] = e; sum[r] += e; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = group16_sum(sum[r]);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt < njt) {
+                const int j = 16 * jt + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 4 * lq + r;
+                    float p = sacc[jt][r] / sum[r];
+                    if (i < Lq && j < Lk) {
+                        const int64_t pi = (((int64_t)g * a.H + h) * Lq + i) * Lk + j;
+                        if (a.p) a.p[pi] = p;
+                        if (a.drop_p > 0.f) p = ortk_keep(a.drop_seed, (uint64_t)pi, a.drop_p) ? p * inv_keep : 0.f;
+                    } else p = 0.f;
+                    sP[(4 * lq + r) * PK_ + j] = p;
+                }
+            }
+        }
+        wave_sync();
+        // O = P V : D[i = 4*lq + r][d = 16*dt + lr]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            if (dt < ndt) {
+                f4 oacc = {0.f, 0.f, 0.f, 0.f};
+                for (int kk = 0; kk < Lkp / 4; ++kk) {
+                    const float av = sP[lr * PK_ + 4 * kk + lq];
+                    const float bv = sV[(4 * kk + lq) * PN_ + 16 * dt + lr];
+                    oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, oacc, 0, 0, 0);
+                }
+                const int dd = 16 * dt + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 4 * lq + r;
+                    if (i < Lq && dd < dk) st_elem(a.o, ((int64_t)g * Lq + i) * a.ldo + h * dk + dd, a.o_dtype, oacc[r]);
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Backward with the same tiling.  Phase 1 (wave = 16-row query tile): dP = dO V^T, dS = P (dP - rowsum(P dP)),
+// dQ = dS K / sqrt(dk); dS / sqrt(dk) and the dropped P go to workgroup-wide LDS arrays.  Phase 2 (waves share the
+// 2 x (Lkp/16) x (DKP/16) output tiles): dK = dS^T Q / sqrt(dk), dV = Pd^T dO over ALL query rows of the group.
+__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, int Lkp, int DKP, int Lqp) {
+    extern __shared__ __attribute__((aligned(16))) float smem_m[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
+    const int Lk = a.Lk, dk = a.dk, Lq = a.Lq;
+    float* sK = smem_m;                 // [Lkp][PN_]  read as [k = key][n = feature]      (dQ = dS K)
+    float* sV = sK + Lkp * PN_;         // [Lkp][PK_]  read as [n = key][k = feature]      (dP = dO V^T)
+    float* sQ = sV + Lkp * PK_;         // [Lqp][PN_]  read as [k = query][n = feature]    (dK = dS^T Q)
+    float* sG = sQ + Lqp * PN_;         // [Lqp][PK_]  dO: A operand of dP, [k][n] operand of dV
+    float* sS = sG + Lqp * PK_;         // [Lqp][PK_]  dS / sqrt(dk)
+    float* sD = sS + Lqp * PK_;         // [Lqp][PK_]  dropped P
+    for (int idx = tid; idx < Lkp * DKP; idx += blockDim.x) {
+        const int j = idx / DKP, dd = idx - j * DKP;
+        float kv = 0.f, vv = 0.f;
+        if (j < Lk && dd < dk) {
+            const int64_t row = (int64_t)g * Lk + j;
+            kv = a.k[row * a.ldk + h * dk + dd];
+            vv = a.v[row * a.ldv + h * dk + dd];
+        }
+        sK[j * PN_ + dd] = kv;
+        sV[j * PK_ + dd] = vv;
+    }
+    for (int idx = tid; idx < Lqp * DKP; idx += blockDim.x) {
+        const int i = idx / DKP, dd = idx - i * DKP;
+        float qv = 0.f, gv = 0.f;
+        if (i < Lq && dd < dk) {
+            const int64_t qrow = (int64_t)g * Lq + i;
+            qv = a.q[qrow * a.ldq + h * dk + dd];
+            gv = a.d_o[qrow * a.lddo + h * dk + dd];
+        }
+        sQ[i * PN_ + dd] = qv;
+        sG[i * PK_ + dd] = gv;
+    }
+    __syncthreads();
+    const float scale = sqrtf((float)dk);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int njt = Lkp >> 4, ndt = DKP >> 4, nit = Lqp >> 4;
+    for (int it = wave; it < nit; it += nw) {
+        const int i0 = it * 16;
+        // dP = dO V^T : D[i = 4*lq + r][j = 16*jt + lr]
+        f4 dp[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            dp[jt] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (jt < njt)
+                for (int kk = 0; kk < DKP / 4; ++kk) {
+                    const float av = sG[(i0 + lr) * PK_ + 4 * kk + lq];
+                    const float bv = sV[(16 * jt + lr) * PK_ + 4 * kk + lq];
+                    dp[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, dp[jt], 0, 0, 0);
+                }
+        }
+        f4 pp[4];
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            pp[jt] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (jt < njt) {
+                const int j = 16 * jt + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 4 * lq + r;
+                    float p = 0.f, d = 0.f, pd = 0.f;
+                    if (i < Lq && j < Lk) {
+                        const int64_t pi = (((int64_t)g * a.H + h) * Lq + i) * Lk + j;
+                        p = a.p[pi];
+                        const bool keep = a.drop_p > 0.f ? ortk_keep(a.drop_seed, (uint64_t)pi, a.drop_p) : true;
+                        d = keep ? dp[jt][r] * inv_keep : 0.f;
+                        pd = keep ? p * inv_keep : 0.f;
+                    }
+                    pp[jt][r] = p; dp[jt][r] = d; dot[r] += p * d;
+                    sD[(i0 + 4 * lq + r) * PK_ + j] = pd;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot[r] = group16_sum(dot[r]);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt < njt) {
+                const int j = 16 * jt + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 4 * lq + r;
+                    const float ds = pp[jt][r] * (dp[jt][r] - dot[r]);
+                    if (a.dscore && i < Lq && j < Lk) a.dscore[(((int64_t)g * a.H + h) * Lq + i) * Lk + j] = ds;
+                    sS[(i0 + 4 * lq + r) * PK_ + j] = ds / scale;
+                }
+            }
+        }
+        wave_sync();
+        // dQ = dS K : D[i][d]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            if (dt < ndt) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int kk = 0; kk < Lkp / 4; ++kk) {
+                    const float av = sS[(i0 + lr) * PK_ + 4 * kk + lq];
+                    const float bv = sK[(4 * kk + lq) * PN_ + 16 * dt + lr];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+                const int dd = 16 * dt + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 4 * lq + r;
+                    if (i < Lq && dd < dk) st_elem(a.dq, ((int64_t)g * Lq + i) * a.lddq + h * dk + dd, a.dqkv_dtype, acc[r]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: output tiles t = (which, jt, dt); A[m = key][k = query] = S^T (read [k][n]-style from sS / sD rows = query)
+    const int ntiles = 2 * njt * ndt;
+    for (int t = wave; t < ntiles; t += nw) {
+        const int which = t / (njt * ndt), rem = t - which * njt * ndt, jt = rem / ndt, dt = rem - jt * ndt;
+        const float* sA = which == 0 ? sS : sD;      // [query][key]
+        const float* sB = which == 0 ? sQ : sG;      // [query][feature]
+        const int pb = which == 0 ? PN_ : PK_;
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < Lqp / 4; ++kk) {
+            const float av = sA[(4 * kk + lq) * PK_ + 16 * jt + lr];    // A[m = 16*jt + lr][k = 4*kk + lq]
+            const float bv = sB[(4 * kk + lq) * pb + 16 * dt + lr];     // B[k][n = 16*dt + lr]
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        const int dd = 16 * dt + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * lq + r;
+            if (j < Lk && dd < dk) {
+                const int64_t row = (int64_t)g * Lk + j;
+                if (which == 0) st_elem(a.d_k, row * a.lddk + h * dk + dd, a.dqkv_dtype, acc[r]);
+                else            st_elem(a.dv, row * a.lddv + h * dk + dd, a.dqkv_dtype, acc[r]);
+            }
+        }
     }
 }
 
@@ -382,7 +662,21 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
                             (int)(sizeof(float) * 4 * (2 * 64 * KP + 128)));
         attr_set = true;
     }
-    if (a->Lk <= 64) {
+    // Dispatch measured on the path's three shapes (scratch/attn_bench.py, us fwd/bwd): 36x36 MFMA 81/132 vs 82/147,
+    // 85x36 MFMA 101/218 vs 170/293, 17x17 (10 240 tiny pairs) MFMA 200/526 vs 138/196 for the per-lane kernels.
+    const bool use_mfma = attn_impl() == 0 ? a->Lq > 32 : attn_impl() == 3;
+    if (a->Lk <= 64 && a->dk % 4 == 0 && use_mfma) {
+        // MFMA form: one workgroup per pair, one wave per 16 query rows (at most 8 waves)
+        const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16);
+        const int nw = (int)std::min<int64_t>(8, ortk_cdiv(a->Lq, 16));
+        const size_t lds = sizeof(float) * ((size_t)Lkp * (PK_ + PN_) + 64 + (size_t)nw * 16 * PK_ * 2);
+        static bool mf_attr = false;
+        if (!mf_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            mf_attr = true;
+        }
+        hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, ortk_s(stream), *a, Lkp, DKP);
+    } else if (a->Lk <= 64 && attn_impl() == 1) {
         const int pairs = a->nkv * a->H;
         hipLaunchKernelGGL(attn_fwd_wave_kernel, dim3((unsigned)ortk_cdiv(pairs, 4)), dim3(256),
                            sizeof(float) * 4 * ((size_t)2 * a->Lk * KP + 128), ortk_s(stream), *a);
@@ -408,6 +702,22 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
         attr_set = true;
     }
     const int pairs = a->nkv * a->H;
+    {
+        const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16), Lqp = (int)ortk_align(a->Lq, 16);
+        const size_t lds = sizeof(float) * ((size_t)Lkp * (PK_ + PN_) + (size_t)Lqp * (PN_ + 3 * PK_));
+        const bool use_mfma = attn_impl() == 0 ? a->Lq > 32 : attn_impl() == 3;
+        if (a->Lk <= 64 && a->dk % 4 == 0 && lds <= 160 * 1024 && use_mfma) {
+            static bool mb_attr = false;
+            if (!mb_attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                mb_attr = true;
+            }
+            const int nw = (int)std::min<int64_t>(8, ortk_cdiv(a->Lq, 16));
+            hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)pairs), dim3(64 * nw), lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
+            ORTK_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const dim3 wgrid((unsigned)ortk_cdiv(pairs, 4)), block(256);
     const size_t wave_lds = sizeof(float) * 4 * ((size_t)2 * a->Lk * KP + 192);
     if (a->Lk <= 32)
