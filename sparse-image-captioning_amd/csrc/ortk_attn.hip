@@ -453,6 +453,67 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
     }
 }
 
+// Decode form (few query rows per K/V group: 1 new token per beam for self-attention, the beams of an image for
+// cross-attention).  One wave per (group, head); K and V of the pair live in REGISTERS — K with lane = key (each
+// lane holds its key's 64 features, loaded as 16 independent float4), V with lane = feature (one coalesced 256-B row
+// per key) — so nothing is staged in LDS and every load of the pair is in flight at once.  Per query: scores are 64
+// FMAs per lane against the broadcast query, soft-max statistics are two wave reductions, P.V is Lk shuffle+FMA.
+// (A first version reduced one key at a time behind per-key branches: 250 us per call, all exposed latency.)
+template <int LKMAX>
+__global__ __launch_bounds__(256) void attn_decode_kernel(ortk_attn_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.nkv * a.H) return;
+    const int g = pair / a.H, h = pair - g * a.H;
+    const int Lk = a.Lk, dk = a.dk, Lq = a.Lq;
+    const int jl = lane < Lk ? lane : Lk - 1;
+    const int64_t myrow = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + jl]
+                                     : (int64_t)g * (a.kv_group_stride > 0 ? a.kv_group_stride : Lk) + jl;
+    // K: lane = key
+    float4 kreg[MAXD / 4];
+    const float* kp = a.k + myrow * a.ldk + h * dk;
+#pragma unroll
+    for (int c = 0; c < MAXD / 4; ++c) kreg[c] = (4 * c < dk) ? *reinterpret_cast<const float4*>(kp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // V: lane = feature; the row of key j is fetched through lane j's row index
+    float vreg[LKMAX];
+    const int dl = lane < dk ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < LKMAX; ++j) {
+        const int64_t row = __shfl(myrow, j < Lk ? j : 0, 64);
+        vreg[j] = (j < Lk) ? a.v[row * a.ldv + h * dk + dl] : 0.f;
+    }
+    const float kmask = (lane < Lk && a.kmask) ? a.kmask[(int64_t)g * Lk + lane] : 1.f;
+    const float scale = sqrtf((float)dk);
+    for (int i = 0; i < Lq; ++i) {
+        const int64_t qrow = (int64_t)g * Lq + i;
+        const float* qp = a.q + qrow * a.ldq + h * dk;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXD / 4; ++c) {
+            if (4 * c < dk) {
+                const float4 q4 = *reinterpret_cast<const float4*>(qp + 4 * c);      // wave-uniform address: broadcast
+                acc += q4.x * kreg[c].x + q4.y * kreg[c].y + q4.z * kreg[c].z + q4.w * kreg[c].w;
+            }
+        }
+        float sc = -INFINITY;
+        const int64_t pbase = (((int64_t)g * a.H + h) * Lq + i) * Lk;
+        if (lane < Lk) {
+            acc = acc / scale;
+            if (kmask == 0.f) acc = -1e9f;
+            if (a.bias) acc = a.bias[pbase + lane] + acc;
+            sc = acc;
+        }
+        const float mx = wave_max(sc);
+        const float e = lane < Lk ? expf(sc - mx) : 0.f;
+        const float p = e / wave_sum(e);
+        if (a.p && lane < Lk) a.p[pbase + lane] = p;
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < LKMAX; ++j) o += __shfl(p, j, 64) * vreg[j];      // p is 0 beyond Lk
+        if (lane < dk) st_elem(a.o, qrow * a.ldo + h * dk + lane, a.o_dtype, o);
+    }
+}
+
 struct TilesB {
     float (*k)[KP]; float (*v)[KP]; float (*dk)[KP]; float (*dv)[KP];   // [Lk][KP] each
     float (*q)[MAXD]; float (*go)[MAXD];                                // [4][MAXD]
@@ -665,7 +726,13 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
     // Dispatch measured on the path's three shapes (scratch/attn_bench.py, us fwd/bwd): 36x36 MFMA 81/132 vs 82/147,
     // 85x36 MFMA 101/218 vs 170/293, 17x17 (10 240 tiny pairs) MFMA 200/526 vs 138/196 for the per-lane kernels.
     const bool use_mfma = attn_impl() == 0 ? a->Lq > 32 : attn_impl() == 3;
-    if (a->Lk <= 64 && a->dk % 4 == 0 && use_mfma) {
+    const bool vec_kq = (a->ldk % 4 == 0) && (a->ldq % 4 == 0) && (a->dk % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->q)) & 15) == 0;
+    if (a->Lq <= 8 && a->Lk <= 64 && a->causal_period == 0 && a->drop_p == 0.f && vec_kq && attn_impl() == 0) {
+        const dim3 dgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
+        if (a->Lk <= 32) hipLaunchKernelGGL(attn_decode_kernel<32>, dgrid, dim3(256), 0, ortk_s(stream), *a);
+        else             hipLaunchKernelGGL(attn_decode_kernel<64>, dgrid, dim3(256), 0, ortk_s(stream), *a);
+    } else if (a->Lk <= 64 && a->dk % 4 == 0 && use_mfma) {
         // MFMA form: one workgroup per pair, one wave per 16 query rows (at most 8 waves)
         const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16);
         const int nw = (int)std::min<int64_t>(8, ortk_cdiv(a->Lq, 16));
