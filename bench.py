@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="xe", choices=("xe", "sparse_xe", "scst", "decode", "sparse_decode"))
+    ap.add_argument("--csr-kernels", action="store_true",
+                    help="sparse_decode: CSR gather products (ortk_spmm_csr) instead of MFMA GEMMs on zero-filled weights; "
+                         "measured slower than bf16 MFMA at 95 %% unstructured sparsity (DESIGN.md section 7)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 256; decode 1024)")
     ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,6 +149,9 @@ def main():
                     if p.dim() >= 2:
                         p.mul_((torch.rand_like(p) < 0.05).float())
     model = model.to(dev)
+    use_csr = args.workload == "sparse_decode" and args.csr_kernels
+    if use_csr:
+        model.enable_sparse_kernels(0.9)     # CSR sparse products (ortk_spmm_csr) for the >= 90 %-sparse weight blocks
     batch = synth_batch(B, S, config.att_feat_size, config.vocab_size, spi, config.max_seq_length, 1000 + rank, dev)
 
     if decode:
@@ -227,13 +233,15 @@ def main():
                    "sparse_xe": "ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; masked dense GEMM)",
                    "scst": "ORT dense SCST: greedy + 5 multinomial rollouts + teacher-forced update (BASELINE configs[3])",
                    "decode": "ORT dense, cached-KV beam-5 decode, 1024 images",
-                   "sparse_decode": "ORT 95% sparse (densified), cached-KV beam-5 decode, 1024 images (BASELINE configs[4])"}[args.workload]
+                   "sparse_decode": "ORT 95% sparse, cached-KV beam-5 decode, 1024 images (BASELINE configs[4])"}[args.workload]
         out = {"metric": "captions/sec", "value": round(value, 1), "unit": "captions/sec", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": cfgname, "images_per_gpu": B, "regions": S, "captions_per_image": spi,
                           "parallelism": f"dp{world}" if world > 1 else "single",
-                          "storage": "fp32 activations/weights, bf16 MFMA operands" if args.precision == "bf16" else "fp32"},
+                          "storage": ("fp32 master weights / residual stream / logits; MFMA-operand tensors stored bf16; fp32 accumulate"
+                                      if args.precision == "bf16" else "fp32"),
+                          "sparse_kernels": "csr" if use_csr else None},
                "roofline": roofline}
         if not args.no_cpu_baseline and world == 1:
             from sparse_image_captioning_amd.utils.config import ORT_DEFAULTS

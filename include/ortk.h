@@ -100,6 +100,18 @@ int ortk_backward(const ortk_config* cfg, const float* params, float* grads, con
 
 /* Cached-attention decoding: CachedTransformerBase._generate_captions (models/transformer.py:471-561)
  * + CaptionModel.batch_beam_search (models/caption_model.py:30-226, group_size 1). */
+/* A pruned (N,K) weight block in chunked CSR form (device pointers).  The K axis is cut in chunks of 512 columns:
+ * row_ptr has ceil(K/512)*N + 1 entries; the non-zeros of row n whose column lies in chunk c are
+ * [row_ptr[c*N+n], row_ptr[c*N+n+1]); col holds the column relative to its chunk; val the fp32 value.
+ * Every list is padded with (col 0, val 0.0f) entries to a multiple of 4 entries, and col / val are allocated with
+ * 4 spare zero entries behind row_ptr[last] (the kernel reads one 4-entry batch ahead).
+ * arena_offset identifies the block inside the parameter arena (ortk_linear_block). */
+typedef struct ortk_csr {
+    const int32_t* row_ptr; const uint16_t* col; const float* val;
+    int32_t N, K;
+    int64_t arena_offset;
+} ortk_csr;
+
 typedef struct ortk_decode_opts {
     int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
     int32_t num_random_sample;
@@ -108,6 +120,10 @@ typedef struct ortk_decode_opts {
     int32_t length_penalty;       /* 0 none, 1 "wu_<alpha>", 2 "avg_<alpha>"   utils/model_utils.py:121-146 */
     double  length_alpha;
     uint64_t seed;                /* multinomial: Gumbel-max over counter-based uniforms */
+    /* Optional (may be NULL / 0): CSR images of pruned weight blocks (see ortk_linear_block / ortk_spmm_csr).  A
+     * projection whose weight block has an entry here runs as a sparse product instead of a dense GEMM. */
+    const struct ortk_csr* sparse;
+    int32_t n_sparse;
 } ortk_decode_opts;
 
 size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, const ortk_decode_opts* o);
@@ -234,6 +250,16 @@ int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, floa
 int ortk_mask_apply(const float* w, const float* m, float* w_eff, int64_t n, int32_t mode, uint32_t seed, ortk_stream stream);
 int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw, float* dm, int64_t n, int32_t mode,
                   uint32_t seed, const float* extra_coef_dev, ortk_stream stream);
+/* The weight blocks the executor multiplies by (packed Q|K|V, the all-layer cross-attention K|V block, ...): block i
+ * is the (N,K) row-major matrix at arena offset *offset.  Returns the number of blocks when i < 0. */
+int ortk_linear_block(const ortk_config* cfg, int32_t i, int64_t* offset, int32_t* N, int32_t* K);
+/* Y = epi(X W~^T), W~ sparse (ortk_csr): v = sum_j val_j X[m, col_j] + bias[n]; relu; v += resid[m,n].
+ * Replaces F.linear on zero-filled pruned weights (scripts/eval_model.py:64-88, pruning/masked_layer.py:134-135).
+ * X / Y dtype: 0 fp32, 1 bf16. */
+int ortk_spmm_csr(const ortk_csr* w, const void* X, int32_t x_dtype, int64_t ldx, const float* bias, void* Y,
+                  int32_t y_dtype, int64_t ldy, int64_t M, int32_t relu, const float* resid, int64_t ldr,
+                  ortk_stream stream);
+
 /* count_dev[0] += number of kept entries (round(sigmoid(m)) for mode 0/1, m != 0 for mode 2) in m[0..n). */
 int ortk_mask_count(const float* m, int64_t n, int32_t mode, float* count_dev, ortk_stream stream);
 

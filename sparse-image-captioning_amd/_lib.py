@@ -35,10 +35,15 @@ class Batch(C.Structure):
                 ("B", C.c_int32), ("S", C.c_int32), ("R", C.c_int32), ("T", C.c_int32)]
 
 
+class Csr(C.Structure):
+    _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
+                ("arena_offset", C.c_int64)]
+
+
 class DecodeOpts(C.Structure):
     _fields_ = [("beam_size", C.c_int32), ("num_random_sample", C.c_int32), ("temperature", C.c_float),
                 ("decoding_constraint", C.c_int32), ("length_penalty", C.c_int32), ("length_alpha", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("sparse", C.POINTER(Csr)), ("n_sparse", C.c_int32)]
 
 
 class GemmArgs(C.Structure):
@@ -111,6 +116,8 @@ SIGNATURES = {
     "ortk_mask_apply": (_I32, [_P, _P, _P, _I64, _I32, _U32, _P]),
     "ortk_mask_bwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _U32, _P, _P]),
     "ortk_mask_count": (_I32, [_P, _I64, _I32, _P, _P]),
+    "ortk_linear_block": (_I32, [_CFG, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ortk_spmm_csr": (_I32, [C.POINTER(Csr), _P, _I32, _I64, _P, _P, _I32, _I64, _I64, _I32, _P, _I64, _P]),
 }
 
 _lib = None

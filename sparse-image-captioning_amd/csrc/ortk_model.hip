@@ -206,6 +206,11 @@ struct Ctx {
     const float* P;          // fp32 parameter arena (biases, LayerNorm, embeddings, and weights in fp32 mode)
     const void* W16;         // bf16 weight arena (mixed precision) or nullptr
     int adt;                 // dtype of (A) buffers
+    const ortk_csr* sp = nullptr; int nsp = 0;   // optional CSR images of pruned weight blocks (forward-only paths)
+    const ortk_csr* csr(int64_t off) const {
+        for (int i = 0; i < nsp; ++i) if (sp[i].arena_offset == off) return sp + i;
+        return nullptr;
+    }
     float p_drop() const { return train ? cfg->drop : 0.f; }
     float p_src() const { return train ? cfg->drop_src : 0.f; }
     uint32_t sub(uint32_t op) const { return ortk_subseed(seed, op); }
@@ -221,6 +226,12 @@ static inline const void* off_elems(const void* p, int64_t n, int dt) { return r
 static int fwd_gemm(const Ctx& c, const void* X, int xdt, int64_t ldx, int64_t woff, const float* bias, void* Y, int ydt, int64_t ldy,
                     int64_t M, int N, int K, bool relu = false, float drop = 0.f, uint32_t seed = 0, const float* resid = nullptr,
                     int64_t ldr = 0, const float* rowscale = nullptr) {
+    if (c.nsp && drop == 0.f && !rowscale) {
+        if (const ortk_csr* w = c.csr(woff)) {
+            if (w->N != N || w->K != K) return ORTK_EINVAL;
+            return ortk_spmm_csr(w, X, xdt, ldx, bias, Y, ydt, ldy, M, relu, resid, ldr, (ortk_stream)c.s);
+        }
+    }
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
     a.A = X; a.a_dtype = xdt; a.lda = ldx; a.B = c.W(woff); a.b_dtype = c.wdt(); a.ldb = K; a.C = Y; a.c_dtype = ydt; a.ldc = ldy;
     a.M = (int)M; a.N = N; a.K = K;
@@ -597,6 +608,30 @@ extern "C" int ortk_encode(const ortk_config* cfg, const float* params, const fl
     return encode_impl(cfg, params, att_feats, boxes, att_masks, B, S, ws, ws_bytes, memory_out, stream);
 }
 
+extern "C" int ortk_linear_block(const ortk_config* cfg, int32_t i, int64_t* offset, int32_t* N, int32_t* K) {
+    if (int e = check_cfg(cfg)) return e;
+    Offsets o; build_layout(*cfg, o, nullptr);
+    const int d = cfg->d_model, ff = cfg->d_ff, L = cfg->n_layers;
+    struct Blk { int64_t off; int N, K; };
+    std::vector<Blk> v;
+    v.push_back({o.att_w, d, cfg->feat});
+    for (int l = 0; l < L; ++l) {
+        const EncOff& e = o.enc[l];
+        v.push_back({e.wqkv, 3 * d, d}); v.push_back({e.wo, d, d}); v.push_back({e.w1, ff, d}); v.push_back({e.w2, d, ff});
+    }
+    for (int l = 0; l < L; ++l) {
+        const DecOff& e = o.dec[l];
+        v.push_back({e.wqkv, 3 * d, d}); v.push_back({e.wo, d, d}); v.push_back({e.cqw, d, d}); v.push_back({e.cow, d, d});
+        v.push_back({e.w1, ff, d}); v.push_back({e.w2, d, ff});
+    }
+    v.push_back({o.ckv_w, L * 2 * d, d});
+    v.push_back({o.gen_w, (int)ortk_align(cfg->vocab, 128), d});
+    if (i < 0) return (int)v.size();
+    if (i >= (int)v.size() || !offset || !N || !K) return ORTK_EINVAL;
+    *offset = v[i].off; *N = v[i].N; *K = v[i].K;
+    return 0;
+}
+
 // ================================================================================================ decoding
 namespace ortk {
 struct DecodeWS {
@@ -686,6 +721,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     hipStream_t s = ortk_s(stream);
     TRY(make_w16(cfg, o, params, w.w16, stream));
     Ctx c{cfg, s, cfg->precision, 0, false, params, w.w16, w.adt};
+    if (op->n_sparse > 0 && op->sparse) { c.sp = op->sparse; c.nsp = op->n_sparse; }
     const float* P = params;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, T = cfg->seq_len, A = w.adt;
     const int64_t Me = (int64_t)B * S;

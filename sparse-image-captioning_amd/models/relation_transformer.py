@@ -235,6 +235,31 @@ class RelationTransformerModel(CaptionModelBase):
         """Device pointer of the arena the kernels read (the `_prune` variant materialises s*W first)."""
         return L.ptr(self._flat)
 
+    def _eff_params_tensor(self):
+        """The arena tensor behind the last ``_eff_params_ptr`` call."""
+        return self._flat
+
+    def enable_sparse_kernels(self, min_sparsity=0.9):
+        """Decode with CSR sparse products (``ortk_spmm_csr``) for every weight block whose fraction of zeros is
+        >= ``min_sparsity`` (pass ``None`` to go back to dense GEMMs).  Same results as the reference's
+        dense-on-zero-filled-weights evaluation (scripts/eval_model.py:64-88) up to fp32 summation order."""
+        self._sparse_min = min_sparsity
+        self._sparse_tab = None
+
+    def _sparse_table(self):
+        """CSR table for the CURRENT effective weights (rebuilt when the weights or masks change)."""
+        if getattr(self, "_sparse_min", None) is None:
+            return None
+        eff = self._eff_params_tensor()
+        mflat = getattr(self, "_mask_flat", None)
+        key = (self._flat.data_ptr(), self._flat._version, None if mflat is None else mflat._version)
+        tab = getattr(self, "_sparse_tab", None)
+        if tab is None or tab[0] != key:
+            from ..sparse import SparseTable
+            tab = (key, SparseTable(self._ccfg, eff, self._sparse_min))
+            self._sparse_tab = tab
+        return tab[1]
+
     def _next_seed(self):
         self._seed_counter += 1
         return (torch.initial_seed() * 1000003 + self._seed_counter) & 0xFFFFFFFFFFFFFFFF or 1
@@ -369,7 +394,11 @@ class RelationTransformerModel(CaptionModelBase):
         seq = torch.empty(B, K, self.seq_length, dtype=torch.long, device=dev)
         lp = torch.empty(B, K, self.seq_length, device=dev)
         score = torch.empty(B, K, device=dev)
-        L.check(lib.ortk_decode(C.byref(self._ccfg), self._eff_params_ptr(False, 0), L.ptr(att_feats), L.ptr(boxes),
+        pptr = self._eff_params_ptr(False, 0)
+        tab = self._sparse_table()
+        if tab is not None and tab.n:
+            o.sparse, o.n_sparse = tab.array, tab.n
+        L.check(lib.ortk_decode(C.byref(self._ccfg), pptr, L.ptr(att_feats), L.ptr(boxes),
                                 L.ptr(att_masks), B, S, C.byref(o), L.ptr(ws), ws.numel(), L.ptr(seq), L.ptr(lp),
                                 L.ptr(score), L.stream_ptr()), "ortk_decode")
         return seq, lp, score

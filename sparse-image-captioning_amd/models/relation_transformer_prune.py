@@ -75,6 +75,9 @@ class RelationTransformerModel(PruningMixin, _Dense):
                                     self._mode(train), self._mask_seed(seed), L.stream_ptr()), "ortk_mask_apply")
         return L.ptr(self._weff)
 
+    def _eff_params_tensor(self):
+        return self._weff
+
     @staticmethod
     def _mask_seed(seed):
         return (int(seed) * 2654435761 + 0x5BD1E995) & 0xFFFFFFFF

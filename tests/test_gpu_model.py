@@ -169,6 +169,16 @@ def test_prune_eval_forward_decode_loss_grads_vs_reference_golden(P, golden):
                    {k: (v.to_dense() if v.is_sparse else v) for k, v in m.cpu().state_dict_sparse().items()})
     seq2, _ = dense(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 3}, mode="sample")
     np.testing.assert_array_equal(seq2.cpu().numpy(), g3["eval/decode_b3/seq"])
+    # the same decode through the CSR sparse kernels (every block of this ~70 %-sparse model qualifies)
+    m = m.cuda()
+    m.enable_sparse_kernels(min_sparsity=0.5)
+    seq3, lp3 = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 3}, mode="sample")
+    assert m._sparse_table().n >= 20
+    np.testing.assert_array_equal(seq3.cpu().numpy(), g3["eval/decode_b3/seq"])
+    close(lp3, g3["eval/decode_b3/logprobs"], 2e-4)
+    dense.enable_sparse_kernels(min_sparsity=0.5)
+    seq4, _ = dense(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 3}, mode="sample")
+    np.testing.assert_array_equal(seq4.cpu().numpy(), g3["eval/decode_b3/seq"])
 
 
 @pytest.mark.parametrize("mtype", ["mag_blind", "mag_uniform", "mag_dist", "snip"])
@@ -290,3 +300,27 @@ def test_large_batch_properties(P, full_state):
         tok = logp.gather(2, best.unsqueeze(2)).squeeze(2)
         valid = best != 0
         assert (tok - lp[:, 0])[valid].abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_sparse_decode_full_size_95pct(P, full_state, precision):
+    """BASELINE configs[4] shape: 95 %-sparse ORT, beam 5.  CSR sparse decode vs the dense-GEMM decode of the same
+    zero-filled weights (the reference's eval flow): identical tokens up to fp32 summation-order near-ties."""
+    m = _model(P, "relation_transformer_prune", C.FULL_CFG, full_state, precision=precision, prune_type="mag_uniform")
+    m.update_masks_once(0.95)
+    g = torch.Generator().manual_seed(5)
+    B, S = 16, 36
+    feats = torch.randn(B, S, 2048, generator=g).abs().cuda()
+    xy = torch.rand(B, S, 2, generator=g) * 0.6
+    boxes = torch.cat([xy, xy + 0.05 + torch.rand(B, S, 2, generator=g) * 0.3], 2).cuda()
+    masks = torch.ones(B, S).cuda(); masks[1, 30:] = 0; masks[7, 20:] = 0
+    opt = {"beam_size": 5}
+    seq_d, lp_d = m(att_feats=feats, boxes=boxes, att_masks=masks, opt=opt, mode="sample")
+    m.enable_sparse_kernels(0.9)
+    seq_s, lp_s = m(att_feats=feats, boxes=boxes, att_masks=masks, opt=opt, mode="sample")
+    tab = m._sparse_table()
+    assert tab.n >= 60 and 0.04 < tab.nnz / sum(bk["N"] * bk["K"] for bk in tab.blocks) < 0.06
+    agree = (seq_d == seq_s).all(-1).float().mean().item()
+    assert agree >= (0.95 if precision == 0 else 0.7), agree
+    same = (seq_d == seq_s).all(-1)
+    assert (lp_d[same] - lp_s[same]).abs().max().item() < (1e-3 if precision == 0 else 0.25)

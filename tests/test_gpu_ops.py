@@ -368,3 +368,37 @@ def test_bf16_storage_paths(L):
     acc = torch.zeros(200, device="cuda")
     L.check(L.lib().ortk_colsum(L.ptr(C16), 1, N, L.ptr(acc), M, N, L.stream_ptr()), "colsum16")
     torch.testing.assert_close(acc.cpu(), C16.float().cpu().sum(0), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("xdt", [0, 1])
+@pytest.mark.parametrize("M,N,K,sp", [(300, 130, 70, 0.8), (5120, 512, 512, 0.95), (100, 512, 2048, 0.95), (33, 2048, 512, 0.9),
+                                      (40000, 64, 600, 0.97), (1, 5, 3, 0.5), (9000, 48, 1030, 0.9)])
+def test_spmm_csr_vs_dense(L, xdt, M, N, K, sp):
+    """ortk_spmm_csr == F.linear on the zero-filled weight (scripts/eval_model.py:64-88 flow), with the fused
+    bias / ReLU / residual epilogue, fp32 and bf16 activations, K spanning several 512-column chunks."""
+    from sparse_image_captioning_amd.sparse import csr_from_dense
+    g = torch.Generator().manual_seed(M + N + K)
+    W = rnd(N, K, seed=1, scale=0.2) * (torch.rand(N, K, generator=g) >= sp).float()
+    W[N // 2] = 0.0                                   # an empty row
+    X, bias, resid = rnd(M, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    Xd = dev(X.bfloat16() if xdt else X)
+    Xr = Xd.float().cpu()
+    rp, col, val = csr_from_dense(dev(W))
+    assert int((val != 0).sum()) == int((W != 0).sum()) and int(rp[-1]) + 4 == val.numel() == col.numel()
+    assert int((rp % 4 != 0).sum()) == 0
+    for relu, use_res, ydt in [(0, False, 0), (1, True, 0), (1, False, 1)]:
+        ref = Xr.double() @ W.double().t() + bias.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        if use_res:
+            ref = ref + resid.double()
+        Y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if ydt else torch.float32)
+        csr = L.Csr(L.ptr(rp), L.ptr(col), L.ptr(val), N, K, 0)
+        r = dev(resid)
+        L.check(L.lib().ortk_spmm_csr(C.byref(csr), L.ptr(Xd), xdt, K, L.ptr(dev(bias)), L.ptr(Y), ydt, N, M, relu,
+                                      L.ptr(r) if use_res else None, N, L.stream_ptr()), "ortk_spmm_csr")
+        got = Y.float().cpu().double()
+        tol = 2e-2 if ydt else 2e-5
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        assert err < tol, (relu, use_res, ydt, err)
