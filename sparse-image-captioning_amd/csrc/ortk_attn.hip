@@ -195,7 +195,11 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, int Lkp, int DKP) {
+// LKP_T / DKP_T (/ LQP_T): padded sizes as compile-time constants for the path's shapes (0 = take the run-time value):
+// with constant trip counts the MFMA loops unroll fully and their LDS reads are issued ahead of the MFMA chain.
+template <int LKP_T, int DKP_T>
+__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, int Lkp_rt, int DKP_rt) {
+    const int Lkp = LKP_T > 0 ? LKP_T : Lkp_rt, DKP = DKP_T > 0 ? DKP_T : DKP_rt;
     extern __shared__ __attribute__((aligned(16))) float smem_m[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
@@ -205,17 +209,18 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, in
     float* sMask = sV + Lkp * PN_;              // [64]
     float* sQ = sMask + 64 + wave * (16 * PK_ * 2);   // [16][PK_]
     float* sP = sQ + 16 * PK_;                  // [16][PK_]   rows = query, k = key
-    for (int idx = tid; idx < Lkp * DKP; idx += blockDim.x) {
-        const int j = idx / DKP, dd = idx - j * DKP;
-        float kv = 0.f, vv = 0.f;
+    // dk % 4 == 0 and 16-byte aligned rows (checked by the launcher): stage with float4 loads
+    for (int idx = tid; idx < Lkp * (DKP / 4); idx += blockDim.x) {
+        const int j = idx / (DKP / 4), dd = (idx - j * (DKP / 4)) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
         if (j < Lk && dd < dk) {
             const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j]
                                            : (int64_t)g * (a.kv_group_stride > 0 ? a.kv_group_stride : Lk) + j;
-            kv = a.k[row * a.ldk + h * dk + dd];
-            vv = a.v[row * a.ldv + h * dk + dd];
+            kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * dk + dd);
+            vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * dk + dd);
         }
-        sK[j * PK_ + dd] = kv;
-        sV[j * PN_ + dd] = vv;
+        float* pk = sK + j * PK_ + dd; pk[0] = kv.x; pk[1] = kv.y; pk[2] = kv.z; pk[3] = kv.w;
+        *reinterpret_cast<float4*>(sV + j * PN_ + dd) = vv;
     }
     if (tid < 64) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
     __syncthreads();
@@ -225,10 +230,12 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, in
     const int njt = Lkp >> 4, ndt = DKP >> 4, nit = (Lq + 15) >> 4;
     for (int it = wave; it < nit; it += nw) {
         const int i0 = it * 16;
-        for (int idx = lane; idx < 16 * DKP; idx += 64) {
-            const int r = idx / DKP, dd = idx - r * DKP;
+        for (int idx = lane; idx < 16 * (DKP / 4); idx += 64) {
+            const int r = idx / (DKP / 4), dd = (idx - r * (DKP / 4)) * 4;
             const int i = i0 + r;
-            sQ[r * PK_ + dd] = (i < Lq && dd < dk) ? a.q[((int64_t)g * Lq + i) * a.ldq + h * dk + dd] : 0.f;
+            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < Lq && dd < dk) qv = *reinterpret_cast<const float4*>(a.q + ((int64_t)g * Lq + i) * a.ldq + h * dk + dd);
+            float* pq = sQ + r * PK_ + dd; pq[0] = qv.x; pq[1] = qv.y; pq[2] = qv.z; pq[3] = qv.w;
         }
         wave_sync();
         // S = Q K^T : D[i = 4*lq + r][j = 16*jt + lr]
@@ -237,6 +244,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, in
         for (int jt = 0; jt < 4; ++jt) {
             sacc[jt] = (f4){0.f, 0.f, 0.f, 0.f};
             if (jt < njt) {
+#pragma unroll
                 for (int kk = 0; kk < DKP / 4; ++kk) {
                     const float av = sQ[lr * PK_ + 4 * kk + lq];
                     const float bv = sK[(16 * jt + lr) * PK_ + 4 * kk + lq];
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, in
         for (int dt = 0; dt < 4; ++dt) {
             if (dt < ndt) {
                 f4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
                 for (int kk = 0; kk < Lkp / 4; ++kk) {
                     const float av = sP[lr * PK_ + 4 * kk + lq];
                     const float bv = sV[(4 * kk + lq) * PN_ + 16 * dt + lr];
@@ -316,7 +325,9 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, in
 // Backward with the same tiling.  Phase 1 (wave = 16-row query tile): dP = dO V^T, dS = P (dP - rowsum(P dP)),
 // dQ = dS K / sqrt(dk); dS / sqrt(dk) and the dropped P go to workgroup-wide LDS arrays.  Phase 2 (waves share the
 // 2 x (Lkp/16) x (DKP/16) output tiles): dK = dS^T Q / sqrt(dk), dV = Pd^T dO over ALL query rows of the group.
-__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, int Lkp, int DKP, int Lqp) {
+template <int LKP_T, int DKP_T, int LQP_T>
+__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, int Lkp_rt, int DKP_rt, int Lqp_rt) {
+    const int Lkp = LKP_T > 0 ? LKP_T : Lkp_rt, DKP = DKP_T > 0 ? DKP_T : DKP_rt, Lqp = LQP_T > 0 ? LQP_T : Lqp_rt;
     extern __shared__ __attribute__((aligned(16))) float smem_m[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
@@ -327,27 +338,27 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
     float* sG = sQ + Lqp * PN_;         // [Lqp][PK_]  dO: A operand of dP, [k][n] operand of dV
     float* sS = sG + Lqp * PK_;         // [Lqp][PK_]  dS / sqrt(dk)
     float* sD = sS + Lqp * PK_;         // [Lqp][PK_]  dropped P
-    for (int idx = tid; idx < Lkp * DKP; idx += blockDim.x) {
-        const int j = idx / DKP, dd = idx - j * DKP;
-        float kv = 0.f, vv = 0.f;
+    for (int idx = tid; idx < Lkp * (DKP / 4); idx += blockDim.x) {
+        const int j = idx / (DKP / 4), dd = (idx - j * (DKP / 4)) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
         if (j < Lk && dd < dk) {
             const int64_t row = (int64_t)g * Lk + j;
-            kv = a.k[row * a.ldk + h * dk + dd];
-            vv = a.v[row * a.ldv + h * dk + dd];
+            kv = *reinterpret_cast<const float4*>(a.k + row * a.ldk + h * dk + dd);
+            vv = *reinterpret_cast<const float4*>(a.v + row * a.ldv + h * dk + dd);
         }
-        sK[j * PN_ + dd] = kv;
-        sV[j * PK_ + dd] = vv;
+        *reinterpret_cast<float4*>(sK + j * PN_ + dd) = kv;
+        float* pv = sV + j * PK_ + dd; pv[0] = vv.x; pv[1] = vv.y; pv[2] = vv.z; pv[3] = vv.w;
     }
-    for (int idx = tid; idx < Lqp * DKP; idx += blockDim.x) {
-        const int i = idx / DKP, dd = idx - i * DKP;
-        float qv = 0.f, gv = 0.f;
+    for (int idx = tid; idx < Lqp * (DKP / 4); idx += blockDim.x) {
+        const int i = idx / (DKP / 4), dd = (idx - i * (DKP / 4)) * 4;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
         if (i < Lq && dd < dk) {
             const int64_t qrow = (int64_t)g * Lq + i;
-            qv = a.q[qrow * a.ldq + h * dk + dd];
-            gv = a.d_o[qrow * a.lddo + h * dk + dd];
+            qv = *reinterpret_cast<const float4*>(a.q + qrow * a.ldq + h * dk + dd);
+            gv = *reinterpret_cast<const float4*>(a.d_o + qrow * a.lddo + h * dk + dd);
         }
-        sQ[i * PN_ + dd] = qv;
-        sG[i * PK_ + dd] = gv;
+        *reinterpret_cast<float4*>(sQ + i * PN_ + dd) = qv;
+        float* pg = sG + i * PK_ + dd; pg[0] = gv.x; pg[1] = gv.y; pg[2] = gv.z; pg[3] = gv.w;
     }
     __syncthreads();
     const float scale = sqrtf((float)dk);
@@ -362,6 +373,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
         for (int jt = 0; jt < 4; ++jt) {
             dp[jt] = (f4){0.f, 0.f, 0.f, 0.f};
             if (jt < njt)
+#pragma unroll
                 for (int kk = 0; kk < DKP / 4; ++kk) {
                     const float av = sG[(i0 + lr) * PK_ + 4 * kk + lq];
                     const float bv = sV[(16 * jt + lr) * PK_ + 4 * kk + lq];
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
         for (int dt = 0; dt < 4; ++dt) {
             if (dt < ndt) {
                 f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
                 for (int kk = 0; kk < Lkp / 4; ++kk) {
                     const float av = sS[(i0 + lr) * PK_ + 4 * kk + lq];
                     const float bv = sK[(4 * kk + lq) * PN_ + 16 * dt + lr];
@@ -435,6 +448,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
         const float* sB = which == 0 ? sQ : sG;      // [query][feature]
         const int pb = which == 0 ? PN_ : PK_;
         f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int kk = 0; kk < Lqp / 4; ++kk) {
             const float av = sA[(4 * kk + lq) * PK_ + 16 * jt + lr];    // A[m = 16*jt + lr][k = 4*kk + lq]
             const float bv = sB[(4 * kk + lq) * pb + 16 * dt + lr];     // B[k][n = 16*dt + lr]
@@ -733,17 +747,22 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
         const dim3 dgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
         if (a->Lk <= 32) hipLaunchKernelGGL(attn_decode_kernel<32>, dgrid, dim3(256), 0, ortk_s(stream), *a);
         else             hipLaunchKernelGGL(attn_decode_kernel<64>, dgrid, dim3(256), 0, ortk_s(stream), *a);
-    } else if (a->Lk <= 64 && a->dk % 4 == 0 && use_mfma) {
+    } else if (a->Lk <= 64 && use_mfma && vec_kq && a->ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(a->v) & 15) == 0) {
         // MFMA form: one workgroup per pair, one wave per 16 query rows (at most 8 waves)
         const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16);
         const int nw = (int)std::min<int64_t>(8, ortk_cdiv(a->Lq, 16));
         const size_t lds = sizeof(float) * ((size_t)Lkp * (PK_ + PN_) + 64 + (size_t)nw * 16 * PK_ * 2);
         static bool mf_attr = false;
         if (!mf_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             mf_attr = true;
         }
-        hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, ortk_s(stream), *a, Lkp, DKP);
+        const dim3 mgrid((unsigned)(a->nkv * a->H)), mblock(64 * nw);
+        if (DKP == 64 && Lkp == 48)      hipLaunchKernelGGL((attn_fwd_mfma_kernel<48, 64>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP);
+        else if (DKP == 64 && Lkp == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, 64>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP);
+        else if (DKP == 64 && Lkp == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, 64>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP);
+        else                             hipLaunchKernelGGL((attn_fwd_mfma_kernel<0, 0>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP);
     } else if (a->Lk <= 64 && attn_impl() == 1) {
         const int pairs = a->nkv * a->H;
         hipLaunchKernelGGL(attn_fwd_wave_kernel, dim3((unsigned)ortk_cdiv(pairs, 4)), dim3(256),
@@ -774,14 +793,23 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
         const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16), Lqp = (int)ortk_align(a->Lq, 16);
         const size_t lds = sizeof(float) * ((size_t)Lkp * (PK_ + PN_) + (size_t)Lqp * (PN_ + 3 * PK_));
         const bool use_mfma = attn_impl() == 0 ? a->Lq > 32 : attn_impl() == 3;
-        if (a->Lk <= 64 && a->dk % 4 == 0 && lds <= 160 * 1024 && use_mfma) {
+        const bool vec = a->dk % 4 == 0 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->lddo % 4 == 0 &&
+                         ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v) |
+                           reinterpret_cast<uintptr_t>(a->d_o)) & 15) == 0;
+        if (a->Lk <= 64 && vec && lds <= 160 * 1024 && use_mfma) {
             static bool mb_attr = false;
             if (!mb_attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<48, 64, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<48, 64, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 mb_attr = true;
             }
             const int nw = (int)std::min<int64_t>(8, ortk_cdiv(a->Lq, 16));
-            hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)pairs), dim3(64 * nw), lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
+            const dim3 mgrid((unsigned)pairs), mblock(64 * nw);
+            if (DKP == 64 && Lkp == 48 && Lqp == 48)      hipLaunchKernelGGL((attn_bwd_mfma_kernel<48, 64, 48>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
+            else if (DKP == 64 && Lkp == 48 && Lqp == 96) hipLaunchKernelGGL((attn_bwd_mfma_kernel<48, 64, 96>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
+            else if (DKP == 64 && Lkp == 32 && Lqp == 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<32, 64, 32>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
+            else                                          hipLaunchKernelGGL((attn_bwd_mfma_kernel<0, 0, 0>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
             ORTK_CHECK_LAUNCH();
             return 0;
         }

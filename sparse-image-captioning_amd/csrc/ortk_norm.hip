@@ -3,6 +3,7 @@
 // One wave (64 lanes) per row, reductions by wavefront shuffles; a row of d <= 2048 floats stays in registers
 // (statically indexed, so nothing spills to scratch): lane l owns columns {4l..4l+3} + 256*it (vector form)
 // or l + 64*it (scalar form for d % 4 != 0 or unaligned rows).
+#include <cstdlib>
 #include "ortk_common.h"
 
 namespace {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ a, const float* __restrict__ stats,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
                                                      float* __restrict__ da, float* __restrict__ db, int64_t rows, int d,
-                                                     float eps) {
+                                                     float eps, int rows_per_block) {
     using C = Cols<VEC, NREG>;
     extern __shared__ float red[];  // [2][d] partial da / db
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < NREG; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
     load_row<VEC, NREG>(a, d, lane, av);
-    const int64_t r0 = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK;
-    for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 4) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    for (int rr = wave; rr < rows_per_block; rr += 4) {
         const int64_t row = r0 + rr;
         if (row >= rows) break;
         float xv[NREG], gv[NREG];
@@ -179,10 +180,13 @@ extern "C" int ortk_layernorm_bwd(const float* dy, const float* x, const float* 
                                   float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, ortk_stream stream) {
     if (!dy || !x || !a || !stats || !dx || !da || !db || d < 2 || d > 2048 || rows < 0) return ORTK_EINVAL;
     if (rows == 0) return 0;
-    dim3 grid((unsigned)ortk_cdiv(rows, LN_ROWS_PER_BLOCK)), block(256);
+    // measured (scratch/ln_bench.py): 64 and 32 rows tie at 21 760 rows (47 us); 32 wins at 9 216 (31.6 vs 35.9 us);
+    // 16 rows and fewer lose to the per-block atomics on da / db
+    const int rpb = rows >= 16384 ? LN_ROWS_PER_BLOCK : LN_ROWS_PER_BLOCK / 2;
+    dim3 grid((unsigned)ortk_cdiv(rows, rpb)), block(256);
     const size_t shm = 2 * (size_t)d * sizeof(float);
     const bool vec = d % 4 == 0 && al16(dy) && al16(x) && al16(a) && al16(dres) && al16(dx);
-#define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps)
+#define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps, rpb)
     if (d <= 512) { if (vec) LN_B(true, 8); else LN_B(false, 8); }
     else          { if (vec) LN_B(true, 32); else LN_B(false, 32); }
 #undef LN_B
