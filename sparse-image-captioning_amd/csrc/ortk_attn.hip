@@ -467,6 +467,294 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-only form for short sequences (Lq, Lk <= 32, dk = 64): the decoder's 17 x 17 causal self-attention is
+// 10 240 tiny (caption, head) pairs per layer.  One wave per pair, no LDS, no barrier: every MFMA operand is loaded
+// from global memory straight into the lane that feeds it.
+//   * the feature sum of Q.K^T is order-free, so lane (lr, lq) feeds features 16*lq .. 16*lq+15 of row lr over the
+//     16 k-steps: four float4 loads per row instead of a transposing LDS image;
+//   * the scores are produced TRANSPOSED (S^T = K Q^T): lane (lr = query i, lq) then holds keys j = 16*jt + 4*lq + r,
+//     which is exactly the A-operand layout of P.V (k-step (jt, r) takes key 16*jt + 4*lq + r from every lane), so
+//     the probabilities never leave their registers; the matching V rows are read as 64-byte row segments.
+// The backward runs the same scheme twice: transposed layout for dQ, natural layout (operands of the dP product
+// swapped, no extra loads) for dK and dV.
+template <int NIT, int NJT>
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(ortk_attn_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.nkv * a.H) return;
+    const int g = pair / a.H, h = pair - g * a.H;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int64_t kv0 = (int64_t)g * (a.kv_group_stride > 0 ? a.kv_group_stride : Lk);
+    const float* qb = a.q + (int64_t)g * Lq * a.ldq + h * 64;
+    const float* kb = a.k + kv0 * a.ldk + h * 64;
+    const float* vb = a.v + kv0 * a.ldv + h * 64;
+    float4 kf[NJT][4], qf[NIT][4];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const float* src = kb + (int64_t)min(16 * jt + lr, Lk - 1) * a.ldk + 16 * lq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kf[jt][c] = *reinterpret_cast<const float4*>(src + 4 * c);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const float* src = qb + (int64_t)min(16 * it + lr, Lq - 1) * a.ldq + 16 * lq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qf[it][c] = *reinterpret_cast<const float4*>(src + 4 * c);
+    }
+    // key mask of this lane's keys j = 16*jt + 4*lq + r
+    float mk[NJT][4];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * lq + r;
+            mk[jt][r] = j < Lk ? (a.kmask ? a.kmask[(int64_t)g * Lk + j] : 1.f) : -1.f;
+        }
+    const float scale = sqrtf(64.f);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    f4 pt[NIT][NJT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        // S^T[j][i]: A = K rows (m = j), B = Q rows (n = i)
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[jt][c].x, qf[it][c].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[jt][c].y, qf[it][c].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[jt][c].z, qf[it][c].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[jt][c].w, qf[it][c].w, acc, 0, 0, 0);
+            }
+            pt[it][jt] = acc;
+        }
+        const int i = 16 * it + lr;
+        const int qpos = a.causal_period > 0 ? i % a.causal_period : 0;
+        const int64_t prow = (((int64_t)g * a.H + h) * Lq + min(i, Lq - 1)) * Lk;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * lq + r;
+                float x = pt[it][jt][r] / scale;
+                if (mk[jt][r] == 0.f || (a.causal_period > 0 && j > qpos)) x = -1e9f;
+                if (mk[jt][r] < 0.f) x = -INFINITY;
+                else if (a.bias) x = a.bias[prow + j] + x;
+                pt[it][jt][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = expf(pt[it][jt][r] - mx); pt[it][jt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * lq + r;
+                float pv = pt[it][jt][r] / sum;
+                if (i < Lq && j < Lk) {
+                    if (a.p) a.p[prow + j] = pv;
+                    if (a.drop_p > 0.f) pv = ortk_keep(a.drop_seed, (uint64_t)(prow + j), a.drop_p) ? pv * inv_keep : 0.f;
+                } else pv = 0.f;
+                pt[it][jt][r] = pv;
+            }
+    }
+    // O[i][d] = sum_j P[i][j] V[j][d]: A = P (held), B = V[16*jt + 4*lq + r][16*dt + lr]
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        float vv[NJT][4];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * lq + r;
+                const float t = vb[(int64_t)min(j, Lk - 1) * a.ldv + 16 * dt + lr];
+                vv[jt][r] = j < Lk ? t : 0.f;
+            }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pt[it][jt][r], vv[jt][r], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * lq + r;
+                if (i < Lq) st_elem(a.o, ((int64_t)g * Lq + i) * a.ldo + h * 64 + 16 * dt + lr, a.o_dtype, acc[r]);
+            }
+        }
+    }
+}
+
+template <int NIT, int NJT>
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(ortk_attn_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.nkv * a.H) return;
+    const int g = pair / a.H, h = pair - g * a.H;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const int lr = lane & 15, lq = lane >> 4;
+    const float* qb = a.q + (int64_t)g * Lq * a.ldq + h * 64;
+    const float* kb = a.k + (int64_t)g * Lk * a.ldk + h * 64;
+    const float* vb = a.v + (int64_t)g * Lk * a.ldv + h * 64;
+    const float* gb = a.d_o + (int64_t)g * Lq * a.lddo + h * 64;
+    const int64_t pbase = ((int64_t)g * a.H + h) * Lq * Lk;
+    float4 vf[NJT][4], gf[NIT][4];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const float* src = vb + (int64_t)min(16 * jt + lr, Lk - 1) * a.ldv + 16 * lq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vf[jt][c] = *reinterpret_cast<const float4*>(src + 4 * c);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const float* src = gb + (int64_t)min(16 * it + lr, Lq - 1) * a.lddo + 16 * lq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gf[it][c] = *reinterpret_cast<const float4*>(src + 4 * c);
+    }
+    const float scale = sqrtf(64.f);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    float dotv[NIT];
+    // ---- transposed layout: lane (lr = i, lq) holds keys j = 16*jt + 4*lq + r   ->  dQ = dS K / sqrt(dk)
+    {
+        f4 ds[NIT][NJT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = 16 * it + lr;
+            f4 pp[NJT];
+            float dot = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};   // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[jt][c].x, gf[it][c].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[jt][c].y, gf[it][c].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[jt][c].z, gf[it][c].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[jt][c].w, gf[it][c].w, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * lq + r;
+                    float pv = 0.f, d = 0.f;
+                    if (i < Lq && j < Lk) {
+                        const int64_t pi = pbase + (int64_t)i * Lk + j;
+                        pv = a.p[pi];
+                        const bool keep = a.drop_p > 0.f ? ortk_keep(a.drop_seed, (uint64_t)pi, a.drop_p) : true;
+                        d = keep ? acc[r] * inv_keep : 0.f;
+                    }
+                    dot += pv * d;
+                    pp[jt][r] = pv; ds[it][jt][r] = d;
+                }
+            }
+            dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
+            dotv[it] = dot;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * lq + r;
+                    const float v = pp[jt][r] * (ds[it][jt][r] - dot);
+                    if (a.dscore && i < Lq && j < Lk) a.dscore[pbase + (int64_t)i * Lk + j] = v;
+                    ds[it][jt][r] = v / scale;
+                }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float kk[NJT][4];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kk[jt][r] = kb[(int64_t)min(16 * jt + 4 * lq + r, Lk - 1) * a.ldk + 16 * dt + lr];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[it][jt][r], kk[jt][r], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + 4 * lq + r;
+                    if (i < Lq) st_elem(a.dq, ((int64_t)g * Lq + i) * a.lddq + h * 64 + 16 * dt + lr, a.dqkv_dtype, acc[r]);
+                }
+            }
+        }
+    }
+    // ---- natural layout: lane (lr = j, lq) holds queries i = 16*it + 4*lq + r   ->  dK = dS^T Q / sqrt(dk), dV = Pd^T dO
+    f4 ds[NJT][NIT], pd[NJT][NIT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int j = 16 * jt + lr;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};   // dP[i][j] = sum_d dO[i][d] V[j][d]  (same operand registers, swapped)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[it][c].x, vf[jt][c].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[it][c].y, vf[jt][c].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[it][c].z, vf[jt][c].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[it][c].w, vf[jt][c].w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * lq + r;
+                const float dot = __shfl(dotv[it], 4 * lq + r, 64);     // lane (lr' = i mod 16, lq' = 0) holds row i's dot
+                float pv = 0.f, d = 0.f, pdv = 0.f;
+                if (i < Lq && j < Lk) {
+                    const int64_t pi = pbase + (int64_t)i * Lk + j;
+                    pv = a.p[pi];
+                    const bool keep = a.drop_p > 0.f ? ortk_keep(a.drop_seed, (uint64_t)pi, a.drop_p) : true;
+                    d = keep ? acc[r] * inv_keep : 0.f;
+                    pdv = keep ? pv * inv_keep : 0.f;
+                }
+                ds[jt][it][r] = pv * (d - dot) / scale;
+                pd[jt][it][r] = pdv;
+            }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        float qq[NIT][4], gg[NIT][4];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = min(16 * it + 4 * lq + r, Lq - 1);
+                qq[it][r] = qb[row * a.ldq + 16 * dt + lr];
+                gg[it][r] = gb[row * a.lddo + 16 * dt + lr];
+            }
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            f4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[jt][it][r], qq[it][r], ak, 0, 0, 0);
+                    av = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[jt][it][r], gg[it][r], av, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * lq + r;
+                if (j < Lk) {
+                    const int64_t row = (int64_t)g * Lk + j;
+                    st_elem(a.d_k, row * a.lddk + h * 64 + 16 * dt + lr, a.dqkv_dtype, ak[r]);
+                    st_elem(a.dv, row * a.lddv + h * 64 + 16 * dt + lr, a.dqkv_dtype, av[r]);
+                }
+            }
+        }
+    }
+}
+
 // Decode form (few query rows per K/V group: 1 new token per beam for self-attention, the beams of an image for
 // cross-attention).  One wave per (group, head); K and V of the pair live in REGISTERS — K with lane = key (each
 // lane holds its key's 64 features, loaded as 16 independent float4), V with lane = feature (one coalesced 256-B row
@@ -723,6 +1011,11 @@ int check(const ortk_attn_args* a) {
     return 0;
 }
 
+// the register-only kernels: training-time short sequences (decode steps with 1-8 query rows keep their own kernels)
+bool small_ok(const ortk_attn_args* a) {
+    return a->dk == 64 && a->Lq <= 32 && a->Lk <= 32 && a->Lq >= 9 && !a->kv_index;
+}
+
 }  // namespace
 
 extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
@@ -747,6 +1040,14 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
         const dim3 dgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
         if (a->Lk <= 32) hipLaunchKernelGGL(attn_decode_kernel<32>, dgrid, dim3(256), 0, ortk_s(stream), *a);
         else             hipLaunchKernelGGL(attn_decode_kernel<64>, dgrid, dim3(256), 0, ortk_s(stream), *a);
+    } else if (small_ok(a) && attn_impl() == 0 && a->ldv % 4 == 0 && a->ldq % 4 == 0 && a->ldk % 4 == 0 &&
+               ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v)) & 15) == 0) {
+        const dim3 sgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
+        const int nit = a->Lq > 16 ? 2 : 1, njt = a->Lk > 16 ? 2 : 1;
+        if (nit == 2 && njt == 2)      hipLaunchKernelGGL((attn_small_fwd_kernel<2, 2>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        else if (nit == 2)             hipLaunchKernelGGL((attn_small_fwd_kernel<2, 1>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        else if (njt == 2)             hipLaunchKernelGGL((attn_small_fwd_kernel<1, 2>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        else                           hipLaunchKernelGGL((attn_small_fwd_kernel<1, 1>), sgrid, dim3(256), 0, ortk_s(stream), *a);
     } else if (a->Lk <= 64 && use_mfma && vec_kq && a->ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(a->v) & 15) == 0) {
         // MFMA form: one workgroup per pair, one wave per 16 query rows (at most 8 waves)
         const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16);
@@ -789,6 +1090,17 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
         attr_set = true;
     }
     const int pairs = a->nkv * a->H;
+    if (small_ok(a) && attn_impl() == 0 && a->ldv % 4 == 0 && a->lddo % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(a->v) | reinterpret_cast<uintptr_t>(a->d_o)) & 15) == 0) {
+        const dim3 sgrid((unsigned)ortk_cdiv(pairs, 4));
+        const int nit = a->Lq > 16 ? 2 : 1, njt = a->Lk > 16 ? 2 : 1;
+        if (nit == 2 && njt == 2)      hipLaunchKernelGGL((attn_small_bwd_kernel<2, 2>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        else if (nit == 2)             hipLaunchKernelGGL((attn_small_bwd_kernel<2, 1>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        else if (njt == 2)             hipLaunchKernelGGL((attn_small_bwd_kernel<1, 2>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        else                           hipLaunchKernelGGL((attn_small_bwd_kernel<1, 1>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        ORTK_CHECK_LAUNCH();
+        return 0;
+    }
     {
         const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16), Lqp = (int)ortk_align(a->Lq, 16);
         const size_t lds = sizeof(float) * ((size_t)Lkp * (PK_ + PN_) + (size_t)Lqp * (PN_ + 3 * PK_));

@@ -211,10 +211,13 @@ def test_attention_shapes(L):
     _attn_case(L, 4, 8, 12, 12, 8, 0, True, True)        # tiny golden geometry (dk = 8)
     _attn_case(L, 2, 2, 5, 100, 32, 0, False, True)      # 100 regions (2 keys per lane)
     _attn_case(L, 3, 4, 1, 1, 16, 1, False, False)       # single key
+    _attn_case(L, 6, 3, 20, 9, 64, 0, True, True)        # register-only kernel: 2 query tiles x 1 key tile, bias
+    _attn_case(L, 5, 2, 12, 31, 64, 0, False, True)      # register-only kernel: 1 x 2 tiles
+    _attn_case(L, 9, 8, 32, 32, 64, 8, False, False)     # register-only kernel: full 2 x 2 tiles, causal period 8
 
 
-def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
-    nkv, H, Lq, Lk, dk = 3, 2, 9, 11, 16
+@pytest.mark.parametrize("nkv,H,Lq,Lk,dk", [(3, 2, 9, 11, 16), (5, 8, 17, 17, 64), (2, 8, 36, 36, 64)])
+def test_attention_dropout_is_consistent_between_fwd_and_bwd(L, nkv, H, Lq, Lk, dk):
     d = H * dk
     q, k, v, do = (dev(rnd(nkv * n, d, seed=s)) for n, s in ((Lq, 1), (Lk, 2), (Lk, 3), (Lq, 4)))
     a = L.AttnArgs()
