@@ -16,6 +16,7 @@
 //
 // Workgroup ids are remapped so that the blocks resident on one XCD (ids b, b+8, ...) walk CONSECUTIVE tiles
 // (n fastest): they share the A panel in that XCD's L2 instead of fetching it 8 times.
+#include <cstdlib>
 #include <vector>
 #include "ortk_common.h"
 
@@ -536,6 +537,150 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
 }
 constexpr size_t BF16_LDS_BYTES = (size_t)4 * IMG_ELEMS * sizeof(__bf16);
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA pipelined variant (both operands bf16 in memory, every tile full).
+//
+// The register-staged kernel above keeps ONE K-tile in flight per workgroup; with this path's K = 512 the MFMA work of
+// a tile (512 cycles) is far shorter than a global load round trip, so each K-step waited ~2 000 cycles (measured:
+// 1.0 us per 64-wide K-step with the workgroup alone on the chip).  Here tiles travel global -> LDS by
+// `global_load_lds_dwordx4` (no VGPRs), through a ring of GNS = 4 stages of 32 k-columns: three tiles are in flight
+// while the fourth is multiplied, a counted `s_waitcnt vmcnt` retires exactly the oldest tile, and ONE raw s_barrier per
+// tile both publishes it and frees the stage consumed in the previous iteration.
+//
+// An LDS-DMA instruction writes 64 x 16 B CONTIGUOUSLY (lane order), so the images cannot be padded; they are made
+// bank-conflict free by an XOR swizzle applied on the SOURCE address (which 16-byte chunk a lane fetches) and again
+// when the fragments are read:
+//   [m][k] image, 64-B rows (4 chunks): chunk' = chunk ^ F[(row >> 2) & 3], F = {0,2,3,1}  -> the 16 lanes of every
+//          ds_read_b128 service group hit 16 distinct 16-B slots of the 256-B bank row;
+//   [k][m] image, 256-B rows (16 chunks): chunk' = chunk ^ 2*((k & 3) | ((k >> 1) & 4))  -> the 8 k-rows x 2 chunks a
+//          32-lane half of ds_read_b64_tr_b16 touches are 16 distinct chunks.
+constexpr int GBK = 32, GNS = 4;
+constexpr int G_IMG = 128 * GBK;                       // bf16 elements per operand image (8 KB)
+constexpr size_t GLDS_RING_BYTES = (size_t)GNS * 2 * G_IMG * sizeof(__bf16);   // 64 KB
+
+__device__ __forceinline__ int swz_mk(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0,2,3,1} packed as 0b01111000
+__device__ __forceinline__ int swz_km(int k) { return 2 * ((k & 3) | ((k >> 1) & 4)); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+// issue this wave's share (2 wave-instructions) of one operand tile of TM rows / columns (128: 8 instructions over
+// 4 waves; 256: 16 instructions over 8 waves)
+template <bool T, int TM>
+__device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int inst = wave * 2 + u;
+        const __bf16* g;
+        if (!T) {
+            const int r = inst * 16 + (lane >> 2), c = (lane & 3) ^ swz_mk(r);
+            g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+        } else {
+            constexpr int CPR = TM / 8;                       // 16-byte chunks per k-row
+            const int f = inst * 64 + lane, kr = f / CPR, c = (f % CPR) ^ swz_km(kr);
+            g = base + (int64_t)(k0 + kr) * ld + tile0 + c * 8;
+        }
+        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
+    }
+}
+
+template <bool T, int TM>
+__device__ __forceinline__ bf16x8 gfrag(const __bf16* img, int m0, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    if (!T) {
+        return *reinterpret_cast<const bf16x8*>(img + (m0 + lr) * GBK + ((lg ^ swz_mk(lr)) << 3));
+    } else {
+        // lane 4q+p of a 16-lane group supplies &img[k = 8*lg + q][m0 + 4p]; it receives column (lane & 15) of 4 k-rows
+        const int q = lr >> 2, pp = lane & 3;
+        const int chunk = ((m0 >> 3) + (pp >> 1)) ^ (2 * q + 8 * (lg & 1));
+        const __bf16* a = img + (8 * lg + q) * TM + (chunk << 3) + 4 * (pp & 1);
+        const bf16x4 lo = tr_read(a), hi = tr_read(a + 4 * TM);      // k + 4: same swizzle (bit 2 of k is not used)
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+
+// BIG = false: 128 x 128 tile, 4 waves (2 x 2), 64 KB ring, two workgroups per CU.
+// BIG = true : 256 x 256 tile, 8 waves (2 x 4, each 128 x 64), 128 KB ring, one workgroup per CU: half the operand
+//              bytes fetched per FLOP (128 FLOP/B instead of 64) — the measured bound of the small tile is the
+//              L2 -> CU fetch rate (~13 B/clk/CU sustained), not MFMA issue.
+template <bool TA, bool TB, bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_bf16_glds_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    constexpr int TM = BIG ? 256 : 128;             // tile rows = tile columns
+    constexpr int MI = BIG ? 8 : 4;                 // 16-row fragments per wave
+    constexpr int IMG = TM * GBK;                   // elements per operand image
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = BIG ? wave >> 2 : wave >> 1, wn = BIG ? wave & 3 : wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks_ = rest / tilesM;
+    const int mb = mt * TM, nb = nt * TM;
+    const int k_begin = ks_ * kchunk;
+    const int k_end = min(p.K, k_begin + kchunk);
+    const __bf16* Ap = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bp = reinterpret_cast<const __bf16*>(p.B);
+    const int T = (k_end - k_begin) / GBK;
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = TA && p.colsum != nullptr && nt == 0;
+    float cs = 0.f;
+
+    auto issue = [&](int t) {
+        __bf16* st = smem16 + (size_t)(t & (GNS - 1)) * 2 * IMG;
+        glds_tile<TA, TM>(Ap, p.lda, mb, k_begin + t * GBK, st, wave, lane);
+        glds_tile<TB, TM>(Bp, p.ldb, nb, k_begin + t * GBK, st + IMG, wave, lane);
+    };
+    for (int t = 0; t < GNS - 1 && t < T; ++t) issue(t);
+    for (int t = 0; t < T; ++t) {
+        // retire tile t (4 DMA instructions per tile and wave; tiles t+1, t+2 may stay in flight), then publish it
+        const int rem = T - 1 - t;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // every wave is past its reads of tile t-1: its stage takes tile t+3
+        if (t + GNS - 1 < T) issue(t + GNS - 1);
+        const __bf16* sA = smem16 + (size_t)(t & (GNS - 1)) * 2 * IMG;
+        const __bf16* sB = sA + IMG;
+        bf16x8 a[MI], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = gfrag<TB, TM>(sB, wn * 64 + 16 * j, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = gfrag<TA, TM>(sA, wm * (16 * MI) + 16 * i, lane);
+        if (TA && do_cs && tid < TM) {
+            // fused bias gradient: column tid of the k-major A tile, straight from the LDS image
+            const int ch = tid >> 3, off = tid & 7;
+#pragma unroll 8
+            for (int kr = 0; kr < GBK; ++kr) cs += (float)sA[kr * TM + (((ch ^ swz_km(kr)) << 3) | off)];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    if (TA && do_cs && tid < TM) atomicAdd(p.colsum + mb + tid, cs);
+    Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
+    if (!BIG && p.accumulate) {
+        __syncthreads();      // the staged C tile reuses the ring
+        epilogue_staged<true>(e, reinterpret_cast<float*>(smem16), mb, nb, wm, wn, lane, wave,
+                              *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]));
+    } else {
+#pragma unroll
+        for (int hh = 0; hh < MI / 4; ++hh)
+            epilogue_tile<true>(e, mb + wm * (16 * MI) + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
+                                *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+    }
+}
+constexpr size_t GLDS_LDS_BYTES = GLDS_RING_BYTES > 128 * CP * sizeof(float) ? GLDS_RING_BYTES : 128 * CP * sizeof(float);
+constexpr size_t GLDS_LDS_BYTES_BIG = (size_t)GNS * 2 * 256 * GBK * sizeof(__bf16);   // 128 KB
+
 typedef void (*gemm16_fn)(ortk_gemm_args, int, int, int);
 template <bool TA, bool TB, bool FAST> gemm16_fn pick16t(int adt, int bdt) {
     if (adt == ORTK_F32 && bdt == ORTK_F32) return gemm_bf16_kernel<TA, TB, float, float, FAST>;
@@ -625,6 +770,38 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
                           al(p.A, 16) && al(p.B, 16) && (p.lda * ea) % 16 == 0 && (p.ldb * eb) % 16 == 0 &&
                           al(p.C, 4 * ec) && (p.ldc % 4) == 0 && al(p.bias, 16) && al(p.resid, 16) && (p.ldr % 4) == 0 &&
                           al(p.gate, 4 * eg) && (p.ldg % 4) == 0;
+        static int impl = -1;   // experiments: 1 = register-staged kernel only, 2 = 128^2 DMA tiles only, 3 = 256^2 whenever legal
+        if (impl < 0) { const char* ev = getenv("ORTK_GEMM_IMPL"); impl = ev ? atoi(ev) : 0; }
+        // Measured in the XE step (bench.py, ms/step): register-staged kernel everywhere 17.9; DMA kernels everywhere
+        // 21.3 (the k-major layouts lose: dgrad 4.1 vs 3.3 ms, wgrad 4.1 vs 3.4 ms per step in isolation); the DMA kernels
+        // therefore serve the forward layout only unless ORTK_GEMM_IMPL >= 2 asks for them everywhere.
+        const bool dma_layout = key == 4 || impl >= 2;
+        if (fast && impl != 1 && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0) {
+            // 256 x 256 tiles when they still give enough workgroups (and no split-K accumulation, which needs the
+            // staged 128 x 128 epilogue); impl 2 = small tiles only, impl 3 = big tiles whenever legal
+            const int64_t big_blocks = (int64_t)(p.M / 256) * (p.N / 256);
+            // measured (scratch/gemm_shapes.py): the big tile wins whenever its grid fills >= 60 % of the CU slots of its
+            // last round (170 blocks: 29.6 vs 33.7 us; 510: 58 vs 72 us) and loses on short grids (72 blocks: 26 vs 17 us;
+            // 288 blocks = 1.1 rounds: 50 vs 44 us)
+            const int64_t rounds = (big_blocks + 255) / 256;
+            const bool fills = big_blocks * 10 >= rounds * 256 * 6;
+            const bool big = !p.accumulate && p.M % 256 == 0 && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
+            gemm16_fn gf;
+            if (big) gf = key == 4 ? gemm_bf16_glds_kernel<false, false, true> : key == 5 ? gemm_bf16_glds_kernel<false, true, true> : gemm_bf16_glds_kernel<true, true, true>;
+            else     gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false> : key == 5 ? gemm_bf16_glds_kernel<false, true, false> : gemm_bf16_glds_kernel<true, true, false>;
+            static bool gl_attr[6] = {false, false, false, false, false, false};
+            const int gi = (key == 4 ? 0 : key == 5 ? 1 : 2) + (big ? 3 : 0);
+            const size_t lds = big ? GLDS_LDS_BYTES_BIG : GLDS_LDS_BYTES;
+            if (!gl_attr[gi]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                gl_attr[gi] = true;
+            }
+            if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, p.M / 256, p.N / 256, kchunk);
+            else     hipLaunchKernelGGL(gf, grid, block, lds, s, p, tilesM, tilesN, kchunk);
+            if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof->push_back(rec); }
+            ORTK_CHECK_LAUNCH();
+            return 0;
+        }
         gemm16_fn fn = key == 4 ? pick16<false, false>(p.a_dtype, p.b_dtype, fast)
                      : key == 5 ? pick16<false, true>(p.a_dtype, p.b_dtype, fast)
                                 : pick16<true, true>(p.a_dtype, p.b_dtype, fast);

@@ -405,3 +405,34 @@ def test_spmm_csr_vs_dense(L, xdt, M, N, K, sp):
         assert torch.isfinite(got).all()
         err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
         assert err < tol, (relu, use_res, ydt, err)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (1280, 512, 2048), (384, 256, 192), (2048, 2048, 192), (4096, 1024, 64)])
+def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
+    """Full-tile bf16 x bf16 shapes take the LDS-DMA pipelined kernel (swizzled images, 4-stage ring): all three operand
+    layouts, fused epilogue, split-K accumulation and fused column sums — against fp32 matmuls of the same bf16 values
+    (fp32 accumulation: tolerance 1e-3 of the output scale, an order of magnitude below bf16 rounding)."""
+    A, B = rnd(M, K, seed=11), rnd(N, K, seed=12)
+    A16, B16 = dev(A).bfloat16(), dev(B).bfloat16()
+    ref = A16.float().cpu().double() @ B16.float().cpu().double().t()
+    sc = ref.abs().max().item()
+    out = gemm(L, A16, B16, M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1)                         # X W^T
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-3 * sc
+    Bt16 = B16.t().contiguous()
+    out = gemm(L, A16, Bt16, M, N, K, 0, 1, 1, a_dtype=1, b_dtype=1)                        # dY W
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-3 * sc
+    At16 = A16.t().contiguous()
+    out = gemm(L, At16, Bt16, M, N, K, 1, 1, 1, a_dtype=1, b_dtype=1)                       # dY^T X
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-3 * sc
+    # epilogue: bias + relu + residual, bf16 output
+    bias, resid = rnd(N, seed=13), rnd(M, N, seed=14)
+    C16 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    gemm(L, A16, B16, M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1, C=C16, c_dtype=1, bias=dev(bias), relu=1, resid=dev(resid))
+    refe = (ref + bias.double()).clamp_min(0) + resid.double()
+    assert (C16.float().cpu().double() - refe).abs().max().item() < 1e-2 * max(sc, 1.0)
+    # split-K accumulation on top of existing content + fused column sums of A
+    for sk in (1, 2, 3):
+        Cacc = torch.ones(M, N, device="cuda"); csum = torch.full((M,), 2.0, device="cuda")
+        gemm(L, At16, Bt16, M, N, K, 1, 1, 1, a_dtype=1, b_dtype=1, C=Cacc, accumulate=1, splitk=sk, colsum=csum)
+        assert (Cacc.cpu().double() - 1 - ref).abs().max().item() < 1e-3 * sc
+        torch.testing.assert_close(csum.cpu(), 2 + At16.float().cpu().sum(0), rtol=1e-3, atol=1e-2)
