@@ -98,6 +98,29 @@ def cpu_baseline(workload, cfg_dict, seconds=12.0):
                       f"oracle/ort_oracle.py on torch CPU fp32, {cores} threads"}
 
 
+def pmc_traffic(workload, precision, B):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command (profiles/README.md):
+    2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction for 16-B/lane streaming reads), launch-weighted over the kernel's
+    instances.  None for workloads / sizes without a committed PMC profile."""
+    if workload != "xe" or precision != "bf16" or B != 256:
+        return None
+    import csv
+    here = os.path.dirname(os.path.abspath(__file__))
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    n = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+    try:
+        for cname, fname in (("FETCH_SIZE", "r01_xe_b256_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_xe_b256_pmc_write_size.csv")):
+            for r in csv.DictReader(open(os.path.join(here, "profiles", fname))):
+                if "gemm_bf16_glds_kernel<false, false" in r["kernel"] and r["counter"] == cname:
+                    tot[cname] += float(r["total"]); n[cname] += int(r["launches"])
+    except (OSError, KeyError, ValueError):
+        return None
+    if not n["FETCH_SIZE"] or not n["WRITE_SIZE"]:
+        return None
+    kb = 2.0 * tot["FETCH_SIZE"] / n["FETCH_SIZE"] + tot["WRITE_SIZE"] / n["WRITE_SIZE"]
+    return round(kb * 1024)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,13 +240,17 @@ def main():
         ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
         tot_ms = sum(v[1] for v in per_key.values())
         tot_fl = sum(v[2] for v in per_key.values())
-        roofline = {"bound": "mfma", "kernel": f"gemm_{args.precision}_kernel<false,false> (forward X*W^T)",
+        roofline = {"bound": "mfma",
+                    "kernel": ("gemm_bf16_glds_kernel<false,false,*> (forward X*W^T, LDS-DMA pipeline)" if args.precision == "bf16"
+                               else "gemm_f32_kernel<false,false> (forward X*W^T)"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
                     "algorithmic_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3),
                     "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                                          "ms_per_step": round(tot_ms, 3)},
-                    "traffic": None}
+                    "traffic": pmc_traffic(args.workload, args.precision, B),
+                    "traffic_note": "HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_xe_b256_pmc_*.csv "
+                                    "(separate rocprofv3 --pmc passes of this command); algorithmic bytes per launch 118.1e6"}
         if not decode:
             step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3 * (0.05 if sparse else 1.0)
             roofline["whole_step"] = {"algorithmic_tflop": round(step_tflop, 3),
