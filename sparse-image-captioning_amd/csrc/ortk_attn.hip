@@ -755,6 +755,59 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(ortk_attn_args a) {
     }
 }
 
+// Decode-time self-attention (ONE query row per K/V group, H = 8, dk = 64): one wave per row serves all 8 heads.
+// Lane l owns features 8l .. 8l+7 of the 512-wide row (head l / 8), so every K / V row of the cache is ONE coalesced
+// 2-KB read shared by the 8 heads; a score is 8 FMAs + a 3-step reduction over the 8 lanes of the head; the soft-max
+// runs redundantly in those lanes; P.V is 8 FMAs per key.  Keys come through the beam ancestry table (kv_index) or
+// a fixed stride.  Replaces 8 x rows workgroups of the generic block kernel (75 us -> see DESIGN.md section 7).
+template <int LKMAX>
+__global__ __launch_bounds__(256) void attn_rowdec_kernel(ortk_attn_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= a.nkv) return;
+    const int Lk = a.Lk;
+    const float* qp = a.q + (int64_t)g * a.ldq + 8 * lane;
+    const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+    const int64_t base = (int64_t)g * (a.kv_group_stride > 0 ? a.kv_group_stride : Lk);
+    float sc[LKMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < LKMAX; ++j) {
+        sc[j] = -INFINITY;
+        if (j < Lk) {
+            const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j] : base + j;
+            const float* kp = a.k + row * a.ldk + 8 * lane;
+            const float4 k0 = *reinterpret_cast<const float4*>(kp), k1 = *reinterpret_cast<const float4*>(kp + 4);
+            float d = q0.x * k0.x + q0.y * k0.y + q0.z * k0.z + q0.w * k0.w + q1.x * k1.x + q1.y * k1.y + q1.z * k1.z + q1.w * k1.w;
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            d *= 0.125f;                                              // 1 / sqrt(64)
+            if (a.kmask && a.kmask[(int64_t)g * Lk + j] == 0.f) d = -1e9f;
+            sc[j] = d;
+            mx = fmaxf(mx, d);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LKMAX; ++j) { const float e = j < Lk ? expf(sc[j] - mx) : 0.f; sc[j] = e; sum += e; }
+    const float inv = 1.f / sum;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < LKMAX; ++j) {
+        if (j < Lk) {
+            const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j] : base + j;
+            const float* vp = a.v + row * a.ldv + 8 * lane;
+            const float4 v0 = *reinterpret_cast<const float4*>(vp), v1 = *reinterpret_cast<const float4*>(vp + 4);
+            const float pj = sc[j] * inv;
+            if (a.p) { if ((lane & 7) == 0) a.p[((int64_t)g * a.H + (lane >> 3)) * Lk + j] = pj; }
+            o[0] += pj * v0.x; o[1] += pj * v0.y; o[2] += pj * v0.z; o[3] += pj * v0.w;
+            o[4] += pj * v1.x; o[5] += pj * v1.y; o[6] += pj * v1.z; o[7] += pj * v1.w;
+        }
+    }
+    const int64_t oi = (int64_t)g * a.ldo + 8 * lane;
+    st_elem4(a.o, oi, a.o_dtype, make_float4(o[0], o[1], o[2], o[3]));
+    st_elem4(a.o, oi + 4, a.o_dtype, make_float4(o[4], o[5], o[6], o[7]));
+}
+
 // Decode form (few query rows per K/V group: 1 new token per beam for self-attention, the beams of an image for
 // cross-attention).  One wave per (group, head); K and V of the pair live in REGISTERS — K with lane = key (each
 // lane holds its key's 64 features, loaded as 16 independent float4), V with lane = feature (one coalesced 256-B row
@@ -1015,6 +1068,10 @@ int check(const ortk_attn_args* a) {
 bool small_ok(const ortk_attn_args* a) {
     return a->dk == 64 && a->Lq <= 32 && a->Lk <= 32 && a->Lq >= 9 && !a->kv_index;
 }
+// forward only: also the decode-time cross-attention (1-8 beams of an image x 36 regions: up to 3 key tiles)
+bool small_fwd_ok(const ortk_attn_args* a) {
+    return a->dk == 64 && a->Lq <= 32 && a->Lk <= 48 && !a->kv_index && (a->Lq >= 9 || a->Lk > 8);
+}
 
 }  // namespace
 
@@ -1035,19 +1092,31 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
     const bool use_mfma = attn_impl() == 0 ? a->Lq > 32 : attn_impl() == 3;
     const bool vec_kq = (a->ldk % 4 == 0) && (a->ldq % 4 == 0) && (a->dk % 4 == 0) &&
                         ((reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->q)) & 15) == 0;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v) |
+                        reinterpret_cast<uintptr_t>(a->o)) & 15) == 0;
+    if (a->Lq == 1 && a->H == 8 && a->dk == 64 && a->Lk <= 32 && a->causal_period == 0 && a->drop_p == 0.f && !a->bias && al16 &&
+        a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->ldo % 4 == 0 && attn_impl() == 0) {
+        const dim3 rgrid((unsigned)ortk_cdiv(a->nkv, 4));
+        if (a->Lk <= 8)       hipLaunchKernelGGL(attn_rowdec_kernel<8>, rgrid, dim3(256), 0, ortk_s(stream), *a);
+        else if (a->Lk <= 16) hipLaunchKernelGGL(attn_rowdec_kernel<16>, rgrid, dim3(256), 0, ortk_s(stream), *a);
+        else if (a->Lk <= 24) hipLaunchKernelGGL(attn_rowdec_kernel<24>, rgrid, dim3(256), 0, ortk_s(stream), *a);
+        else                  hipLaunchKernelGGL(attn_rowdec_kernel<32>, rgrid, dim3(256), 0, ortk_s(stream), *a);
+        ORTK_CHECK_LAUNCH();
+        return 0;
+    }
     // measured on the 1024-image beam-5 decode: 95-105 us per call vs 75 us for the block kernel -> opt-in only (impl 4)
     if (a->Lq <= 8 && a->Lk <= 64 && a->causal_period == 0 && a->drop_p == 0.f && vec_kq && attn_impl() == 4) {
         const dim3 dgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
         if (a->Lk <= 32) hipLaunchKernelGGL(attn_decode_kernel<32>, dgrid, dim3(256), 0, ortk_s(stream), *a);
         else             hipLaunchKernelGGL(attn_decode_kernel<64>, dgrid, dim3(256), 0, ortk_s(stream), *a);
-    } else if (small_ok(a) && attn_impl() == 0 && a->ldv % 4 == 0 && a->ldq % 4 == 0 && a->ldk % 4 == 0 &&
+    } else if (small_fwd_ok(a) && attn_impl() == 0 && a->ldv % 4 == 0 && a->ldq % 4 == 0 && a->ldk % 4 == 0 &&
                ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v)) & 15) == 0) {
         const dim3 sgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
-        const int nit = a->Lq > 16 ? 2 : 1, njt = a->Lk > 16 ? 2 : 1;
-        if (nit == 2 && njt == 2)      hipLaunchKernelGGL((attn_small_fwd_kernel<2, 2>), sgrid, dim3(256), 0, ortk_s(stream), *a);
-        else if (nit == 2)             hipLaunchKernelGGL((attn_small_fwd_kernel<2, 1>), sgrid, dim3(256), 0, ortk_s(stream), *a);
-        else if (njt == 2)             hipLaunchKernelGGL((attn_small_fwd_kernel<1, 2>), sgrid, dim3(256), 0, ortk_s(stream), *a);
-        else                           hipLaunchKernelGGL((attn_small_fwd_kernel<1, 1>), sgrid, dim3(256), 0, ortk_s(stream), *a);
+        const int nit = a->Lq > 16 ? 2 : 1, njt = (a->Lk + 15) / 16;
+#define ORTK_SMALL_FWD(NI, NJ) hipLaunchKernelGGL((attn_small_fwd_kernel<NI, NJ>), sgrid, dim3(256), 0, ortk_s(stream), *a)
+        if (nit == 2) { if (njt == 3) ORTK_SMALL_FWD(2, 3); else if (njt == 2) ORTK_SMALL_FWD(2, 2); else ORTK_SMALL_FWD(2, 1); }
+        else          { if (njt == 3) ORTK_SMALL_FWD(1, 3); else if (njt == 2) ORTK_SMALL_FWD(1, 2); else ORTK_SMALL_FWD(1, 1); }
+#undef ORTK_SMALL_FWD
     } else if (a->Lk <= 64 && use_mfma && vec_kq && a->ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(a->v) & 15) == 0) {
         // MFMA form: one workgroup per pair, one wave per 16 query rows (at most 8 waves)
         const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16);

@@ -214,6 +214,30 @@ def test_attention_shapes(L):
     _attn_case(L, 6, 3, 20, 9, 64, 0, True, True)        # register-only kernel: 2 query tiles x 1 key tile, bias
     _attn_case(L, 5, 2, 12, 31, 64, 0, False, True)      # register-only kernel: 1 x 2 tiles
     _attn_case(L, 9, 8, 32, 32, 64, 8, False, False)     # register-only kernel: full 2 x 2 tiles, causal period 8
+    _attn_case(L, 6, 8, 5, 36, 64, 0, False, True)       # decode cross-attention: 5 beams x 36 regions (3 key tiles)
+    _attn_case(L, 6, 8, 1, 36, 64, 0, False, True)       # first beam pass: one row per image
+    _attn_case(L, 40, 8, 1, 13, 64, 0, False, False)     # decode self-attention: one row, all 8 heads in one wave
+    _attn_case(L, 7, 8, 1, 32, 64, 0, False, True)       # ... longest supported cache, with key mask
+
+
+def test_attention_decode_row_kernel_with_ancestry_table(L):
+    """Decode self-attention through the beam ancestry table (kv_index): row g attends to arbitrary cache rows."""
+    rows, H, dk, Lk = 50, 8, 64, 11
+    d = H * dk
+    g = torch.Generator().manual_seed(3)
+    q = rnd(rows, d, seed=1); cache_k = rnd(rows * 18, d, seed=2); cache_v = rnd(rows * 18, d, seed=3)
+    idx = torch.randint(0, rows * 18, (rows, Lk), generator=g, dtype=torch.int32)
+    kk = cache_k[idx.long()].view(rows, Lk, H, dk).transpose(1, 2); vv = cache_v[idx.long()].view(rows, Lk, H, dk).transpose(1, 2)
+    ref = O.attention(q.view(rows, 1, H, dk).transpose(1, 2), kk, vv, None, None).transpose(1, 2).reshape(rows, d)
+    a = L.AttnArgs()
+    qd, kd, vd, idd = dev(q), dev(cache_k), dev(cache_v), dev(idx)
+    for odt in (0, 1):
+        o = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16 if odt else torch.float32)
+        a.q, a.k, a.v, a.o, a.kv_index = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), idd.data_ptr()
+        a.ldq = a.ldk = a.ldv = a.ldo = d
+        a.nkv, a.H, a.Lq, a.Lk, a.dk, a.o_dtype = rows, H, 1, Lk, dk, odt
+        L.check(L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()), "attn_fwd")
+        torch.testing.assert_close(o.float().cpu(), ref, rtol=1e-2 if odt else 1e-4, atol=1e-2 if odt else 1e-5)
 
 
 @pytest.mark.parametrize("nkv,H,Lq,Lk,dk", [(3, 2, 9, 11, 16), (5, 8, 17, 17, 64), (2, 8, 36, 36, 64)])
