@@ -50,8 +50,37 @@ __device__ __forceinline__ double length_pen(int kind, double alpha, int len, do
     return p;
 }
 
-__global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logp, int t) {
+// same reductions, in the same order, as log_softmax_kernel (ortk_embed_loss.hip): the fused step is bit-identical to
+// log_softmax followed by the unfused step
+__device__ __forceinline__ float blk_max(float v, float* sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < 4; ++w) r = fmaxf(r, sh[w]);
+    return r;
+}
+__device__ __forceinline__ float blk_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < 4; ++w) r += sh[w];
+    return r;
+}
+
+// FUSED: `logp` holds raw generator logits; the row's log-soft-max (of logits * scale) is taken here — max, sum and
+// candidate scan are three strided passes over the row (the 2nd and 3rd hit L2), with 8 independent loads in flight
+// per thread.  Saves the separate log-soft-max launch (read + write of rows x V fp32 per step).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logp, int t, float scale) {
     __shared__ float sv[256 * MAXB];
+    __shared__ float sh_red[4];
+    __shared__ float row_mx[MAXB], row_lse[MAXB];
     __shared__ int si[256 * MAXB];
     __shared__ float red_v[4];
     __shared__ int red_i[4], red_pos[4];
@@ -71,16 +100,46 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
         const float* lp = logp + srow * st.ldv;
         const float cum = t == 0 ? 0.f : st.cum[(int64_t)img * b + q];
         const int prev = (st.decoding_constraint && t > 0) ? st.seq[cur][((int64_t)img * b + q) * L + t - 1] : -1;
-        for (int v = tid; v < V; v += 256) {
-            if (v == prev) continue;
-            float cv = cum + lp[v];
-            int ci = q * V + v;
-            if (better(cv, ci, bv[MAXB - 1], bi[MAXB - 1])) {
+        float mx = 0.f, lse = 0.f;
+        if (FUSED) {
+            float m = -INFINITY;
+            for (int v0 = tid; v0 < V; v0 += 256 * 8) {
+                float z[8];
 #pragma unroll
-                for (int k = 0; k < MAXB; ++k) {
-                    if (better(cv, ci, bv[k], bi[k])) {
-                        const float tv = bv[k]; const int ti = bi[k];
-                        bv[k] = cv; bi[k] = ci; cv = tv; ci = ti;
+                for (int u = 0; u < 8; ++u) { const int v = v0 + 256 * u; z[u] = v < V ? lp[v] * scale : -INFINITY; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m = fmaxf(m, z[u]);
+            }
+            mx = blk_max(m, sh_red);
+            float sum = 0.f;
+            for (int v0 = tid; v0 < V; v0 += 256 * 8) {
+                float z[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int v = v0 + 256 * u; z[u] = v < V ? lp[v] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (v0 + 256 * u < V) sum += expf(z[u] * scale - mx);
+            }
+            sum = blk_sum(sum, sh_red);
+            lse = logf(sum);
+            if (tid == 0) { row_mx[q] = mx; row_lse[q] = lse; }
+        }
+        for (int v0 = tid; v0 < V; v0 += 256 * 8) {
+            float z[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int v = v0 + 256 * u; z[u] = v < V ? lp[v] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = v0 + 256 * u;
+                if (v >= V || v == prev) continue;
+                float cv = cum + (FUSED ? (z[u] * scale - mx) - lse : z[u]);
+                int ci = q * V + v;
+                if (better(cv, ci, bv[MAXB - 1], bi[MAXB - 1])) {
+#pragma unroll
+                    for (int k = 0; k < MAXB; ++k) {
+                        if (better(cv, ci, bv[k], bi[k])) {
+                            const float tv = bv[k]; const int ti = bi[k];
+                            bv[k] = cv; bi[k] = ci; cv = tv; ci = ti;
+                        }
                     }
                 }
             }
@@ -125,7 +184,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
             st.tok_lp[nxt][nrow * L + u] = st.tok_lp[cur][prow * L + u];
         }
         st.seq[nxt][nrow * L + t] = tok;
-        st.tok_lp[nxt][nrow * L + t] = logp[srow * st.ldv + tok];
+        const int pq = t == 0 ? 0 : parent;
+        st.tok_lp[nxt][nrow * L + t] = FUSED ? (logp[srow * st.ldv + tok] * scale - row_mx[pq]) - row_lse[pq] : logp[srow * st.ldv + tok];
         st.it[nrow] = tok;
         // keys of the next pass: ancestors' cache rows, then this beam's own slot at time t+1
         const int32_t* src = st.kvidx[cur] + srow * (t + 1);
@@ -290,10 +350,11 @@ int kvidx_init(int32_t* kvidx, int64_t rows, int32_t row_mult, int32_t tmax, hip
     ORTK_CHECK_LAUNCH();
     return 0;
 }
-int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s) {
+int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused, float scale) {
     if (st.b < 1 || st.b > MAXB) return ORTK_EINVAL;
     if (st.B == 0) return 0;
-    hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t);
+    if (fused) hipLaunchKernelGGL(beam_step_kernel<true>, dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
+    else       hipLaunchKernelGGL(beam_step_kernel<false>, dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, 1.f);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

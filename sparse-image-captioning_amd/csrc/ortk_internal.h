@@ -27,7 +27,8 @@ struct BeamState {
     double length_alpha;
     int32_t tmax;             // cache time capacity
 };
-int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s);
+// fused = true: `logp` holds raw logits and the log-soft-max of (logits * scale) is taken inside the step
+int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false, float scale = 1.f);
 int beam_finalize(const BeamState& st, int64_t* seq_out, float* lp_out, float* score_out, hipStream_t s);
 
 struct SampleState {

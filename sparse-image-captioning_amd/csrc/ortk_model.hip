@@ -502,7 +502,7 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
     // (train, seed) must match the forward's; the bf16 weight copy made by the forward is still in the workspace
     Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
     float* G = grads;
-    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, A = w.adt;
+    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const int64_t Me = w.Me, Md = w.Md;
     const float inv_keep = c.p_drop() > 0.f ? 1.f / (1.f - c.p_drop()) : 1.f;
@@ -789,9 +789,11 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.
         const float scale = (beam && t > 0) ? 1.f / op->temperature : 1.f;
-        TRY(ortk_log_softmax(w.logits, rows, V, w.ldv, scale, stream));
-        if (beam) TRY(beam_step(bs, w.logits, t, s));
-        else TRY(sample_step(ss, w.logits, t, s));
+        if (beam) TRY(beam_step(bs, w.logits, t, s, true, scale));     // log-soft-max fused into the candidate scan
+        else {
+            TRY(ortk_log_softmax(w.logits, rows, V, w.ldv, scale, stream));
+            TRY(sample_step(ss, w.logits, t, s));
+        }
     }
     if (beam) TRY(beam_finalize(bs, seq_out, logprob_out, score_out, s));
     else {
