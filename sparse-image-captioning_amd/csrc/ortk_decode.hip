@@ -76,7 +76,7 @@ __device__ __forceinline__ float blk_sum(float v, float* sh) {
 // FUSED: `logp` holds raw generator logits; the row's log-soft-max (of logits * scale) is taken here — max, sum and
 // candidate scan are three strided passes over the row (the 2nd and 3rd hit L2), with 8 independent loads in flight
 // per thread.  Saves the separate log-soft-max launch (read + write of rows x V fp32 per step).
-template <bool FUSED>
+template <bool FUSED, int NPT>
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logp, int t, float scale) {
     __shared__ float sv[256 * MAXB];
     __shared__ float sh_red[4];
@@ -95,6 +95,85 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
     int bi[MAXB];
 #pragma unroll
     for (int k = 0; k < MAXB; ++k) { bv[k] = -INFINITY; bi[k] = 0x7FFFFFFF; }
+    bool staged = false;     // true once sv / si hold the candidates (fast path); block-uniform
+    if (FUSED && NPT > 0) {
+        // Register-resident rows: each thread holds its NPT strided elements of a row (ONE memory round trip per row, the
+        // next row's loads are issued before the current row is reduced); max and sum-exp run in the element order of
+        // log_softmax_kernel.  Candidate selection without per-thread sorted lists (their insertion network ran for almost
+        // every element because some lane of the wave always inserted): per row, tau = the b-th largest of the 16
+        // half-wave-quarter maxima is a lower bound of the row's b-th best, so only the handful of elements >= tau go to
+        // the LDS candidate list; the b block-wide arg-max rounds below then pick the exact top-b (value, then index).
+        __shared__ float gmax[16];
+        __shared__ int cand_cnt;
+        for (int k = 0; k < MAXB; ++k) { sv[tid * MAXB + k] = -INFINITY; si[tid * MAXB + k] = 0x7FFFFFFF; }
+        if (tid == 0) cand_cnt = 0;
+        float zn[NPT > 0 ? NPT : 1];
+        {
+            const float* lp0 = logp + (t == 0 ? (int64_t)img : (int64_t)img * b) * st.ldv;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) { const int v = tid + 256 * u; zn[u] = v < V ? lp0[v] : 0.f; }
+        }
+        for (int q = 0; q < nq; ++q) {
+            float z[NPT > 0 ? NPT : 1];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) z[u] = zn[u];
+            if (q + 1 < nq) {
+                const float* lpn = logp + ((int64_t)img * b + q + 1) * st.ldv;
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) { const int v = tid + 256 * u; zn[u] = v < V ? lpn[v] : 0.f; }
+            }
+            const float cum = t == 0 ? 0.f : st.cum[(int64_t)img * b + q];
+            const int prev = (st.decoding_constraint && t > 0) ? st.seq[cur][((int64_t)img * b + q) * L + t - 1] : -1;
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) m = fmaxf(m, z[u] * scale);
+            const float mx = blk_max(m, sh_red);
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) sum += expf(z[u] * scale - mx);
+            sum = blk_sum(sum, sh_red);
+            const float lse = logf(sum);
+            if (tid == 0) { row_mx[q] = mx; row_lse[q] = lse; }
+            float tm = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int v = tid + 256 * u;
+                const bool ok = v < V && v != prev;
+                z[u] = ok ? cum + ((z[u] * scale - mx) - lse) : -INFINITY;
+                tm = fmaxf(tm, z[u]);
+            }
+#pragma unroll
+            for (int o2 = 8; o2 > 0; o2 >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o2, 64));
+            __syncthreads();                       // gmax of the previous row fully consumed
+            if ((lane & 15) == 0) gmax[wave * 4 + (lane >> 4)] = tm;
+            __syncthreads();
+            float gm[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gm[u] = gmax[u];
+            float tau = -INFINITY;
+            for (int r = 0; r < b; ++r) {
+                float best = gm[0];
+#pragma unroll
+                for (int u = 1; u < 16; ++u) best = fmaxf(best, gm[u]);
+                tau = best;
+                bool removed = false;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (!removed && gm[u] == best) { gm[u] = -INFINITY; removed = true; }
+            }
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int v = tid + 256 * u;
+                if (v < V && v != prev && z[u] >= tau) {
+                    const int pos = atomicAdd(&cand_cnt, 1);
+                    if (pos < 256 * MAXB) { sv[pos] = z[u]; si[pos] = q * V + v; }
+                }
+            }
+        }
+        __syncthreads();
+        staged = cand_cnt <= 256 * MAXB;           // overflow (massive ties): redo with the exact per-thread lists
+        __syncthreads();
+    }
+    if (!staged) {
     for (int q = 0; q < nq; ++q) {
         const int64_t srow = t == 0 ? img : (int64_t)img * b + q;
         const float* lp = logp + srow * st.ldv;
@@ -147,6 +226,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
     }
 #pragma unroll
     for (int k = 0; k < MAXB; ++k) { sv[tid * MAXB + k] = bv[k]; si[tid * MAXB + k] = bi[k]; }
+    }
     __syncthreads();
     // b rounds of block-wide arg-max over the 256*MAXB staged candidates (each thread scans its own MAXB)
     for (int r = 0; r < b; ++r) {
@@ -353,8 +433,9 @@ int kvidx_init(int32_t* kvidx, int64_t rows, int32_t row_mult, int32_t tmax, hip
 int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused, float scale) {
     if (st.b < 1 || st.b > MAXB) return ORTK_EINVAL;
     if (st.B == 0) return 0;
-    if (fused) hipLaunchKernelGGL(beam_step_kernel<true>, dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
-    else       hipLaunchKernelGGL(beam_step_kernel<false>, dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, 1.f);
+    if (fused && st.V <= 256 * 40) hipLaunchKernelGGL((beam_step_kernel<true, 40>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
+    else if (fused) hipLaunchKernelGGL((beam_step_kernel<true, 0>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
+    else            hipLaunchKernelGGL((beam_step_kernel<false, 0>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, 1.f);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
