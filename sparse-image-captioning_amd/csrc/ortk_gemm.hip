@@ -604,8 +604,10 @@ __device__ __forceinline__ bf16x8 gfrag(const __bf16* img, int m0, int lane) {
 // BIG = true : 256 x 256 tile, 8 waves (2 x 4, each 128 x 64), 128 KB ring, one workgroup per CU: half the operand
 //              bytes fetched per FLOP (128 FLOP/B instead of 64) — the measured bound of the small tile is the
 //              L2 -> CU fetch rate (~13 B/clk/CU sustained), not MFMA issue.
-template <bool TA, bool TB, bool BIG>
-__global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_bf16_glds_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+// NS = ring depth (4, or 8 for grids of at most one workgroup per CU: with 7 tiles in flight almost the whole K = 512
+// panel of a decode-sized GEMM is requested up front and the K loop stops being a chain of fetch latencies).
+template <bool TA, bool TB, bool BIG, int NS>
+__global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm_bf16_glds_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
     constexpr int TM = BIG ? 256 : 128;             // tile rows = tile columns
     constexpr int MI = BIG ? 8 : 4;                 // 16-row fragments per wave
     constexpr int IMG = TM * GBK;                   // elements per operand image
@@ -630,22 +632,28 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_bf16_glds_k
     float cs = 0.f;
 
     auto issue = [&](int t) {
-        __bf16* st = smem16 + (size_t)(t & (GNS - 1)) * 2 * IMG;
+        __bf16* st = smem16 + (size_t)(t & (NS - 1)) * 2 * IMG;
         glds_tile<TA, TM>(Ap, p.lda, mb, k_begin + t * GBK, st, wave, lane);
         glds_tile<TB, TM>(Bp, p.ldb, nb, k_begin + t * GBK, st + IMG, wave, lane);
     };
-    for (int t = 0; t < GNS - 1 && t < T; ++t) issue(t);
+    for (int t = 0; t < NS - 1 && t < T; ++t) issue(t);
     for (int t = 0; t < T; ++t) {
-        // retire tile t (4 DMA instructions per tile and wave; tiles t+1, t+2 may stay in flight), then publish it
-        const int rem = T - 1 - t;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // retire tile t (4 DMA instructions per tile and wave; up to NS-2 later tiles may stay in flight), then publish it
+        const int rem = min(T - 1 - t, NS - 2);
+        switch (rem) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // every wave is past its reads of tile t-1: its stage takes tile t+3
-        if (t + GNS - 1 < T) issue(t + GNS - 1);
-        const __bf16* sA = smem16 + (size_t)(t & (GNS - 1)) * 2 * IMG;
+        // every wave is past its reads of tile t-1: its stage takes tile t+NS-1
+        if (t + NS - 1 < T) issue(t + NS - 1);
+        const __bf16* sA = smem16 + (size_t)(t & (NS - 1)) * 2 * IMG;
         const __bf16* sB = sA + IMG;
         bf16x8 a[MI], b[4];
 #pragma unroll
@@ -786,12 +794,16 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             const int64_t rounds = (big_blocks + 255) / 256;
             const bool fills = big_blocks * 10 >= rounds * 256 * 6;
             const bool big = !p.accumulate && p.M % 256 == 0 && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
+            // 8-deep ring for grids of at most one workgroup per CU (decode-time projections): measured SLOWER in the
+            // 1024-image decode (36.9 vs 35.8 ms) -> experiment only (ORTK_GEMM_IMPL=5)
+            const bool deep = !big && (int64_t)tilesM * tilesN * splitk <= 256 && impl == 5;
             gemm16_fn gf;
-            if (big) gf = key == 4 ? gemm_bf16_glds_kernel<false, false, true> : key == 5 ? gemm_bf16_glds_kernel<false, true, true> : gemm_bf16_glds_kernel<true, true, true>;
-            else     gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false> : key == 5 ? gemm_bf16_glds_kernel<false, true, false> : gemm_bf16_glds_kernel<true, true, false>;
-            static bool gl_attr[6] = {false, false, false, false, false, false};
-            const int gi = (key == 4 ? 0 : key == 5 ? 1 : 2) + (big ? 3 : 0);
-            const size_t lds = big ? GLDS_LDS_BYTES_BIG : GLDS_LDS_BYTES;
+            if (big)       gf = key == 4 ? gemm_bf16_glds_kernel<false, false, true, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, true, 4> : gemm_bf16_glds_kernel<true, true, true, 4>;
+            else if (deep) gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 8> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 8> : gemm_bf16_glds_kernel<true, true, false, 8>;
+            else           gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 4> : gemm_bf16_glds_kernel<true, true, false, 4>;
+            static bool gl_attr[9] = {false, false, false, false, false, false, false, false, false};
+            const int gi = (key == 4 ? 0 : key == 5 ? 1 : 2) + (big ? 3 : deep ? 6 : 0);
+            const size_t lds = big ? GLDS_LDS_BYTES_BIG : deep ? 2 * GLDS_RING_BYTES : GLDS_LDS_BYTES;
             if (!gl_attr[gi]) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 gl_attr[gi] = true;
