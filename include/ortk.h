@@ -138,6 +138,21 @@ int ortk_encode(const ortk_config* cfg, const float* params, const float* att_fe
                 const float* att_masks, int32_t B, int32_t S, void* ws, size_t ws_bytes, float* memory_out,
                 ortk_stream stream);
 
+/* Per-step host API: what RelationTransformerModel.get_logprobs_state (relation_transformer.py:374-387) runs per call.
+ * ortk_project_memory: cross_kv (mem_rows, L*2*d) = memory (mem_rows, d) x the stacked src_attn K|V weights of all layers
+ *   (the reference fills its src_attn caches on the first step, transformer.py:255-273).
+ * ortk_decode_step: tokens it (rows) at position t -> log-probs logp_out (rows, ld_out).  self_k / self_v are
+ *   (L, rows, tmax, d) fp32 caches holding positions < t; position t is appended.  `rows / kv_groups` consecutive rows share
+ *   the cross_kv (kv_groups*S, L*2*d) and att_masks (kv_groups, S) of one group.
+ * Workspace for both: ortk_decode_step_workspace_bytes(cfg, rows). */
+size_t ortk_decode_step_workspace_bytes(const ortk_config* cfg, int32_t rows);
+int ortk_project_memory(const ortk_config* cfg, const float* params, const float* memory, int64_t mem_rows, void* ws,
+                        size_t ws_bytes, float* cross_kv, ortk_stream stream);
+int ortk_decode_step(const ortk_config* cfg, const float* params, const int64_t* it, int32_t t, int32_t rows,
+                     int32_t kv_groups, int32_t S, const float* cross_kv, const float* att_masks, float* self_k,
+                     float* self_v, int32_t tmax, void* ws, size_t ws_bytes, float* logp_out, int64_t ld_out,
+                     ortk_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Operator-level entry points (each is also what the executor calls; exported for parity tests).
  * ---------------------------------------------------------------------------------------------- */

@@ -704,6 +704,55 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
     return w.bytes;
 }
 
+// One position of the cached-attention decoder for `rows` rows (transformer.py:172-210 with the caches of :240-273):
+// embeds the tokens at position t, appends this position's K/V to the self-attention caches ((row, tmax, d) per layer;
+// the keys of a row are its own slots 0..t unless the beam ancestry table kvidx is given), attends to the projected
+// memory of the row's group (`per_group` consecutive rows share one), and leaves the generator logits in b.logits.
+struct StepBufs {
+    const int64_t* it; float *xa, *xb; void* y; float* qkv; void* o; float* q; void* h; float* logits; float* st; int64_t ldv;
+    const float* ckv; const float* att_masks;
+    float* cache_k[MAXLAYERS]; float* cache_v[MAXLAYERS];
+};
+static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64_t rows, int groups, int per_group, int row_mult,
+                        int S, int T, int t, const int32_t* kvidx) {
+    const ortk_config* cfg = c.cfg;
+    const float* P = c.P;
+    ortk_stream stream = (ortk_stream)c.s; hipStream_t s = c.s;
+    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = c.adt;
+    const float* att_masks = w.att_masks;
+    const int B = groups, per_img = per_group;
+        TRY(ortk_embed_fwd(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, 1, t, d, cfg->pad_id, 0.f, 0, stream));
+        float* x = w.xa; float* xn = w.xb;
+        for (int l = 0; l < L; ++l) {
+            const DecOff& e = o.dec[l];
+            TRY(ln_fwd(c, x, e.n0a, e.n0b, w.y, A, w.st, rows));
+            TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, 3 * d, d));
+            TRY(kv_append(w.qkv, w.cache_k[l], w.cache_v[l], rows, d, row_mult, T, t, s));
+            ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+            a.q = w.qkv; a.ldq = 3 * d; a.k = w.cache_k[l]; a.v = w.cache_v[l]; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
+            a.nkv = (int)rows; a.H = H; a.Lq = 1; a.Lk = t + 1; a.dk = dk;
+            if (kvidx) a.kv_index = kvidx; else a.kv_group_stride = T;
+            TRY(ortk_attention_fwd(&a, stream));
+            TRY(fwd_gemm(c, w.o, A, d, e.wo, P + e.bo, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
+            std::swap(x, xn);
+            TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
+            TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
+            std::memset(&a, 0, sizeof(a));
+            a.q = w.q; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
+            a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
+            TRY(ortk_attention_fwd(&a, stream));
+            TRY(fwd_gemm(c, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
+            std::swap(x, xn);
+            TRY(ln_fwd(c, x, e.n2a, e.n2b, w.y, A, w.st, rows));
+            TRY(fwd_gemm(c, w.y, A, d, e.w1, P + e.b1, w.h, A, ff, rows, ff, d, true));
+            TRY(fwd_gemm(c, w.h, A, ff, e.w2, P + e.b2, xn, ORTK_F32, d, rows, d, ff, false, 0.f, 0, x, d));
+            std::swap(x, xn);
+        }
+        TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.y, A, w.st, rows));
+        TRY(fwd_gemm(c, w.y, A, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, (int)w.ldv, d));
+    return 0;
+}
+
 extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const float* att_feats, const float* boxes,
                            const float* att_masks, int32_t B, int32_t S, const ortk_decode_opts* op, void* ws, size_t ws_bytes,
                            int64_t* seq_out, float* logprob_out, float* score_out, ortk_stream stream) {
@@ -723,7 +772,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     Ctx c{cfg, s, cfg->precision, 0, false, params, w.w16, w.adt};
     if (op->n_sparse > 0 && op->sparse) { c.sp = op->sparse; c.nsp = op->n_sparse; }
     const float* P = params;
-    const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, T = cfg->seq_len, A = w.adt;
+    const int d = cfg->d_model, L = cfg->n_layers, V = cfg->vocab, T = cfg->seq_len, A = w.adt;
     const int64_t Me = (int64_t)B * S;
     // No activations are kept: every encoder layer reuses one buffer set, and the residual stream is updated in
     // place (x is dead once xm = x + attn(...) exists, so the FFN sublayer writes its output back over x).
@@ -757,35 +806,9 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         const int64_t rows = first_beam ? B : rows_full;
         const int per_img = first_beam ? 1 : K;
         const int row_mult = first_beam ? K : 1;
-        TRY(ortk_embed_fwd(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, 1, t, d, cfg->pad_id, 0.f, 0, stream));
-        float* x = w.xa; float* xn = w.xb;
-        for (int l = 0; l < L; ++l) {
-            const DecOff& e = o.dec[l];
-            TRY(ln_fwd(c, x, e.n0a, e.n0b, w.y, A, w.st, rows));
-            TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, 3 * d, d));
-            TRY(kv_append(w.qkv, w.cache_k[l], w.cache_v[l], rows, d, row_mult, T, t, s));
-            ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-            a.q = w.qkv; a.ldq = 3 * d; a.k = w.cache_k[l]; a.v = w.cache_v[l]; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
-            a.nkv = (int)rows; a.H = H; a.Lq = 1; a.Lk = t + 1; a.dk = dk;
-            if (beam) a.kv_index = w.kvidx[t & 1]; else a.kv_group_stride = T;
-            TRY(ortk_attention_fwd(&a, stream));
-            TRY(fwd_gemm(c, w.o, A, d, e.wo, P + e.bo, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
-            std::swap(x, xn);
-            TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
-            TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
-            std::memset(&a, 0, sizeof(a));
-            a.q = w.q; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
-            a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
-            TRY(ortk_attention_fwd(&a, stream));
-            TRY(fwd_gemm(c, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
-            std::swap(x, xn);
-            TRY(ln_fwd(c, x, e.n2a, e.n2b, w.y, A, w.st, rows));
-            TRY(fwd_gemm(c, w.y, A, d, e.w1, P + e.b1, w.h, A, ff, rows, ff, d, true));
-            TRY(fwd_gemm(c, w.h, A, ff, e.w2, P + e.b2, xn, ORTK_F32, d, rows, d, ff, false, 0.f, 0, x, d));
-            std::swap(x, xn);
-        }
-        TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.y, A, w.st, rows));
-        TRY(fwd_gemm(c, w.y, A, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, (int)w.ldv, d));
+        StepBufs sb{w.it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, w.ckv, att_masks};
+        for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
+        TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.
         const float scale = (beam && t > 0) ? 1.f / op->temperature : 1.f;
@@ -800,5 +823,66 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         TRY(sample_finalize(ss, s));
         if (score_out) TRY(ortk_fill(score_out, rows_full, 0.f, stream));
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ per-step host API
+namespace ortk {
+struct StepWS { void* w16; float *xa, *xb; void* y; float* qkv; void* o; float* q; void* h; float* logits; float* st; int64_t ldv; size_t bytes; };
+static void carve_step(const ortk_config& c, int64_t rows, void* base, StepWS& w) {
+    const int64_t d = c.d_model, ff = c.d_ff;
+    const size_t es = ortk_esize(c.precision ? ORTK_BF16 : ORTK_F32);
+    Bump b{reinterpret_cast<char*>(base), 0};
+    Offsets o; build_layout(c, o, nullptr);
+    w.ldv = ortk_align(c.vocab, 128);
+    w.w16 = c.precision ? b.take_bytes((size_t)o.total * 2) : nullptr;
+    w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = b.take_bytes((size_t)rows * d * es);
+    w.qkv = b.take<float>(rows * 3 * d); w.o = b.take_bytes((size_t)rows * d * es); w.q = b.take<float>(rows * d);
+    w.h = b.take_bytes((size_t)rows * ff * es); w.logits = b.take<float>(rows * w.ldv); w.st = b.take<float>(rows * 2);
+    w.bytes = (b.off + 255) & ~(size_t)255;
+}
+}  // namespace ortk
+
+extern "C" size_t ortk_decode_step_workspace_bytes(const ortk_config* cfg, int32_t rows) {
+    if (check_cfg(cfg) || rows < 1) return 0;
+    StepWS w; carve_step(*cfg, rows, nullptr, w);
+    return w.bytes;
+}
+
+extern "C" int ortk_project_memory(const ortk_config* cfg, const float* params, const float* memory, int64_t mem_rows, void* ws,
+                                   size_t ws_bytes, float* cross_kv, ortk_stream stream) {
+    if (int e = check_cfg(cfg)) return e;
+    if (!params || !memory || !cross_kv || !ws || mem_rows < 1) return ORTK_EINVAL;
+    Offsets o; build_layout(*cfg, o, nullptr);
+    StepWS w; carve_step(*cfg, 1, ws, w);
+    if (w.bytes > ws_bytes) return ORTK_ENOSPC;
+    TRY(make_w16(cfg, o, params, w.w16, stream));
+    Ctx c{cfg, ortk_s(stream), cfg->precision, 0, false, params, w.w16, cfg->precision ? ORTK_BF16 : ORTK_F32};
+    const int d = cfg->d_model, L = cfg->n_layers;
+    return fwd_gemm(c, memory, ORTK_F32, d, o.ckv_w, params + o.ckv_b, cross_kv, ORTK_F32, (int64_t)L * 2 * d, mem_rows, L * 2 * d, d);
+}
+
+extern "C" int ortk_decode_step(const ortk_config* cfg, const float* params, const int64_t* it, int32_t t, int32_t rows,
+                                int32_t kv_groups, int32_t S, const float* cross_kv, const float* att_masks, float* self_k,
+                                float* self_v, int32_t tmax, void* ws, size_t ws_bytes, float* logp_out, int64_t ld_out,
+                                ortk_stream stream) {
+    if (int e = check_cfg(cfg)) return e;
+    if (!params || !it || !cross_kv || !att_masks || !self_k || !self_v || !ws || !logp_out) return ORTK_EINVAL;
+    if (rows < 1 || kv_groups < 1 || rows % kv_groups || S < 1 || S > 128 || t < 0 || t >= tmax || ld_out < cfg->vocab) return ORTK_EINVAL;
+    Offsets o; build_layout(*cfg, o, nullptr);
+    StepWS w; carve_step(*cfg, rows, ws, w);
+    if (w.bytes > ws_bytes) return ORTK_ENOSPC;
+    TRY(make_w16(cfg, o, params, w.w16, stream));
+    Ctx c{cfg, ortk_s(stream), cfg->precision, 0, false, params, w.w16, cfg->precision ? ORTK_BF16 : ORTK_F32};
+    const int64_t d = cfg->d_model;
+    StepBufs sb{it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, cross_kv, att_masks};
+    for (int l = 0; l < cfg->n_layers; ++l) {
+        sb.cache_k[l] = self_k + (int64_t)l * rows * tmax * d;
+        sb.cache_v[l] = self_v + (int64_t)l * rows * tmax * d;
+    }
+    TRY(decoder_step(c, o, sb, rows, kv_groups, rows / kv_groups, 1, S, tmax, t, nullptr));
+    TRY(ortk_log_softmax(w.logits, rows, cfg->vocab, w.ldv, 1.f, stream));
+    if (hipMemcpy2DAsync(logp_out, (size_t)ld_out * 4, w.logits, (size_t)w.ldv * 4, (size_t)cfg->vocab * 4, (size_t)rows,
+                         hipMemcpyDeviceToDevice, ortk_s(stream)) != hipSuccess) return ORTK_EINVAL;
     return 0;
 }

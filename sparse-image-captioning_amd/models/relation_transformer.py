@@ -442,10 +442,58 @@ class RelationTransformerModel(CaptionModelBase):
             self.done_beams = out
         return self.done_beams
 
+    @torch.no_grad()
     def get_logprobs_state(self, it, memory, mask, state):
-        raise NotImplementedError(
-            "the per-step host API (relation_transformer.py:374-387) is replaced by the fused on-device decode loop "
-            "(ortk_decode); use mode='sample'")
+        """One cached-attention decoder step — ``get_logprobs_state`` (relation_transformer.py:374-387).
+
+        ``it`` (rows,) int64, ``memory`` (rows, S, d) from :meth:`encode`, ``mask`` (rows, S) or (rows, 1, S), ``state`` =
+        ``None`` on the first call, afterwards the list returned by the previous call (possibly re-ordered along dim 1 by a
+        beam search, caption_model.py:106-110).  Returns ``(logp (rows, V), state)`` with the reference's state layout
+        (transformer.py:457-469): ``[ys (1, rows, 1)]`` + per decoder layer ``self K, self V (h, rows, t+1, d_k)``,
+        ``src K, src V (h, rows, S, d_k)``.  The position is the length of the self-attention cache (the reference keeps it
+        in a module counter reset by ``reset_cache``).  This is the API-compatible path: every call re-packs the caches;
+        ``mode="sample"`` runs the whole loop on the device."""
+        lib = L.lib()
+        rows, S, d = memory.shape
+        Lr, H = self.num_layers, self.num_heads
+        dk, T = d // H, self.seq_length
+        dev = self._flat.device
+        it = it.to(dev).long().contiguous()
+        masks = mask.reshape(rows, S).to(dev).float().contiguous()
+        pptr = self._eff_params_ptr(False, 0)
+        nbytes = lib.ortk_decode_step_workspace_bytes(C.byref(self._ccfg), rows)
+        ws = self._workspace(("step", rows), nbytes, True)
+        self_k = torch.zeros(Lr, rows, T, d, device=dev)
+        self_v = torch.zeros(Lr, rows, T, d, device=dev)
+        if state is None:
+            t = 0
+            ckv = torch.empty(rows * S, Lr * 2 * d, device=dev)
+            mem = memory.to(dev).float().contiguous()
+            L.check(lib.ortk_project_memory(C.byref(self._ccfg), pptr, L.ptr(mem), rows * S, L.ptr(ws), ws.numel(),
+                                            L.ptr(ckv), L.stream_ptr()), "ortk_project_memory")
+        else:
+            caches = state[1:]
+            assert len(caches) == 4 * Lr, "state must come from get_logprobs_state"
+            t = caches[0].size(2)
+            assert t < T, "cache is full"
+            unhead = lambda c: c.permute(1, 2, 0, 3).reshape(rows, c.size(2), d)      # (h, rows, len, dk) -> (rows, len, d)
+            ckv = torch.empty(rows, S, Lr, 2, d, device=dev)
+            for l in range(Lr):
+                self_k[l, :, :t] = unhead(caches[4 * l])
+                self_v[l, :, :t] = unhead(caches[4 * l + 1])
+                ckv[:, :, l, 0] = unhead(caches[4 * l + 2])
+                ckv[:, :, l, 1] = unhead(caches[4 * l + 3])
+            ckv = ckv.view(rows * S, Lr * 2 * d)
+        logp = torch.empty(rows, self.vocab_size, device=dev)
+        L.check(lib.ortk_decode_step(C.byref(self._ccfg), pptr, L.ptr(it), t, rows, rows, S, L.ptr(ckv), L.ptr(masks),
+                                     L.ptr(self_k), L.ptr(self_v), T, L.ptr(ws), ws.numel(), L.ptr(logp), self.vocab_size,
+                                     L.stream_ptr()), "ortk_decode_step")
+        head = lambda x: x.reshape(rows, -1, H, dk).permute(2, 0, 1, 3).contiguous()  # (rows, len, d) -> (h, rows, len, dk)
+        ckv5 = ckv.view(rows, S, Lr, 2, d)
+        new_state = [it.view(1, rows, 1)]
+        for l in range(Lr):
+            new_state += [head(self_k[l, :, :t + 1]), head(self_v[l, :, :t + 1]), head(ckv5[:, :, l, 0]), head(ckv5[:, :, l, 1])]
+        return logp, new_state
 
     @torch.no_grad()
     def encode(self, att_feats, boxes, att_masks=None):

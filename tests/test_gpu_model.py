@@ -90,6 +90,37 @@ def test_decode_options_vs_reference_golden(P, g1):
         m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"num_random_sample": 2, "beam_size": 2}, mode="sample")
 
 
+def test_get_logprobs_state_step_api_vs_reference_golden(P, g1):
+    """The per-step host API (relation_transformer.py:374-387): log-probs of two steps and the state layout equal the
+    reference's; a beam-style re-ordering of the returned state (caption_model.py:106-110) equals the oracle's."""
+    m, b = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state()), _cuda(H.g1_batch())
+    mem = m.encode(b["att_feats"], b["boxes"], b["att_masks"])
+    amask = b["att_masks"][:, None, :mem.size(1)]
+    it = torch.full((3,), C.BOS, dtype=torch.long, device="cuda")
+    lp0, st = m.get_logprobs_state(it, mem, amask, None)
+    close(lp0, g1["step/logp0"], 1e-4)
+    it1 = lp0.argmax(-1)
+    lp1, st = m.get_logprobs_state(it1, mem, amask, st)
+    close(lp1, g1["step/logp1"], 1e-4)
+    shapes = np.array([list(x.shape) + [0] * (4 - x.dim()) for x in st], np.int64)
+    np.testing.assert_array_equal(shapes, g1["step/state_shapes"])
+    # beam-style reorder of rows (state tensors carry the rows on dim 1), against the oracle's cached decoder
+    cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
+    Pm = H.g1_state()
+    bc = H.g1_batch()
+    omem = O.encode(Pm, cfg, bc["att_feats"], bc["boxes"], bc["att_masks"])
+    ost = O.DecodeState(Pm, cfg, omem, bc["att_masks"])
+    O.decode_step(ost, it.cpu()); O.decode_step(ost, it1.cpu())
+    idx = torch.tensor([2, 0, 0])
+    ost.reorder(idx); ost.memory, ost.att_masks = ost.memory[idx], ost.att_masks[idx]
+    it2 = torch.tensor([5, 7, 9])
+    ref = O.decode_step(ost, it2)
+    st2 = [x[:, idx.cuda()] for x in st]
+    lp2, st3 = m.get_logprobs_state(it2.cuda(), mem[idx.cuda()], amask[idx.cuda()], st2)
+    close(lp2, ref.numpy(), 1e-4)
+    assert st3[1].shape[2] == 3 and torch.equal(st3[0].view(-1).cpu(), it2)
+
+
 def test_multinomial_matches_oracle_and_scst_loss(P, g1):
     """Gumbel-max sampling with the shared counter hash: tokens equal the oracle's; the SCST rollout's differentiable
     log-probs (teacher-forced recompute) give the reference's RewardCriterion value on the reference's own rollout."""
