@@ -42,7 +42,7 @@ typedef struct ortk_config {
     int32_t d_model, d_ff, n_layers, n_heads;
     int32_t vocab, feat, seq_len;              /* vocab_size, att_feat_size, max_seq_length          */
     int32_t pad_id, bos_id, eos_id, unk_id;
-    int32_t box_trig;                          /* !no_box_trigonometric_embedding (only 1 supported) */
+    int32_t box_trig;                          /* !no_box_trigonometric_embedding: 1 = 64-d sin/cos embedding, 0 = 4-d log-ratios */
     int32_t precision;                         /* 0 fp32 MFMA, 1 bf16 MFMA                           */
     float   drop_src, drop;                    /* att_embed dropout; every other dropout (0.1 | 0.1/3)*/
 } ortk_config;
@@ -189,7 +189,8 @@ int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const fl
 
 /* Geometry bias of BoxMultiHeadedAttention (relation_transformer.py:196-256,177-183,286):
  * out[l,b,h,i,j] = log(max(relu(WG[l,h].e_ij + bG[l,h]), 1e-6)).  wg[l]/bg[l] are per-layer device pointers
- * laid out (h,64)/(h).  dim_mat = the 8 fp32 wavelengths 1/1000^(k/8) as torch computes them. */
+ * laid out (h,64)/(h).  dim_mat = the 8 fp32 wavelengths 1/1000^(k/8) as torch computes them; dim_mat = NULL selects the
+ * non-trigonometric mode (embedding = the 4 log-ratios, WG laid out (h,4); ortk_box_embedding then writes (B,S,S,4)). */
 int ortk_box_logbias_fwd(const float* boxes, const float* const* wg, const float* const* bg, const float* dim_mat,
                          float* out, int32_t L, int32_t B, int32_t S, int32_t H, ortk_stream stream);
 /* dscore (L,B,H,S,S) -> dwg[l] (H,64) += , dbg[l] (H) += . */

@@ -42,7 +42,6 @@ static int check_cfg(const ortk_config* c) {
     if (c->n_heads < 1 || c->n_heads > 8 || c->d_model % c->n_heads) return ORTK_EINVAL;
     if (c->d_model / c->n_heads > 64) return ORTK_EINVAL;
     if (c->vocab < 2 || c->feat < 1 || c->seq_len < 1 || c->seq_len > 64) return ORTK_EINVAL;
-    if (!c->box_trig) return ORTK_ENOSYS;
     if (c->precision != 0 && c->precision != 1) return ORTK_EINVAL;
     return 0;
 }
@@ -70,7 +69,8 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         align(); e.bqkv = add(L_(p + ".self_attn", 0, "bias"), {d}); add(L_(p + ".self_attn", 1, "bias"), {d}); add(L_(p + ".self_attn", 2, "bias"), {d});
         align(); e.wo = add(L_(p + ".self_attn", 3, "weight"), {d, d});
         align(); e.bo = add(L_(p + ".self_attn", 3, "bias"), {d});
-        align(); e.wg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".weight", {1, 64});
+        const int64_t dg = c.box_trig ? 64 : 4;   // relation_transformer.py:131-136
+        align(); e.wg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".weight", {1, dg});
         align(); e.bg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".bias", {1});
         align(); e.w1 = add(p + ".feed_forward.w_1.weight", {ff, d});
         align(); e.b1 = add(p + ".feed_forward.w_1.bias", {ff});
@@ -316,7 +316,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
                  nullptr, 0, masks));
     const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS];
     for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; }
-    TRY(ortk_box_logbias_fwd(boxes, wg, bg, dim_mat(), logbias, L, B, S, H, (ortk_stream)c.s));
+    TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s));
     const float* x = x0;
     for (int l = 0; l < L; ++l) {
         const EncOff& e = o.enc[l]; const EncPtrs& b = bufs[l];
@@ -589,7 +589,7 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
         const float* P = params;
         const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS]; float* dwg[MAXLAYERS]; float* dbg[MAXLAYERS];
         for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; dwg[l] = G + o.enc[l].wg; dbg[l] = G + o.enc[l].bg; }
-        TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, dim_mat(), w.dscore, dwg, dbg, L, B, S, H, stream));
+        TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, stream));
     }
     // att_embed: x0 = dropout(relu(.) * mask)  ->  d(pre-activation) = dx * [x0 > 0] / (1 - p_src)
     TRY(ortk_gate_apply(dx, w.x0, w.gt, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));

@@ -17,7 +17,7 @@ def dense_param_shapes(cfg: dict) -> dict:
             s[f"{pre}.linears.{i}.bias"] = (d,)
         if box:
             for i in range(h):
-                s[f"{pre}.WGs.{i}.weight"] = (1, 64)
+                s[f"{pre}.WGs.{i}.weight"] = (1, 4 if cfg.get("no_box_trigonometric_embedding") else 64)
                 s[f"{pre}.WGs.{i}.bias"] = (1,)
 
     def ffn(pre):

@@ -121,6 +121,32 @@ def test_get_logprobs_state_step_api_vs_reference_golden(P, g1):
     assert st3[1].shape[2] == 3 and torch.equal(st3[0].view(-1).cpu(), it2)
 
 
+def test_non_trigonometric_box_embedding_vs_reference_golden(P, golden):
+    """`no_box_trigonometric_embedding`: WG is Linear(4, 1) on the raw log-ratios (relation_transformer.py:131-136,243-256)."""
+    from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
+    g5 = golden("g5_tiny_notrig")
+    cfgd = dict(C.TINY_CFG, no_box_trigonometric_embedding=True)
+    state = H.torch_state(H.dense_param_shapes(cfgd), C.G1_SEED, C.G1_GEN_SCALE, C.G1_EOS_BIAS)
+    m, b = _model(P, "relation_transformer", cfgd, state), _cuda(H.g1_batch())
+    assert tuple(m.state_dict()["model.encoder.layers.0.self_attn.WGs.0.weight"].shape) == (1, 4)
+    logp = m(att_feats=b["att_feats"], boxes=b["boxes"], seqs=b["seqs"], att_masks=b["att_masks"])
+    close(logp, g5["logp"], 1e-4)
+    loss = LanguageModelCriterion()(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - float(g5["xe_loss"])) < 1e-4
+    loss.backward()
+    grads = dict(m.named_parameters())
+    for k in list(g5.keys()):
+        if k.startswith("grad/"):
+            ref = g5[k]
+            np.testing.assert_allclose(grads[k[5:]].grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    tot = sum(p.grad.double().abs().sum().item() for p in m.parameters())
+    assert abs(tot - float(g5["grad_abs_sum"])) / float(g5["grad_abs_sum"]) < 1e-4
+    for bs in (1, 3):
+        seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": bs}, mode="sample")
+        np.testing.assert_array_equal(seq.cpu().numpy(), g5[f"decode_b{bs}/seq"])
+        close(lp, g5[f"decode_b{bs}/logprobs"], 2e-4)
+
+
 def test_multinomial_matches_oracle_and_scst_loss(P, g1):
     """Gumbel-max sampling with the shared counter hash: tokens equal the oracle's; the SCST rollout's differentiable
     log-probs (teacher-forced recompute) give the reference's RewardCriterion value on the reference's own rollout."""

@@ -270,3 +270,24 @@ def test_full_size_config1(golden):
         seq, lp, _ = O.beam_search(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"], 5)
         np.testing.assert_array_equal(seq.numpy(), g2["decode_b5/seq"])
         close(lp, g2["decode_b5/logprobs"], 2e-4)
+
+
+def test_non_trigonometric_box_embedding_vs_reference_golden(golden):
+    """G5: `no_box_trigonometric_embedding` (4-d geometry embedding, relation_transformer.py:131-136,243-256)."""
+    g5 = golden("g5_tiny_notrig")
+    cfgd = dict(C.TINY_CFG, no_box_trigonometric_embedding=True)
+    cfg = _cfg(cfgd)
+    P = H.torch_state(H.dense_param_shapes(cfgd), C.G1_SEED, C.G1_GEN_SCALE, C.G1_EOS_BIAS, requires_grad=True)
+    b = H.g1_batch()
+    logp = O.forward_logp(P, cfg, b["att_feats"], b["boxes"], b["seqs"], b["att_masks"])
+    close(logp, g5["logp"], 5e-5)
+    loss = O.xe_loss(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - float(g5["xe_loss"])) < 1e-5
+    loss.backward()
+    for k in list(g5.keys()):
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(P[k[5:]].grad.numpy(), g5[k], rtol=2e-3, atol=2e-5, err_msg=k)
+    with torch.no_grad():
+        Pd = {k: v.detach() for k, v in P.items()}
+        seq, lp, _ = O.beam_search(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"], beam_size=3)
+        np.testing.assert_array_equal(seq.numpy(), g5["decode_b3/seq"])
