@@ -124,6 +124,10 @@ typedef struct ortk_decode_opts {
      * projection whose weight block has an entry here runs as a sparse product instead of a dense GEMM. */
     const struct ortk_csr* sparse;
     int32_t n_sparse;
+    /* multinomial only: also decode ONE greedy row per image in the same pass (the SCST baseline of
+     * utils/training.py:220-237): K = num_random_sample + 1, row 0 of each image is the arg-max decode, rows 1.. are
+     * the samples — token for token what two separate calls return, at half the launches. */
+    int32_t with_greedy;
 } ortk_decode_opts;
 
 size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, const ortk_decode_opts* o);

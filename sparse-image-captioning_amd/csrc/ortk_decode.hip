@@ -347,7 +347,7 @@ __global__ void sample_init_kernel(SampleState st, int bos) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < st.rows; i += (int64_t)gridDim.x * 256) {
         st.it[i] = bos; st.unfinished[i] = bos != st.eos;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.last_step[0] = -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st.last_step[0] = -1; st.last_step[1] = -1; }
 }
 
 __device__ __forceinline__ float gumbel(uint64_t seed, int t, int row, int v) {
@@ -363,11 +363,15 @@ __global__ __launch_bounds__(256) void sample_step_kernel(SampleState st, const 
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* lp = logp + (int64_t)row * st.ldv;
     const int prev = (st.decoding_constraint && t > 0) ? (int)st.seq[(int64_t)row * st.L + t - 1] : -1;
+    const bool is_greedy = st.greedy_stride > 0 && row % st.greedy_stride == 0;
+    const bool samp = st.sample && !is_greedy;
+    // the hash is keyed by the row index the sample would have in a samples-only call
+    const int hrow = st.greedy_stride > 0 ? row - row / st.greedy_stride - 1 : row;
     float mv = -INFINITY; int mi = 0x7FFFFFFF;
     for (int v = tid; v < st.V; v += 256) {
         if (v == prev) continue;
         float x = lp[v];
-        if (st.sample) x = x / st.temperature + gumbel(st.seed, t, row, v);
+        if (samp) x = x / st.temperature + gumbel(st.seed, t, hrow, v);
         if (better(x, v, mv, mi)) { mv = x; mi = v; }
     }
 #pragma unroll
@@ -387,16 +391,18 @@ __global__ __launch_bounds__(256) void sample_step_kernel(SampleState st, const 
         const int now = unf && (mi != st.eos);
         st.unfinished[row] = now;
         // the reference leaves the loop at the first step where no row is unfinished (transformer.py:550-551)
-        if (unf && !now) atomicMax(st.last_step, t);
-        if (now && t == st.L - 1) atomicMax(st.last_step, t);
+        int32_t* last = st.last_step + (is_greedy ? 1 : 0);
+        if (unf && !now) atomicMax(last, t);
+        if (now && t == st.L - 1) atomicMax(last, t);
     }
 }
 
 __global__ void sample_finalize_kernel(SampleState st) {
-    const int last = st.last_step[0];
     const int64_t n = (int64_t)st.rows * st.L;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int t = (int)(i % st.L);
+        const int64_t row = i / st.L;
+        const int last = st.last_step[(st.greedy_stride > 0 && row % st.greedy_stride == 0) ? 1 : 0];
         if (t > last) { st.lp[i] = 0.f; st.seq[i] = 0; }
     }
 }

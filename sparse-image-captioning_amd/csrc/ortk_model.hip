@@ -692,7 +692,7 @@ static int encode_impl(const ortk_config* cfg, const float* params, const float*
 }
 
 static int decode_K(const ortk_decode_opts* o) {
-    if (o->num_random_sample > 0) return o->beam_size < 1 ? o->num_random_sample : -1;
+    if (o->num_random_sample > 0) return o->beam_size < 1 ? o->num_random_sample + (o->with_greedy ? 1 : 0) : -1;
     return o->beam_size >= 1 ? o->beam_size : -1;
 }
 
@@ -798,6 +798,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         ss.lp = logprob_out; ss.unfinished = w.unfinished; ss.last_step = w.last_step;
         ss.decoding_constraint = op->decoding_constraint; ss.sample = op->num_random_sample > 0; ss.temperature = op->temperature;
         ss.seed = op->seed;
+        ss.greedy_stride = (op->num_random_sample > 0 && op->with_greedy) ? K : 0;
         TRY(sample_init(ss, cfg->bos_id, s));
     }
     for (int t = 0; t < T; ++t) {

@@ -378,9 +378,10 @@ class RelationTransformerModel(CaptionModelBase):
         for k in ("group_size",):
             if int(opt.get(k, 1)) != 1:
                 raise NotImplementedError("diverse beam groups (group_size > 1) are not implemented in the HIP path")
+        o.with_greedy = 1 if (o.num_random_sample > 0 and opt.get("with_greedy", False)) else 0
         if o.num_random_sample > 0:
             assert o.beam_size < 1, f"Beam size must be < 1, saw {o.beam_size}"      # transformer.py:509
-            K = o.num_random_sample
+            K = o.num_random_sample + o.with_greedy
         else:
             assert o.beam_size >= 1, f"Beam size must be >= 1, saw {o.beam_size}"    # transformer.py:514
             assert o.beam_size <= self.vocab_size                                    # transformer.py:482

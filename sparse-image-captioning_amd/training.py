@@ -103,13 +103,14 @@ class NativeTrainer:
         m = self.model
         was_training = m.training
         greedy = None
-        if baseline == "greedy":
-            m.eval()
-            greedy, _ = m(att_feats=data["att_feats"], boxes=data["boxes"], att_masks=data.get("att_masks"), mode="sample")
-        m.train(was_training)
         with torch.no_grad():
+            # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
+            # token for token what the two calls of utils/training.py:220-237 return, at half the launches
             seq, _ = m(att_feats=data["att_feats"], boxes=data["boxes"], att_masks=data.get("att_masks"), mode="sample",
-                       opt={"num_random_sample": num_samples, "beam_size": 0})
+                       opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy"})
+        if baseline == "greedy":
+            greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
+        m.train(was_training)
         reward = reward_fn(seq, greedy).to(self.dev).float().reshape(-1)
         rows = seq.view(-1, seq.size(-1))
         mask = (rows != m.pad_idx).float()

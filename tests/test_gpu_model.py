@@ -121,6 +121,23 @@ def test_get_logprobs_state_step_api_vs_reference_golden(P, g1):
     assert st3[1].shape[2] == 3 and torch.equal(st3[0].view(-1).cpu(), it2)
 
 
+def test_combined_greedy_and_samples_decode_equals_two_calls(P, g1):
+    """`with_greedy`: one decode pass returns [greedy, sample_1..ns] per image == the two calls of the SCST step
+    (utils/training.py:220-237): same tokens, same log-probs, same zero padding after each call's own last step."""
+    m, b = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state()), _cuda(H.g1_batch())
+    kw = dict(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], mode="sample")
+    with torch.no_grad():
+        gs, glp = m(opt={"beam_size": 1}, **kw)
+        ss, slp = m(opt={"num_random_sample": 3, "beam_size": 0, "seed": 11, "temperature": 0.9}, **kw)
+        cs, clp = m(opt={"num_random_sample": 3, "beam_size": 0, "seed": 11, "temperature": 0.9, "with_greedy": True}, **kw)
+    assert cs.shape == (3, 4, gs.size(-1))
+    np.testing.assert_array_equal(cs[:, :1].cpu().numpy(), gs.cpu().numpy())
+    np.testing.assert_array_equal(cs[:, 1:].cpu().numpy(), ss.cpu().numpy())
+    np.testing.assert_array_equal(g1["decode_b1/seq"], gs.cpu().numpy())
+    close(clp[:, :1], glp.cpu().numpy(), 1e-6)
+    close(clp[:, 1:], slp.cpu().numpy(), 1e-6)
+
+
 def test_non_trigonometric_box_embedding_vs_reference_golden(P, golden):
     """`no_box_trigonometric_embedding`: WG is Linear(4, 1) on the raw log-ratios (relation_transformer.py:131-136,243-256)."""
     from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
