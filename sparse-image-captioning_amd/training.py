@@ -119,6 +119,16 @@ class NativeTrainer:
         loss = self._step(tf, mask * reward[:, None], mask, train)
         return loss, reward, seq, greedy
 
+    @staticmethod
+    def scorer_reward_fn(scorer, ref_ids, eos_idx=3, pad_idx=0):
+        """``reward_fn`` for :meth:`scst_step` from a :class:`..scst.CaptionScorer` and the images' reference captions
+        (lists of token-id lists): reward = score(sample) - score(baseline), as ``compute_scst_loss`` does
+        (utils/training.py:251-254)."""
+        def fn(seq, greedy):
+            sc_sample, sc_baseline = scorer.score_sequences(ref_ids, seq, greedy, eos_idx=eos_idx, pad_idx=pad_idx)
+            return torch.from_numpy(sc_sample - sc_baseline).float()
+        return fn
+
     def _step(self, data, tok_weight, norm_mask, train):
         m = self.model
         self.step_count += 1
