@@ -230,6 +230,14 @@ class RelationTransformerModel(CaptionModelBase):
                 return e["shape"]
         return None
 
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts the reference's checkpoint formats as they are on disk: dense, COO-sparse (``model_best_pruned_sparse.pth``,
+        prune.py:200-221) and fp16-cast (``scripts/eval_model.py:73-77``) — entries are densified and cast to the fp32 arena."""
+        from ..utils.model_utils import densify_state_dict
+        sd = {k: (v.float() if isinstance(v, torch.Tensor) and v.is_floating_point() and v.dtype != torch.float32 else v)
+              for k, v in densify_state_dict(state_dict).items()}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
     # ------------------------------------------------------------------ helpers
     def _eff_params_ptr(self, train, seed):
         """Device pointer of the arena the kernels read (the `_prune` variant materialises s*W first)."""

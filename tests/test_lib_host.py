@@ -176,3 +176,26 @@ def test_dim_mat_constants_match_torch():
     libm.powf.argtypes = [C.c_float, C.c_float]
     mine = np.array([np.float32(1.0) / np.float32(libm.powf(1000.0, kk / 8.0)) for kk in range(8)], np.float32)
     np.testing.assert_array_equal(mine, ref)
+
+
+def test_checkpoint_formats_sparse_coo_and_fp16_load_directly():
+    """prune.py:200-221 / eval_model.py:64-88: a COO-sparse (and fp16-cast) checkpoint of the prune model loads into the dense
+    class without a manual densify step and reproduces the masked weights."""
+    import sparse_image_captioning_amd as P
+    from sparse_image_captioning_amd.utils.config import Config
+    from sparse_image_captioning_amd.utils.model_utils import densify_state_dict, count_nonzero
+    cfg = Config(**Cm.TINY_CFG)
+    pm = P.get_model("relation_transformer_prune")(cfg)
+    pm.load_state_dict(H.torch_state(H.prune_param_shapes(Cm.TINY_CFG), Cm.G1_SEED, keep_prob=Cm.G3_KEEP), strict=False)
+    sparse = pm.state_dict_sparse()
+    assert any(v.is_sparse for v in sparse.values())
+    half = {k: (v.half() if not v.is_sparse else v) for k, v in sparse.items()}
+    dense = P.get_model("relation_transformer")(cfg)
+    missing, unexpected = dense.load_state_dict(half, strict=False)
+    assert not unexpected
+    ref = densify_state_dict(sparse)
+    got = dense.state_dict()
+    for k, v in ref.items():
+        assert torch.allclose(got[k], v.float(), atol=2e-3), k
+    w = got["model.decoder.layers.0.feed_forward.w_1.weight"]
+    assert 0.1 < float(count_nonzero(w)) / w.numel() < 0.5
