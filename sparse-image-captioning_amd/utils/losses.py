@@ -19,3 +19,25 @@ class RewardCriterion(nn.Module):
         mask = mask.float()
         output = -input * (mask * reward).contiguous().view(-1)
         return torch.sum(output) / torch.sum(mask)
+
+
+class LabelSmoothing(nn.Module):
+    """``LabelSmoothing`` (utils/losses.py:46-77): masked mean over tokens of KL(q || exp(input)), q = 1 - smoothing on the
+    target and smoothing / (V - 1) elsewhere.  Written in closed form instead of materialising q and calling KLDivLoss:
+    KL = c (log c - x_t) + s (V - 1) log s - s (sum_v x_v - x_t), with 0 log 0 = 0."""
+
+    def __init__(self, size=0, padding_idx=0, smoothing=0.0):
+        super().__init__()
+        self.confidence = 1.0 - smoothing
+        self.smoothing = smoothing
+
+    def forward(self, input, target, mask):
+        target = target[:, : input.size(1)]
+        mask = mask[:, : input.size(1)].reshape(-1).to(input.dtype)
+        x = input.reshape(-1, input.size(-1))
+        V = x.size(1)
+        xt = x.gather(1, target.reshape(-1, 1)).squeeze(1)
+        c, s = self.confidence, self.smoothing / (V - 1)
+        xlogx = lambda p: p * torch.log(torch.tensor(p, dtype=x.dtype)).item() if p > 0 else 0.0
+        kl = xlogx(c) - c * xt + (V - 1) * xlogx(s) - s * (x.sum(1) - xt)
+        return (kl * mask).sum() / mask.sum()

@@ -199,3 +199,22 @@ def test_checkpoint_formats_sparse_coo_and_fp16_load_directly():
         assert torch.allclose(got[k], v.float(), atol=2e-3), k
     w = got["model.decoder.layers.0.feed_forward.w_1.weight"]
     assert 0.1 < float(count_nonzero(w)) / w.numel() < 0.5
+
+
+def test_label_smoothing_criterion_vs_reference_golden():
+    """utils/losses.py:46-77 (used when --label_smoothing > 0, scripts/train_transformer.py:33-34)."""
+    import json
+    sys_path = os.path.join(ROOT, "tests", "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_losses", os.path.join(sys_path, "make_golden_losses.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    from sparse_image_captioning_amd.utils.losses import LabelSmoothing
+    gold = json.load(open(os.path.join(sys_path, "g7_label_smoothing.json")))
+    for sm, want in gold.items():
+        x, tgt, mask = mg.inputs()
+        x.requires_grad_()
+        loss = LabelSmoothing(smoothing=float(sm))(x, tgt, mask)
+        grad, = torch.autograd.grad(loss, x)
+        assert abs(float(loss) - want["loss"]) < 1e-5
+        assert abs(float(grad.abs().sum()) - want["grad_abs_sum"]) < 1e-4
+        assert abs(float(grad[0, 0, 5]) - want["grad_0_0_5"]) < 1e-6
