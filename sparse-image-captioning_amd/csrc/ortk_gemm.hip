@@ -689,6 +689,103 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
 constexpr size_t GLDS_LDS_BYTES = GLDS_RING_BYTES > 128 * CP * sizeof(float) ? GLDS_RING_BYTES : 128 * CP * sizeof(float);
 constexpr size_t GLDS_LDS_BYTES_BIG = (size_t)GNS * 2 * 256 * GBK * sizeof(__bf16);   // 128 KB
 
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 64-column K-steps, two LDS stages (2 x 64 KB), 8 waves (2 x 4, each 128 x 64).
+// The 32-column stages above request HALF cache lines from [m][k] operands (64 bytes of each 128-byte line per
+// instruction, the other half one stage later): measured, that costs about as much as the 2x fewer bytes of the big
+// tile save.  Here an [m][k] row is a full 128-byte line (8 chunks), swizzled by chunk' = chunk ^ ((row >> 1) & 7):
+// the 16 lanes of every ds_read_b128 service group then hit 16 distinct 16-byte slots.
+constexpr int HBK = 64;
+__device__ __forceinline__ int swz_mk64(int row) { return (row >> 1) & 7; }
+
+template <bool T>
+__device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int inst = wave * 4 + u;                         // 32 wave-instructions of 1 KB per 256 x 64 operand tile
+        const __bf16* g;
+        if (!T) {
+            const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
+            g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+        } else {
+            const int f = inst * 64 + lane, kr = f >> 5, c = (f & 31) ^ swz_km(kr);     // 32 chunks per 512-byte k-row
+            g = base + (int64_t)(k0 + kr) * ld + tile0 + c * 8;
+        }
+        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
+    }
+}
+
+template <bool T>
+__device__ __forceinline__ bf16x8 gfrag64(const __bf16* img, int m0, int ks, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    if (!T) {
+        return *reinterpret_cast<const bf16x8*>(img + (m0 + lr) * HBK + (((ks * 4 + lg) ^ swz_mk64(lr)) << 3));
+    } else {
+        const int q = lr >> 2, pp = lane & 3;
+        const int chunk = ((m0 >> 3) + (pp >> 1)) ^ (2 * q + 8 * (lg & 1));
+        const __bf16* a = img + (ks * 32 + 8 * lg + q) * 256 + (chunk << 3) + 4 * (pp & 1);
+        const bf16x4 lo = tr_read(a), hi = tr_read(a + 4 * 256);
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    constexpr int IMG = 256 * HBK;                  // elements per operand image (32 KB)
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks_ = rest / tilesM;
+    const int mb = mt * 256, nb = nt * 256;
+    const int k_begin = ks_ * kchunk;
+    const int k_end = min(p.K, k_begin + kchunk);
+    const __bf16* Ap = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bp = reinterpret_cast<const __bf16*>(p.B);
+    const int T = (k_end - k_begin) / HBK;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int t) {
+        __bf16* st = smem16 + (size_t)(t & 1) * 2 * IMG;
+        glds_tile64<TA>(Ap, p.lda, mb, k_begin + t * HBK, st, wave, lane);
+        glds_tile64<TB>(Bp, p.ldb, nb, k_begin + t * HBK, st + IMG, wave, lane);
+    };
+    if (T > 0) issue(0);
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t landed (this wave's share)
+        __builtin_amdgcn_s_barrier();                          // ... everyone's share; and tile t-1 is fully consumed
+        asm volatile("" ::: "memory");
+        if (t + 1 < T) issue(t + 1);
+        const __bf16* sA = smem16 + (size_t)(t & 1) * 2 * IMG;
+        const __bf16* sB = sA + IMG;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[8], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = gfrag64<TB>(sB, wn * 64 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = gfrag64<TA>(sA, wm * 128 + 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+        epilogue_tile<true>(e, mb + wm * 128 + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
+                            *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+}
+constexpr size_t DMA256_LDS_BYTES = (size_t)2 * 2 * 256 * HBK * sizeof(__bf16);   // 128 KB
+
 typedef void (*gemm16_fn)(ortk_gemm_args, int, int, int);
 template <bool TA, bool TB, bool FAST> gemm16_fn pick16t(int adt, int bdt) {
     if (adt == ORTK_F32 && bdt == ORTK_F32) return gemm_bf16_kernel<TA, TB, float, float, FAST>;
@@ -808,8 +905,20 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 gl_attr[gi] = true;
             }
-            if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, p.M / 256, p.N / 256, kchunk);
-            else     hipLaunchKernelGGL(gf, grid, block, lds, s, p, tilesM, tilesN, kchunk);
+            if (big && impl != 6 && p.K % HBK == 0) {
+                // 64-column stages (full cache lines); impl 6 = the 32-column 4-stage ring for comparison
+                gemm16_fn g2 = key == 4 ? gemm_bf16_dma256_kernel<false, false> : key == 5 ? gemm_bf16_dma256_kernel<false, true>
+                                                                                              : gemm_bf16_dma256_kernel<true, true>;
+                static bool a2[3] = {false, false, false};
+                const int g2i = key == 4 ? 0 : key == 5 ? 1 : 2;
+                if (!a2[g2i]) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA256_LDS_BYTES);
+                    a2[g2i] = true;
+                }
+                hipLaunchKernelGGL(g2, dim3((unsigned)big_blocks), dim3(512), DMA256_LDS_BYTES, s, p, p.M / 256, p.N / 256, kchunk);
+            }
+            else if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, p.M / 256, p.N / 256, kchunk);
+            else          hipLaunchKernelGGL(gf, grid, block, lds, s, p, tilesM, tilesN, kchunk);
             if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof->push_back(rec); }
             ORTK_CHECK_LAUNCH();
             return 0;

@@ -431,7 +431,7 @@ def test_spmm_csr_vs_dense(L, xdt, M, N, K, sp):
         assert err < tol, (relu, use_res, ydt, err)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (1280, 512, 2048), (384, 256, 192), (2048, 2048, 192), (4096, 1024, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (1280, 512, 2048), (384, 256, 192), (2048, 2048, 192), (4096, 1024, 64), (4096, 2560, 192), (3328, 3072, 64)])
 def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
     """Full-tile bf16 x bf16 shapes take the LDS-DMA pipelined kernel (swizzled images, 4-stage ring): all three operand
     layouts, fused epilogue, split-K accumulation and fused column sums — against fp32 matmuls of the same bf16 values
