@@ -190,6 +190,12 @@ int ortk_layernorm_fwd(const float* x, const float* a, const float* b, void* y, 
 /* dx = dLN/dx (+ dres if non-NULL); da, db accumulate (+=). */
 int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
                        float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, ortk_stream stream);
+/* Same, with a second output dz (dz_dtype 0 fp32 / 1 bf16) = what ortk_dropout_apply(dx, dz, dz_dtype, rows*d, drop_p,
+ * drop_seed) would write: the gradient entering the previous sublayer's out-projection (SublayerConnection dropout,
+ * transformer.py:345-358), produced in the same pass instead of a separate read of dx. */
+int ortk_layernorm_bwd_drop(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
+                            float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
+                            float drop_p, uint32_t drop_seed, ortk_stream stream);
 
 /* Geometry bias of BoxMultiHeadedAttention (relation_transformer.py:196-256,177-183,286):
  * out[l,b,h,i,j] = log(max(relu(WG[l,h].e_ij + bG[l,h]), 1e-6)).  wg[l]/bg[l] are per-layer device pointers

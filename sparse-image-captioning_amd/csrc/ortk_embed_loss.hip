@@ -103,6 +103,44 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
     }
 }
 
+// Register-resident form (V <= 256 * NPT): each thread keeps its strided slice of the row, so the 870 MB logits tensor
+// is read ONCE instead of three times; max, sum and gradient run in the element order of xent_kernel (bit-identical).
+template <int NPT>
+__global__ __launch_bounds__(256) void xent_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                       int64_t target_stride, int T, const float* __restrict__ weight,
+                                                       const float* __restrict__ norm_dev, float* __restrict__ loss_dev, int V,
+                                                       int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl) {
+    __shared__ float sh[4];
+    const int64_t r = blockIdx.x;
+    const float* row = logits + r * ld;
+    const int tid = threadIdx.x;
+    float z[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) { const int c = tid + 256 * u; z[u] = c < V ? row[c] : 0.f; }
+    const int64_t tgt = targets[(r / T) * target_stride + (r % T)];
+    const float w = weight[r] / norm_dev[0];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) mx = fmaxf(mx, z[u]);
+    mx = block_max(mx, sh);
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) s += expf(z[u] - mx);
+    s = block_sum(s, sh);
+    const float lse = logf(s);
+    if (tid == 0 && w != 0.f) atomicAdd(loss_dev, -((row[tgt] - mx) - lse) * w);
+    __syncthreads();     // dlogits may alias logits (fp32 mode): row[tgt] is read before any element is overwritten
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int c = tid + 256 * u;
+        if (c < (int)ld_dl) {
+            float g = 0.f;
+            if (c < V && w != 0.f) g = (expf((z[u] - mx) - lse) - (c == tgt ? 1.f : 0.f)) * w;
+            st_elem(dlogits, r * ld_dl + c, dl_dt, g);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp,
                                                               int64_t ld_in, void* __restrict__ dlogits, int dl_dt, int64_t ld_out, int V) {
     __shared__ float sh[4];
@@ -209,8 +247,12 @@ extern "C" int ortk_xent_fwd_bwd(const float* logits, const int64_t* targets, in
     if (dl_dtype != ORTK_F32 && dl_dtype != ORTK_BF16) return ORTK_EINVAL;
     if ((const void*)dlogits == (const void*)logits && (dl_dtype != ORTK_F32 || ld_dl != ld)) return ORTK_EINVAL;
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logits, targets, target_stride, T, weight,
-                       norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl);
+    if (V <= 256 * 40 && ld_dl <= 256 * 40 && V > 256 * 8)
+        hipLaunchKernelGGL(xent_reg_kernel<40>, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logits, targets, target_stride, T,
+                           weight, norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl);
+    else
+        hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logits, targets, target_stride, T, weight,
+                           norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

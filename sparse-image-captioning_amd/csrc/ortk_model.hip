@@ -269,15 +269,20 @@ static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, cons
 static int ln_fwd(const Ctx& c, const float* x, int64_t a, int64_t b, void* y, int ydt, float* st, int64_t rows) {
     return ortk_layernorm_fwd(x, c.P + a, c.P + b, y, ydt, st, rows, c.cfg->d_model, 1e-6f, (ortk_stream)c.s);
 }
+// next_op >= 0: also emit, into `dz`, the dropout-masked / bf16 copy of dx that the NEXT drop_bwd(dx, dz, ., next_op) would
+// produce (that call then finds its work done, see drop_bwd)
 static int ln_bwd(const Ctx& c, const float* dy, const float* x, float* G, int64_t a, int64_t b, const float* st,
-                  const float* dres, float* dx, int64_t rows) {
-    return ortk_layernorm_bwd(dy, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, (ortk_stream)c.s);
+                  const float* dres, float* dx, int64_t rows, void* dz = nullptr, int next_op = -1) {
+    const bool fuse = dz && next_op >= 0 && (c.p_drop() > 0.f || c.adt == ORTK_BF16);
+    return ortk_layernorm_bwd_drop(dy, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, fuse ? dz : nullptr,
+                                   c.adt, c.p_drop(), fuse ? c.sub((uint32_t)next_op) : 0, (ortk_stream)c.s);
 }
 // gradient through a residual-branch dropout: the buffer (and its dtype) holding dx * keep/(1-p).
 // Mixed precision always goes through `tmp` (it also performs the fp32 -> bf16 conversion of the GEMM operand).
-static int drop_bwd(const Ctx& c, const float* dx, void* tmp, int64_t n, uint32_t op, const void** out, int* out_dt) {
+static int drop_bwd(const Ctx& c, const float* dx, void* tmp, int64_t n, uint32_t op, const void** out, int* out_dt,
+                    bool done_by_ln_bwd = false) {
     if (c.p_drop() > 0.f || c.adt == ORTK_BF16) {
-        TRY(ortk_dropout_apply(dx, tmp, c.adt, n, c.p_drop(), c.sub(op), (ortk_stream)c.s));
+        if (!done_by_ln_bwd) TRY(ortk_dropout_apply(dx, tmp, c.adt, n, c.p_drop(), c.sub(op), (ortk_stream)c.s));
         *out = tmp; *out_dt = c.adt;
     } else { *out = dx; *out_dt = ORTK_F32; }
     return 0;
@@ -512,20 +517,20 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
     TRY(wgrad_gemm(c, w.dlogits, A, w.ldv, w.dec_out, A, d, G + o.gen_w, G + o.gen_b, Md, Vp, d));
     TRY(dgrad_gemm(c, w.dlogits, A, w.ldv, o.gen_w, w.gy, ORTK_F32, d, Md, Vp, d));
     float* dx = w.ga; float* dx2 = w.gb;
-    TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md));
+    TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md, w.gt, dop(L - 1, 5)));
     for (int l = L - 1; l >= 0; --l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         const float* xin = l == 0 ? w.dx0 : w.dec[l - 1].xout;
         const void* dt; int dtt;
         // feed-forward sublayer
-        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 5), &dt, &dtt));
+        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 5), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Md, d, ff));
         TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Md, d, ff, b.h, A, ff, inv_keep));
         TRY(wgrad_gemm(c, w.gh, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
         TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Md, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, Md));
+        TRY(ln_bwd(c, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, Md, w.gt, dop(l, 3)));
         // cross-attention sublayer
-        TRY(drop_bwd(c, dx2, w.gt, Md * d, dop(l, 3), &dt, &dtt));
+        TRY(drop_bwd(c, dx2, w.gt, Md * d, dop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
@@ -537,9 +542,9 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gt, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
         TRY(dgrad_gemm(c, w.gt, A, d, e.cqw, w.gy, ORTK_F32, d, Md, d, d));
-        TRY(ln_bwd(c, w.gy, b.xm1, G, e.n1a, e.n1b, b.st2, dx2, dx, Md));
+        TRY(ln_bwd(c, w.gy, b.xm1, G, e.n1a, e.n1b, b.st2, dx2, dx, Md, w.gt, dop(l, 1)));
         // self-attention sublayer
-        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 1), &dt, &dtt));
+        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Md, d, d));
         std::memset(&a, 0, sizeof(a));
@@ -550,7 +555,7 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
         TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, 3 * d, d));
-        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md));
+        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md, w.gt, l > 0 ? (int)dop(l - 1, 5) : -1));
         std::swap(dx, dx2);
     }
     TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), stream));
@@ -559,18 +564,18 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
     TRY(dgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, o.ckv_w, w.gy, ORTK_F32, d, Me, L * 2 * d, d));
     // encoder
     dx = w.ga; dx2 = w.gb;
-    TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me));
+    TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me, w.gt, eop(L - 1, 3)));
     for (int l = L - 1; l >= 0; --l) {
         const EncOff& e = o.enc[l]; const EncBuf& b = w.enc[l];
         const float* xin = l == 0 ? w.x0 : w.enc[l - 1].xout;
         const void* dt; int dtt;
-        TRY(drop_bwd(c, dx, w.gt, Me * d, eop(l, 3), &dt, &dtt));
+        TRY(drop_bwd(c, dx, w.gt, Me * d, eop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Me, d, ff));
         TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Me, d, ff, b.h, A, ff, inv_keep));
         TRY(wgrad_gemm(c, w.gh, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
         TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Me, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me));
-        TRY(drop_bwd(c, dx2, w.gt, Me * d, eop(l, 1), &dt, &dtt));
+        TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me, w.gt, eop(l, 1)));
+        TRY(drop_bwd(c, dx2, w.gt, Me * d, eop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Me, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
@@ -582,7 +587,7 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
         TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, 3 * d, d));
-        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me));
+        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, w.gt, l > 0 ? (int)eop(l - 1, 3) : -1));
     }
     // geometry bias weights
     {

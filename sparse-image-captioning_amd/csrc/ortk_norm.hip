@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ a, const float* __restrict__ stats,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
                                                      float* __restrict__ da, float* __restrict__ db, int64_t rows, int d,
-                                                     float eps, int rows_per_block) {
+                                                     float eps, int rows_per_block, void* __restrict__ dz, int dz_dt,
+                                                     float drop_p, uint32_t drop_seed) {
     using C = Cols<VEC, NREG>;
     extern __shared__ float red[];  // [2][d] partial da / db
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -135,10 +136,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     o.w = r * (gv[it * 4 + 3] - mg) - coef * xv[it * 4 + 3];
                     if (res) { const float4 t = *reinterpret_cast<const float4*>(res + c); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
                     *reinterpret_cast<float4*>(dxr + c) = o;
+                    if (dz) {   // second output: the dropout-masked (and possibly bf16) copy the next out-projection's GEMMs read
+                        const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)c;
+                        const float ik = 1.f / (1.f - drop_p);
+                        float4 z;
+                        z.x = (drop_p > 0.f && !ortk_keep(drop_seed, i0, drop_p)) ? 0.f : o.x * ik;
+                        z.y = (drop_p > 0.f && !ortk_keep(drop_seed, i0 + 1, drop_p)) ? 0.f : o.y * ik;
+                        z.z = (drop_p > 0.f && !ortk_keep(drop_seed, i0 + 2, drop_p)) ? 0.f : o.z * ik;
+                        z.w = (drop_p > 0.f && !ortk_keep(drop_seed, i0 + 3, drop_p)) ? 0.f : o.w * ik;
+                        st_elem4(dz, (int64_t)i0, dz_dt, z);
+                    }
                 } else {
                     float o = r * (gv[it] - mg) - coef * xv[it];
                     if (res) o += res[c];
                     dxr[c] = o;
+                    if (dz) {
+                        const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)c;
+                        st_elem(dz, (int64_t)i0, dz_dt, (drop_p > 0.f && !ortk_keep(drop_seed, i0, drop_p)) ? 0.f : o * (1.f / (1.f - drop_p)));
+                    }
                 }
             }
         }
@@ -176,20 +191,27 @@ extern "C" int ortk_layernorm_fwd(const float* x, const float* a, const float* b
     return 0;
 }
 
-extern "C" int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
-                                  float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, ortk_stream stream) {
+extern "C" int ortk_layernorm_bwd_drop(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
+                                       float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
+                                       float drop_p, uint32_t drop_seed, ortk_stream stream) {
     if (!dy || !x || !a || !stats || !dx || !da || !db || d < 2 || d > 2048 || rows < 0) return ORTK_EINVAL;
+    if (dz && ((dz_dtype != ORTK_F32 && dz_dtype != ORTK_BF16) || drop_p < 0.f || drop_p >= 1.f)) return ORTK_EINVAL;
     if (rows == 0) return 0;
     // measured (scratch/ln_bench.py): 64 and 32 rows tie at 21 760 rows (47 us); 32 wins at 9 216 (31.6 vs 35.9 us);
     // 16 rows and fewer lose to the per-block atomics on da / db
     const int rpb = rows >= 16384 ? LN_ROWS_PER_BLOCK : LN_ROWS_PER_BLOCK / 2;
     dim3 grid((unsigned)ortk_cdiv(rows, rpb)), block(256);
     const size_t shm = 2 * (size_t)d * sizeof(float);
-    const bool vec = d % 4 == 0 && al16(dy) && al16(x) && al16(a) && al16(dres) && al16(dx);
-#define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps, rpb)
+    const bool vec = d % 4 == 0 && al16(dy) && al16(x) && al16(a) && al16(dres) && al16(dx) && (dz == nullptr || (reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+#define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps, rpb, dz, (int)dz_dtype, drop_p, drop_seed)
     if (d <= 512) { if (vec) LN_B(true, 8); else LN_B(false, 8); }
     else          { if (vec) LN_B(true, 32); else LN_B(false, 32); }
 #undef LN_B
     ORTK_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
+                                  float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, ortk_stream stream) {
+    return ortk_layernorm_bwd_drop(dy, x, a, stats, dres, dx, da, db, rows, d, eps, nullptr, 0, 0.f, 0, stream);
 }

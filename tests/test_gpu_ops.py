@@ -119,6 +119,29 @@ def test_layernorm_fwd_bwd(L, rows, d):
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("rows,d,p,dt", [(300, 512, 0.1, 1), (77, 512, 0.0, 1), (33, 100, 0.25, 0), (64, 2048, 0.1, 1)])
+def test_layernorm_bwd_with_fused_dropout_output(L, rows, d, p, dt):
+    """ortk_layernorm_bwd_drop == ortk_layernorm_bwd followed by ortk_dropout_apply on its dx (bitwise)."""
+    x, dy, a, b, dres = rnd(rows, d, seed=1), rnd(rows, d, seed=2), 1 + 0.1 * rnd(d, seed=3), rnd(d, seed=4), rnd(rows, d, seed=5)
+    xd, dyd, ad, bd, rd = dev(x), dev(dy), dev(a), dev(b), dev(dres)
+    y = torch.empty(rows, d, device="cuda"); st = torch.empty(rows, 2, device="cuda")
+    L.check(L.lib().ortk_layernorm_fwd(L.ptr(xd), L.ptr(ad), L.ptr(bd), L.ptr(y), 0, L.ptr(st), rows, d, 1e-6, L.stream_ptr()), "ln")
+    tdt = torch.bfloat16 if dt else torch.float32
+    dx1, dx2 = torch.empty_like(xd), torch.empty_like(xd)
+    z1, z2 = torch.empty(rows, d, device="cuda", dtype=tdt), torch.empty(rows, d, device="cuda", dtype=tdt)
+    da1, db1, da2, db2 = (torch.zeros(d, device="cuda") for _ in range(4))
+    L.check(L.lib().ortk_layernorm_bwd(L.ptr(dyd), L.ptr(xd), L.ptr(ad), L.ptr(st), L.ptr(rd), L.ptr(dx1), L.ptr(da1), L.ptr(db1),
+                                       rows, d, 1e-6, L.stream_ptr()), "ln_bwd")
+    L.check(L.lib().ortk_dropout_apply(L.ptr(dx1), L.ptr(z1), dt, rows * d, p, 99, L.stream_ptr()), "drop")
+    L.check(L.lib().ortk_layernorm_bwd_drop(L.ptr(dyd), L.ptr(xd), L.ptr(ad), L.ptr(st), L.ptr(rd), L.ptr(dx2), L.ptr(da2), L.ptr(db2),
+                                            rows, d, 1e-6, L.ptr(z2), dt, p, 99, L.stream_ptr()), "ln_bwd_drop")
+    assert torch.equal(dx1, dx2) and torch.equal(z1, z2)
+    torch.testing.assert_close(da1, da2, rtol=1e-5, atol=1e-5)
+    if p > 0:
+        frac = (z2 == 0).float().mean().item()
+        assert abs(frac - p) < 0.03
+
+
 def _boxes(B, S, seed):
     import common as Cm
     return torch.from_numpy(Cm.make_inputs(seed, B, S, 4, 10, 1)["boxes"])
