@@ -90,10 +90,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float eps, int rows_per_block, void* __restrict__ dz, int dz_dt,
                                                      float drop_p, uint32_t drop_seed) {
     using C = Cols<VEC, NREG>;
-    extern __shared__ float red[];  // [2][d] partial da / db
+    extern __shared__ float red[];  // [4 waves][2][d] partial da / db
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < 2 * d; c += 256) red[c] = 0.f;
-    __syncthreads();
     float pa[NREG], pb[NREG], av[NREG];
 #pragma unroll
     for (int i = 0; i < NREG; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
@@ -158,18 +156,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
-    // combine the 4 waves' column partials
+    // combine the 4 waves' column partials: plain stores to per-wave LDS rows, then each thread sums 4 values per column
+    // (LDS float atomics were the slow part of this tail)
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it)
 #pragma unroll
         for (int u = 0; u < C::W; ++u) {
             const int c = C::col(lane, it) + u;
-            if (c < d) { atomicAdd(&red[c], pa[it * C::W + u]); atomicAdd(&red[d + c], pb[it * C::W + u]); }
+            if (c < d) { red[wave * 2 * d + c] = pa[it * C::W + u]; red[wave * 2 * d + d + c] = pb[it * C::W + u]; }
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 256) {
-        atomicAdd(&da[c], red[c]);
-        atomicAdd(&db[c], red[d + c]);
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        const float v = (red[c] + red[2 * d + c]) + (red[4 * d + c] + red[6 * d + c]);
+        atomicAdd(c < d ? &da[c] : &db[c - d], v);
     }
 }
 
@@ -201,7 +201,7 @@ extern "C" int ortk_layernorm_bwd_drop(const float* dy, const float* x, const fl
     // 16 rows and fewer lose to the per-block atomics on da / db
     const int rpb = rows >= 16384 ? LN_ROWS_PER_BLOCK : LN_ROWS_PER_BLOCK / 2;
     dim3 grid((unsigned)ortk_cdiv(rows, rpb)), block(256);
-    const size_t shm = 2 * (size_t)d * sizeof(float);
+    const size_t shm = 8 * (size_t)d * sizeof(float);
     const bool vec = d % 4 == 0 && al16(dy) && al16(x) && al16(a) && al16(dres) && al16(dx) && (dz == nullptr || (reinterpret_cast<uintptr_t>(dz) & 15) == 0);
 #define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps, rpb, dz, (int)dz_dtype, drop_p, drop_seed)
     if (d <= 512) { if (vec) LN_B(true, 8); else LN_B(false, 8); }
