@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="xe", choices=("xe", "sparse_xe", "scst", "decode", "sparse_decode"))
+    ap.add_argument("--overlap-allreduce", default="auto", choices=("auto", "on", "off"),
+                    help="all-reduce the decoder half of the gradients while the encoder half of the backward runs "
+                         "(auto: on when more than one rank)")
     ap.add_argument("--csr-kernels", action="store_true",
                     help="sparse_decode: CSR gather products (ortk_spmm_csr) instead of MFMA GEMMs on zero-filled weights; "
                          "measured slower than bf16 MFMA at 95 %% unstructured sparsity (DESIGN.md section 7)")
@@ -195,7 +198,8 @@ def main():
     else:
         model.train()
         tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000,
-                           sparsity_target=0.95 if args.workload == "sparse_xe" else None, max_train_step=100000)
+                           sparsity_target=0.95 if args.workload == "sparse_xe" else None, max_train_step=100000,
+                           overlap_allreduce={"auto": None, "on": True, "off": False}[args.overlap_allreduce])
 
         def step():
             tr.xe_step(batch)

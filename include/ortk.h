@@ -97,6 +97,13 @@ int ortk_loss_external(const ortk_config* cfg, const ortk_batch* batch, void* ws
 /* Backward through decoder, encoder, geometry bias and att_embed; ACCUMULATES into `grads` (arena mirror). */
 int ortk_backward(const ortk_config* cfg, const float* params, float* grads, const ortk_batch* batch,
                   void* ws, size_t ws_bytes, int32_t train, uint64_t seed, ortk_stream stream);
+/* The same in two halves, so that a data-parallel host can start the all-reduce of the decoder half's gradients while
+ * the encoder half still runs: phase 1 = generator + decoder stack + token embedding + cross-attention K/V projections
+ * (afterwards every gradient at arena offsets >= ortk_arena_decoder_offset(cfg) is final), phase 2 = encoder stack,
+ * geometry bias, att_embed (must follow phase 1 on the same workspace); phase 0 = both (== ortk_backward). */
+int ortk_backward_phase(const ortk_config* cfg, const float* params, float* grads, const ortk_batch* batch,
+                        void* ws, size_t ws_bytes, int32_t train, uint64_t seed, int32_t phase, ortk_stream stream);
+int64_t ortk_arena_decoder_offset(const ortk_config* cfg);
 
 /* Cached-attention decoding: CachedTransformerBase._generate_captions (models/transformer.py:471-561)
  * + CaptionModel.batch_beam_search (models/caption_model.py:30-226, group_size 1). */

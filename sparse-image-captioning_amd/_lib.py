@@ -87,6 +87,8 @@ SIGNATURES = {
     "ortk_loss": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _P]),
     "ortk_loss_external": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _I64, _P]),
     "ortk_backward": (_I32, [_CFG, _P, _P, C.POINTER(Batch), _P, _SZ, _I32, _U64, _P]),
+    "ortk_backward_phase": (_I32, [_CFG, _P, _P, C.POINTER(Batch), _P, _SZ, _I32, _U64, _I32, _P]),
+    "ortk_arena_decoder_offset": (_I64, [_CFG]),
     "ortk_decode_workspace_bytes": (_SZ, [_CFG, _I32, _I32, C.POINTER(DecodeOpts)]),
     "ortk_decode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, C.POINTER(DecodeOpts), _P, _SZ, _P, _P, _P, _P]),
     "ortk_encode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P, _P]),

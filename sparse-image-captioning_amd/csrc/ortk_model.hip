@@ -496,8 +496,20 @@ extern "C" int ortk_loss_external(const ortk_config* cfg, const ortk_batch* bt, 
     return ortk_log_softmax_bwd(logp, dlogp, ldv, w.dlogits, w.adt, w.ldv, w.Md, cfg->vocab, stream);
 }
 
+extern "C" int64_t ortk_arena_decoder_offset(const ortk_config* cfg) {
+    if (check_cfg(cfg)) return -1;
+    Offsets o; build_layout(*cfg, o, nullptr);
+    return o.dec[0].wqkv;
+}
+
 extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float* grads, const ortk_batch* bt, void* ws,
                              size_t ws_bytes, int32_t train, uint64_t seed, ortk_stream stream) {
+    return ortk_backward_phase(cfg, params, grads, bt, ws, ws_bytes, train, seed, 0, stream);
+}
+
+extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, float* grads, const ortk_batch* bt, void* ws,
+                                   size_t ws_bytes, int32_t train, uint64_t seed, int32_t phase, ortk_stream stream) {
+    if (phase < 0 || phase > 2) return ORTK_EINVAL;
     if (int e = check_cfg(cfg)) return e;
     if (int e = check_batch(cfg, bt, true)) return e;
     if (!params || !grads || !ws) return ORTK_EINVAL;
@@ -512,11 +524,14 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
     const int64_t Me = w.Me, Md = w.Md;
     const float inv_keep = c.p_drop() > 0.f ? 1.f / (1.f - c.p_drop()) : 1.f;
 
+    float* dx = w.ga; float* dx2 = w.gb;
+    if (phase != 2) {
+    // ---- decoder half: generator, decoder stack, token embedding, cross-attention K/V projections; leaves the gradient
+    // of the encoder memory in w.gy.  Every gradient at arena offsets >= ortk_arena_decoder_offset is final afterwards.
     // generator (over the padded vocabulary: pad columns of dlogits are exact zeros)
     const int Vp = (int)w.ldv;
     TRY(wgrad_gemm(c, w.dlogits, A, w.ldv, w.dec_out, A, d, G + o.gen_w, G + o.gen_b, Md, Vp, d));
     TRY(dgrad_gemm(c, w.dlogits, A, w.ldv, o.gen_w, w.gy, ORTK_F32, d, Md, Vp, d));
-    float* dx = w.ga; float* dx2 = w.gb;
     TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md, w.gt, dop(L - 1, 5)));
     for (int l = L - 1; l >= 0; --l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
@@ -562,7 +577,9 @@ extern "C" int ortk_backward(const ortk_config* cfg, const float* params, float*
     // cross-attention K/V projections of all layers, and the gradient of the encoder memory
     TRY(wgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, L * 2 * d, d));
     TRY(dgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, o.ckv_w, w.gy, ORTK_F32, d, Me, L * 2 * d, d));
-    // encoder
+    }
+    if (phase == 1) return 0;
+    // ---- encoder half (reads the memory gradient left in w.gy)
     dx = w.ga; dx2 = w.gb;
     TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me, w.gt, eop(L - 1, 3)));
     for (int l = L - 1; l >= 0; --l) {

@@ -46,6 +46,15 @@ def reduce_scalar_sum(t):
     return t
 
 
+def allreduce_async(t):
+    """Start an in-place SUM all-reduce of `t` (a contiguous slice of the gradient arena) and return its handle
+    (``.wait()`` makes the current stream wait for it), or None when there is nothing to exchange.  With the nccl (= RCCL)
+    backend the collective first waits for the work already queued on the current stream, then runs on its own stream."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def allreduce_arena(*arenas):
     """In-place SUM of flat gradient arenas; one collective per arena (each is one contiguous bucket)."""
     if world() > 1:

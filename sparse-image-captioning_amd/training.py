@@ -27,7 +27,8 @@ def noam_rate(step, d_model, factor, warmup):
 
 class NativeTrainer:
     def __init__(self, model, noamopt_factor=1.0, noamopt_warmup=20000, grad_clip=0.1, betas=(0.9, 0.98), eps=1e-9,
-                 prune_supermask_lr=100.0, mask_eps=1e-2, sparsity_target=None, sparsity_weight=None, max_train_step=1):
+                 prune_supermask_lr=100.0, mask_eps=1e-2, sparsity_target=None, sparsity_weight=None, max_train_step=1,
+                 overlap_allreduce=None):
         L.require_gpu()
         self.model = model
         self.dev = model._flat.device
@@ -54,6 +55,12 @@ class NativeTrainer:
                 max(5.0, 1.5 / (1.0 - sparsity_target)) if sparsity_target is not None else 0.0)
             self.max_train_step = max_train_step
         self.world = parallel.world()
+        # Data-parallel overlap: the decoder half of the backward finishes first, so its 154 MB of gradients are all-reduced
+        # (RCCL, on the collective's own stream) while the encoder half still runs.  Dense models only: the masked variants
+        # post-process the whole gradient arena (ortk_mask_bwd) before the exchange.  Default: on whenever world > 1.
+        self.overlap = (self.world > 1 if overlap_allreduce is None else bool(overlap_allreduce)) and not self.masked
+        self._dec_off = int(L.lib().ortk_arena_decoder_offset(C.byref(model._ccfg)))
+        self._pending = None
 
     # ------------------------------------------------------------------ pieces
     def _batch(self, data, tok_weight):
@@ -72,12 +79,26 @@ class NativeTrainer:
                                  L.stream_ptr()), "ortk_forward")
         L.check(lib.ortk_loss(C.byref(m._ccfg), C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(norm), L.ptr(self.loss_dev),
                               L.stream_ptr()), "ortk_loss")
-        L.check(lib.ortk_backward(C.byref(m._ccfg), pptr, L.ptr(self.grads), C.byref(batch), L.ptr(ws), ws.numel(), int(train),
-                                  seed, L.stream_ptr()), "ortk_backward")
+        if self.overlap:
+            for phase in (1, 2):
+                L.check(lib.ortk_backward_phase(C.byref(m._ccfg), pptr, L.ptr(self.grads), C.byref(batch), L.ptr(ws), ws.numel(),
+                                                int(train), seed, phase, L.stream_ptr()), "ortk_backward_phase")
+                if phase == 1:      # the collective waits for the work queued so far, then runs beside phase 2
+                    self._pending = parallel.allreduce_async(self.grads[self._dec_off:])
+        else:
+            L.check(lib.ortk_backward(C.byref(m._ccfg), pptr, L.ptr(self.grads), C.byref(batch), L.ptr(ws), ws.numel(), int(train),
+                                      seed, L.stream_ptr()), "ortk_backward")
         return seed
 
     def _allreduce(self):
-        # RCCL over xGMI: one flat 222 MB bucket (SUM; every rank's loss is already divided by the GLOBAL norm)
+        # RCCL over xGMI (SUM; every rank's loss is already divided by the GLOBAL norm): one flat 222 MB bucket, or — with the
+        # overlap — the decoder half already in flight and the 80 MB encoder half now
+        if self.overlap:
+            parallel.allreduce_arena(self.grads[:self._dec_off])
+            if self._pending is not None:
+                self._pending.wait()
+                self._pending = None
+            return
         parallel.allreduce_arena(self.grads, self.dm if (self.masked and self.train_masks) else None)
 
     def _adam(self, p, g, m, v, lr, eps):

@@ -38,7 +38,11 @@ def _worker(rank, world, port, out_dir):
     names = sorted(P)
     arena = torch.cat([P[n].grad.reshape(-1) for n in names])
     loss_t = loss.detach().reshape(1).clone()
-    parallel.allreduce_arena(arena, loss_t)
+    # the trainer's overlapped exchange: the tail ("decoder half") starts asynchronously, the head follows, then wait
+    split = arena.numel() // 3
+    pending = parallel.allreduce_async(arena[split:])
+    parallel.allreduce_arena(arena[:split], loss_t)
+    pending.wait()
     if rank == 0:
         np.savez(os.path.join(out_dir, "dp.npz"), arena=arena.numpy(), loss=loss_t.numpy())
     dist.barrier()
