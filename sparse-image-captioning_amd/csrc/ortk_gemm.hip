@@ -265,10 +265,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
 //   * k-major operand (dY^T / X for wgrad, W for dgrad):           image [k][m], pitch 136 bf16;  the fragment is
 //     gathered by two hardware-transposing reads (ds_read_b64_tr_b16).
 constexpr int BK16 = 64;
-constexpr int PITCH_MK = BK16 + 8;     // [m][k] image: 144 B rows (16-B aligned, rows spread over banks)
-constexpr int PITCH_KM = 128 + 8;      // [k][m] image: 272 B rows (16-B aligned; 8-B aligned for the transposing read)
-constexpr int IMG_ELEMS = 128 * PITCH_MK > BK16 * PITCH_KM ? 128 * PITCH_MK : BK16 * PITCH_KM;
-constexpr size_t BF16_LDS_BYTES_C = (size_t)4 * IMG_ELEMS * 2;   // 2 stages x (A + B) images of bf16
+// Both images are UNPADDED and XOR-swizzled at 16-byte-chunk granularity (the padded pitches 72 / 136 of the first version
+// showed SQ_LDS_BANK_CONFLICT = 33 % of the LDS cycles: ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, ...,
+// not in 16 consecutive lanes):
+//   [m][k] image: 128-byte rows (8 chunks), chunk' = chunk ^ ((row >> 1) & 7);
+//   [k][m] image: 256-byte rows (16 chunks), chunk' = chunk ^ 2*((k & 3) | ((k >> 1) & 4)).
+// (the same layouts the LDS-DMA kernels below use, where the counter reads 0)
+constexpr int PITCH_MK = BK16;
+constexpr int PITCH_KM = 128;
+constexpr int IMG_ELEMS = 128 * BK16;                             // 16 KB per operand image
+__device__ __forceinline__ int swz_mk64(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_km(int k) { return 2 * ((k & 3) | ((k >> 1) & 4)); }
+// element offset of (row, col) inside a swizzled image
+template <bool T> __device__ __forceinline__ int img_off(int row, int col) {
+    return row * (T ? PITCH_KM : PITCH_MK) + ((((col >> 3) ^ (T ? swz_km(row) : swz_mk64(row))) << 3) | (col & 7));
+}
+constexpr size_t BF16_LDS_BYTES_C = (size_t)128 * (128 + 4) * sizeof(float);   // the staged C tile (epilogue) is the larger user
 
 __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
@@ -356,7 +368,7 @@ __device__ __forceinline__ void stage_store(const CT (&r)[N], __bf16* img, int t
 #pragma unroll
     for (int u = 0; u < S::NCH; ++u) {
         const int f = tid + 256 * u;
-        lds_put(img + (f / S::CPR) * S::PITCH + (f % S::CPR) * S::EPC, r[u]);
+        lds_put(img + img_off<T>(f / S::CPR, (f % S::CPR) * S::EPC), r[u]);
         if (CS) chunk_add(cs, r[u]);
     }
 }
@@ -366,11 +378,11 @@ template <bool T>
 __device__ __forceinline__ bf16x8 frag(const __bf16* img, int m0, int ks, int lane) {
     const int lr = lane & 15, lg = lane >> 4;
     if (!T) {
-        return *reinterpret_cast<const bf16x8*>(img + (m0 + lr) * PITCH_MK + ks * 32 + 8 * lg);
+        return *reinterpret_cast<const bf16x8*>(img + img_off<false>(m0 + lr, ks * 32 + 8 * lg));
     } else {
         // lane 4q+p of a 16-lane group supplies &img[k0 + q][m0 + 4p]; it receives column (lane & 15) of 4 k-rows
-        const __bf16* p = img + (ks * 32 + 8 * lg + (lr >> 2)) * PITCH_KM + m0 + 4 * (lane & 3);
-        const bf16x4 lo = tr_read(p), hi = tr_read(p + 4 * PITCH_KM);
+        const __bf16* p = img + img_off<true>(ks * 32 + 8 * lg + (lr >> 2), m0 + 4 * (lane & 3));
+        const bf16x4 lo = tr_read(p), hi = tr_read(p + 4 * PITCH_KM);     // k + 4: same swizzle (bit 2 of k is not used)
         return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 }
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
     if (p.accumulate) epilogue_staged<FAST>(e, reinterpret_cast<float*>(smem16), mb, nb, wm, wn, lane, wave, acc);
     else epilogue_tile<FAST>(e, mb + wm * 64 + (lane & 15), nb + wn * 64 + 4 * (lane >> 4), acc);
 }
-constexpr size_t BF16_LDS_BYTES = (size_t)4 * IMG_ELEMS * sizeof(__bf16);
+constexpr size_t BF16_LDS_BYTES = (size_t)4 * IMG_ELEMS * sizeof(__bf16) > BF16_LDS_BYTES_C ? (size_t)4 * IMG_ELEMS * sizeof(__bf16) : BF16_LDS_BYTES_C;
 
 
 // ------------------------------------------------------------------------------------------------
@@ -560,8 +572,6 @@ constexpr int G_IMG = 128 * GBK;                       // bf16 elements per oper
 constexpr size_t GLDS_RING_BYTES = (size_t)GNS * 2 * G_IMG * sizeof(__bf16);   // 64 KB
 
 __device__ __forceinline__ int swz_mk(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0,2,3,1} packed as 0b01111000
-__device__ __forceinline__ int swz_km(int k) { return 2 * ((k & 3) | ((k >> 1) & 4)); }
-
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
@@ -697,7 +707,6 @@ constexpr size_t GLDS_LDS_BYTES_BIG = (size_t)GNS * 2 * 256 * GBK * sizeof(__bf1
 // tile save.  Here an [m][k] row is a full 128-byte line (8 chunks), swizzled by chunk' = chunk ^ ((row >> 1) & 7):
 // the 16 lanes of every ds_read_b128 service group then hit 16 distinct 16-byte slots.
 constexpr int HBK = 64;
-__device__ __forceinline__ int swz_mk64(int row) { return (row >> 1) & 7; }
 
 template <bool T>
 __device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane) {
