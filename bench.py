@@ -111,7 +111,8 @@ def pmc_traffic(workload, precision, B):
     try:
         for cname, fname in (("FETCH_SIZE", "r01_xe_b256_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_xe_b256_pmc_write_size.csv")):
             for r in csv.DictReader(open(os.path.join(here, "profiles", fname))):
-                if "gemm_bf16_glds_kernel<false, false" in r["kernel"] and r["counter"] == cname:
+                fwd = "gemm_bf16_glds_kernel<false, false" in r["kernel"] or "gemm_bf16_dma256_kernel<false, false" in r["kernel"]
+                if fwd and r["counter"] == cname:
                     tot[cname] += float(r["total"]); n[cname] += int(r["launches"])
     except (OSError, KeyError, ValueError):
         return None
@@ -245,7 +246,7 @@ def main():
         tot_ms = sum(v[1] for v in per_key.values())
         tot_fl = sum(v[2] for v in per_key.values())
         roofline = {"bound": "mfma",
-                    "kernel": ("gemm_bf16_glds_kernel<false,false,*> (forward X*W^T, LDS-DMA pipeline)" if args.precision == "bf16"
+                    "kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> (forward X*W^T, LDS-DMA pipeline)" if args.precision == "bf16"
                                else "gemm_f32_kernel<false,false> (forward X*W^T)"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
