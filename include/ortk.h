@@ -235,6 +235,8 @@ typedef struct ortk_attn_args {
     const float* d_o; void* dq; void* d_k; void* dv; float* dscore;  /* dscore (nkv,H,Lq,Lk) or NULL */
     int64_t lddo, lddq, lddk, lddv;
     int32_t o_dtype, dqkv_dtype;    /* storage type of O (fwd) and of dQ/dK/dV (bwd): 0 = fp32, 1 = bf16 */
+    int32_t kv_dtype;               /* forward only: 1 = k / v point to bf16 rows (ldk / ldv in elements, multiples of 8): the
+                                     * decode-time caches in mixed precision; served for 1-16 query rows, Lk <= 48, dk = 64 */
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);

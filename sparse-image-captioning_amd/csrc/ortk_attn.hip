@@ -467,6 +467,26 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
     }
 }
 
+// K / V rows may be stored as bf16 (decode-time caches in mixed precision: ortk_attn_args.kv_dtype = 1)
+template <typename T> __device__ __forceinline__ void ld_row16(const T* p, float4 (&o)[4]);
+template <> __device__ __forceinline__ void ld_row16<float>(const float* p, float4 (&o)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = *reinterpret_cast<const float4*>(p + 4 * c);
+}
+template <> __device__ __forceinline__ void ld_row16<__bf16>(const __bf16* p, float4 (&o)[4]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p), b = *reinterpret_cast<const bf16x8*>(p + 8);
+    o[0] = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]); o[1] = make_float4((float)a[4], (float)a[5], (float)a[6], (float)a[7]);
+    o[2] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]); o[3] = make_float4((float)b[4], (float)b[5], (float)b[6], (float)b[7]);
+}
+template <typename T> __device__ __forceinline__ void ld_row8(const T* p, float4& lo, float4& hi);
+template <> __device__ __forceinline__ void ld_row8<float>(const float* p, float4& lo, float4& hi) {
+    lo = *reinterpret_cast<const float4*>(p); hi = *reinterpret_cast<const float4*>(p + 4);
+}
+template <> __device__ __forceinline__ void ld_row8<__bf16>(const __bf16* p, float4& lo, float4& hi) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+    lo = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]); hi = make_float4((float)a[4], (float)a[5], (float)a[6], (float)a[7]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-only form for short sequences (Lq, Lk <= 32, dk = 64): the decoder's 17 x 17 causal self-attention is
 // 10 240 tiny (caption, head) pairs per layer.  One wave per pair, no LDS, no barrier: every MFMA operand is loaded
@@ -478,7 +498,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
 //     the probabilities never leave their registers; the matching V rows are read as 64-byte row segments.
 // The backward runs the same scheme twice: transposed layout for dQ, natural layout (operands of the dP product
 // swapped, no extra loads) for dK and dV.
-template <int NIT, int NJT>
+template <int NIT, int NJT, typename KVT>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(ortk_attn_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * 4 + wave;
@@ -488,15 +508,11 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(ortk_attn_args a) {
     const int lr = lane & 15, lq = lane >> 4;
     const int64_t kv0 = (int64_t)g * (a.kv_group_stride > 0 ? a.kv_group_stride : Lk);
     const float* qb = a.q + (int64_t)g * Lq * a.ldq + h * 64;
-    const float* kb = a.k + kv0 * a.ldk + h * 64;
-    const float* vb = a.v + kv0 * a.ldv + h * 64;
+    const KVT* kb = reinterpret_cast<const KVT*>(a.k) + kv0 * a.ldk + h * 64;
+    const KVT* vb = reinterpret_cast<const KVT*>(a.v) + kv0 * a.ldv + h * 64;
     float4 kf[NJT][4], qf[NIT][4];
 #pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) {
-        const float* src = kb + (int64_t)min(16 * jt + lr, Lk - 1) * a.ldk + 16 * lq;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) kf[jt][c] = *reinterpret_cast<const float4*>(src + 4 * c);
-    }
+    for (int jt = 0; jt < NJT; ++jt) ld_row16<KVT>(kb + (int64_t)min(16 * jt + lr, Lk - 1) * a.ldk + 16 * lq, kf[jt]);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const float* src = qb + (int64_t)min(16 * it + lr, Lq - 1) * a.ldq + 16 * lq;
@@ -575,7 +591,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(ortk_attn_args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * lq + r;
-                const float t = vb[(int64_t)min(j, Lk - 1) * a.ldv + 16 * dt + lr];
+                const float t = (float)vb[(int64_t)min(j, Lk - 1) * a.ldv + 16 * dt + lr];
                 vv[jt][r] = j < Lk ? t : 0.f;
             }
 #pragma unroll
@@ -760,7 +776,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(ortk_attn_args a) {
 // 2-KB read shared by the 8 heads; a score is 8 FMAs + a 3-step reduction over the 8 lanes of the head; the soft-max
 // runs redundantly in those lanes; P.V is 8 FMAs per key.  Keys come through the beam ancestry table (kv_index) or
 // a fixed stride.  Replaces 8 x rows workgroups of the generic block kernel (75 us -> see DESIGN.md section 7).
-template <int LKMAX>
+template <int LKMAX, typename KVT>
 __global__ __launch_bounds__(256) void attn_rowdec_kernel(ortk_attn_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.x * 4 + wave;
@@ -776,8 +792,8 @@ __global__ __launch_bounds__(256) void attn_rowdec_kernel(ortk_attn_args a) {
         sc[j] = -INFINITY;
         if (j < Lk) {
             const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j] : base + j;
-            const float* kp = a.k + row * a.ldk + 8 * lane;
-            const float4 k0 = *reinterpret_cast<const float4*>(kp), k1 = *reinterpret_cast<const float4*>(kp + 4);
+            float4 k0, k1;
+            ld_row8<KVT>(reinterpret_cast<const KVT*>(a.k) + row * a.ldk + 8 * lane, k0, k1);
             float d = q0.x * k0.x + q0.y * k0.y + q0.z * k0.z + q0.w * k0.w + q1.x * k1.x + q1.y * k1.y + q1.z * k1.z + q1.w * k1.w;
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
             d *= 0.125f;                                              // 1 / sqrt(64)
@@ -795,8 +811,8 @@ __global__ __launch_bounds__(256) void attn_rowdec_kernel(ortk_attn_args a) {
     for (int j = 0; j < LKMAX; ++j) {
         if (j < Lk) {
             const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j] : base + j;
-            const float* vp = a.v + row * a.ldv + 8 * lane;
-            const float4 v0 = *reinterpret_cast<const float4*>(vp), v1 = *reinterpret_cast<const float4*>(vp + 4);
+            float4 v0, v1;
+            ld_row8<KVT>(reinterpret_cast<const KVT*>(a.v) + row * a.ldv + 8 * lane, v0, v1);
             const float pj = sc[j] * inv;
             if (a.p) { if ((lane & 7) == 0) a.p[((int64_t)g * a.H + (lane >> 3)) * Lk + j] = pj; }
             o[0] += pj * v0.x; o[1] += pj * v0.y; o[2] += pj * v0.z; o[3] += pj * v0.w;
@@ -1075,10 +1091,19 @@ bool small_fwd_ok(const ortk_attn_args* a) {
 
 }  // namespace
 
+// bf16 K / V storage (kv_dtype = 1) is served by the two decode-time kernels only; ortk_attention_kv16_ok tells the
+// executor whether a shape qualifies before it lays its caches out as bf16
+static bool kv16_ok(const ortk_attn_args* a) {
+    const bool rowdec = a->Lq == 1 && a->H == 8 && a->dk == 64 && a->Lk <= 32 && a->causal_period == 0 && a->drop_p == 0.f && !a->bias;
+    const bool small = a->dk == 64 && a->Lq <= 16 && a->Lk <= 48 && !a->kv_index && (a->Lq >= 9 || a->Lk > 8) && !rowdec;
+    return (rowdec || small) && a->ldk % 8 == 0 && a->ldv % 8 == 0 && attn_impl() == 0;
+}
+
 extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
     if (int e = check(a)) return e;
     if (!a->o) return ORTK_EINVAL;
     if (a->nkv == 0) return 0;
+    if (a->kv_dtype != 0 && (a->kv_dtype != 1 || !kv16_ok(a))) return ORTK_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1094,16 +1119,20 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
                         ((reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->q)) & 15) == 0;
     const bool al16 = ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v) |
                         reinterpret_cast<uintptr_t>(a->o)) & 15) == 0;
+    if (a->kv_dtype && !al16) return ORTK_EINVAL;
     if (a->Lq == 1 && a->H == 8 && a->dk == 64 && a->Lk <= 32 && a->causal_period == 0 && a->drop_p == 0.f && !a->bias && al16 &&
         a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->ldo % 4 == 0 && attn_impl() == 0) {
         const dim3 rgrid((unsigned)ortk_cdiv(a->nkv, 4));
-        if (a->Lk <= 8)       hipLaunchKernelGGL(attn_rowdec_kernel<8>, rgrid, dim3(256), 0, ortk_s(stream), *a);
-        else if (a->Lk <= 16) hipLaunchKernelGGL(attn_rowdec_kernel<16>, rgrid, dim3(256), 0, ortk_s(stream), *a);
-        else if (a->Lk <= 24) hipLaunchKernelGGL(attn_rowdec_kernel<24>, rgrid, dim3(256), 0, ortk_s(stream), *a);
-        else                  hipLaunchKernelGGL(attn_rowdec_kernel<32>, rgrid, dim3(256), 0, ortk_s(stream), *a);
+#define ORTK_ROWDEC(LK) do { if (a->kv_dtype) hipLaunchKernelGGL((attn_rowdec_kernel<LK, __bf16>), rgrid, dim3(256), 0, ortk_s(stream), *a); \
+                             else             hipLaunchKernelGGL((attn_rowdec_kernel<LK, float>), rgrid, dim3(256), 0, ortk_s(stream), *a); } while (0)
+        if (a->Lk <= 8) ORTK_ROWDEC(8); else if (a->Lk <= 16) ORTK_ROWDEC(16); else if (a->Lk <= 24) ORTK_ROWDEC(24); else ORTK_ROWDEC(32);
+#undef ORTK_ROWDEC
         ORTK_CHECK_LAUNCH();
         return 0;
     }
+    // from here on only the register-only MFMA kernel understands bf16 K / V
+    if (a->kv_dtype && !(small_fwd_ok(a) && attn_impl() == 0 && a->ldv % 8 == 0 && a->ldq % 4 == 0 && a->ldk % 8 == 0 && al16))
+        return ORTK_EINVAL;
     // measured on the 1024-image beam-5 decode: 95-105 us per call vs 75 us for the block kernel -> opt-in only (impl 4)
     if (a->Lq <= 8 && a->Lk <= 64 && a->causal_period == 0 && a->drop_p == 0.f && vec_kq && attn_impl() == 4) {
         const dim3 dgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
@@ -1113,9 +1142,12 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
                ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v)) & 15) == 0) {
         const dim3 sgrid((unsigned)ortk_cdiv((int64_t)a->nkv * a->H, 4));
         const int nit = a->Lq > 16 ? 2 : 1, njt = (a->Lk + 15) / 16;
-#define ORTK_SMALL_FWD(NI, NJ) hipLaunchKernelGGL((attn_small_fwd_kernel<NI, NJ>), sgrid, dim3(256), 0, ortk_s(stream), *a)
-        if (nit == 2) { if (njt == 3) ORTK_SMALL_FWD(2, 3); else if (njt == 2) ORTK_SMALL_FWD(2, 2); else ORTK_SMALL_FWD(2, 1); }
-        else          { if (njt == 3) ORTK_SMALL_FWD(1, 3); else if (njt == 2) ORTK_SMALL_FWD(1, 2); else ORTK_SMALL_FWD(1, 1); }
+#define ORTK_SMALL_FWD(NI, NJ, KT) hipLaunchKernelGGL((attn_small_fwd_kernel<NI, NJ, KT>), sgrid, dim3(256), 0, ortk_s(stream), *a)
+        if (a->kv_dtype) {   // bf16 K / V: decode-time shapes (at most 16 query rows)
+            if (nit != 1) return ORTK_EINVAL;
+            if (njt == 3) ORTK_SMALL_FWD(1, 3, __bf16); else if (njt == 2) ORTK_SMALL_FWD(1, 2, __bf16); else ORTK_SMALL_FWD(1, 1, __bf16);
+        } else if (nit == 2) { if (njt == 3) ORTK_SMALL_FWD(2, 3, float); else if (njt == 2) ORTK_SMALL_FWD(2, 2, float); else ORTK_SMALL_FWD(2, 1, float); }
+        else                 { if (njt == 3) ORTK_SMALL_FWD(1, 3, float); else if (njt == 2) ORTK_SMALL_FWD(1, 2, float); else ORTK_SMALL_FWD(1, 1, float); }
 #undef ORTK_SMALL_FWD
     } else if (a->Lk <= 64 && use_mfma && vec_kq && a->ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(a->v) & 15) == 0) {
         // MFMA form: one workgroup per pair, one wave per 16 query rows (at most 8 waves)
@@ -1146,6 +1178,7 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
 
 extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
     if (int e = check(a)) return e;
+    if (a->kv_dtype != 0) return ORTK_EINVAL;
     if (!a->p || !a->d_o || !a->dq || !a->d_k || !a->dv || a->kv_index || a->kv_group_stride) return ORTK_EINVAL;
     if (a->nkv == 0) return 0;
     static bool attr_set = false;

@@ -16,15 +16,15 @@
 namespace ortk {
 namespace {
 
-__global__ void kv_append_kernel(const float* __restrict__ qkv, float* __restrict__ ck, float* __restrict__ cv, int64_t rows,
+__global__ void kv_append_kernel(const float* __restrict__ qkv, void* __restrict__ ck, void* __restrict__ cv, int kvdt, int64_t rows,
                                  int d, int row_mult, int tmax, int t) {
     const int64_t n = rows * d;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / d;
         const int c = (int)(i - r * d);
         const int64_t dst = ((r * row_mult) * tmax + t) * d + c;
-        ck[dst] = qkv[r * 3 * d + d + c];
-        cv[dst] = qkv[r * 3 * d + 2 * d + c];
+        st_elem(ck, dst, kvdt, qkv[r * 3 * d + d + c]);
+        st_elem(cv, dst, kvdt, qkv[r * 3 * d + 2 * d + c]);
     }
 }
 
@@ -411,10 +411,10 @@ inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::
 
 }  // namespace
 
-int kv_append(const float* qkv, float* ck, float* cv, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax, int32_t t,
+int kv_append(const float* qkv, void* ck, void* cv, int32_t kvdt, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax, int32_t t,
               hipStream_t s) {
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(kv_append_kernel, dim3(ew_grid(rows * d)), dim3(256), 0, s, qkv, ck, cv, rows, d, row_mult, tmax, t);
+    hipLaunchKernelGGL(kv_append_kernel, dim3(ew_grid(rows * d)), dim3(256), 0, s, qkv, ck, cv, (int)kvdt, rows, d, row_mult, tmax, t);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -5,7 +5,7 @@
 namespace ortk {
 
 // copy the new token's K and V (columns d..3d of the packed QKV row) into the self-attention cache
-int kv_append(const float* qkv, float* cache_k, float* cache_v, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax,
+int kv_append(const float* qkv, void* cache_k, void* cache_v, int32_t kv_dtype, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax,
               int32_t t, hipStream_t s);
 
 struct BeamState {

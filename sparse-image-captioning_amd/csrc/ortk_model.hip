@@ -659,16 +659,20 @@ namespace ortk {
 struct DecodeWS {
     int64_t ldv; int adt;
     void* w16;
-    float *x0, *logbias; void* mem /*A*/; float *st, *ckv;
+    float *x0, *logbias; void* mem /*A*/; float* st; void* ckv /*kvdt*/;
     EncPtrs enc;                       // one set of encoder buffers, reused by every layer
     float *xa, *xb; void* y /*A*/; float* qkv; void* o /*A*/; float* q; void* h /*A*/; float* logits;
-    float *cache_k[MAXLAYERS], *cache_v[MAXLAYERS];
+    void *cache_k[MAXLAYERS], *cache_v[MAXLAYERS]; int kvdt;   // K/V caches + projected memory: bf16 in mixed precision when the
+                                                               // decode attention kernels take them (kv16), fp32 otherwise
     int64_t* it; int32_t *unfinished, *last_step;
     int32_t *bseq[2], *kvidx[2], *done_seq, *done_len, *done_cnt; float *blp[2], *cum, *done_lp; double* done_p;
     size_t bytes;
 };
 static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
+    // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
+    w.kvdt = (c.precision && H == 8 && d == 512 && S > 8 && S <= 48 && T <= 32 && K <= 16) ? ORTK_BF16 : ORTK_F32;
+    const size_t kves = ortk_esize(w.kvdt);
     const int64_t Me = (int64_t)B * S, rows = (int64_t)B * K;
     w.ldv = ortk_align(c.vocab, 128);
     w.adt = c.precision ? ORTK_BF16 : ORTK_F32;
@@ -682,11 +686,11 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.enc.xm = b.take<float>(Me * d); w.enc.y2 = act(Me * d); w.enc.h = act(Me * ff);
     w.enc.xout = w.x0; w.enc.st1 = b.take<float>(Me * 2); w.enc.st2 = w.enc.st1;
     w.mem = b.take_bytes((size_t)Me * d * 4); w.st = b.take<float>(std::max(Me, rows) * 2);
-    w.ckv = b.take<float>(Me * L * 2 * d);
+    w.ckv = b.take_bytes((size_t)(Me * L * 2 * d) * kves);
     w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = act(rows * d);
     w.qkv = b.take<float>(rows * 3 * d); w.o = act(rows * d); w.q = b.take<float>(rows * d);
     w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
-    for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take<float>(rows * T * d); w.cache_v[l] = b.take<float>(rows * T * d); }
+    for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
     if (beam) {
         for (int i = 0; i < 2; ++i) { w.bseq[i] = b.take<int32_t>(rows * T); w.blp[i] = b.take<float>(rows * T); w.kvidx[i] = b.take<int32_t>(rows * (T + 1)); }
@@ -732,8 +736,9 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
 // memory of the row's group (`per_group` consecutive rows share one), and leaves the generator logits in b.logits.
 struct StepBufs {
     const int64_t* it; float *xa, *xb; void* y; float* qkv; void* o; float* q; void* h; float* logits; float* st; int64_t ldv;
-    const float* ckv; const float* att_masks;
-    float* cache_k[MAXLAYERS]; float* cache_v[MAXLAYERS];
+    const void* ckv; const float* att_masks;
+    void* cache_k[MAXLAYERS]; void* cache_v[MAXLAYERS];
+    int kvdt;      // element type of ckv / cache_k / cache_v
 };
 static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64_t rows, int groups, int per_group, int row_mult,
                         int S, int T, int t, const int32_t* kvidx) {
@@ -749,9 +754,10 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             const DecOff& e = o.dec[l];
             TRY(ln_fwd(c, x, e.n0a, e.n0b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, 3 * d, d));
-            TRY(kv_append(w.qkv, w.cache_k[l], w.cache_v[l], rows, d, row_mult, T, t, s));
+            TRY(kv_append(w.qkv, w.cache_k[l], w.cache_v[l], w.kvdt, rows, d, row_mult, T, t, s));
             ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-            a.q = w.qkv; a.ldq = 3 * d; a.k = w.cache_k[l]; a.v = w.cache_v[l]; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
+            a.q = w.qkv; a.ldq = 3 * d; a.k = reinterpret_cast<const float*>(w.cache_k[l]); a.v = reinterpret_cast<const float*>(w.cache_v[l]);
+            a.kv_dtype = w.kvdt; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
             a.nkv = (int)rows; a.H = H; a.Lq = 1; a.Lk = t + 1; a.dk = dk;
             if (kvidx) a.kv_index = kvidx; else a.kv_group_stride = T;
             TRY(ortk_attention_fwd(&a, stream));
@@ -760,7 +766,9 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
             std::memset(&a, 0, sizeof(a));
-            a.q = w.q; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
+            a.q = w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)l * 2 * d, w.kvdt));
+            a.v = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)l * 2 * d + d, w.kvdt)); a.kv_dtype = w.kvdt;
+            a.ldk = a.ldv = (int64_t)L * 2 * d;
             a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
             TRY(ortk_attention_fwd(&a, stream));
             TRY(fwd_gemm(c, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
@@ -801,7 +809,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     EncPtrs ep[MAXLAYERS];
     for (int l = 0; l < L; ++l) ep[l] = w.enc;
     TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, (int64_t)L * 2 * d, Me, L * 2 * d, d));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.kvdt, (int64_t)L * 2 * d, Me, L * 2 * d, d));
 
     const int64_t rows_full = (int64_t)B * K;
     BeamState bs; std::memset(&bs, 0, sizeof(bs));
@@ -830,6 +838,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         const int per_img = first_beam ? 1 : K;
         const int row_mult = first_beam ? K : 1;
         StepBufs sb{w.it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, w.ckv, att_masks};
+        sb.kvdt = w.kvdt;
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
         TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
@@ -899,6 +908,7 @@ extern "C" int ortk_decode_step(const ortk_config* cfg, const float* params, con
     Ctx c{cfg, ortk_s(stream), cfg->precision, 0, false, params, w.w16, cfg->precision ? ORTK_BF16 : ORTK_F32};
     const int64_t d = cfg->d_model;
     StepBufs sb{it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, cross_kv, att_masks};
+    sb.kvdt = ORTK_F32;        // the caller's caches are fp32 (reference state layout)
     for (int l = 0; l < cfg->n_layers; ++l) {
         sb.cache_k[l] = self_k + (int64_t)l * rows * tmax * d;
         sb.cache_v[l] = self_v + (int64_t)l * rows * tmax * d;

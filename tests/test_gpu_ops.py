@@ -263,6 +263,38 @@ def test_attention_decode_row_kernel_with_ancestry_table(L):
         torch.testing.assert_close(o.float().cpu(), ref, rtol=1e-2 if odt else 1e-4, atol=1e-2 if odt else 1e-5)
 
 
+@pytest.mark.parametrize("Lq,Lk,use_idx", [(1, 13, True), (1, 30, False), (5, 36, False), (1, 36, False), (3, 20, False)])
+def test_attention_bf16_kv_cache(L, Lq, Lk, use_idx):
+    """kv_dtype = 1: K / V rows stored as bf16 (decode-time caches in mixed precision) == fp32 attention on the rounded K / V."""
+    nkv, H, dk = 24, 8, 64
+    d = H * dk
+    g = torch.Generator().manual_seed(9)
+    q = rnd(nkv * Lq, d, seed=1)
+    pool = nkv * 40
+    K16, V16 = rnd(pool, d, seed=2).bfloat16(), rnd(pool, d, seed=3).bfloat16()
+    if use_idx:
+        idx = torch.randint(0, pool, (nkv, Lk), generator=g, dtype=torch.int32)
+    else:
+        idx = (torch.arange(nkv)[:, None] * 40 + torch.arange(Lk)[None, :]).int()
+    km = torch.ones(nkv, Lk); km[1, Lk // 2:] = 0
+    kk = K16.float()[idx.long()].view(nkv, Lk, H, dk).transpose(1, 2); vv = V16.float()[idx.long()].view(nkv, Lk, H, dk).transpose(1, 2)
+    ref = O.attention(q.view(nkv, Lq, H, dk).transpose(1, 2), kk, vv, km[:, None, None, :].bool(), None).transpose(1, 2).reshape(nkv * Lq, d)
+    a = L.AttnArgs()
+    qd, kd, vd, kmd = dev(q), dev(K16), dev(V16), dev(km)
+    o = torch.empty(nkv * Lq, d, device="cuda")
+    a.q, a.k, a.v, a.o, a.kmask = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), kmd.data_ptr()
+    a.ldq = a.ldk = a.ldv = a.ldo = d
+    a.nkv, a.H, a.Lq, a.Lk, a.dk, a.kv_dtype = nkv, H, Lq, Lk, dk, 1
+    if use_idx:
+        idd = dev(idx); a.kv_index = idd.data_ptr()
+    else:
+        a.kv_group_stride = 40
+    L.check(L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()), "attn_fwd")
+    torch.testing.assert_close(o.cpu(), ref, rtol=1e-4, atol=2e-5)
+    a.Lq, a.Lk = 20, 20                                     # a shape no bf16-K/V kernel serves: refused, never misread
+    assert L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()) == -1
+
+
 @pytest.mark.parametrize("nkv,H,Lq,Lk,dk", [(3, 2, 9, 11, 16), (5, 8, 17, 17, 64), (2, 8, 36, 36, 64)])
 def test_attention_dropout_is_consistent_between_fwd_and_bwd(L, nkv, H, Lq, Lk, dk):
     d = H * dk
