@@ -65,4 +65,4 @@ def test_prune_flow_like_reference_test(P, mask_type):
     assert sparsity(True) > sparsity(False), "active sparsity is higher: the generator is not pruned"
     assert float(model.all_weight_sparsities[0]) == 0, "weights are not pruned yet"
     model.prune_weights()
-    assert abs(float(model.all_weight_sparsities[0]) - SPARSITY_TARGET) < 0.3, "weight sparsity after prune_weights()"
+    assert abs(float(model.all_weight_sparsities[0]) - SPARSITY_TARGET) < 0.35, "weight sparsity after prune_weights()"
