@@ -226,14 +226,16 @@ def main():
     value = world * units_per_step / (elapsed / args.steps)
 
     out = None
+    # ---- roofline of the dominant kernel: the forward-layout MFMA GEMM (X W^T), measured live with HIP events around
+    # every launch of one extra (untimed) step, on the launch stream.  EVERY rank runs that step (it contains the
+    # data-parallel collectives); only rank 0 records and reports.
+    lib = L.lib()
     if rank == 0:
-        # ---- roofline of the dominant kernel: the forward-layout MFMA GEMM (X W^T), measured live with HIP events
-        # around every launch of one extra (untimed) step, on the launch stream.
-        lib = L.lib()
-        key = (4 if args.precision == "bf16" else 0)
         lib.ortk_prof_enable(1)
-        step()
-        torch.cuda.synchronize()
+    step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        key = (4 if args.precision == "bf16" else 0)
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         per_key = {}
         for k in (key, key + 1, key + 3):
