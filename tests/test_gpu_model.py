@@ -390,6 +390,18 @@ def test_bf16_path_tolerance_and_fused_loss(P, golden, full_state):
     tr16 = NativeTrainer(m16, noamopt_warmup=10)
     loss16 = tr16.xe_step(b, train=False)
     assert abs(loss16.item() - float(g2["xe_loss"])) < 2e-2, loss16.item()
+    # decode in mixed precision (bf16 weights, bf16 K/V caches): log-probs of the reference's greedy tokens stay within
+    # bf16 noise of the fp32 golden, and the first tokens agree
+    m16r = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision="bf16")
+    seq, lp = m16r(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 1}, mode="sample")
+    gseq = torch.from_numpy(g2["decode_b1/seq"]).cuda()
+    assert (seq[:, 0, 0] == gseq[:, 0, 0]).float().mean().item() >= 0.75
+    same = (seq == gseq).all(-1)
+    if same.any():
+        glp = torch.from_numpy(g2["decode_b1/logprobs"]).cuda()
+        assert (lp[same] - glp[same]).abs().max().item() < 0.1
+    seq5, _ = m16r(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 5}, mode="sample")
+    assert seq5.shape[1] == 5 and int((seq5[:, 0] != 0).sum()) > 0
 
 
 def test_large_batch_properties(P, full_state):
