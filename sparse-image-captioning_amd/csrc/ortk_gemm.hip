@@ -818,6 +818,8 @@ bool g_prof_on = false;
 std::vector<ProfRec>* g_prof = nullptr;
 }  // namespace
 
+namespace ortk { bool ortk_prof_active() { return g_prof_on; } }
+
 extern "C" int ortk_prof_enable(int32_t on) {
     if (!g_prof) g_prof = new std::vector<ProfRec>();
     for (auto& r : *g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

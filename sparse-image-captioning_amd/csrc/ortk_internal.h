@@ -4,6 +4,9 @@
 
 namespace ortk {
 
+// true while bench.py's per-launch GEMM timing is on (the executor then keeps every GEMM on the caller's stream)
+bool ortk_prof_active();
+
 // copy the new token's K and V (columns d..3d of the packed QKV row) into the self-attention cache
 int kv_append(const float* qkv, void* cache_k, void* cache_v, int32_t kv_dtype, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax,
               int32_t t, hipStream_t s);
