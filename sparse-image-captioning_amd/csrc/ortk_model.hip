@@ -205,26 +205,27 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
 // Side stream for the weight-gradient GEMMs of the backward.  dW = dY^T X and dX = dY W of a projection both only READ dY,
 // nothing reads dW before the optimizer, and each of them alone leaves a partly filled last round of workgroups (680
 // tiles on 512 slots, 384 split-K workgroups, ...): the wgrad runs on this stream beside the dgrad on the caller's stream
-// (fork: the side stream waits for dY; join: the caller's stream waits for the wgrad before anything may overwrite dY).
-// MEASURED (XE step, B = 256): 17.31 ms with the side stream vs 17.03 ms without — the 3 cross-stream synchronisations per
-// projection cost more than the tail filling gains, so it is OFF unless ORTK_SIDE_STREAM=1 (kept as an experiment; the
-// 88 GPU tests pass either way).
+// (fork: the side stream waits for the event "dY produced"; lazy join: the caller's stream waits for a wgrad only right
+// before a kernel that OVERWRITES the buffer this wgrad reads, so the side stream may lag by a few kernels).  Mixed
+// precision only (there every dY is one of a few bf16 temporaries); set ORTK_SIDE_STREAM=0 to keep everything on the
+// caller's stream.  Free-running microbenchmark (scratch/gemm_concurrent.py): dgrad + wgrad of w1 172 -> 128 us, of
+// qkv 124 -> 87 us, of the 512 x 512 projections no change.
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t ev[16];
+    hipEvent_t ev[64];
     int next = 0;
     bool ok = false, tried = false;
     bool init() {
         if (tried) return ok;
         tried = true;
         const char* e = getenv("ORTK_SIDE_STREAM");
-        if (!e || atoi(e) == 0) return false;
+        if (e && atoi(e) == 0) return false;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
         for (auto& x : ev) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
         return true;
     }
-    hipEvent_t take() { hipEvent_t e = ev[next]; next = (next + 1) & 15; return e; }
+    hipEvent_t take() { hipEvent_t e = ev[next]; next = (next + 1) & 63; return e; }
 };
 static SideStream g_side;
 
@@ -235,9 +236,24 @@ struct Ctx {
     int adt;                 // dtype of (A) buffers
     const ortk_csr* sp = nullptr; int nsp = 0;   // optional CSR images of pruned weight blocks (forward-only paths)
     bool use_side = false;                       // backward only: weight-gradient GEMMs on g_side
-    mutable hipEvent_t pending = nullptr;        // completion of the last forked wgrad, not yet joined
-    int join() const {                           // the caller's stream waits for the forked wgrad (before dY may change)
-        if (pending) { if (hipStreamWaitEvent(s, pending, 0) != hipSuccess) return ORTK_EINVAL; pending = nullptr; }
+    struct Pend { const void* buf; hipEvent_t done; };
+    mutable Pend pend[8] = {};                   // buffers a forked, not yet joined wgrad reads
+    mutable hipEvent_t last_done = nullptr;
+    void reads(const void* buf, hipEvent_t done) const {
+        for (auto& p : pend) if (p.buf == buf || p.buf == nullptr) { p.buf = buf; p.done = done; last_done = done; return; }
+        pend[0] = Pend{buf, done}; last_done = done;     // table full (never with this path's 5 temporaries): still correct,
+    }                                                    // join_all() below covers whatever fell out
+    int before_write(const void* buf) const {            // the caller's stream is about to overwrite `buf`
+        for (auto& p : pend)
+            if (p.buf == buf) {
+                if (hipStreamWaitEvent(s, p.done, 0) != hipSuccess) return ORTK_EINVAL;
+                p.buf = nullptr;
+            }
+        return 0;
+    }
+    int join() const {                                   // everything forked so far (the side stream runs in order)
+        if (last_done) { if (hipStreamWaitEvent(s, last_done, 0) != hipSuccess) return ORTK_EINVAL; last_done = nullptr; }
+        for (auto& p : pend) p.buf = nullptr;
         return 0;
     }
     const ortk_csr* csr(int64_t off) const {
@@ -279,8 +295,8 @@ static int dgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, int6
     a.A = dY; a.a_dtype = dydt; a.lda = lddy; a.B = c.W(woff); a.b_dtype = c.wdt(); a.ldb = Kin; a.transB = 1;
     a.C = dX; a.c_dtype = dxdt; a.ldc = lddx; a.M = (int)M; a.N = Kin; a.K = Nout;
     a.gate = gate; a.gate_dtype = gdt; a.ldg = ldg; a.gate_scale = gate_scale; a.precision = c.prec;
-    TRY(ortk_gemm(&a, (ortk_stream)c.s));
-    return c.join();      // the wgrad of the same dY (forked just before) must be done before dY's buffer is reused
+    TRY(c.before_write(dX));
+    return ortk_gemm(&a, (ortk_stream)c.s);
 }
 // dW += dY^T X ; db += colsum(dY)
 static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, const void* X, int xdt, int64_t ldx, float* dW, float* db,
@@ -297,13 +313,12 @@ static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, cons
     a.splitk = (int)std::max<int64_t>(1, std::min(sk, max_sk));
     if (c.prec) a.colsum = db;             // bias gradient fused into the wgrad kernel (bf16-MFMA path)
     if (c.use_side) {
-        TRY(c.join());                                     // at most one forked wgrad at a time
         hipEvent_t ready = g_side.take(), done = g_side.take();
         if (hipEventRecord(ready, c.s) != hipSuccess || hipStreamWaitEvent(g_side.s, ready, 0) != hipSuccess) return ORTK_EINVAL;
         TRY(ortk_gemm(&a, (ortk_stream)g_side.s));
         if (db && !c.prec) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)g_side.s));
         if (hipEventRecord(done, g_side.s) != hipSuccess) return ORTK_EINVAL;
-        c.pending = done;
+        c.reads(dY, done);
         return 0;
     }
     TRY(ortk_gemm(&a, (ortk_stream)c.s));
@@ -318,6 +333,7 @@ static int ln_fwd(const Ctx& c, const float* x, int64_t a, int64_t b, void* y, i
 static int ln_bwd(const Ctx& c, const float* dy, const float* x, float* G, int64_t a, int64_t b, const float* st,
                   const float* dres, float* dx, int64_t rows, void* dz = nullptr, int next_op = -1) {
     const bool fuse = dz && next_op >= 0 && (c.p_drop() > 0.f || c.adt == ORTK_BF16);
+    if (fuse) TRY(c.before_write(dz));
     return ortk_layernorm_bwd_drop(dy, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, fuse ? dz : nullptr,
                                    c.adt, c.p_drop(), fuse ? c.sub((uint32_t)next_op) : 0, (ortk_stream)c.s);
 }
@@ -562,7 +578,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     // (train, seed) must match the forward's; the bf16 weight copy made by the forward is still in the workspace
     Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
-    c.use_side = !ortk_prof_active() && g_side.init();
+    c.use_side = c.adt == ORTK_BF16 && !ortk_prof_active() && g_side.init();
     float* G = grads;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
@@ -599,6 +615,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.d_o = w.gy; a.lddo = d; a.dq = w.gt; a.lddq = d; a.dqkv_dtype = A;
         a.d_k = off_elems(w.gkv, (int64_t)l * 2 * d, A); a.dv = off_elems(w.gkv, (int64_t)l * 2 * d + d, A);
         a.lddk = a.lddv = (int64_t)L * 2 * d;
+        TRY(c.before_write(w.gt));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gt, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
         TRY(dgrad_gemm(c, w.gt, A, d, e.cqw, w.gy, ORTK_F32, d, Md, d, d));
@@ -612,6 +629,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, d, A); a.dv = off_elems(w.gqkv, 2 * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+        TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
         TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, 3 * d, d));
@@ -647,6 +665,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, d, A); a.dv = off_elems(w.gqkv, 2 * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         a.dscore = w.dscore + (int64_t)l * B * H * S * S;
+        TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
         TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, 3 * d, d));
@@ -660,6 +679,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, stream));
     }
     // att_embed: x0 = dropout(relu(.) * mask)  ->  d(pre-activation) = dx * [x0 > 0] / (1 - p_src)
+    TRY(c.before_write(w.gt));
     TRY(ortk_gate_apply(dx, w.x0, w.gt, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));
     TRY(wgrad_gemm(c, w.gt, A, d, bt->att_feats, ORTK_F32, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
     return c.join();       // every gradient is final in the caller's stream order
