@@ -153,7 +153,7 @@ struct TrainWS {
     float *dx0, *keymask, *ckv; void* dec_out /*A*/; float *st_out, *logits; void* dlogits /*A; aliases logits in fp32*/;
     DecBuf dec[MAXLAYERS];
     // backward temporaries
-    float *ga, *gb, *gy; void *gt /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
+    float *ga, *gb, *gy; void *gt /*A*/, *gt2 /*A*/, *gt3 /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
     size_t bytes;
 };
 
@@ -194,7 +194,7 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     w.logits = b.take<float>(Md * w.ldv);
     w.dlogits = c.precision ? act(Md * w.ldv) : (void*)w.logits;
     w.ga = b.take<float>(Mx * d); w.gb = b.take<float>(Mx * d); w.gy = b.take<float>(Mx * d);
-    w.gt = act(Mx * d); w.gqkv = act(Mx * 3 * d); w.gh = act(Mx * ff); w.gkv = act(Me * L * 2 * d);
+    w.gt = act(Mx * d); w.gt2 = act(Mx * d); w.gt3 = act(Mx * d); w.gqkv = act(Mx * 3 * d); w.gh = act(Mx * ff); w.gkv = act(Me * L * 2 * d);
     w.scalar = b.take<float>(64);
     w.bytes = (b.off + 255) & ~(size_t)255;
 }
@@ -586,6 +586,12 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     const float inv_keep = c.p_drop() > 0.f ? 1.f / (1.f - c.p_drop()) : 1.f;
 
     float* dx = w.ga; float* dx2 = w.gb;
+    // the (rows, d) bf16 gradient temporary rotates over three buffers: its producers (ln_bwd's masked copy, the cross-
+    // attention dQ, the att_embed gate) never have to wait for the side-stream wgrad that still reads the previous one
+    void* gt_pool[3] = {w.gt, w.gt2, w.gt3};
+    int gt_i = 0;
+    void* gt_cur = w.gt;
+    auto gt_new = [&]() { gt_i = (gt_i + 1) % 3; gt_cur = gt_pool[gt_i]; return gt_cur; };
     if (phase != 2) {
     // ---- decoder half: generator, decoder stack, token embedding, cross-attention K/V projections; leaves the gradient
     // of the encoder memory in w.gy.  Every gradient at arena offsets >= ortk_arena_decoder_offset is final afterwards.
@@ -593,35 +599,35 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     const int Vp = (int)w.ldv;
     TRY(wgrad_gemm(c, w.dlogits, A, w.ldv, w.dec_out, A, d, G + o.gen_w, G + o.gen_b, Md, Vp, d));
     TRY(dgrad_gemm(c, w.dlogits, A, w.ldv, o.gen_w, w.gy, ORTK_F32, d, Md, Vp, d));
-    TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md, w.gt, dop(L - 1, 5)));
+    TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md, gt_new(), dop(L - 1, 5)));
     for (int l = L - 1; l >= 0; --l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         const float* xin = l == 0 ? w.dx0 : w.dec[l - 1].xout;
         const void* dt; int dtt;
         // feed-forward sublayer
-        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 5), &dt, &dtt, true));
+        TRY(drop_bwd(c, dx, gt_cur, Md * d, dop(l, 5), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Md, d, ff));
         TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Md, d, ff, b.h, A, ff, inv_keep));
         TRY(wgrad_gemm(c, w.gh, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
         TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Md, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, Md, w.gt, dop(l, 3)));
+        TRY(ln_bwd(c, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, Md, gt_new(), dop(l, 3)));
         // cross-attention sublayer
-        TRY(drop_bwd(c, dx2, w.gt, Md * d, dop(l, 3), &dt, &dtt, true));
+        TRY(drop_bwd(c, dx2, gt_cur, Md * d, dop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
         a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
         a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
-        a.d_o = w.gy; a.lddo = d; a.dq = w.gt; a.lddq = d; a.dqkv_dtype = A;
+        a.d_o = w.gy; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
         a.d_k = off_elems(w.gkv, (int64_t)l * 2 * d, A); a.dv = off_elems(w.gkv, (int64_t)l * 2 * d + d, A);
         a.lddk = a.lddv = (int64_t)L * 2 * d;
-        TRY(c.before_write(w.gt));
+        TRY(c.before_write(gt_cur));
         TRY(ortk_attention_bwd(&a, stream));
-        TRY(wgrad_gemm(c, w.gt, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
-        TRY(dgrad_gemm(c, w.gt, A, d, e.cqw, w.gy, ORTK_F32, d, Md, d, d));
-        TRY(ln_bwd(c, w.gy, b.xm1, G, e.n1a, e.n1b, b.st2, dx2, dx, Md, w.gt, dop(l, 1)));
+        TRY(wgrad_gemm(c, gt_cur, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
+        TRY(dgrad_gemm(c, gt_cur, A, d, e.cqw, w.gy, ORTK_F32, d, Md, d, d));
+        TRY(ln_bwd(c, w.gy, b.xm1, G, e.n1a, e.n1b, b.st2, dx2, dx, Md, gt_new(), dop(l, 1)));
         // self-attention sublayer
-        TRY(drop_bwd(c, dx, w.gt, Md * d, dop(l, 1), &dt, &dtt, true));
+        TRY(drop_bwd(c, dx, gt_cur, Md * d, dop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Md, d, d));
         std::memset(&a, 0, sizeof(a));
@@ -633,7 +639,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
         TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, 3 * d, d));
-        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md, w.gt, l > 0 ? (int)dop(l - 1, 5) : -1));
+        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md, gt_new(), l > 0 ? (int)dop(l - 1, 5) : -1));
         std::swap(dx, dx2);
     }
     TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), stream));
@@ -645,18 +651,18 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     if (phase == 1) return 0;
     // ---- encoder half (reads the memory gradient left in w.gy)
     dx = w.ga; dx2 = w.gb;
-    TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me, w.gt, eop(L - 1, 3)));
+    TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me, gt_new(), eop(L - 1, 3)));
     for (int l = L - 1; l >= 0; --l) {
         const EncOff& e = o.enc[l]; const EncBuf& b = w.enc[l];
         const float* xin = l == 0 ? w.x0 : w.enc[l - 1].xout;
         const void* dt; int dtt;
-        TRY(drop_bwd(c, dx, w.gt, Me * d, eop(l, 3), &dt, &dtt, true));
+        TRY(drop_bwd(c, dx, gt_cur, Me * d, eop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Me, d, ff));
         TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Me, d, ff, b.h, A, ff, inv_keep));
         TRY(wgrad_gemm(c, w.gh, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
         TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Me, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me, w.gt, eop(l, 1)));
-        TRY(drop_bwd(c, dx2, w.gt, Me * d, eop(l, 1), &dt, &dtt, true));
+        TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me, gt_new(), eop(l, 1)));
+        TRY(drop_bwd(c, dx2, gt_cur, Me * d, eop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Me, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
@@ -669,7 +675,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
         TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, 3 * d, d));
-        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, w.gt, l > 0 ? (int)eop(l - 1, 3) : -1));
+        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, gt_new(), l > 0 ? (int)eop(l - 1, 3) : -1));
     }
     // geometry bias weights
     {
@@ -679,9 +685,9 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, stream));
     }
     // att_embed: x0 = dropout(relu(.) * mask)  ->  d(pre-activation) = dx * [x0 > 0] / (1 - p_src)
-    TRY(c.before_write(w.gt));
-    TRY(ortk_gate_apply(dx, w.x0, w.gt, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));
-    TRY(wgrad_gemm(c, w.gt, A, d, bt->att_feats, ORTK_F32, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
+    TRY(c.before_write(gt_new()));
+    TRY(ortk_gate_apply(dx, w.x0, gt_cur, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));
+    TRY(wgrad_gemm(c, gt_cur, A, d, bt->att_feats, ORTK_F32, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
     return c.join();       // every gradient is final in the caller's stream order
 }
 
