@@ -135,6 +135,9 @@ typedef struct ortk_decode_opts {
      * utils/training.py:220-237): K = num_random_sample + 1, row 0 of each image is the arg-max decode, rows 1.. are
      * the samples — token for token what two separate calls return, at half the launches. */
     int32_t with_greedy;
+    /* multinomial only: index of this call's first output row in the full batch, so that a host that decodes a batch
+     * in several chunks (e.g. one per stream) draws the same tokens as one call would (the Gumbel hash is keyed by row) */
+    int64_t sample_row_offset;
 } ortk_decode_opts;
 
 size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, const ortk_decode_opts* o);

@@ -43,7 +43,7 @@ class Csr(C.Structure):
 class DecodeOpts(C.Structure):
     _fields_ = [("beam_size", C.c_int32), ("num_random_sample", C.c_int32), ("temperature", C.c_float),
                 ("decoding_constraint", C.c_int32), ("length_penalty", C.c_int32), ("length_alpha", C.c_double),
-                ("seed", C.c_uint64), ("sparse", C.POINTER(Csr)), ("n_sparse", C.c_int32), ("with_greedy", C.c_int32)]
+                ("seed", C.c_uint64), ("sparse", C.POINTER(Csr)), ("n_sparse", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64)]
 
 
 class GemmArgs(C.Structure):

@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void sample_step_kernel(SampleState st, const 
     const bool is_greedy = st.greedy_stride > 0 && row % st.greedy_stride == 0;
     const bool samp = st.sample && !is_greedy;
     // the hash is keyed by the row index the sample would have in a samples-only call
-    const int hrow = st.greedy_stride > 0 ? row - row / st.greedy_stride - 1 : row;
+    const int64_t grow = st.row_offset + row;
+    const int hrow = (int)(st.greedy_stride > 0 ? grow - grow / st.greedy_stride - 1 : grow);
     float mv = -INFINITY; int mi = 0x7FFFFFFF;
     for (int v = tid; v < st.V; v += 256) {
         if (v == prev) continue;

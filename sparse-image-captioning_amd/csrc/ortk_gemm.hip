@@ -17,6 +17,7 @@
 // Workgroup ids are remapped so that the blocks resident on one XCD (ids b, b+8, ...) walk CONSECUTIVE tiles
 // (n fastest): they share the A panel in that XCD's L2 instead of fetching it 8 times.
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 #include "ortk_common.h"
 
@@ -815,6 +816,7 @@ template <bool TA, bool TB> gemm16_fn pick16(int adt, int bdt, bool fast) {
 namespace {
 struct ProfRec { hipEvent_t a, b; int key; double flops; };
 bool g_prof_on = false;
+std::mutex g_prof_mu;          // decode chunks may be driven by several host threads
 std::vector<ProfRec>* g_prof = nullptr;
 }  // namespace
 
@@ -930,7 +932,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             }
             else if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, p.M / 256, p.N / 256, kchunk);
             else          hipLaunchKernelGGL(gf, grid, block, lds, s, p, tilesM, tilesN, kchunk);
-            if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof->push_back(rec); }
+            if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
             ORTK_CHECK_LAUNCH();
             return 0;
         }
@@ -947,7 +949,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         }
         hipLaunchKernelGGL(fn, grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk);
     }
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof->push_back(rec); }
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -46,6 +46,7 @@ struct SampleState {
     float temperature;
     uint64_t seed;
     int32_t greedy_stride;    // K > 0: rows with row % K == 0 decode greedily (last_step[1]); the others sample (last_step[0])
+    int64_t row_offset;       // index of row 0 in the full batch (chunked decoding): the Gumbel hash is keyed by the global row
 };
 int sample_init(const SampleState& st, int32_t bos, hipStream_t s);
 int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s);

@@ -901,6 +901,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         ss.decoding_constraint = op->decoding_constraint; ss.sample = op->num_random_sample > 0; ss.temperature = op->temperature;
         ss.seed = op->seed;
         ss.greedy_stride = (op->num_random_sample > 0 && op->with_greedy) ? K : 0;
+        ss.row_offset = op->sample_row_offset;
         TRY(sample_init(ss, cfg->bos_id, s));
     }
     for (int t = 0; t < T; ++t) {

@@ -164,6 +164,30 @@ def test_two_phase_backward_and_overlapped_trainer_step(P, golden):
     assert torch.equal(g[off:], dec_half) and float(g[:off].abs().sum()) > 0.0
 
 
+def test_chunked_multi_stream_decode_equals_single_call(P, full_state):
+    """`decode_streams`: the batch decoded as chunks on several streams / host threads returns exactly what one call returns
+    (beam search: always; sampling: same tokens thanks to the global row offset of the Gumbel hash)."""
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state)
+    g = torch.Generator().manual_seed(11)
+    B, S = 37, 36
+    feats = torch.randn(B, S, 2048, generator=g).abs().cuda()
+    xy = torch.rand(B, S, 2, generator=g) * 0.6
+    boxes = torch.cat([xy, xy + 0.05 + torch.rand(B, S, 2, generator=g) * 0.3], 2).cuda()
+    masks = torch.ones(B, S).cuda(); masks[3, 30:] = 0
+    kw = dict(att_feats=feats, boxes=boxes, att_masks=masks, mode="sample")
+    with torch.no_grad():
+        for opt in ({"beam_size": 5}, {"beam_size": 1}, {"num_random_sample": 3, "beam_size": 0, "seed": 5, "with_greedy": True}):
+            s1, l1 = m(opt=dict(opt, decode_streams=1), **kw)
+            for n in (2, 3):
+                s2, l2 = m(opt=dict(opt, decode_streams=n), **kw)
+                assert torch.equal(s1, s2), (opt, n)
+                if opt.get("beam_size", 0) > 1:
+                    assert torch.equal(l1, l2)
+                else:       # log-probs after a row's EOS are zeroed from the chunk's (not the batch's) last step on
+                    live = s1 != 0
+                    assert torch.equal(l1[live], l2[live])
+
+
 def test_combined_greedy_and_samples_decode_equals_two_calls(P, g1):
     """`with_greedy`: one decode pass returns [greedy, sample_1..ns] per image == the two calls of the SCST step
     (utils/training.py:220-237): same tokens, same log-probs, same zero padding after each call's own last step."""
