@@ -251,6 +251,22 @@ struct Ctx {
             }
         return 0;
     }
+    // generic fork / mark / wait for other independent work (forward: geometry bias, cross-attention K/V projection;
+    // backward: token-embedding and geometry-bias gradients)
+    int fork() const {                                   // the side stream waits for everything queued on `s` so far
+        hipEvent_t e = g_side.take();
+        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(g_side.s, e, 0) != hipSuccess) return ORTK_EINVAL;
+        return 0;
+    }
+    int side_mark(hipEvent_t* out) const {               // completion point of the work queued on the side stream so far
+        hipEvent_t e = g_side.take();
+        if (hipEventRecord(e, g_side.s) != hipSuccess) return ORTK_EINVAL;
+        last_done = e;
+        if (out) *out = e;
+        return 0;
+    }
+    int wait_ev(hipEvent_t e) const { return (e && hipStreamWaitEvent(s, e, 0) != hipSuccess) ? ORTK_EINVAL : 0; }
+    Ctx on_side() const { Ctx t = *this; t.s = g_side.s; t.use_side = false; return t; }
     int join() const {                                   // everything forked so far (the side stream runs in order)
         if (last_done) { if (hipStreamWaitEvent(s, last_done, 0) != hipSuccess) return ORTK_EINVAL; last_done = nullptr; }
         for (auto& p : pend) p.buf = nullptr;
@@ -381,7 +397,15 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
                  nullptr, 0, masks));
     const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS];
     for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; }
-    TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s));
+    // the geometry bias only depends on the boxes and WG: beside att_embed / the first LayerNorm and QKV projection
+    hipEvent_t box_done = nullptr;
+    if (c.use_side) {
+        TRY(c.fork());
+        TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)g_side.s));
+        TRY(c.side_mark(&box_done));
+    } else {
+        TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s));
+    }
     const float* x = x0;
     for (int l = 0; l < L; ++l) {
         const EncOff& e = o.enc[l]; const EncPtrs& b = bufs[l];
@@ -391,6 +415,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
         a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
         a.kmask = masks; a.bias = logbias + (int64_t)l * B * H * S * S; a.p = b.P;
         a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
+        if (l == 0) TRY(c.wait_ev(box_done));
         TRY(ortk_attention_fwd(&a, (ortk_stream)c.s));
         TRY(fwd_gemm(c, b.o, A, d, e.wo, P + e.bo, b.xm, ORTK_F32, d, Me, d, d, false, c.p_drop(), c.sub(eop(l, 1)), x, d));
         TRY(ln_fwd(c, b.xm, e.n1a, e.n1b, b.y2, A, b.st2, Me));
@@ -493,25 +518,42 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const int64_t Me = w.Me, Md = w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
+    c.use_side = c.adt == ORTK_BF16 && !ortk_prof_active() && g_side.init();
+    // Self-attention sublayer (and the cross-attention query projection) of decoder layer l, on context `cx`'s stream.
+    auto self_part = [&](const Ctx& cx, int l, const float* x) -> int {
+        const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
+        TRY(ln_fwd(cx, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
+        TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Md, 3 * d, d));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
+        a.kmask = w.keymask; a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.causal_period = T;
+        a.drop_p = cx.p_drop(); a.drop_seed = cx.sub(dop(l, 0));
+        TRY(ortk_attention_fwd(&a, (ortk_stream)cx.s));
+        TRY(fwd_gemm(cx, b.o1, A, d, e.wo, P + e.bo, b.xm1, ORTK_F32, d, Md, d, d, false, cx.p_drop(), cx.sub(dop(l, 1)), x, d));
+        TRY(ln_fwd(cx, b.xm1, e.n1a, e.n1b, b.y2, A, b.st2, Md));
+        TRY(fwd_gemm(cx, b.y2, A, d, e.cqw, P + e.cqb, b.qc, ORTK_F32, d, Md, d, d));
+        return 0;
+    };
+    // The token side of decoder layer 0 (embedding, self-attention sublayer, cross-attention query) does not depend on the
+    // encoder: with the side stream it runs beside the encoder stack (after the geometry bias, which the encoder needs first).
+    hipEvent_t prefix_done = nullptr;
+    if (c.use_side) {
+        TRY(c.fork());                     // the side stream sees the bf16 weight copy
+    }
     TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem));
+    {
+        const Ctx cx = c.use_side ? c.on_side() : c;
+        TRY(ortk_embed_fwd(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, R, T, 0, d, cfg->pad_id, c.p_drop(),
+                           c.sub(OP_EMB), (ortk_stream)cx.s));
+        if (c.use_side) { TRY(self_part(cx, 0, w.dx0)); TRY(c.side_mark(&prefix_done)); }
+    }
     // decoder
-    TRY(ortk_embed_fwd(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, R, T, 0, d, cfg->pad_id, c.p_drop(),
-                       c.sub(OP_EMB), stream));
     TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, (int64_t)L * 2 * d, Me, L * 2 * d, d));
     const float* x = w.dx0;
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
-        TRY(ln_fwd(c, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
-        TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Md, 3 * d, d));
+        if (l == 0 && c.use_side) TRY(c.wait_ev(prefix_done)); else TRY(self_part(c, l, x));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
-        a.kmask = w.keymask; a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.causal_period = T;
-        a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
-        TRY(ortk_attention_fwd(&a, stream));
-        TRY(fwd_gemm(c, b.o1, A, d, e.wo, P + e.bo, b.xm1, ORTK_F32, d, Md, d, d, false, c.p_drop(), c.sub(dop(l, 1)), x, d));
-        TRY(ln_fwd(c, b.xm1, e.n1a, e.n1b, b.y2, A, b.st2, Md));
-        TRY(fwd_gemm(c, b.y2, A, d, e.cqw, P + e.cqb, b.qc, ORTK_F32, d, Md, d, d));
-        std::memset(&a, 0, sizeof(a));
         a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
         a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
@@ -642,7 +684,16 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md, gt_new(), l > 0 ? (int)dop(l - 1, 5) : -1));
         std::swap(dx, dx2);
     }
-    TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), stream));
+    // the embedding gradient (atomics into the 5 M-element table) only feeds the optimizer: beside the K/V projection GEMMs
+    if (c.use_side) {
+        TRY(c.fork());
+        TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), (ortk_stream)g_side.s));
+        hipEvent_t e_done = nullptr;
+        TRY(c.side_mark(&e_done));
+        c.reads(dx, e_done);               // dx (w.ga / w.gb) is rewritten by the encoder half
+    } else {
+        TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), stream));
+    }
     // cross-attention K/V projections of all layers, and the gradient of the encoder memory
     TRY(wgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, L * 2 * d, d));
     TRY(dgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, o.ckv_w, w.gy, ORTK_F32, d, Me, L * 2 * d, d));
@@ -682,12 +733,24 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         const float* P = params;
         const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS]; float* dwg[MAXLAYERS]; float* dbg[MAXLAYERS];
         for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; dwg[l] = G + o.enc[l].wg; dbg[l] = G + o.enc[l].bg; }
-        TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, stream));
+        // only feeds the optimizer: beside the att_embed gradient
+        if (c.use_side) {
+            TRY(c.fork());
+            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, (ortk_stream)g_side.s));
+            TRY(c.side_mark(nullptr));
+        } else {
+            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, stream));
+        }
     }
     // att_embed: x0 = dropout(relu(.) * mask)  ->  d(pre-activation) = dx * [x0 > 0] / (1 - p_src)
     TRY(c.before_write(gt_new()));
     TRY(ortk_gate_apply(dx, w.x0, gt_cur, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));
-    TRY(wgrad_gemm(c, gt_cur, A, d, bt->att_feats, ORTK_F32, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
+    {   // the last weight gradient stays on the caller's stream: the side stream is busy with the geometry-bias gradient
+        const bool us = c.use_side;
+        c.use_side = false;
+        TRY(wgrad_gemm(c, gt_cur, A, d, bt->att_feats, ORTK_F32, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
+        c.use_side = us;
+    }
     return c.join();       // every gradient is final in the caller's stream order
 }
 
