@@ -240,6 +240,10 @@ typedef struct ortk_attn_args {
     int32_t o_dtype, dqkv_dtype;    /* storage type of O (fwd) and of dQ/dK/dV (bwd): 0 = fp32, 1 = bf16 */
     int32_t kv_dtype;               /* forward only: 1 = k / v point to bf16 rows (ldk / ldv in elements, multiples of 8): the
                                      * decode-time caches in mixed precision; served for 1-16 query rows, Lk <= 48, dk = 64 */
+    /* forward only, Lq = 1 (cached self-attention, transformer.py:265-269): the K / V of the NEW position (fp32 rows
+     * k_new[g*ld_new ..], v_new[..]) become key Lk-1 of group g: they are written to that key's cache row and attended to
+     * in the same launch (no separate cache-append pass). */
+    const float* k_new; const float* v_new; int64_t ld_new;
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);

@@ -793,7 +793,13 @@ __global__ __launch_bounds__(256) void attn_rowdec_kernel(ortk_attn_args a) {
         if (j < Lk) {
             const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j] : base + j;
             float4 k0, k1;
-            ld_row8<KVT>(reinterpret_cast<const KVT*>(a.k) + row * a.ldk + 8 * lane, k0, k1);
+            if (a.k_new && j == Lk - 1) {      // the new position: take K from the projection output and append it to the cache
+                ld_row8<float>(a.k_new + (int64_t)g * a.ld_new + 8 * lane, k0, k1);
+                st_elem4(const_cast<float*>(a.k), row * a.ldk + 8 * lane, Elem<KVT>::DT, k0);
+                st_elem4(const_cast<float*>(a.k), row * a.ldk + 8 * lane + 4, Elem<KVT>::DT, k1);
+            } else {
+                ld_row8<KVT>(reinterpret_cast<const KVT*>(a.k) + row * a.ldk + 8 * lane, k0, k1);
+            }
             float d = q0.x * k0.x + q0.y * k0.y + q0.z * k0.z + q0.w * k0.w + q1.x * k1.x + q1.y * k1.y + q1.z * k1.z + q1.w * k1.w;
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
             d *= 0.125f;                                              // 1 / sqrt(64)
@@ -812,7 +818,13 @@ __global__ __launch_bounds__(256) void attn_rowdec_kernel(ortk_attn_args a) {
         if (j < Lk) {
             const int64_t row = a.kv_index ? (int64_t)a.kv_index[(int64_t)g * Lk + j] : base + j;
             float4 v0, v1;
-            ld_row8<KVT>(reinterpret_cast<const KVT*>(a.v) + row * a.ldv + 8 * lane, v0, v1);
+            if (a.v_new && j == Lk - 1) {
+                ld_row8<float>(a.v_new + (int64_t)g * a.ld_new + 8 * lane, v0, v1);
+                st_elem4(const_cast<float*>(a.v), row * a.ldv + 8 * lane, Elem<KVT>::DT, v0);
+                st_elem4(const_cast<float*>(a.v), row * a.ldv + 8 * lane + 4, Elem<KVT>::DT, v1);
+            } else {
+                ld_row8<KVT>(reinterpret_cast<const KVT*>(a.v) + row * a.ldv + 8 * lane, v0, v1);
+            }
             const float pj = sc[j] * inv;
             if (a.p) { if ((lane & 7) == 0) a.p[((int64_t)g * a.H + (lane >> 3)) * Lk + j] = pj; }
             o[0] += pj * v0.x; o[1] += pj * v0.y; o[2] += pj * v0.z; o[3] += pj * v0.w;
@@ -1091,6 +1103,19 @@ bool small_fwd_ok(const ortk_attn_args* a) {
 
 }  // namespace
 
+// cache append for the kernels that do not do it themselves (k_new / v_new): one thread per element of the new rows
+__global__ void attn_kv_append_kernel(ortk_attn_args a) {
+    const int d = a.H * a.dk;
+    const int64_t n = (int64_t)a.nkv * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / d; const int c = (int)(i - g * d);
+        const int j = a.Lk - 1;
+        const int64_t row = a.kv_index ? (int64_t)a.kv_index[g * a.Lk + j] : g * (a.kv_group_stride > 0 ? a.kv_group_stride : a.Lk) + j;
+        st_elem(const_cast<float*>(a.k), row * a.ldk + c, a.kv_dtype, a.k_new[g * a.ld_new + c]);
+        st_elem(const_cast<float*>(a.v), row * a.ldv + c, a.kv_dtype, a.v_new[g * a.ld_new + c]);
+    }
+}
+
 // bf16 K / V storage (kv_dtype = 1) is served by the two decode-time kernels only; ortk_attention_kv16_ok tells the
 // executor whether a shape qualifies before it lays its caches out as bf16
 static bool kv16_ok(const ortk_attn_args* a) {
@@ -1099,11 +1124,28 @@ static bool kv16_ok(const ortk_attn_args* a) {
     return (rowdec || small) && a->ldk % 8 == 0 && a->ldv % 8 == 0 && attn_impl() == 0;
 }
 
-extern "C" int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream) {
-    if (int e = check(a)) return e;
-    if (!a->o) return ORTK_EINVAL;
-    if (a->nkv == 0) return 0;
-    if (a->kv_dtype != 0 && (a->kv_dtype != 1 || !kv16_ok(a))) return ORTK_EINVAL;
+extern "C" int ortk_attention_fwd(const ortk_attn_args* a_in, ortk_stream stream) {
+    if (int e = check(a_in)) return e;
+    if (!a_in->o) return ORTK_EINVAL;
+    if (a_in->nkv == 0) return 0;
+    if (a_in->kv_dtype != 0 && (a_in->kv_dtype != 1 || !kv16_ok(a_in))) return ORTK_EINVAL;
+    ortk_attn_args a_local = *a_in;
+    ortk_attn_args* a = &a_local;
+    if ((a->k_new != nullptr) != (a->v_new != nullptr)) return ORTK_EINVAL;
+    if (a->k_new && (a->Lq != 1 || a->ld_new < (int64_t)a->H * a->dk)) return ORTK_EINVAL;
+    if (a->k_new) {
+        const bool rowdec = a->H == 8 && a->dk == 64 && a->Lk <= 32 && a->causal_period == 0 && a->drop_p == 0.f && !a->bias &&
+                            a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->ldo % 4 == 0 && a->ld_new % 4 == 0 && attn_impl() == 0 &&
+                            ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v) |
+                              reinterpret_cast<uintptr_t>(a->o) | reinterpret_cast<uintptr_t>(a->k_new) | reinterpret_cast<uintptr_t>(a->v_new)) & 15) == 0;
+        if (!rowdec) {       // every other kernel: append first, then attend to the cache as usual
+            const int64_t n = (int64_t)a->nkv * a->H * a->dk;
+            hipLaunchKernelGGL(attn_kv_append_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ortk_cdiv(n, 256), 2048))), dim3(256), 0,
+                               ortk_s(stream), *a);
+            ORTK_CHECK_LAUNCH();
+            a->k_new = a->v_new = nullptr;
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -875,11 +875,11 @@ struct StepBufs {
     void* cache_k[MAXLAYERS]; void* cache_v[MAXLAYERS];
     int kvdt;      // element type of ckv / cache_k / cache_v
 };
-static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64_t rows, int groups, int per_group, int row_mult,
+static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64_t rows, int groups, int per_group, int /*row_mult*/,
                         int S, int T, int t, const int32_t* kvidx) {
     const ortk_config* cfg = c.cfg;
     const float* P = c.P;
-    ortk_stream stream = (ortk_stream)c.s; hipStream_t s = c.s;
+    ortk_stream stream = (ortk_stream)c.s;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = c.adt;
     const float* att_masks = w.att_masks;
     const int B = groups, per_img = per_group;
@@ -889,8 +889,8 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             const DecOff& e = o.dec[l];
             TRY(ln_fwd(c, x, e.n0a, e.n0b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, 3 * d, d));
-            TRY(kv_append(w.qkv, w.cache_k[l], w.cache_v[l], w.kvdt, rows, d, row_mult, T, t, s));
             ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+            a.k_new = w.qkv + d; a.v_new = w.qkv + 2 * d; a.ld_new = 3 * d;    // this position's K / V join the cache inside the kernel
             a.q = w.qkv; a.ldq = 3 * d; a.k = reinterpret_cast<const float*>(w.cache_k[l]); a.v = reinterpret_cast<const float*>(w.cache_v[l]);
             a.kv_dtype = w.kvdt; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
             a.nkv = (int)rows; a.H = H; a.Lq = 1; a.Lk = t + 1; a.dk = dk;

@@ -243,6 +243,34 @@ def test_attention_shapes(L):
     _attn_case(L, 7, 8, 1, 32, 64, 0, False, True)       # ... longest supported cache, with key mask
 
 
+@pytest.mark.parametrize("H,dk,kvdt", [(8, 64, 0), (8, 64, 1), (4, 16, 0)])
+def test_attention_appends_new_key_to_cache(L, H, dk, kvdt):
+    """k_new / v_new: the K / V of the new position become key Lk-1 — written to the cache row and attended to in the same
+    call (row kernel), or appended by a helper launch first (every other kernel)."""
+    rows, Lk, T = 21, 7, 18
+    d = H * dk
+    q, kn, vn = rnd(rows, d, seed=1), rnd(rows, d, seed=2), rnd(rows, d, seed=3)
+    tdt = torch.bfloat16 if kvdt else torch.float32
+    ck, cv = rnd(rows * T, d, seed=4).to(tdt), rnd(rows * T, d, seed=5).to(tdt)
+    want_k, want_v = ck.clone().float(), cv.clone().float()
+    slot = torch.arange(rows) * T + (Lk - 1)
+    want_k[slot], want_v[slot] = kn, vn
+    idx = (torch.arange(rows)[:, None] * T + torch.arange(Lk)[None, :])
+    # the new key is used at full precision in this step; the cache holds it in its storage type
+    kk = want_k[idx].view(rows, Lk, H, dk).transpose(1, 2); vv = want_v[idx].view(rows, Lk, H, dk).transpose(1, 2)
+    ref = O.attention(q.view(rows, 1, H, dk).transpose(1, 2), kk, vv, None, None).transpose(1, 2).reshape(rows, d)
+    a = L.AttnArgs()
+    qd, knd, vnd, ckd, cvd = dev(q), dev(kn), dev(vn), dev(ck), dev(cv)
+    o = torch.empty(rows, d, device="cuda")
+    a.q, a.k, a.v, a.o = qd.data_ptr(), ckd.data_ptr(), cvd.data_ptr(), o.data_ptr()
+    a.k_new, a.v_new, a.ld_new = knd.data_ptr(), vnd.data_ptr(), d
+    a.ldq = a.ldk = a.ldv = a.ldo = d
+    a.nkv, a.H, a.Lq, a.Lk, a.dk, a.kv_dtype, a.kv_group_stride = rows, H, 1, Lk, dk, kvdt, T
+    L.check(L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()), "attn_fwd")
+    torch.testing.assert_close(o.cpu(), ref, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(ckd.float().cpu(), want_k.to(tdt).float()); torch.testing.assert_close(cvd.float().cpu(), want_v.to(tdt).float())
+
+
 def test_attention_decode_row_kernel_with_ancestry_table(L):
     """Decode self-attention through the beam ancestry table (kv_index): row g attends to arbitrary cache rows."""
     rows, H, dk, Lk = 50, 8, 64, 11
