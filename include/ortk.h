@@ -244,6 +244,10 @@ typedef struct ortk_attn_args {
      * k_new[g*ld_new ..], v_new[..]) become key Lk-1 of group g: they are written to that key's cache row and attended to
      * in the same launch (no separate cache-append pass). */
     const float* k_new; const float* v_new; int64_t ld_new;
+    /* backward only: 0 = dQ, dK, dV (and dscore) in one call; 1 then 2 = the same work as two calls — part 1 guarantees dQ
+     * (and dscore), part 2 completes dK / dV — so that a host can keep part 2 off its critical path (a kernel that cannot
+     * split does everything in part 1 and nothing in part 2). */
+    int32_t bwd_part;
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);

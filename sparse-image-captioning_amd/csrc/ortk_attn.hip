@@ -325,7 +325,11 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(ortk_attn_args a, in
 // Backward with the same tiling.  Phase 1 (wave = 16-row query tile): dP = dO V^T, dS = P (dP - rowsum(P dP)),
 // dQ = dS K / sqrt(dk); dS / sqrt(dk) and the dropped P go to workgroup-wide LDS arrays.  Phase 2 (waves share the
 // 2 x (Lkp/16) x (DKP/16) output tiles): dK = dS^T Q / sqrt(dk), dV = Pd^T dO over ALL query rows of the group.
-template <int LKP_T, int DKP_T, int LQP_T>
+// PART: 0 = everything; 1 = dQ (and dscore) only — phase 1 alone, no Q / dropped-P images: 79 KB of LDS at the cross-
+// attention shape, two workgroups per CU; 2 = dK and dV only (phase 1 without the dQ product, then phase 2).  The
+// executor runs part 1 on the critical path and part 2, whose results are only needed for the cross-attention K/V
+// projection at the end of the decoder backward, on its side stream.
+template <int LKP_T, int DKP_T, int LQP_T, int PART>
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, int Lkp_rt, int DKP_rt, int Lqp_rt) {
     const int Lkp = LKP_T > 0 ? LKP_T : Lkp_rt, DKP = DKP_T > 0 ? DKP_T : DKP_rt, Lqp = LQP_T > 0 ? LQP_T : Lqp_rt;
     extern __shared__ __attribute__((aligned(16))) float smem_m[];
@@ -334,10 +338,10 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
     const int Lk = a.Lk, dk = a.dk, Lq = a.Lq;
     float* sK = smem_m;                 // [Lkp][PN_]  read as [k = key][n = feature]      (dQ = dS K)
     float* sV = sK + Lkp * PN_;         // [Lkp][PK_]  read as [n = key][k = feature]      (dP = dO V^T)
-    float* sQ = sV + Lkp * PK_;         // [Lqp][PN_]  read as [k = query][n = feature]    (dK = dS^T Q)
-    float* sG = sQ + Lqp * PN_;         // [Lqp][PK_]  dO: A operand of dP, [k][n] operand of dV
+    float* sQ = sV + Lkp * PK_;         // [Lqp][PN_]  read as [k = query][n = feature]    (dK = dS^T Q)       (not PART 1)
+    float* sG = PART == 1 ? sQ : sQ + Lqp * PN_;   // [Lqp][PK_]  dO: A operand of dP, [k][n] operand of dV
     float* sS = sG + Lqp * PK_;         // [Lqp][PK_]  dS / sqrt(dk)
-    float* sD = sS + Lqp * PK_;         // [Lqp][PK_]  dropped P
+    float* sD = sS + Lqp * PK_;         // [Lqp][PK_]  dropped P                                           (not PART 1)
     for (int idx = tid; idx < Lkp * (DKP / 4); idx += blockDim.x) {
         const int j = idx / (DKP / 4), dd = (idx - j * (DKP / 4)) * 4;
         float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
             qv = *reinterpret_cast<const float4*>(a.q + qrow * a.ldq + h * dk + dd);
             gv = *reinterpret_cast<const float4*>(a.d_o + qrow * a.lddo + h * dk + dd);
         }
-        *reinterpret_cast<float4*>(sQ + i * PN_ + dd) = qv;
+        if (PART != 1) *reinterpret_cast<float4*>(sQ + i * PN_ + dd) = qv;
         float* pg = sG + i * PK_ + dd; pg[0] = gv.x; pg[1] = gv.y; pg[2] = gv.z; pg[3] = gv.w;
     }
     __syncthreads();
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
                         pd = keep ? p * inv_keep : 0.f;
                     }
                     pp[jt][r] = p; dp[jt][r] = d; dot[r] += p * d;
-                    sD[(i0 + 4 * lq + r) * PK_ + j] = pd;
+                    if (PART != 1) sD[(i0 + 4 * lq + r) * PK_ + j] = pd;
                 }
             }
         }
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
                 for (int r = 0; r < 4; ++r) {
                     const int i = i0 + 4 * lq + r;
                     const float ds = pp[jt][r] * (dp[jt][r] - dot[r]);
-                    if (a.dscore && i < Lq && j < Lk) a.dscore[(((int64_t)g * a.H + h) * Lq + i) * Lk + j] = ds;
+                    if (PART != 2 && a.dscore && i < Lq && j < Lk) a.dscore[(((int64_t)g * a.H + h) * Lq + i) * Lk + j] = ds;
                     sS[(i0 + 4 * lq + r) * PK_ + j] = ds / scale;
                 }
             }
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
         // dQ = dS K : D[i][d]
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            if (dt < ndt) {
+            if (PART != 2 && dt < ndt) {
                 f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < Lkp / 4; ++kk) {
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(ortk_attn_args a, in
             }
         }
     }
+    if (PART == 1) return;
     __syncthreads();
     // phase 2: output tiles t = (which, jt, dt); A[m = key][k = query] = S^T (read [k][n]-style from sS / sD rows = query)
     const int ntiles = 2 * njt * ndt;
@@ -1220,7 +1225,7 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a_in, ortk_stream stream
 
 extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
     if (int e = check(a)) return e;
-    if (a->kv_dtype != 0) return ORTK_EINVAL;
+    if (a->kv_dtype != 0 || a->bwd_part < 0 || a->bwd_part > 2) return ORTK_EINVAL;
     if (!a->p || !a->d_o || !a->dq || !a->d_k || !a->dv || a->kv_index || a->kv_group_stride) return ORTK_EINVAL;
     if (a->nkv == 0) return 0;
     static bool attr_set = false;
@@ -1253,23 +1258,32 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
                          ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->v) |
                            reinterpret_cast<uintptr_t>(a->d_o)) & 15) == 0;
         if (a->Lk <= 64 && vec && lds <= 160 * 1024 && use_mfma) {
-            static bool mb_attr = false;
-            if (!mb_attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<48, 64, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<48, 64, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                mb_attr = true;
-            }
             const int nw = (int)std::min<int64_t>(8, ortk_cdiv(a->Lq, 16));
             const dim3 mgrid((unsigned)pairs), mblock(64 * nw);
-            if (DKP == 64 && Lkp == 48 && Lqp == 48)      hipLaunchKernelGGL((attn_bwd_mfma_kernel<48, 64, 48>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
-            else if (DKP == 64 && Lkp == 48 && Lqp == 96) hipLaunchKernelGGL((attn_bwd_mfma_kernel<48, 64, 96>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
-            else if (DKP == 64 && Lkp == 32 && Lqp == 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<32, 64, 32>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
-            else                                          hipLaunchKernelGGL((attn_bwd_mfma_kernel<0, 0, 0>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP, Lqp);
+            const size_t lds1 = sizeof(float) * ((size_t)Lkp * (PN_ + PK_) + (size_t)Lqp * 2 * PK_);    // PART 1: no Q / dropped-P images
+            typedef void (*bwd_fn)(ortk_attn_args, int, int, int);
+            bwd_fn fn; size_t bytes = lds;
+            if (a->bwd_part == 1 && DKP == 64 && Lkp == 48 && Lqp == 96)      { fn = attn_bwd_mfma_kernel<48, 64, 96, 1>; bytes = lds1; }
+            else if (a->bwd_part == 2 && DKP == 64 && Lkp == 48 && Lqp == 96) fn = attn_bwd_mfma_kernel<48, 64, 96, 2>;
+            else if (a->bwd_part == 1)                                        { fn = attn_bwd_mfma_kernel<0, 0, 0, 1>; bytes = lds1; }
+            else if (a->bwd_part == 2)                                        fn = attn_bwd_mfma_kernel<0, 0, 0, 2>;
+            else if (DKP == 64 && Lkp == 48 && Lqp == 48)                     fn = attn_bwd_mfma_kernel<48, 64, 48, 0>;
+            else if (DKP == 64 && Lkp == 48 && Lqp == 96)                     fn = attn_bwd_mfma_kernel<48, 64, 96, 0>;
+            else if (DKP == 64 && Lkp == 32 && Lqp == 32)                     fn = attn_bwd_mfma_kernel<32, 64, 32, 0>;
+            else                                                              fn = attn_bwd_mfma_kernel<0, 0, 0, 0>;
+            static bwd_fn seen[16]; static int nseen = 0;
+            bool known = false;
+            for (int i = 0; i < nseen; ++i) known |= seen[i] == fn;
+            if (!known) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (nseen < 16) seen[nseen++] = fn;
+            }
+            hipLaunchKernelGGL(fn, mgrid, mblock, bytes, ortk_s(stream), *a, Lkp, DKP, Lqp);
             ORTK_CHECK_LAUNCH();
             return 0;
         }
     }
+    if (a->bwd_part == 2) return 0;     // the kernels below compute everything in one go: part 1 already did
     const dim3 wgrid((unsigned)ortk_cdiv(pairs, 4)), block(256);
     const size_t wave_lds = sizeof(float) * 4 * ((size_t)2 * a->Lk * KP + 192);
     if (a->Lk <= 32)

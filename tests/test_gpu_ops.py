@@ -271,6 +271,33 @@ def test_attention_appends_new_key_to_cache(L, H, dk, kvdt):
     torch.testing.assert_close(ckd.float().cpu(), want_k.to(tdt).float()); torch.testing.assert_close(cvd.float().cpu(), want_v.to(tdt).float())
 
 
+@pytest.mark.parametrize("nkv,H,Lq,Lk,dk", [(3, 8, 85, 36, 64), (2, 8, 36, 36, 64), (4, 8, 17, 17, 64), (2, 2, 40, 20, 16)])
+def test_attention_backward_in_two_parts(L, nkv, H, Lq, Lk, dk):
+    """bwd_part 1 (dQ) then 2 (dK, dV) == bwd_part 0, whichever kernel serves the shape."""
+    d = H * dk
+    q, k, v, do = (dev(rnd(nkv * n, d, seed=s)) for n, s in ((Lq, 1), (Lk, 2), (Lk, 3), (Lq, 4)))
+    o = torch.empty(nkv * Lq, d, device="cuda"); p = torch.empty(nkv, H, Lq, Lk, device="cuda")
+    km = torch.ones(nkv, Lk); km[0, Lk - 3:] = 0
+    kmd = dev(km)
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.o, a.p, a.kmask = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), p.data_ptr(), kmd.data_ptr()
+    a.ldq = a.ldk = a.ldv = a.ldo = d
+    a.nkv, a.H, a.Lq, a.Lk, a.dk = nkv, H, Lq, Lk, dk
+    a.drop_p, a.drop_seed = 0.1, 5
+    L.check(L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()), "attn_fwd")
+    outs = {}
+    for parts in ((0,), (1, 2)):
+        dq, dk_, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+        a.d_o, a.dq, a.d_k, a.dv = do.data_ptr(), dq.data_ptr(), dk_.data_ptr(), dv.data_ptr()
+        a.lddo = a.lddq = a.lddk = a.lddv = d
+        for part in parts:
+            a.bwd_part = part
+            L.check(L.lib().ortk_attention_bwd(C.byref(a), L.stream_ptr()), "attn_bwd")
+        outs[parts] = (dq.clone(), dk_.clone(), dv.clone())
+    for x, y in zip(outs[(0,)], outs[(1, 2)]):
+        assert torch.isfinite(y).all() and torch.equal(x, y)
+
+
 def test_attention_decode_row_kernel_with_ancestry_table(L):
     """Decode self-attention through the beam ancestry table (kv_index): row g attends to arbitrary cache rows."""
     rows, H, dk, Lk = 50, 8, 64, 11
