@@ -726,6 +726,21 @@ __device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int
     }
 }
 
+// one 1-KB piece (wave-instruction) of a 256 x 64 operand tile: piece index u = 0..3 of this wave
+template <bool T>
+__device__ __forceinline__ void glds_piece64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane, int u) {
+    const int inst = wave * 4 + u;
+    const __bf16* g;
+    if (!T) {
+        const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
+        g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+    } else {
+        const int f = inst * 64 + lane, kr = f >> 5, c = (f & 31) ^ swz_km(kr);
+        g = base + (int64_t)(k0 + kr) * ld + tile0 + c * 8;
+    }
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
+}
+
 template <bool T>
 __device__ __forceinline__ bf16x8 gfrag64(const __bf16* img, int m0, int ks, int lane) {
     const int lr = lane & 15, lg = lane >> 4;
@@ -770,7 +785,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t landed (this wave's share)
         __builtin_amdgcn_s_barrier();                          // ... everyone's share; and tile t-1 is fully consumed
         asm volatile("" ::: "memory");
-        if (t + 1 < T) issue(t + 1);
+        // The 8 DMA pieces of the next tile are issued ONE per group of 8 MFMAs instead of as a burst at the top of the
+        // iteration: a burst of 64 pieces per CU queues in the texture-address unit while the waves wait to issue
+        // (PMC: TA busy 44 %, 128-byte requests return in ~450 cycles, yet a tile took ~7 000 cycles to land).
+        const bool next = t + 1 < T;
+        __bf16* nst = smem16 + (size_t)((t + 1) & 1) * 2 * IMG;
+        const int nk0 = k_begin + (t + 1) * HBK;
         const __bf16* sA = smem16 + (size_t)(t & 1) * 2 * IMG;
         const __bf16* sB = sA + IMG;
 #pragma unroll
@@ -781,10 +801,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = gfrag64<TA>(sA, wm * 128 + 16 * i, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i) {
+                if (next && (i & 1) == 0) {
+                    const int u = ks * 4 + (i >> 1);               // 0..7: pieces 0-3 of A, then 0-3 of B
+                    if (u < 4) glds_piece64<TA>(Ap, p.lda, mb, nk0, nst, wave, lane, u);
+                    else       glds_piece64<TB>(Bp, p.ldb, nb, nk0, nst + IMG, wave, lane, u - 4);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
         }
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
