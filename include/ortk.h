@@ -45,6 +45,10 @@ typedef struct ortk_config {
     int32_t box_trig;                          /* !no_box_trigonometric_embedding: 1 = 64-d sin/cos embedding, 0 = 4-d log-ratios */
     int32_t precision;                         /* 0 fp32 MFMA, 1 bf16 MFMA                           */
     float   drop_src, drop;                    /* att_embed dropout; every other dropout (0.1 | 0.1/3)*/
+    /* ACORT layer sharing (`share_layer_encoder / share_layer_decoder`, relation_transformer.py:80-88, transformer.py:175-183):
+     * 0 = layer l has its own weights; k > 0 = layer l IS layer k-1 (k-1 < l, itself unshared): same arena offsets, the
+     * gradients of both positions accumulate there, the arena holds one entry set per distinct layer. */
+    int32_t share_enc[16], share_dec[16];
 } ortk_config;
 
 /* ------------------------------------------------------------------------------------------------
@@ -280,6 +284,8 @@ int ortk_dropout_apply(const float* x, void* y, int32_t y_dtype, int64_t n, floa
 /* fp32 -> bf16 copy (the working copy of the weight arena in precision 1). */
 int ortk_cast_bf16(const float* x, void* y, int64_t n, ortk_stream stream);
 int ortk_fill(float* x, int64_t n, float value, ortk_stream stream);
+/* y[r, 0..cols) += x[r, 0..cols): x and y are column blocks of (rows, ld) matrices of `dtype` (0 fp32, 1 bf16) */
+int ortk_axpy_cols(const void* x, void* y, int32_t dtype, int64_t ld, int64_t rows, int32_t cols, ortk_stream stream);
 int ortk_sum(const float* x, int64_t n, float* out_dev, ortk_stream stream);  /* *out_dev = sum(x) */
 
 /* clip_grad_value_ + Adam (utils/optim.py:116-126,187-191; torch.optim.Adam update rule).

@@ -26,7 +26,8 @@ class Config(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("d_ff", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
                 ("vocab", C.c_int32), ("feat", C.c_int32), ("seq_len", C.c_int32),
                 ("pad_id", C.c_int32), ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("unk_id", C.c_int32),
-                ("box_trig", C.c_int32), ("precision", C.c_int32), ("drop_src", C.c_float), ("drop", C.c_float)]
+                ("box_trig", C.c_int32), ("precision", C.c_int32), ("drop_src", C.c_float), ("drop", C.c_float),
+                ("share_enc", C.c_int32 * 16), ("share_dec", C.c_int32 * 16)]
 
 
 class Batch(C.Structure):
@@ -123,6 +124,7 @@ SIGNATURES = {
     "ortk_decode_step_workspace_bytes": (_SZ, [_CFG, _I32]),
     "ortk_project_memory": (_I32, [_CFG, _P, _P, _I64, _P, _SZ, _P, _P]),
     "ortk_decode_step": (_I32, [_CFG, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _SZ, _P, _I64, _P]),
+    "ortk_axpy_cols": (_I32, [_P, _P, _I32, _I64, _I64, _I32, _P]),
     "ortk_linear_block": (_I32, [_CFG, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ortk_spmm_csr": (_I32, [C.POINTER(Csr), _P, _I32, _I64, _P, _P, _I32, _I64, _I64, _I32, _P, _I64, _P]),
 }

@@ -192,6 +192,14 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (__bf16)x[i];
 }
 
+__global__ __launch_bounds__(256) void add_cols_kernel(const void* __restrict__ x, void* __restrict__ y, int dt, int64_t ld, int64_t rows, int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols; const int c = (int)(i - r * cols);
+        st_elem(y, r * ld + c, dt, ld_elem(y, r * ld + c, dt) + ld_elem(x, r * ld + c, dt));
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
 }
@@ -297,6 +305,15 @@ extern "C" int ortk_cast_bf16(const float* x, void* y, int64_t n, ortk_stream st
     if (!x || !y || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return ORTK_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ortk_s(stream), x, reinterpret_cast<__bf16*>(y), n);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+// y[r, 0..cols) += x[r, 0..cols) for two column blocks of one (rows, ld) matrix (dtype 0 fp32 / 1 bf16)
+extern "C" int ortk_axpy_cols(const void* x, void* y, int32_t dtype, int64_t ld, int64_t rows, int32_t cols, ortk_stream stream) {
+    if (!x || !y || rows < 0 || cols < 0 || ld < cols || (dtype != ORTK_F32 && dtype != ORTK_BF16)) return ORTK_EINVAL;
+    if (rows == 0 || cols == 0) return 0;
+    hipLaunchKernelGGL(add_cols_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, ortk_s(stream), x, y, (int)dtype, ld, rows, cols);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

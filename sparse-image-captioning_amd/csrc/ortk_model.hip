@@ -29,6 +29,8 @@ struct Offsets {
     DecOff dec[MAXLAYERS];
     int64_t dec_na, dec_nb;
     int64_t ckv_w, ckv_b;
+    int ckv_slot[MAXLAYERS];   // decoder layer -> its slice of the packed cross-attention K|V block (shared layers: same slice)
+    int ckv_slots;             // number of distinct decoder layers
     int64_t lut, gen_w, gen_b;
     int64_t total;      // trainable floats (gradient / Adam mirrors have this size)
     int64_t pe;         // positional-encoding BUFFER (1, PE_ROWS, d), stored after the trainable part
@@ -44,6 +46,11 @@ static int check_cfg(const ortk_config* c) {
     if (c->d_model / c->n_heads > 64) return ORTK_EINVAL;
     if (c->vocab < 2 || c->feat < 1 || c->seq_len < 1 || c->seq_len > 64) return ORTK_EINVAL;
     if (c->precision != 0 && c->precision != 1) return ORTK_EINVAL;
+    for (int l = 0; l < c->n_layers; ++l)
+        for (const int32_t* sh : {c->share_enc, c->share_dec}) {
+            const int k = sh[l];
+            if (k < 0 || k > l || (k > 0 && sh[k - 1] != 0)) return ORTK_EINVAL;   // shares an earlier, itself unshared layer
+        }
     return 0;
 }
 
@@ -66,6 +73,7 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
     for (int l = 0; l < L; ++l) {
         const std::string p = "model.encoder.layers." + std::to_string(l);
         EncOff& e = o.enc[l];
+        if (c.share_enc[l] > 0) { e = o.enc[c.share_enc[l] - 1]; continue; }      // the same module: no storage of its own
         align(); e.wqkv = add(L_(p + ".self_attn", 0, "weight"), {d, d}); add(L_(p + ".self_attn", 1, "weight"), {d, d}); add(L_(p + ".self_attn", 2, "weight"), {d, d});
         align(); e.bqkv = add(L_(p + ".self_attn", 0, "bias"), {d}); add(L_(p + ".self_attn", 1, "bias"), {d}); add(L_(p + ".self_attn", 2, "bias"), {d});
         align(); e.wo = add(L_(p + ".self_attn", 3, "weight"), {d, d});
@@ -81,9 +89,12 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         align(); e.n1a = add(p + ".sublayer.1.norm.a_2", {d}); align(); e.n1b = add(p + ".sublayer.1.norm.b_2", {d});
     }
     align(); o.enc_na = add("model.encoder.norm.a_2", {d}); align(); o.enc_nb = add("model.encoder.norm.b_2", {d});
+    o.ckv_slots = 0;
+    for (int l = 0; l < L; ++l) o.ckv_slot[l] = c.share_dec[l] > 0 ? o.ckv_slot[c.share_dec[l] - 1] : o.ckv_slots++;
     for (int l = 0; l < L; ++l) {
         const std::string p = "model.decoder.layers." + std::to_string(l);
         DecOff& e = o.dec[l];
+        if (c.share_dec[l] > 0) { e = o.dec[c.share_dec[l] - 1]; continue; }
         align(); e.wqkv = add(L_(p + ".self_attn", 0, "weight"), {d, d}); add(L_(p + ".self_attn", 1, "weight"), {d, d}); add(L_(p + ".self_attn", 2, "weight"), {d, d});
         align(); e.bqkv = add(L_(p + ".self_attn", 0, "bias"), {d}); add(L_(p + ".self_attn", 1, "bias"), {d}); add(L_(p + ".self_attn", 2, "bias"), {d});
         align(); e.wo = add(L_(p + ".self_attn", 3, "weight"), {d, d});
@@ -104,11 +115,13 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
     // cross-attention K / V projections of ALL decoder layers: one (L*2d, d) matrix
     align(); o.ckv_w = off;
     for (int l = 0; l < L; ++l) {
+        if (c.share_dec[l] > 0) continue;
         const std::string p = "model.decoder.layers." + std::to_string(l) + ".src_attn";
         add(L_(p, 1, "weight"), {d, d}); add(L_(p, 2, "weight"), {d, d});
     }
     align(); o.ckv_b = off;
     for (int l = 0; l < L; ++l) {
+        if (c.share_dec[l] > 0) continue;
         const std::string p = "model.decoder.layers." + std::to_string(l) + ".src_attn";
         add(L_(p, 1, "bias"), {d}); add(L_(p, 2, "bias"), {d});
     }
@@ -548,13 +561,14 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
         if (c.use_side) { TRY(self_part(cx, 0, w.dx0)); TRY(c.side_mark(&prefix_done)); }
     }
     // decoder
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, (int64_t)L * 2 * d, Me, L * 2 * d, d));
+    const int U = o.ckv_slots;            // distinct decoder layers: one K|V slice each in the packed projection
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, (int64_t)U * 2 * d, Me, U * 2 * d, d));
     const float* x = w.dx0;
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         if (l == 0 && c.use_side) TRY(c.wait_ev(prefix_done)); else TRY(self_part(c, l, x));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
+        a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)o.ckv_slot[l] * 2 * d; a.v = a.k + d; a.ldk = a.ldv = (int64_t)U * 2 * d;
         a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         TRY(ortk_attention_fwd(&a, stream));
@@ -626,6 +640,11 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const int64_t Me = w.Me, Md = w.Md;
     const float inv_keep = c.p_drop() > 0.f ? 1.f / (1.f - c.p_drop()) : 1.f;
+    // dK|dV slice of every decoder layer in w.gkv: distinct layers first (the order of the packed K|V weight block), the
+    // layers that share one of them behind
+    const int U = o.ckv_slots;
+    int gslot[MAXLAYERS];
+    { int extra = U; for (int l = 0; l < L; ++l) gslot[l] = cfg->share_dec[l] > 0 ? extra++ : o.ckv_slot[l]; }
 
     float* dx = w.ga; float* dx2 = w.gb;
     // the (rows, d) bf16 gradient temporary rotates over three buffers: its producers (ln_bwd's masked copy, the cross-
@@ -658,10 +677,10 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)l * 2 * d; a.v = w.ckv + (int64_t)l * 2 * d + d; a.ldk = a.ldv = (int64_t)L * 2 * d;
+        a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)o.ckv_slot[l] * 2 * d; a.v = a.k + d; a.ldk = a.ldv = (int64_t)U * 2 * d;
         a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         a.d_o = w.gy; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
-        a.d_k = off_elems(w.gkv, (int64_t)l * 2 * d, A); a.dv = off_elems(w.gkv, (int64_t)l * 2 * d + d, A);
+        a.d_k = off_elems(w.gkv, (int64_t)gslot[l] * 2 * d, A); a.dv = off_elems(w.gkv, (int64_t)gslot[l] * 2 * d + d, A);
         a.lddk = a.lddv = (int64_t)L * 2 * d;
         TRY(c.before_write(gt_cur));
         TRY(ortk_attention_bwd(&a, stream));
@@ -695,8 +714,13 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), stream));
     }
     // cross-attention K/V projections of all layers, and the gradient of the encoder memory
-    TRY(wgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, L * 2 * d, d));
-    TRY(dgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, o.ckv_w, w.gy, ORTK_F32, d, Me, L * 2 * d, d));
+    // layers that share weights also share the projected K|V: their dK|dV slices add up into the slice of the layer they share
+    for (int l = 0; l < L; ++l)
+        if (cfg->share_dec[l] > 0)
+            TRY(ortk_axpy_cols(off_elems(w.gkv, (int64_t)gslot[l] * 2 * d, A), off_elems(w.gkv, (int64_t)o.ckv_slot[l] * 2 * d, A), A,
+                               (int64_t)L * 2 * d, Me, 2 * d, stream));
+    TRY(wgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, U * 2 * d, d));
+    TRY(dgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, o.ckv_w, w.gy, ORTK_F32, d, Me, U * 2 * d, d));
     TRY(c.join());
     }
     if (phase == 1) return 0;
@@ -781,7 +805,7 @@ extern "C" int ortk_linear_block(const ortk_config* cfg, int32_t i, int64_t* off
         v.push_back({e.wqkv, 3 * d, d}); v.push_back({e.wo, d, d}); v.push_back({e.cqw, d, d}); v.push_back({e.cow, d, d});
         v.push_back({e.w1, ff, d}); v.push_back({e.w2, d, ff});
     }
-    v.push_back({o.ckv_w, L * 2 * d, d});
+    v.push_back({o.ckv_w, o.ckv_slots * 2 * d, d});
     v.push_back({o.gen_w, (int)ortk_align(cfg->vocab, 128), d});
     if (i < 0) return (int)v.size();
     if (i >= (int)v.size() || !offset || !N || !K) return ORTK_EINVAL;
@@ -901,9 +925,9 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
             std::memset(&a, 0, sizeof(a));
-            a.q = w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)l * 2 * d, w.kvdt));
-            a.v = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)l * 2 * d + d, w.kvdt)); a.kv_dtype = w.kvdt;
-            a.ldk = a.ldv = (int64_t)L * 2 * d;
+            a.q = w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)o.ckv_slot[l] * 2 * d, w.kvdt));
+            a.v = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)o.ckv_slot[l] * 2 * d + d, w.kvdt)); a.kv_dtype = w.kvdt;
+            a.ldk = a.ldv = (int64_t)o.ckv_slots * 2 * d;
             a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
             TRY(ortk_attention_fwd(&a, stream));
             TRY(fwd_gemm(c, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
@@ -944,7 +968,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     EncPtrs ep[MAXLAYERS];
     for (int l = 0; l < L; ++l) ep[l] = w.enc;
     TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.kvdt, (int64_t)L * 2 * d, Me, L * 2 * d, d));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.kvdt, (int64_t)o.ckv_slots * 2 * d, Me, o.ckv_slots * 2 * d, d));
 
     const int64_t rows_full = (int64_t)B * K;
     BeamState bs; std::memset(&bs, 0, sizeof(bs));
@@ -1027,7 +1051,9 @@ extern "C" int ortk_project_memory(const ortk_config* cfg, const float* params, 
     TRY(make_w16(cfg, o, params, w.w16, stream));
     Ctx c{cfg, ortk_s(stream), cfg->precision, 0, false, params, w.w16, cfg->precision ? ORTK_BF16 : ORTK_F32};
     const int d = cfg->d_model, L = cfg->n_layers;
-    return fwd_gemm(c, memory, ORTK_F32, d, o.ckv_w, params + o.ckv_b, cross_kv, ORTK_F32, (int64_t)L * 2 * d, mem_rows, L * 2 * d, d);
+    const int U = o.ckv_slots;      // distinct decoder layers (ortk_config.share_dec)
+    (void)L;
+    return fwd_gemm(c, memory, ORTK_F32, d, o.ckv_w, params + o.ckv_b, cross_kv, ORTK_F32, (int64_t)U * 2 * d, mem_rows, U * 2 * d, d);
 }
 
 extern "C" int ortk_decode_step(const ortk_config* cfg, const float* params, const int64_t* it, int32_t t, int32_t rows,

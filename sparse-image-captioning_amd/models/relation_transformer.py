@@ -36,8 +36,35 @@ class ObjectRelationBatchLayout:
         parser.add_argument("--max_seq_length", type=int, default=18)
 
 
+def parse_share_layer(value, n_layers, what):
+    """``share_layer_encoder / share_layer_decoder`` (transformer.py:599-614: a sequence of layer ids such as (0, 0, 1, 1, 2, 2))
+    -> per position, 0 = first use of that id, k > 0 = the same module as position k - 1."""
+    if value is None or value == "" or value == ():
+        return [0] * n_layers
+    if isinstance(value, str):
+        value = [int(v) for v in value.replace("(", "").replace(")", "").replace("[", "").replace("]", "").split(",") if v.strip()]
+    if not isinstance(value, (tuple, list)):
+        raise TypeError(f"`{what}` must be a tuple or list, saw {type(value)}")          # relation_transformer.py:83-84
+    value = [int(v) for v in value]
+    if len(value) != n_layers:
+        raise NotImplementedError(f"`{what}` has {len(value)} entries but num_layers = {n_layers}: the HIP path keeps one layer "
+                                  "count for both stacks")
+    if sorted(set(value)) != list(range(len(set(value)))):
+        raise IndexError(f"`{what}` ids must be 0..{len(set(value)) - 1}")              # relation_transformer.py:85-86 indexes a list
+    first, out = {}, []
+    for l, v in enumerate(value):
+        out.append(0 if v not in first else first[v] + 1)
+        first.setdefault(v, l)
+    return out
+
+
 def make_ccfg(config, precision, drop, train_drop_src=None):
     c = L.Config()
+    get = config.get if hasattr(config, "get") else (lambda k, d=None: getattr(config, k, d))
+    for l, v in enumerate(parse_share_layer(get("share_layer_encoder", None), int(config.num_layers), "share_layer_encoder")):
+        c.share_enc[l] = v
+    for l, v in enumerate(parse_share_layer(get("share_layer_decoder", None), int(config.num_layers), "share_layer_decoder")):
+        c.share_dec[l] = v
     c.d_model, c.d_ff = int(config.d_model), int(config.dim_feedforward)
     c.n_layers, c.n_heads = int(config.num_layers), int(config.num_heads)
     c.vocab, c.feat, c.seq_len = int(config.vocab_size), int(config.att_feat_size), int(config.max_seq_length)
@@ -104,9 +131,9 @@ class RelationTransformerModel(CaptionModelBase):
     def __init__(self, config, precision=None):
         super().__init__()
         self.config = config
-        for k in ("share_att_encoder", "share_att_decoder", "share_layer_encoder", "share_layer_decoder"):
+        for k in ("share_att_encoder", "share_att_decoder"):
             if config.get(k, None) if hasattr(config, "get") else getattr(config, k, None):
-                raise NotImplementedError(f"`{k}` (ACORT weight sharing) is not implemented in the HIP path yet")
+                raise NotImplementedError(f"`{k}` (ACORT Q/K/V projection sharing) is not implemented in the HIP path yet")
         # attributes the callers read (transformer.py:418-437; utils/training.py:253)
         self.d_model, self.dim_feedforward = config.d_model, config.dim_feedforward
         self.num_layers, self.num_heads = config.num_layers, config.num_heads
@@ -158,6 +185,14 @@ class RelationTransformerModel(CaptionModelBase):
                     mp = nn.Parameter(torch.empty(0))
                     node.register_parameter(parts[-1] + suffix, mp)
                     self._params[e["name"] + suffix] = (node, parts[-1] + suffix, mp)
+
+        # ACORT layer sharing: a shared position is the SAME module object as the position it shares (as in the reference's
+        # ModuleList of repeated modules): state_dict() lists every position, parameters() each tensor once
+        for stack, share in (("encoder", self._ccfg.share_enc), ("decoder", self._ccfg.share_dec)):
+            layers = self._modules["model"]._modules[stack]._modules["layers"]
+            for l in range(self.num_layers):
+                if share[l] > 0:
+                    layers.add_module(str(l), layers._modules[str(share[l] - 1)])
 
     def _arenas(self):
         return {"": "_flat"}
@@ -500,6 +535,8 @@ class RelationTransformerModel(CaptionModelBase):
         in a module counter reset by ``reset_cache``).  This is the API-compatible path: every call re-packs the caches;
         ``mode="sample"`` runs the whole loop on the device."""
         lib = L.lib()
+        if any(self._ccfg.share_dec[l] for l in range(self.num_layers)):
+            raise NotImplementedError("get_logprobs_state with share_layer_decoder: use mode='sample'")
         rows, S, d = memory.shape
         Lr, H = self.num_layers, self.num_heads
         dk, T = d // H, self.seq_length

@@ -81,3 +81,23 @@ def unpack_bits(bits, shapes):
         out.append(flat[off:off + n].reshape(shp).astype(np.float32))
         off += n
     return out
+
+
+def shared_layer_state(cfg, param_names, seed, gen_scale=1.0, eos_bias=0.0, requires_grad=False):
+    """Weights of a `share_layer_*` model: tensors for the reference's named_parameters() (each shared tensor once, under
+    its first position's name) + alias entries so that EVERY layer position has its keys (the oracle indexes by position)."""
+    shapes = dense_param_shapes(cfg)
+    state = torch_state({n: shapes[n] for n in param_names}, seed, gen_scale, eos_bias, requires_grad=requires_grad)
+    L = cfg["num_layers"]
+    for stack, key in (("encoder", "share_layer_encoder"), ("decoder", "share_layer_decoder")):
+        ids = list(cfg.get(key) or range(L))
+        first = {}
+        for l, v in enumerate(ids):
+            first.setdefault(v, l)
+        for l, v in enumerate(ids):
+            if first[v] != l:
+                src, dst = f"model.{stack}.layers.{first[v]}.", f"model.{stack}.layers.{l}."
+                for n in list(state):
+                    if n.startswith(src):
+                        state[dst + n[len(src):]] = state[n]
+    return state

@@ -291,3 +291,29 @@ def test_non_trigonometric_box_embedding_vs_reference_golden(golden):
         Pd = {k: v.detach() for k, v in P.items()}
         seq, lp, _ = O.beam_search(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"], beam_size=3)
         np.testing.assert_array_equal(seq.numpy(), g5["decode_b3/seq"])
+
+
+def test_share_layer_vs_reference_golden(golden):
+    """G8: ACORT layer sharing — positions that share a module read the same tensors; their gradients add up."""
+    g8 = golden("g8_tiny_share_layer")
+    cfgd = dict(C.TINY_CFG, num_layers=3, share_layer_encoder=(0, 1, 0), share_layer_decoder=(0, 0, 1))
+    cfg = _cfg({k: v for k, v in cfgd.items() if not k.startswith("share_")})
+    names = [str(n) for n in g8["param_names"]]
+    P = H.shared_layer_state(cfgd, names, C.G1_SEED, C.G1_GEN_SCALE, C.G1_EOS_BIAS, requires_grad=True)
+    b = H.g1_batch()
+    logp = O.forward_logp(P, cfg, b["att_feats"], b["boxes"], b["seqs"], b["att_masks"])
+    close(logp, g8["logp"], 5e-5)
+    loss = O.xe_loss(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - float(g8["xe_loss"])) < 1e-5
+    loss.backward()
+    for n in names:
+        ref = g8["grad/" + n]
+        np.testing.assert_allclose(P[n].grad.numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=n)
+    # cached decoding is pinned with encoder sharing only (the reference's shared decoder modules share ONE K/V cache between
+    # their positions: make_golden_share.py)
+    cfgb = dict(C.TINY_CFG, num_layers=3, share_layer_encoder=(0, 1, 0))
+    Pb = H.shared_layer_state(cfgb, [str(n) for n in g8["enc_only/param_names"]], C.G1_SEED, C.G1_GEN_SCALE, C.G1_EOS_BIAS)
+    with torch.no_grad():
+        seq, lp, _ = O.beam_search(Pb, cfg, b["att_feats"], b["boxes"], b["att_masks"], beam_size=3)
+        np.testing.assert_array_equal(seq.numpy(), g8["enc_only/decode_b3/seq"])
+        close(lp, g8["enc_only/decode_b3/logprobs"], 1e-4)
