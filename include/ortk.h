@@ -49,6 +49,11 @@ typedef struct ortk_config {
      * 0 = layer l has its own weights; k > 0 = layer l IS layer k-1 (k-1 < l, itself unshared): same arena offsets, the
      * gradients of both positions accumulate there, the arena holds one entry set per distinct layer. */
     int32_t share_enc[16], share_dec[16];
+    /* ACORT projection sharing inside an attention module (`share_att_encoder / share_att_decoder`,
+     * relation_transformer.py:140-142,162-175; transformer.py:223-225,258-263): 0 = W_q, W_k, W_v, W_o (linears.0-3);
+     * 1 = "kv": K = V = linears.1(key), W_o = linears.2;  2 = "qk": Q = linears.0(query), K = linears.0(key),
+     * V = linears.1(value), W_o = linears.2.  Three linears per module in the state_dict, as in the reference. */
+    int32_t share_att_enc, share_att_dec;
 } ortk_config;
 
 /* ------------------------------------------------------------------------------------------------

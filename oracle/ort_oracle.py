@@ -43,6 +43,7 @@ class OCfg:
         self.vocab_size = 10001
         self.bos_token_id, self.eos_token_id, self.unk_token_id, self.pad_token_id = 2, 3, 1, 0
         self.no_box_trigonometric_embedding = False
+        self.share_att_encoder = self.share_att_decoder = None      # None | "kv" | "qk" (ACORT)
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -99,6 +100,27 @@ def _linear(P, prefix, x):
     return F.linear(x, P[prefix + ".weight"], P[prefix + ".bias"])
 
 
+def project_qkv(P, prefix: str, share_att, xq: Tensor, xkv: Tensor, h: int, need_kv: bool = True):
+    """Q / K / V heads and the name of the output projection of one attention module.
+    share_att None: linears.0/1/2, output linears.3.  "kv": K = V = linears.1(key).  "qk": K = linears.0(key),
+    V = linears.1(value); output linears.2 in both (relation_transformer.py:142,162-175; transformer.py:225,258-263)."""
+    assert share_att in (None, "kv", "qk"), f"Invalid `share_att`: {share_att}"
+    q = _heads(_linear(P, prefix + "linears.0", xq), h)
+    out = prefix + ("linears.2" if share_att else "linears.3")
+    if not need_kv:
+        return q, None, None, out
+    if share_att == "kv":
+        k = _heads(_linear(P, prefix + "linears.1", xkv), h)
+        v = k
+    elif share_att == "qk":
+        k = _heads(_linear(P, prefix + "linears.0", xkv), h)
+        v = _heads(_linear(P, prefix + "linears.1", xkv), h)
+    else:
+        k = _heads(_linear(P, prefix + "linears.1", xkv), h)
+        v = _heads(_linear(P, prefix + "linears.2", xkv), h)
+    return q, k, v, out
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], bias: Optional[Tensor] = None) -> Tensor:
     """transformer.py:285-295 / relation_transformer.py:258-293 (mask fill BEFORE the additive log-bias)."""
     scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(q.size(-1))
@@ -130,11 +152,9 @@ def encode(P, cfg, att_feats: Tensor, boxes: Tensor, att_masks: Tensor) -> Tenso
     for l in range(cfg.num_layers):
         pre = f"model.encoder.layers.{l}."
         y = layer_norm(x, P[pre + "sublayer.0.norm.a_2"], P[pre + "sublayer.0.norm.b_2"])
-        q = _heads(_linear(P, pre + "self_attn.linears.0", y), h)
-        k = _heads(_linear(P, pre + "self_attn.linears.1", y), h)
-        v = _heads(_linear(P, pre + "self_attn.linears.2", y), h)
+        q, k, v, out = project_qkv(P, pre + "self_attn.", getattr(cfg, "share_att_encoder", None), y, y, h)
         o = attention(q, k, v, kmask, box_logbias(P, l, emb, h))
-        x = x + _linear(P, pre + "self_attn.linears.3", _merge(o))
+        x = x + _linear(P, out, _merge(o))
         y = layer_norm(x, P[pre + "sublayer.1.norm.a_2"], P[pre + "sublayer.1.norm.b_2"])
         x = x + _linear(P, pre + "feed_forward.w_2", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
     return layer_norm(x, P["model.encoder.norm.a_2"], P["model.encoder.norm.b_2"])
@@ -166,18 +186,15 @@ def decode_tf(P, cfg, memory: Tensor, att_masks: Tensor, seq_in: Tensor) -> Tens
     causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
     self_mask = ((seq_in != cfg.pad_token_id)[:, None, :] & causal[None])[:, None]  # (R,1,T,T)
     src_mask = (att_masks != 0)[:, None, None, :]
+    sa = getattr(cfg, "share_att_decoder", None)
     for l in range(cfg.num_layers):
         pre = f"model.decoder.layers.{l}."
         y = layer_norm(x, P[pre + "sublayer.0.norm.a_2"], P[pre + "sublayer.0.norm.b_2"])
-        q = _heads(_linear(P, pre + "self_attn.linears.0", y), h)
-        k = _heads(_linear(P, pre + "self_attn.linears.1", y), h)
-        v = _heads(_linear(P, pre + "self_attn.linears.2", y), h)
-        x = x + _linear(P, pre + "self_attn.linears.3", _merge(attention(q, k, v, self_mask)))
+        q, k, v, out = project_qkv(P, pre + "self_attn.", sa, y, y, h)
+        x = x + _linear(P, out, _merge(attention(q, k, v, self_mask)))
         y = layer_norm(x, P[pre + "sublayer.1.norm.a_2"], P[pre + "sublayer.1.norm.b_2"])
-        q = _heads(_linear(P, pre + "src_attn.linears.0", y), h)
-        k = _heads(_linear(P, pre + "src_attn.linears.1", memory), h)
-        v = _heads(_linear(P, pre + "src_attn.linears.2", memory), h)
-        x = x + _linear(P, pre + "src_attn.linears.3", _merge(attention(q, k, v, src_mask)))
+        q, k, v, out = project_qkv(P, pre + "src_attn.", sa, y, memory, h)
+        x = x + _linear(P, out, _merge(attention(q, k, v, src_mask)))
         y = layer_norm(x, P[pre + "sublayer.2.norm.a_2"], P[pre + "sublayer.2.norm.b_2"])
         x = x + _linear(P, pre + "feed_forward.w_2", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
     return layer_norm(x, P["model.decoder.norm.a_2"], P["model.decoder.norm.b_2"])
@@ -251,23 +268,21 @@ def decode_step(st: DecodeState, it: Tensor) -> Tensor:
     x = embed_tokens(P, cfg, it[:, None], pos0=st.step)
     st.step += 1
     src_mask = (st.att_masks != 0)[:, None, None, :]
+    sa = getattr(cfg, "share_att_decoder", None)
     for l in range(cfg.num_layers):
         pre = f"model.decoder.layers.{l}."
         y = layer_norm(x, P[pre + "sublayer.0.norm.a_2"], P[pre + "sublayer.0.norm.b_2"])
-        q = _heads(_linear(P, pre + "self_attn.linears.0", y), h)
-        k = _heads(_linear(P, pre + "self_attn.linears.1", y), h)
-        v = _heads(_linear(P, pre + "self_attn.linears.2", y), h)
+        q, k, v, out = project_qkv(P, pre + "self_attn.", sa, y, y, h)
         if st.self_k[l] is not None:
             k = torch.cat((st.self_k[l], k), 2)
             v = torch.cat((st.self_v[l], v), 2)
         st.self_k[l], st.self_v[l] = k, v
-        x = x + _linear(P, pre + "self_attn.linears.3", _merge(attention(q, k, v, None)))
+        x = x + _linear(P, out, _merge(attention(q, k, v, None)))
         y = layer_norm(x, P[pre + "sublayer.1.norm.a_2"], P[pre + "sublayer.1.norm.b_2"])
-        q = _heads(_linear(P, pre + "src_attn.linears.0", y), h)
+        q, k, v, out = project_qkv(P, pre + "src_attn.", sa, y, st.memory, h, need_kv=st.src_k[l] is None)
         if st.src_k[l] is None:
-            st.src_k[l] = _heads(_linear(P, pre + "src_attn.linears.1", st.memory), h)
-            st.src_v[l] = _heads(_linear(P, pre + "src_attn.linears.2", st.memory), h)
-        x = x + _linear(P, pre + "src_attn.linears.3", _merge(attention(q, st.src_k[l], st.src_v[l], src_mask)))
+            st.src_k[l], st.src_v[l] = k, v
+        x = x + _linear(P, out, _merge(attention(q, st.src_k[l], st.src_v[l], src_mask)))
         y = layer_norm(x, P[pre + "sublayer.2.norm.a_2"], P[pre + "sublayer.2.norm.b_2"])
         x = x + _linear(P, pre + "feed_forward.w_2", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
     x = layer_norm(x, P["model.decoder.norm.a_2"], P["model.decoder.norm.b_2"])

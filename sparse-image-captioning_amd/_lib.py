@@ -27,7 +27,8 @@ class Config(C.Structure):
                 ("vocab", C.c_int32), ("feat", C.c_int32), ("seq_len", C.c_int32),
                 ("pad_id", C.c_int32), ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("unk_id", C.c_int32),
                 ("box_trig", C.c_int32), ("precision", C.c_int32), ("drop_src", C.c_float), ("drop", C.c_float),
-                ("share_enc", C.c_int32 * 16), ("share_dec", C.c_int32 * 16)]
+                ("share_enc", C.c_int32 * 16), ("share_dec", C.c_int32 * 16),
+                ("share_att_enc", C.c_int32), ("share_att_dec", C.c_int32)]
 
 
 class Batch(C.Structure):

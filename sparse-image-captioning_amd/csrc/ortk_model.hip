@@ -31,6 +31,8 @@ struct Offsets {
     int64_t ckv_w, ckv_b;
     int ckv_slot[MAXLAYERS];   // decoder layer -> its slice of the packed cross-attention K|V block (shared layers: same slice)
     int ckv_slots;             // number of distinct decoder layers
+    int64_t cw;                // width of one slice: 2d ([K|V]; share_att "qk": [Q=K|V]), d with share_att "kv" (K = V)
+    int64_t cv;                // column of V inside a slice (d, or 0 with "kv")
     int64_t lut, gen_w, gen_b;
     int64_t total;      // trainable floats (gradient / Adam mirrors have this size)
     int64_t pe;         // positional-encoding BUFFER (1, PE_ROWS, d), stored after the trainable part
@@ -39,6 +41,16 @@ struct Offsets {
 constexpr int64_t PE_ROWS = 5000;  // transformer.py:365 (max_len), kept for state_dict compatibility
 struct Entry { std::string name; int64_t offset, numel; int ndim; int64_t shape[4]; int kind; };  // kind: 0 param, 1 maskable param, 2 buffer
 
+// Projection sharing inside an attention module (ortk_config.share_att_*): which d-wide column block of the packed
+// projection output holds Q (always 0), K and V; and where the attention backward puts dQ (0), dK, dV so that, after
+// adding block `gsrc` into block `gdst`, the first n blocks are the gradient of the packed projection output.
+struct AttMode { int n, k, v, gk, gv, gsrc, gdst; };
+static inline AttMode att_mode(int m) {
+    if (m == 1) return AttMode{2, 1, 1, 1, 2, 2, 1};      // "kv": [Q | K=V]
+    if (m == 2) return AttMode{2, 0, 1, 2, 1, 2, 0};      // "qk": [Q=K | V]
+    return AttMode{3, 1, 2, 1, 2, -1, -1};
+}
+
 static int check_cfg(const ortk_config* c) {
     if (!c) return ORTK_EINVAL;
     if (c->d_model < 8 || c->d_model > 2048 || c->d_ff < 1 || c->n_layers < 1 || c->n_layers > MAXLAYERS) return ORTK_EINVAL;
@@ -46,6 +58,7 @@ static int check_cfg(const ortk_config* c) {
     if (c->d_model / c->n_heads > 64) return ORTK_EINVAL;
     if (c->vocab < 2 || c->feat < 1 || c->seq_len < 1 || c->seq_len > 64) return ORTK_EINVAL;
     if (c->precision != 0 && c->precision != 1) return ORTK_EINVAL;
+    if (c->share_att_enc < 0 || c->share_att_enc > 2 || c->share_att_dec < 0 || c->share_att_dec > 2) return ORTK_EINVAL;
     for (int l = 0; l < c->n_layers; ++l)
         for (const int32_t* sh : {c->share_enc, c->share_dec}) {
             const int k = sh[l];
@@ -68,16 +81,20 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         const int64_t at = off; off += e.numel; return at;
     };
     auto L_ = [](const std::string& p, int i, const char* w) { return p + ".linears." + std::to_string(i) + "." + w; };
+    // packed projections per attention module: 3 (Q, K, V) or, with share_att, 2; the output projection is the next linear
+    const int ne = att_mode(c.share_att_enc).n, nd = att_mode(c.share_att_dec).n;
+    const bool cqk = c.share_att_dec == 2;     // cross-attention Q and K share linears.0: it lives in the packed K|V block
+    o.cw = c.share_att_dec == 1 ? d : 2 * d; o.cv = c.share_att_dec == 1 ? 0 : d;
     align(); o.att_w = add("att_embed.0.weight", {d, F});
     align(); o.att_b = add("att_embed.0.bias", {d});
     for (int l = 0; l < L; ++l) {
         const std::string p = "model.encoder.layers." + std::to_string(l);
         EncOff& e = o.enc[l];
         if (c.share_enc[l] > 0) { e = o.enc[c.share_enc[l] - 1]; continue; }      // the same module: no storage of its own
-        align(); e.wqkv = add(L_(p + ".self_attn", 0, "weight"), {d, d}); add(L_(p + ".self_attn", 1, "weight"), {d, d}); add(L_(p + ".self_attn", 2, "weight"), {d, d});
-        align(); e.bqkv = add(L_(p + ".self_attn", 0, "bias"), {d}); add(L_(p + ".self_attn", 1, "bias"), {d}); add(L_(p + ".self_attn", 2, "bias"), {d});
-        align(); e.wo = add(L_(p + ".self_attn", 3, "weight"), {d, d});
-        align(); e.bo = add(L_(p + ".self_attn", 3, "bias"), {d});
+        align(); e.wqkv = off; for (int i = 0; i < ne; ++i) add(L_(p + ".self_attn", i, "weight"), {d, d});
+        align(); e.bqkv = off; for (int i = 0; i < ne; ++i) add(L_(p + ".self_attn", i, "bias"), {d});
+        align(); e.wo = add(L_(p + ".self_attn", ne, "weight"), {d, d});
+        align(); e.bo = add(L_(p + ".self_attn", ne, "bias"), {d});
         const int64_t dg = c.box_trig ? 64 : 4;   // relation_transformer.py:131-136
         align(); e.wg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".weight", {1, dg});
         align(); e.bg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".bias", {1});
@@ -95,14 +112,14 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         const std::string p = "model.decoder.layers." + std::to_string(l);
         DecOff& e = o.dec[l];
         if (c.share_dec[l] > 0) { e = o.dec[c.share_dec[l] - 1]; continue; }
-        align(); e.wqkv = add(L_(p + ".self_attn", 0, "weight"), {d, d}); add(L_(p + ".self_attn", 1, "weight"), {d, d}); add(L_(p + ".self_attn", 2, "weight"), {d, d});
-        align(); e.bqkv = add(L_(p + ".self_attn", 0, "bias"), {d}); add(L_(p + ".self_attn", 1, "bias"), {d}); add(L_(p + ".self_attn", 2, "bias"), {d});
-        align(); e.wo = add(L_(p + ".self_attn", 3, "weight"), {d, d});
-        align(); e.bo = add(L_(p + ".self_attn", 3, "bias"), {d});
-        align(); e.cqw = add(L_(p + ".src_attn", 0, "weight"), {d, d});
-        align(); e.cqb = add(L_(p + ".src_attn", 0, "bias"), {d});
-        align(); e.cow = add(L_(p + ".src_attn", 3, "weight"), {d, d});
-        align(); e.cob = add(L_(p + ".src_attn", 3, "bias"), {d});
+        align(); e.wqkv = off; for (int i = 0; i < nd; ++i) add(L_(p + ".self_attn", i, "weight"), {d, d});
+        align(); e.bqkv = off; for (int i = 0; i < nd; ++i) add(L_(p + ".self_attn", i, "bias"), {d});
+        align(); e.wo = add(L_(p + ".self_attn", nd, "weight"), {d, d});
+        align(); e.bo = add(L_(p + ".self_attn", nd, "bias"), {d});
+        e.cqw = e.cqb = -1;                   // "qk": set below, inside the packed K|V block
+        if (!cqk) { align(); e.cqw = add(L_(p + ".src_attn", 0, "weight"), {d, d}); align(); e.cqb = add(L_(p + ".src_attn", 0, "bias"), {d}); }
+        align(); e.cow = add(L_(p + ".src_attn", nd, "weight"), {d, d});
+        align(); e.cob = add(L_(p + ".src_attn", nd, "bias"), {d});
         align(); e.w1 = add(p + ".feed_forward.w_1.weight", {ff, d});
         align(); e.b1 = add(p + ".feed_forward.w_1.bias", {ff});
         align(); e.w2 = add(p + ".feed_forward.w_2.weight", {d, ff});
@@ -112,19 +129,24 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         align(); e.n2a = add(p + ".sublayer.2.norm.a_2", {d}); align(); e.n2b = add(p + ".sublayer.2.norm.b_2", {d});
     }
     align(); o.dec_na = add("model.decoder.norm.a_2", {d}); align(); o.dec_nb = add("model.decoder.norm.b_2", {d});
-    // cross-attention K / V projections of ALL decoder layers: one (L*2d, d) matrix
+    // cross-attention K / V projections of ALL distinct decoder layers: one (U*cw, d) matrix.  Slice of a layer:
+    // [W_k; W_v] (linears.1, .2) | "kv": [W_kv] (linears.1) | "qk": [W_qk; W_v] (linears.0, .1; also the query projection)
+    const int c0 = cqk ? 0 : 1, c1 = c.share_att_dec == 1 ? 1 : c0 + 1;
     align(); o.ckv_w = off;
     for (int l = 0; l < L; ++l) {
         if (c.share_dec[l] > 0) continue;
         const std::string p = "model.decoder.layers." + std::to_string(l) + ".src_attn";
-        add(L_(p, 1, "weight"), {d, d}); add(L_(p, 2, "weight"), {d, d});
+        if (cqk) o.dec[l].cqw = off;
+        for (int i = c0; i <= c1; ++i) add(L_(p, i, "weight"), {d, d});
     }
     align(); o.ckv_b = off;
     for (int l = 0; l < L; ++l) {
         if (c.share_dec[l] > 0) continue;
         const std::string p = "model.decoder.layers." + std::to_string(l) + ".src_attn";
-        add(L_(p, 1, "bias"), {d}); add(L_(p, 2, "bias"), {d});
+        if (cqk) o.dec[l].cqb = off;
+        for (int i = c0; i <= c1; ++i) add(L_(p, i, "bias"), {d});
     }
+    if (cqk) for (int l = 0; l < L; ++l) if (c.share_dec[l] > 0) { o.dec[l].cqw = o.dec[c.share_dec[l] - 1].cqw; o.dec[l].cqb = o.dec[c.share_dec[l] - 1].cqb; }
     align(); o.lut = add("model.tgt_embed.0.lut.weight", {V, d});
     // The generator rows are padded (with zeros that no state_dict entry covers) to a multiple of the GEMM tile:
     // logits are computed for Vp = align(V,128) columns with full tiles; the pad logits are exactly 0, have zero
@@ -285,8 +307,8 @@ struct Ctx {
         for (auto& p : pend) p.buf = nullptr;
         return 0;
     }
-    const ortk_csr* csr(int64_t off) const {
-        for (int i = 0; i < nsp; ++i) if (sp[i].arena_offset == off) return sp + i;
+    const ortk_csr* csr(int64_t off, int N, int K) const {   // (with share_att "qk" a (d,d) projection starts where the K|V block does)
+        for (int i = 0; i < nsp; ++i) if (sp[i].arena_offset == off && sp[i].N == N && sp[i].K == K) return sp + i;
         return nullptr;
     }
     float p_drop() const { return train ? cfg->drop : 0.f; }
@@ -305,8 +327,7 @@ static int fwd_gemm(const Ctx& c, const void* X, int xdt, int64_t ldx, int64_t w
                     int64_t M, int N, int K, bool relu = false, float drop = 0.f, uint32_t seed = 0, const float* resid = nullptr,
                     int64_t ldr = 0, const float* rowscale = nullptr) {
     if (c.nsp && drop == 0.f && !rowscale) {
-        if (const ortk_csr* w = c.csr(woff)) {
-            if (w->N != N || w->K != K) return ORTK_EINVAL;
+        if (const ortk_csr* w = c.csr(woff, N, K)) {
             return ortk_spmm_csr(w, X, xdt, ldx, bias, Y, ydt, ldy, M, relu, resid, ldr, (ortk_stream)c.s);
         }
     }
@@ -420,12 +441,13 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
         TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s));
     }
     const float* x = x0;
+    const AttMode am = att_mode(cfg.share_att_enc);
     for (int l = 0; l < L; ++l) {
         const EncOff& e = o.enc[l]; const EncPtrs& b = bufs[l];
         TRY(ln_fwd(c, x, e.n0a, e.n0b, b.y1, A, b.st1, Me));
-        TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Me, 3 * d, d));
+        TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Me, am.n * d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
+        a.q = b.qkv; a.k = b.qkv + am.k * d; a.v = b.qkv + am.v * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
         a.kmask = masks; a.bias = logbias + (int64_t)l * B * H * S * S; a.p = b.P;
         a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         if (l == 0) TRY(c.wait_ev(box_done));
@@ -532,13 +554,15 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     const int64_t Me = w.Me, Md = w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
     c.use_side = c.adt == ORTK_BF16 && !ortk_prof_active() && g_side.init();
+    const AttMode am = att_mode(cfg->share_att_dec);
+    const int64_t cw = o.cw, cv = o.cv;
     // Self-attention sublayer (and the cross-attention query projection) of decoder layer l, on context `cx`'s stream.
     auto self_part = [&](const Ctx& cx, int l, const float* x) -> int {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         TRY(ln_fwd(cx, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
-        TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Md, 3 * d, d));
+        TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Md, am.n * d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
+        a.q = b.qkv; a.k = b.qkv + am.k * d; a.v = b.qkv + am.v * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
         a.kmask = w.keymask; a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.causal_period = T;
         a.drop_p = cx.p_drop(); a.drop_seed = cx.sub(dop(l, 0));
         TRY(ortk_attention_fwd(&a, (ortk_stream)cx.s));
@@ -562,13 +586,13 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     }
     // decoder
     const int U = o.ckv_slots;            // distinct decoder layers: one K|V slice each in the packed projection
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, (int64_t)U * 2 * d, Me, U * 2 * d, d));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, U * cw, Me, (int)(U * cw), d));
     const float* x = w.dx0;
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         if (l == 0 && c.use_side) TRY(c.wait_ev(prefix_done)); else TRY(self_part(c, l, x));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)o.ckv_slot[l] * 2 * d; a.v = a.k + d; a.ldk = a.ldv = (int64_t)U * 2 * d;
+        a.q = b.qc; a.ldq = d; a.k = w.ckv + o.ckv_slot[l] * cw; a.v = a.k + cv; a.ldk = a.ldv = U * cw;
         a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         TRY(ortk_attention_fwd(&a, stream));
@@ -645,6 +669,15 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     const int U = o.ckv_slots;
     int gslot[MAXLAYERS];
     { int extra = U; for (int l = 0; l < L; ++l) gslot[l] = cfg->share_dec[l] > 0 ? extra++ : o.ckv_slot[l]; }
+    // share_att: column blocks of w.gqkv that receive dQ (0) / dK / dV, and the add that folds the shared projection's two
+    // gradients together before the (rows, n*d) projection GEMMs.  Cross-attention with "kv": all dK slices (width d)
+    // first, all dV slices behind them (column L*d on), folded by one add over L*d columns.
+    const AttMode ame = att_mode(cfg->share_att_enc), amd = att_mode(cfg->share_att_dec);
+    const int64_t cw = o.cw, cv = o.cv, ldg = (int64_t)L * 2 * d, gdv = cfg->share_att_dec == 1 ? (int64_t)L * d : d;
+    auto fold = [&](const AttMode& m, int64_t rows) -> int {
+        if (m.gsrc < 0) return 0;
+        return ortk_axpy_cols(off_elems(w.gqkv, (int64_t)m.gsrc * d, A), off_elems(w.gqkv, (int64_t)m.gdst * d, A), A, 3 * d, rows, d, stream);
+    };
 
     float* dx = w.ga; float* dx2 = w.gb;
     // the (rows, d) bf16 gradient temporary rotates over three buffers: its producers (ln_bwd's masked copy, the cross-
@@ -677,11 +710,11 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qc; a.ldq = d; a.k = w.ckv + (int64_t)o.ckv_slot[l] * 2 * d; a.v = a.k + d; a.ldk = a.ldv = (int64_t)U * 2 * d;
+        a.q = b.qc; a.ldq = d; a.k = w.ckv + o.ckv_slot[l] * cw; a.v = a.k + cv; a.ldk = a.ldv = U * cw;
         a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         a.d_o = w.gy; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
-        a.d_k = off_elems(w.gkv, (int64_t)gslot[l] * 2 * d, A); a.dv = off_elems(w.gkv, (int64_t)gslot[l] * 2 * d + d, A);
-        a.lddk = a.lddv = (int64_t)L * 2 * d;
+        a.d_k = off_elems(w.gkv, gslot[l] * cw, A); a.dv = off_elems(w.gkv, gslot[l] * cw + gdv, A);
+        a.lddk = a.lddv = ldg;
         TRY(c.before_write(gt_cur));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, gt_cur, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
@@ -692,14 +725,15 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Md, d, d));
         std::memset(&a, 0, sizeof(a));
-        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+        a.q = b.qkv; a.k = b.qkv + amd.k * d; a.v = b.qkv + amd.v * d; a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
-        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, d, A); a.dv = off_elems(w.gqkv, 2 * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, amd.gk * d, A); a.dv = off_elems(w.gqkv, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
-        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
-        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, 3 * d, d));
+        TRY(fold(amd, Md));
+        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, amd.n * d, d));
+        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, amd.n * d, d));
         TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md, gt_new(), l > 0 ? (int)dop(l - 1, 5) : -1));
         std::swap(dx, dx2);
     }
@@ -715,12 +749,13 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     }
     // cross-attention K/V projections of all layers, and the gradient of the encoder memory
     // layers that share weights also share the projected K|V: their dK|dV slices add up into the slice of the layer they share
+    if (cfg->share_att_dec == 1)           // K = V: dK += dV, all layers at once
+        TRY(ortk_axpy_cols(off_elems(w.gkv, gdv, A), w.gkv, A, ldg, Me, (int64_t)L * d, stream));
     for (int l = 0; l < L; ++l)
         if (cfg->share_dec[l] > 0)
-            TRY(ortk_axpy_cols(off_elems(w.gkv, (int64_t)gslot[l] * 2 * d, A), off_elems(w.gkv, (int64_t)o.ckv_slot[l] * 2 * d, A), A,
-                               (int64_t)L * 2 * d, Me, 2 * d, stream));
-    TRY(wgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, U * 2 * d, d));
-    TRY(dgrad_gemm(c, w.gkv, A, (int64_t)L * 2 * d, o.ckv_w, w.gy, ORTK_F32, d, Me, U * 2 * d, d));
+            TRY(ortk_axpy_cols(off_elems(w.gkv, gslot[l] * cw, A), off_elems(w.gkv, o.ckv_slot[l] * cw, A), A, ldg, Me, cw, stream));
+    TRY(wgrad_gemm(c, w.gkv, A, ldg, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, (int)(U * cw), d));
+    TRY(dgrad_gemm(c, w.gkv, A, ldg, o.ckv_w, w.gy, ORTK_F32, d, Me, (int)(U * cw), d));
     TRY(c.join());
     }
     if (phase == 1) return 0;
@@ -741,15 +776,16 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Me, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-        a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+        a.q = b.qkv; a.k = b.qkv + ame.k * d; a.v = b.qkv + ame.v * d; a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
-        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, d, A); a.dv = off_elems(w.gqkv, 2 * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, ame.gk * d, A); a.dv = off_elems(w.gqkv, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         a.dscore = w.dscore + (int64_t)l * B * H * S * S;
         TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
-        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
-        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, 3 * d, d));
+        TRY(fold(ame, Me));
+        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, ame.n * d, d));
+        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, ame.n * d, d));
         TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, gt_new(), l > 0 ? (int)eop(l - 1, 3) : -1));
     }
     // geometry bias weights
@@ -793,19 +829,21 @@ extern "C" int ortk_linear_block(const ortk_config* cfg, int32_t i, int64_t* off
     if (int e = check_cfg(cfg)) return e;
     Offsets o; build_layout(*cfg, o, nullptr);
     const int d = cfg->d_model, ff = cfg->d_ff, L = cfg->n_layers;
+    const int ne = att_mode(cfg->share_att_enc).n, nd = att_mode(cfg->share_att_dec).n;
     struct Blk { int64_t off; int N, K; };
     std::vector<Blk> v;
     v.push_back({o.att_w, d, cfg->feat});
     for (int l = 0; l < L; ++l) {
         const EncOff& e = o.enc[l];
-        v.push_back({e.wqkv, 3 * d, d}); v.push_back({e.wo, d, d}); v.push_back({e.w1, ff, d}); v.push_back({e.w2, d, ff});
+        v.push_back({e.wqkv, ne * d, d}); v.push_back({e.wo, d, d}); v.push_back({e.w1, ff, d}); v.push_back({e.w2, d, ff});
     }
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l];
-        v.push_back({e.wqkv, 3 * d, d}); v.push_back({e.wo, d, d}); v.push_back({e.cqw, d, d}); v.push_back({e.cow, d, d});
+        v.push_back({e.wqkv, nd * d, d}); v.push_back({e.wo, d, d}); v.push_back({e.cow, d, d});
+        if (cfg->share_att_dec != 2) v.push_back({e.cqw, d, d});      // "qk": part of the packed K|V block below
         v.push_back({e.w1, ff, d}); v.push_back({e.w2, d, ff});
     }
-    v.push_back({o.ckv_w, o.ckv_slots * 2 * d, d});
+    v.push_back({o.ckv_w, (int)(o.ckv_slots * o.cw), d});
     v.push_back({o.gen_w, (int)ortk_align(cfg->vocab, 128), d});
     if (i < 0) return (int)v.size();
     if (i >= (int)v.size() || !offset || !N || !K) return ORTK_EINVAL;
@@ -907,14 +945,15 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = c.adt;
     const float* att_masks = w.att_masks;
     const int B = groups, per_img = per_group;
+    const AttMode am = att_mode(cfg->share_att_dec);
         TRY(ortk_embed_fwd(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, 1, t, d, cfg->pad_id, 0.f, 0, stream));
         float* x = w.xa; float* xn = w.xb;
         for (int l = 0; l < L; ++l) {
             const DecOff& e = o.dec[l];
             TRY(ln_fwd(c, x, e.n0a, e.n0b, w.y, A, w.st, rows));
-            TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, 3 * d, d));
+            TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, am.n * d, d));
             ortk_attn_args a; std::memset(&a, 0, sizeof(a));
-            a.k_new = w.qkv + d; a.v_new = w.qkv + 2 * d; a.ld_new = 3 * d;    // this position's K / V join the cache inside the kernel
+            a.k_new = w.qkv + am.k * d; a.v_new = w.qkv + am.v * d; a.ld_new = 3 * d;    // this position's K / V join the cache inside the kernel
             a.q = w.qkv; a.ldq = 3 * d; a.k = reinterpret_cast<const float*>(w.cache_k[l]); a.v = reinterpret_cast<const float*>(w.cache_v[l]);
             a.kv_dtype = w.kvdt; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
             a.nkv = (int)rows; a.H = H; a.Lq = 1; a.Lk = t + 1; a.dk = dk;
@@ -925,9 +964,9 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
             std::memset(&a, 0, sizeof(a));
-            a.q = w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)o.ckv_slot[l] * 2 * d, w.kvdt));
-            a.v = reinterpret_cast<const float*>(off_elems(w.ckv, (int64_t)o.ckv_slot[l] * 2 * d + d, w.kvdt)); a.kv_dtype = w.kvdt;
-            a.ldk = a.ldv = (int64_t)o.ckv_slots * 2 * d;
+            a.q = w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw, w.kvdt));
+            a.v = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw + o.cv, w.kvdt)); a.kv_dtype = w.kvdt;
+            a.ldk = a.ldv = o.ckv_slots * o.cw;
             a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
             TRY(ortk_attention_fwd(&a, stream));
             TRY(fwd_gemm(c, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
@@ -968,7 +1007,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     EncPtrs ep[MAXLAYERS];
     for (int l = 0; l < L; ++l) ep[l] = w.enc;
     TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.kvdt, (int64_t)o.ckv_slots * 2 * d, Me, o.ckv_slots * 2 * d, d));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.kvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
 
     const int64_t rows_full = (int64_t)B * K;
     BeamState bs; std::memset(&bs, 0, sizeof(bs));
@@ -1053,7 +1092,7 @@ extern "C" int ortk_project_memory(const ortk_config* cfg, const float* params, 
     const int d = cfg->d_model, L = cfg->n_layers;
     const int U = o.ckv_slots;      // distinct decoder layers (ortk_config.share_dec)
     (void)L;
-    return fwd_gemm(c, memory, ORTK_F32, d, o.ckv_w, params + o.ckv_b, cross_kv, ORTK_F32, (int64_t)U * 2 * d, mem_rows, U * 2 * d, d);
+    return fwd_gemm(c, memory, ORTK_F32, d, o.ckv_w, params + o.ckv_b, cross_kv, ORTK_F32, U * o.cw, mem_rows, (int)(U * o.cw), d);
 }
 
 extern "C" int ortk_decode_step(const ortk_config* cfg, const float* params, const int64_t* it, int32_t t, int32_t rows,

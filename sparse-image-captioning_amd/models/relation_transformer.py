@@ -58,9 +58,20 @@ def parse_share_layer(value, n_layers, what):
     return out
 
 
+def parse_share_att(value, what):
+    """``share_att_encoder / share_att_decoder`` (relation_transformer.py:140, transformer.py:223: None, "kv" or "qk")
+    -> ortk_config.share_att_* (0, 1, 2)."""
+    if value in (None, "", "None", "none"):          # str_to_none, transformer.py:591
+        return 0
+    assert value in ("kv", "qk"), f"Invalid `share_att`: {value}"           # the reference's own assertion
+    return 1 if value == "kv" else 2
+
+
 def make_ccfg(config, precision, drop, train_drop_src=None):
     c = L.Config()
     get = config.get if hasattr(config, "get") else (lambda k, d=None: getattr(config, k, d))
+    c.share_att_enc = parse_share_att(get("share_att_encoder", None), "share_att_encoder")
+    c.share_att_dec = parse_share_att(get("share_att_decoder", None), "share_att_decoder")
     for l, v in enumerate(parse_share_layer(get("share_layer_encoder", None), int(config.num_layers), "share_layer_encoder")):
         c.share_enc[l] = v
     for l, v in enumerate(parse_share_layer(get("share_layer_decoder", None), int(config.num_layers), "share_layer_decoder")):
@@ -131,9 +142,6 @@ class RelationTransformerModel(CaptionModelBase):
     def __init__(self, config, precision=None):
         super().__init__()
         self.config = config
-        for k in ("share_att_encoder", "share_att_decoder"):
-            if config.get(k, None) if hasattr(config, "get") else getattr(config, k, None):
-                raise NotImplementedError(f"`{k}` (ACORT Q/K/V projection sharing) is not implemented in the HIP path yet")
         # attributes the callers read (transformer.py:418-437; utils/training.py:253)
         self.d_model, self.dim_feedforward = config.d_model, config.dim_feedforward
         self.num_layers, self.num_heads = config.num_layers, config.num_heads
@@ -537,6 +545,8 @@ class RelationTransformerModel(CaptionModelBase):
         lib = L.lib()
         if any(self._ccfg.share_dec[l] for l in range(self.num_layers)):
             raise NotImplementedError("get_logprobs_state with share_layer_decoder: use mode='sample'")
+        if self._ccfg.share_att_dec:
+            raise NotImplementedError("get_logprobs_state with share_att_decoder: use mode='sample'")
         rows, S, d = memory.shape
         Lr, H = self.num_layers, self.num_heads
         dk, T = d // H, self.seq_length

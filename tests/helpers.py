@@ -12,7 +12,8 @@ def dense_param_shapes(cfg: dict) -> dict:
     s = {"att_embed.0.weight": (d, Fs), "att_embed.0.bias": (d,)}
 
     def attn(pre, box):
-        for i in range(4):
+        share = cfg.get("share_att_encoder" if box else "share_att_decoder")
+        for i in range(3 if share else 4):          # relation_transformer.py:142, transformer.py:225
             s[f"{pre}.linears.{i}.weight"] = (d, d)
             s[f"{pre}.linears.{i}.bias"] = (d,)
         if box:

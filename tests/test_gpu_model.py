@@ -261,6 +261,62 @@ def test_share_layer_vs_reference_golden(P, golden):
     assert sd["model.encoder.layers.2.feed_forward.w_1.weight"].data_ptr() == sd["model.encoder.layers.0.feed_forward.w_1.weight"].data_ptr()
 
 
+@pytest.mark.parametrize("tag,enc,dec", [("kv_qk", "kv", "qk"), ("qk_kv", "qk", "kv")])
+def test_share_att_vs_reference_golden(P, golden, tag, enc, dec):
+    """ACORT projection sharing inside the attention modules (`share_att_encoder / share_att_decoder` = "kv" | "qk"): three
+    linears per module as in the reference, log-probs, loss, every gradient (the shared projection receives both of its
+    roles' gradients), greedy and beam-3 tokens; plus one native trainer step and the mixed-precision forward."""
+    from sparse_image_captioning_amd.utils.config import Config
+    from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
+    g9 = golden("g9_tiny_share_att")
+    cfgd = dict(C.TINY_CFG, share_att_encoder=enc, share_att_decoder=dec)
+    names = [str(n) for n in g9[tag + "/param_names"]]
+    m = P.get_model("relation_transformer")(Config(**cfgd))
+    assert set(n for n, _ in m.named_parameters()) == set(names)
+    assert sum(p.numel() for p in m.parameters()) == int(g9[tag + "/n_params"])
+    state = H.torch_state(H.dense_param_shapes(cfgd), C.G1_SEED, C.G1_GEN_SCALE, C.G1_EOS_BIAS)
+    missing, unexpected = m.load_state_dict(state, strict=False)
+    assert not unexpected and all(k.endswith(".pe") for k in missing)
+    m = m.cuda().eval()
+    b = _cuda(H.g1_batch())
+    logp = m(att_feats=b["att_feats"], boxes=b["boxes"], seqs=b["seqs"], att_masks=b["att_masks"])
+    close(logp, g9[tag + "/logp"], 1e-4)
+    loss = LanguageModelCriterion()(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - float(g9[tag + "/xe_loss"])) < 1e-4
+    loss.backward()
+    grads = dict(m.named_parameters())
+    for n in names:
+        ref = g9[f"{tag}/grad/{n}"]
+        np.testing.assert_allclose(grads[n].grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(ref).max())), err_msg=n)
+    for bs in (1, 3):
+        seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": bs}, mode="sample")
+        np.testing.assert_array_equal(seq.cpu().numpy(), g9[f"{tag}/decode_b{bs}/seq"])
+        close(lp, g9[f"{tag}/decode_b{bs}/logprobs"], 2e-4)
+    with pytest.raises(NotImplementedError):
+        m.get_logprobs_state(b["seqs"][:, 0], torch.zeros(b["seqs"].size(0), 12, cfgd["d_model"], device="cuda"),
+                             torch.ones(b["seqs"].size(0), 12, device="cuda"), None)
+    from sparse_image_captioning_amd.training import NativeTrainer
+    tr = NativeTrainer(m, noamopt_warmup=10)
+    l0 = float(tr.xe_step(b, train=False))
+    assert abs(l0 - float(g9[tag + "/xe_loss"])) < 1e-4
+    l1 = float(tr.xe_step(b, train=False))
+    assert np.isfinite(l1) and l1 != l0
+    # mixed precision (side-stream executor): loss close to fp32's, gradients finite
+    mb = P.get_model("relation_transformer")(Config(**cfgd), precision="bf16")
+    mb.load_state_dict(state, strict=False)
+    mb = mb.cuda().eval()
+    lb = mb(att_feats=b["att_feats"], boxes=b["boxes"], seqs=b["seqs"], att_masks=b["att_masks"])
+    lossb = LanguageModelCriterion()(lb, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(lossb.item() - float(g9[tag + "/xe_loss"])) < 0.05
+    lossb.backward()
+    gb = dict(mb.named_parameters())
+    for n in ("model.decoder.layers.0.src_attn.linears.0.weight", "model.encoder.layers.0.self_attn.linears.1.weight",
+              "model.decoder.layers.1.self_attn.linears.0.weight"):
+        a, r = gb[n].grad.float().cpu().numpy(), g9[f"{tag}/grad/{n}"]
+        assert np.isfinite(a).all()
+        assert np.abs(a - r).max() < 0.08 * max(np.abs(r).max(), 1e-3), n
+
+
 def test_non_trigonometric_box_embedding_vs_reference_golden(P, golden):
     """`no_box_trigonometric_embedding`: WG is Linear(4, 1) on the raw log-ratios (relation_transformer.py:131-136,243-256)."""
     from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion

@@ -317,3 +317,33 @@ def test_share_layer_vs_reference_golden(golden):
         seq, lp, _ = O.beam_search(Pb, cfg, b["att_feats"], b["boxes"], b["att_masks"], beam_size=3)
         np.testing.assert_array_equal(seq.numpy(), g8["enc_only/decode_b3/seq"])
         close(lp, g8["enc_only/decode_b3/logprobs"], 1e-4)
+
+
+@pytest.mark.parametrize("tag,enc,dec", [("kv_qk", "kv", "qk"), ("qk_kv", "qk", "kv")])
+def test_share_att_vs_reference_golden(golden, tag, enc, dec):
+    """G9: ACORT projection sharing (K = V from one linear, or Q and K from one linear), three linears per module."""
+    g9 = golden("g9_tiny_share_att")
+    cfgd = dict(C.TINY_CFG, share_att_encoder=enc, share_att_decoder=dec)
+    cfg = _cfg(cfgd)
+    names = [str(n) for n in g9[tag + "/param_names"]]
+    shapes = H.dense_param_shapes(cfgd)
+    assert set(names) == set(shapes) and sum(int(np.prod(v)) for v in shapes.values()) == int(g9[tag + "/n_params"])
+    P = H.torch_state(shapes, C.G1_SEED, C.G1_GEN_SCALE, C.G1_EOS_BIAS, requires_grad=True)
+    b = H.g1_batch()
+    logp = O.forward_logp(P, cfg, b["att_feats"], b["boxes"], b["seqs"], b["att_masks"])
+    close(logp, g9[tag + "/logp"], 5e-5)
+    loss = O.xe_loss(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - float(g9[tag + "/xe_loss"])) < 1e-5
+    loss.backward()
+    for n in names:
+        ref = g9[f"{tag}/grad/{n}"]
+        np.testing.assert_allclose(P[n].grad.numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=n)
+    with torch.no_grad():
+        Pd = {k: v.detach() for k, v in P.items()}
+        for bs in (1, 3):
+            if bs == 1:
+                seq, lp = O.sample_greedy_or_multinomial(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"])[:2]
+            else:
+                seq, lp, _ = O.beam_search(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"], beam_size=3)
+            np.testing.assert_array_equal(seq.numpy(), g9[f"{tag}/decode_b{bs}/seq"])
+            close(lp, g9[f"{tag}/decode_b{bs}/logprobs"], 1e-4)
