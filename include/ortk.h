@@ -163,6 +163,7 @@ int ortk_encode(const ortk_config* cfg, const float* params, const float* att_fe
 
 /* Per-step host API: what RelationTransformerModel.get_logprobs_state (relation_transformer.py:374-387) runs per call.
  * ortk_project_memory: cross_kv (mem_rows, L*2*d) = memory (mem_rows, d) x the stacked src_attn K|V weights of all layers
+ *   (in general U*cw columns: U = distinct decoder layers under share_dec; cw = d with share_att_dec "kv", otherwise 2*d)
  *   (the reference fills its src_attn caches on the first step, transformer.py:255-273).
  * ortk_decode_step: tokens it (rows) at position t -> log-probs logp_out (rows, ld_out).  self_k / self_v are
  *   (L, rows, tmax, d) fp32 caches holding positions < t; position t is appended.  `rows / kv_groups` consecutive rows share
