@@ -71,8 +71,8 @@ __device__ __forceinline__ float4 ldrow4(const float* __restrict__ p, int n0, in
 // Epilogue of one wave's 64x64 sub-tile: acc[i][j] holds C[m = mrow0 + 16 i][n = ncol0 + 16 j + 0..3].
 // Bias is loaded once per j; residual / gate rows are fetched as float4 for all four j of a row BEFORE any of that
 // row's stores (independent loads in flight together instead of 16 load->store chains per thread).
-template <bool FAST>
-__device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0, f32x4 (&acc)[4][4]) {
+template <bool FAST, int MI = 4, int NJ = 4>
+__device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0, f32x4 (&acc)[MI][NJ]) {
     const bool first = e.first_split;
     // FAST: the launcher has verified full tiles and vector alignment of every pointer -> no bounds / alignment tests
     const bool vec_b = FAST || (e.bias && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0));
@@ -82,20 +82,20 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
     const int EN = FAST ? 0x7FFFFFFF : e.N, EM = FAST ? 0x7FFFFFFF : e.M;   // bounds the compiler can fold away
     const bool c16 = e.c_dt == ORTK_BF16, g16 = e.g_dt == ORTK_BF16;
     const float inv_keep = e.drop_p > 0.f ? 1.f / (1.f - e.drop_p) : 1.f;
-    float4 bias4[4];
+    float4 bias4[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int n0 = ncol0 + 16 * j;
         bias4[j] = (e.bias && first && n0 < EN) ? ldrow4(e.bias + n0, n0, EN, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
         const int m = mrow0 + 16 * i;
         if (m >= EM) continue;
         const float rs = e.rowscale ? e.rowscale[m] : 1.f;
-        float4 res[4], gat[4];
+        float4 res[NJ], gat[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int n0 = ncol0 + 16 * j;
             res[j] = (e.resid && first && n0 < EN) ? ldrow4(e.resid + (int64_t)m * e.ldr + n0, n0, EN, vec_r) : make_float4(0.f, 0.f, 0.f, 0.f);
             gat[j] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -109,7 +109,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int n0 = ncol0 + 16 * j;
             if (n0 >= EN) continue;
             const float bb[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
@@ -822,6 +822,109 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
 }
 constexpr size_t DMA256_LDS_BYTES = (size_t)2 * 2 * 256 * HBK * sizeof(__bf16);   // 128 KB
 
+
+// ------------------------------------------------------------------------------------------------
+// 64 x 64 tile, 64-column K-steps, forward layout only, for SHORT grids: the decode-time projections (rows = images x
+// beams, a few thousand at most) give the 128 x 128 kernels 48-640 workgroups, so most CUs idle or the last round is
+// nearly empty, and every workgroup walks its K panel as a chain of fetch round trips.  Four times as many workgroups
+// of a quarter of the size; ring of NS stages of 16 KB (A 64 x 64 + B 64 x 64 bf16):
+//   NS = 8 (128 KB, one workgroup per CU): a whole K = 512 panel is requested up front — one round trip, not K/BK of them;
+//   NS = 3 ( 48 KB, three per CU) for the longer grids.
+// 4 waves as 2 x 2, each 32 x 32 (2 x 2 MFMA 16x16x32 per 32 columns).  Same [m][k] image and swizzle as the 256-tile
+// kernel above (full 128-byte rows, chunk' = chunk ^ ((row >> 1) & 7)).
+template <int NS>
+__global__ __launch_bounds__(256, NS > 4 ? 1 : NS == 4 ? 2 : 3) void gemm_bf16_dma64_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    constexpr int IMG = 64 * HBK;                   // elements per operand image (8 KB)
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, mt = bid / tilesN;
+    const int mb = mt * 64, nb = nt * 64;
+    const __bf16* Ap = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bp = reinterpret_cast<const __bf16*>(p.B);
+    const int T = p.K / HBK;
+    (void)tilesM; (void)kchunk;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one 1-KB piece = 8 rows of 128 bytes; this wave moves pieces 2*wave, 2*wave + 1 of each operand image
+    auto piece = [&](const __bf16* base, int64_t ld, int tile0, int k0, __bf16* img, int inst) {
+        const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
+        const __bf16* g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
+    };
+    auto issue = [&](int t) {
+        __bf16* st = smem16 + (size_t)(t % NS) * 2 * IMG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) piece(Ap, p.lda, mb, t * HBK, st, wave * 2 + u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) piece(Bp, p.ldb, nb, t * HBK, st + IMG, wave * 2 + u);
+    };
+    // The epilogue's operands (bias, residual rows) are requested FIRST, ahead of the operand stages, instead of after the
+    // K loop: one fetch round trip less on a kernel that is a handful of round trips long (being the oldest loads they
+    // never make a counted stage wait stricter).  The launcher sends only epilogues without dropout / gate / row scale here.
+    const int mrow0 = mb + wm * 32 + (lane & 15), ncol0 = nb + wn * 32 + 4 * (lane >> 4);
+    f32x4 bias4[2], res4[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            res4[i][j] = p.resid ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)(mrow0 + 16 * i) * p.ldr + ncol0 + 16 * j)
+                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int t = 0; t < NS - 1 && t < T; ++t) issue(t);
+    for (int t = 0; t < T; ++t) {
+        // retire stage t (4 DMA instructions per stage and wave; up to NS-2 later stages stay in flight), then publish it
+        const int rem = min(T - 1 - t, NS - 2);
+        switch (rem) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NS - 1 < T) issue(t + NS - 1);          // every wave is past its reads of stage t-1
+        const __bf16* sA = smem16 + (size_t)(t % NS) * 2 * IMG;
+        const __bf16* sB = sA + IMG;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = gfrag64<false>(sB, wn * 32 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = gfrag64<false>(sA, wm * 32 + 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] + bias4[j][r];
+                if (p.relu) x = fmaxf(x, 0.f);
+                v[r] = x + res4[i][j][r];
+            }
+            st_elem4(p.C, (int64_t)(mrow0 + 16 * i) * p.ldc + ncol0 + 16 * j, p.c_dtype, make_float4(v[0], v[1], v[2], v[3]));
+        }
+}
+constexpr size_t DMA64_STAGE_BYTES = (size_t)2 * 64 * HBK * sizeof(__bf16);   // 16 KB
+
 typedef void (*gemm16_fn)(ortk_gemm_args, int, int, int);
 template <bool TA, bool TB, bool FAST> gemm16_fn pick16t(int adt, int bdt) {
     if (adt == ORTK_F32 && bdt == ORTK_F32) return gemm_bf16_kernel<TA, TB, float, float, FAST>;
@@ -920,6 +1023,29 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         // 21.3 (the k-major layouts lose: dgrad 4.1 vs 3.3 ms, wgrad 4.1 vs 3.4 ms per step in isolation); the DMA kernels
         // therefore serve the forward layout only unless ORTK_GEMM_IMPL >= 2 asks for them everywhere.
         const bool dma_layout = key == 4 || impl >= 2;
+        // short forward grids (decode-time projections): 64 x 64 tiles
+        // Measured with bias + residual epilogues (scratch/gemm_t64.py, us, 128^2/256^2 kernels -> 64^2): 1536x512x512 16.4 -> 7.9,
+        // 1536x512x2048 33.3 -> 15.6, 5120x512x512 16.8 -> 10.5, 5120x512x2048 35.9 -> 23.4, 5120x2048x512 31.4 -> 29.1,
+        // 9216x512x512 23.3 -> 17.6; past ~640 big tiles or with the generator's N = 10240 the small tiles lose (5120x10240x512
+        // 163 -> 178, 21760x1536x512 87 -> 106).
+        static int t64 = -2;    // ORTK_GEMM_T64: use them while the 128 x 128 grid has at most this many workgroups (-1 = never)
+        if (t64 == -2) { const char* ev = getenv("ORTK_GEMM_T64"); t64 = ev ? atoi(ev) : 640; }
+        if (fast && key == 4 && impl != 1 && !p.accumulate && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.K % HBK == 0 &&
+            p.drop_p == 0.f && !p.gate && !p.rowscale && (int64_t)tilesM * tilesN <= t64 && p.N <= 2048) {
+            const int tm = p.M / 64, tn = p.N / 64;
+            const bool one = (int64_t)tm * tn <= 256 + 64;          // one workgroup per CU: the whole K = 512 panel in flight
+            gemm16_fn g = one ? gemm_bf16_dma64_kernel<8> : gemm_bf16_dma64_kernel<3>;    // else three per CU
+            const size_t lds = (one ? 8 : 3) * DMA64_STAGE_BYTES;
+            static bool attr64[2] = {false, false};
+            if (!attr64[one]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr64[one] = true;
+            }
+            hipLaunchKernelGGL(g, dim3((unsigned)(tm * tn)), dim3(256), lds, s, p, tm, tn, kchunk);
+            if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
+            ORTK_CHECK_LAUNCH();
+            return 0;
+        }
         if (fast && impl != 1 && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0) {
             // 256 x 256 tiles when they still give enough workgroups (and no split-K accumulation, which needs the
             // staged 128 x 128 epilogue); impl 2 = small tiles only, impl 3 = big tiles whenever legal
