@@ -258,6 +258,9 @@ typedef struct ortk_attn_args {
      * (and dscore), part 2 completes dK / dV — so that a host can keep part 2 off its critical path (a kernel that cannot
      * split does everything in part 1 and nothing in part 2). */
     int32_t bwd_part;
+    /* 0 = fp32 products (v_mfma_f32_16x16x4_f32: the parity mode); 1 = the operands of the four products are rounded to bf16
+     * (fp32 accumulation, fp32 soft-max; served for dk = 64, Lk <= 64, 32 < Lq <= 128 — other shapes run the fp32 kernels) */
+    int32_t precision;
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);

@@ -1,0 +1,316 @@
+// ortk_attn16.hip — bf16-MFMA attention for the mixed-precision mode (ortk_attn_args.precision = 1), forward and backward,
+// for the two block shapes of the training step: encoder self-attention (36 x 36 regions, additive geometry bias) and
+// decoder cross-attention (all captions of an image, 5 x 17 = 85 query rows, against its 36 regions); dk = 64.
+//
+// Same mathematics as the fp32-MFMA kernels of ortk_attn.hip (transformer.py:285-295, relation_transformer.py:258-293)
+// — score = q.k / sqrt(dk); score[mask == 0] = -1e9; score += bias; P = softmax; O = dropout(P) V — with the operands of
+// the four small products rounded to bf16 (fp32 accumulation, fp32 soft-max, fp32 P saved for the backward).  Why a
+// second family: the fp32 kernels keep fp32 images of Q, K, V, dO, dS, P in LDS (109 KB for the cross-attention backward:
+// ONE workgroup per CU, its load -> compute -> store phases fully exposed, 166 us where the HBM traffic needs 40) and
+// feed v_mfma_f32_16x16x4_f32 one dword per lane and multiply-add.  Here every image is bf16 with 144-byte rows (30 KB
+// forward, 53-71 KB backward: 2-5 workgroups per CU), a fragment is one ds_read_b128 or two ds_read_b64_tr_b16, and a
+// 16 x 16 x 64 product is two v_mfma_f32_16x16x32_bf16.
+//
+// Layout rules (lane = (lr = lane & 15, lq = lane >> 4); MFMA(X, Y) gives D[x = 4*lq + r][y = lr], both operands
+// supplying [index = lr][k = 8*lq .. 8*lq + 7]):
+//   * every product is computed TRANSPOSED so that a lane ends up with 4 CONSECUTIVE elements of an output row:
+//     scores S^T[key j = 16*jt + 4*lq + r][query i = lr] (soft-max over keys = in-lane + 2 shuffles; P rows, bias rows and
+//     the LDS images of P / dS are 16- and 8-byte vector accesses), outputs O / dQ / dK / dV as [feature 4 consecutive][row];
+//   * an operand whose k index runs along its image ROWS (K in dS.K, Q / dO / dS / P in the dK, dV products, V in P.V) is
+//     gathered by the hardware-transposing LDS read; padded k ranges (keys 36 -> 64, queries 85 -> 96, 36 -> 64) are zero
+//     rows / columns of the images.
+// The pitch of 72 bf16 (144 B) makes the 16 rows of a ds_read_b128 service group fall on 16 distinct 16-byte slots.
+#include "ortk_common.h"
+
+namespace {
+
+constexpr int P16 = 72;                 // bf16 elements per image row
+constexpr int DK = 64;
+
+__device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// [index = row][k = k0 .. k0+7]: 8 consecutive elements of an image row
+__device__ __forceinline__ bf16x8 frag_row(const __bf16* img, int row, int k0) {
+    return *reinterpret_cast<const bf16x8*>(img + row * P16 + k0);
+}
+// [index = x0 + lr][k = k0 + 8*lq .. +7] where k runs along the image ROWS: two transposing reads of 4 rows x 16 columns
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int k0, int x0, int lane) {
+    const int lr = lane & 15, lq = lane >> 4;
+    const __bf16* p = img + (k0 + 8 * lq + (lr >> 2)) * P16 + x0 + 4 * (lane & 3);
+    typedef bf16x4 __attribute__((address_space(3))) * lds4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + 4 * P16));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x4 cvt4(float4 v) { return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w}; }
+__device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
+    return (bf16x8){(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+}
+__device__ __forceinline__ f32x4 mma(bf16x8 x, bf16x8 y, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc, 0, 0, 0); }
+
+// rows [0, rows) of a (.., 64)-column fp32 matrix slice -> bf16 image; rows [rows, rows_pad) are zeroed
+__device__ __forceinline__ void stage_rows(__bf16* img, const float* src, int64_t ld, int rows, int rows_pad, int tid, int nthr) {
+    for (int idx = tid; idx < rows_pad * 16; idx += nthr) {
+        const int r = idx >> 4, c = (idx & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + c);
+        *reinterpret_cast<bf16x4*>(img + r * P16 + c) = cvt4(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// One workgroup per (group g, head h); one wave per 16-row query tile.  NJT = key tiles (Lk <= 16 * NJT <= 64).
+template <int NJT>
+__global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 sm16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
+    const int Lk = a.Lk, Lq = a.Lq;
+    __bf16* sK = sm16;                              // [16*NJT][P16]  rows = key            (row fragments)
+    __bf16* sV = sK + 16 * NJT * P16;               // [64][P16]      rows = key, zero-padded (k of P.V: transposing reads)
+    __bf16* sP = sV + 64 * P16 + wave * 16 * P16;   // [16][P16]      this wave's dropped P: rows = query, columns = key 0..63
+    float* sMask = reinterpret_cast<float*>(sm16 + (16 * NJT + 64 + 16 * nw) * P16);   // [64]
+    stage_rows(sK, a.k + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
+    stage_rows(sV, a.v + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 64, tid, blockDim.x);
+    if (tid < 64) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
+    // key columns 16*NJT .. 63 of the P image are never written below: zero them once
+    for (int idx = lane; idx < 16 * 16; idx += 64) *reinterpret_cast<bf16x4*>(sP + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));
+    __syncthreads();
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int lr = lane & 15, lq = lane >> 4;
+    const bool vec_p = (Lk & 3) == 0;               // P / bias rows start 16-byte aligned
+    const int nit = (Lq + 15) >> 4;
+    for (int it = wave; it < nit; it += nw) {
+        const int i = it * 16 + lr;                 // this lane's query (operand row and output row)
+        const bool iv = i < Lq;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+            if (iv) {
+                const float* qp = a.q + ((int64_t)g * Lq + i) * a.ldq + h * DK + 32 * ks + 8 * lq;
+                q0 = *reinterpret_cast<const float4*>(qp); q1 = *reinterpret_cast<const float4*>(qp + 4);
+            }
+            qf[ks] = cvt8(q0, q1);
+        }
+        // S^T[j = 16*jt + 4*lq + r][i = lr]
+        f32x4 s[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) s[jt] = mma(frag_row(sK, 16 * jt + lr, 32 * ks + 8 * lq), qf[ks], s[jt]);
+        }
+        const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
+        const int qpos = a.causal_period > 0 ? i % a.causal_period : 0;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int j0 = 16 * jt + 4 * lq;
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias && iv) {
+                if (vec_p && j0 < Lk) b4 = *reinterpret_cast<const float4*>(a.bias + prow + j0);
+                else { float* bp = &b4.x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) bp[r] = a.bias[prow + j0 + r]; }
+            }
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + r;
+                const float mk = sMask[j];
+                float x = s[jt][r] * 0.125f;                                      // 1 / sqrt(64)
+                if (mk == 0.f || (a.causal_period > 0 && j > qpos)) x = -1e9f;
+                if (mk < 0.f) x = -INFINITY;                                      // padded key: not part of the row
+                else if (a.bias && iv) x = bb[r] + x;
+                s[jt][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = expf(s[jt][r] - mx); s[jt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int j0 = 16 * jt + 4 * lq;
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = (iv && j0 + r < Lk) ? s[jt][r] / sum : 0.f;
+            if (a.p && iv) {
+                if (vec_p && j0 < Lk) *reinterpret_cast<float4*>(a.p + prow + j0) = make_float4(p[0], p[1], p[2], p[3]);
+                else for (int r = 0; r < 4; ++r) if (j0 + r < Lk) a.p[prow + j0 + r] = p[r];
+            }
+            if (a.drop_p > 0.f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = ortk_keep(a.drop_seed, (uint64_t)(prow + j0 + r), a.drop_p) ? p[r] * inv_keep : 0.f;
+            *reinterpret_cast<bf16x4*>(sP + lr * P16 + j0) = cvt4(make_float4(p[0], p[1], p[2], p[3]));
+        }
+        wsync();
+        // O^T[d = 16*dt + 4*lq + r][i = lr] = sum_j V[j][d] Pd[i][j]
+        const bf16x8 pf0 = frag_row(sP, lr, 8 * lq), pf1 = frag_row(sP, lr, 32 + 8 * lq);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+            o = mma(frag_tr(sV, 0, 16 * dt, lane), pf0, o);
+            if (NJT > 2) o = mma(frag_tr(sV, 32, 16 * dt, lane), pf1, o);
+            if (iv) st_elem4(a.o, ((int64_t)g * Lq + i) * a.ldo + h * DK + 16 * dt + 4 * lq, a.o_dtype, make_float4(o[0], o[1], o[2], o[3]));
+        }
+        wsync();
+    }
+}
+static size_t fwd16_lds(int njt, int nw) { return (size_t)(16 * njt + 64 + 16 * nw) * P16 * sizeof(__bf16) + 64 * sizeof(float); }
+
+// ------------------------------------------------------------------------------------------------ backward
+// Phase 1 (wave = 16-row query tile): dP^T = V dO^T, dS = P (dP - rowsum(P dP)), dQ = dS K / sqrt(dk); dS / sqrt(dk) and the
+// dropped P go to workgroup-wide images.  Phase 2 (the 2 x NJT x 4 output tiles shared by the waves): dK = dS^T Q / sqrt(dk),
+// dV = Pd^T dO over all query rows of the group.  Lqp = query rows padded to a multiple of 32 (k range of phase 2).
+template <int NJT>
+__global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int Lqp) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 sm16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
+    const int Lk = a.Lk, Lq = a.Lq;
+    __bf16* sK = sm16;                      // [64][P16]      rows = key, zero-padded   (k of dS.K: transposing reads)
+    __bf16* sV = sK + 64 * P16;             // [16*NJT][P16]  rows = key                (row fragments of dP^T = V dO^T)
+    __bf16* sQ = sV + 16 * NJT * P16;       // [Lqp][P16]     rows = query              (k of dS^T Q: transposing reads)
+    __bf16* sG = sQ + Lqp * P16;            // [Lqp][P16]     dO: row fragments in phase 1, transposing reads in phase 2
+    __bf16* sS = sG + Lqp * P16;            // [Lqp][P16]     dS / sqrt(dk): rows = query, columns = key 0..63
+    __bf16* sD = sS + Lqp * P16;            // [Lqp][P16]     dropped P
+    stage_rows(sK, a.k + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 64, tid, blockDim.x);
+    stage_rows(sV, a.v + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
+    stage_rows(sQ, a.q + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
+    stage_rows(sG, a.d_o + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
+    // dS / P images: the key columns 16*NJT .. 63 and the query rows past the last wave tile are never written below
+    for (int idx = tid; idx < 2 * Lqp * 16; idx += blockDim.x)
+        *reinterpret_cast<bf16x4*>(sS + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));   // sD follows sS
+    __syncthreads();
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int lr = lane & 15, lq = lane >> 4;
+    const bool vec_p = (Lk & 3) == 0;
+    const int nit = (Lq + 15) >> 4;
+    for (int it = wave; it < nit; it += nw) {
+        const int i0 = it * 16, i = i0 + lr;
+        const bool iv = i < Lq;
+        const bf16x8 g0 = frag_row(sG, i, 8 * lq), g1 = frag_row(sG, i, 32 + 8 * lq);
+        const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
+        // dP^T[j = 16*jt + 4*lq + r][i = lr]
+        f32x4 dp[NJT], pp[NJT];
+        float dot = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            dp[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[jt] = mma(frag_row(sV, 16 * jt + lr, 8 * lq), g0, dp[jt]);
+            dp[jt] = mma(frag_row(sV, 16 * jt + lr, 32 + 8 * lq), g1, dp[jt]);
+            const int j0 = 16 * jt + 4 * lq;
+            float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iv) {
+                if (vec_p && j0 < Lk) p4 = *reinterpret_cast<const float4*>(a.p + prow + j0);
+                else { float* q = &p4.x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) q[r] = a.p[prow + j0 + r]; }
+            }
+            const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+            float pd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = iv && j0 + r < Lk;
+                const bool keep = valid && (a.drop_p > 0.f ? ortk_keep(a.drop_seed, (uint64_t)(prow + j0 + r), a.drop_p) : true);
+                const float d = keep ? dp[jt][r] * inv_keep : 0.f;
+                pd[r] = keep ? pv[r] * inv_keep : 0.f;
+                pp[jt][r] = valid ? pv[r] : 0.f; dp[jt][r] = d; dot += pp[jt][r] * d;
+            }
+            *reinterpret_cast<bf16x4*>(sD + i * P16 + j0) = cvt4(make_float4(pd[0], pd[1], pd[2], pd[3]));
+        }
+        dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int j0 = 16 * jt + 4 * lq;
+            float ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[r] = pp[jt][r] * (dp[jt][r] - dot);
+            if (a.dscore && iv) {
+                if (vec_p && j0 < Lk) *reinterpret_cast<float4*>(a.dscore + prow + j0) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                else for (int r = 0; r < 4; ++r) if (j0 + r < Lk) a.dscore[prow + j0 + r] = ds[r];
+            }
+            *reinterpret_cast<bf16x4*>(sS + i * P16 + j0) = cvt4(make_float4(ds[0] * 0.125f, ds[1] * 0.125f, ds[2] * 0.125f, ds[3] * 0.125f));
+        }
+        wsync();
+        // dQ^T[d = 16*dt + 4*lq + r][i = lr] = sum_j K[j][d] dSs[i][j]
+        const bf16x8 s0 = frag_row(sS, i, 8 * lq), s1 = frag_row(sS, i, 32 + 8 * lq);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = mma(frag_tr(sK, 0, 16 * dt, lane), s0, acc);
+            if (NJT > 2) acc = mma(frag_tr(sK, 32, 16 * dt, lane), s1, acc);
+            if (iv) st_elem4(a.dq, ((int64_t)g * Lq + i) * a.lddq + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        }
+    }
+    __syncthreads();
+    // phase 2: tile t = (which, jt, dt): D[d = 16*dt + 4*lq + r][j = 16*jt + lr] = sum_i B[i][d] A[i][j]
+    const int ntiles = 2 * NJT * 4;
+    for (int t = wave; t < ntiles; t += nw) {
+        const int which = t / (NJT * 4), rem = t - which * NJT * 4, jt = rem >> 2, dt = rem & 3;
+        const __bf16* sA = which == 0 ? sS : sD;      // [query][key]
+        const __bf16* sB = which == 0 ? sQ : sG;      // [query][feature]
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < Lqp; k0 += 32) acc = mma(frag_tr(sB, k0, 16 * dt, lane), frag_tr(sA, k0, 16 * jt, lane), acc);
+        const int j = 16 * jt + lr;
+        if (j < Lk) {
+            const int64_t row = (int64_t)g * Lk + j;
+            const float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (which == 0) st_elem4(a.d_k, row * a.lddk + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, v);
+            else            st_elem4(a.dv, row * a.lddv + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, v);
+        }
+    }
+}
+static size_t bwd16_lds(int njt, int Lqp) { return (size_t)(64 + 16 * njt + 4 * Lqp) * P16 * sizeof(__bf16); }
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+namespace ortk {
+
+// shapes / layouts these kernels serve (everything else stays with the fp32-MFMA family)
+bool attn16_ok(const ortk_attn_args* a, bool bwd) {
+    if (a->precision != 1 || a->dk != 64 || a->Lk < 1 || a->Lk > 64 || a->Lq <= 32 || a->Lq > 128) return false;
+    if (a->kv_index || a->kv_group_stride > 0 || a->kv_dtype != 0 || a->k_new || a->v_new) return false;
+    if ((a->ldq | a->ldk | a->ldv) % 4 || !al16(a->q) || !al16(a->k) || !al16(a->v)) return false;
+    if (!bwd) {
+        const int64_t eo = a->o_dtype == ORTK_BF16 ? 2 : 4;
+        if (a->ldo % 4 || (reinterpret_cast<uintptr_t>(a->o) % (4 * eo)) || (a->p && !al16(a->p)) || (a->bias && !al16(a->bias))) return false;
+    } else {
+        const int64_t eg = a->dqkv_dtype == ORTK_BF16 ? 2 : 4;
+        if (!a->p || !a->d_o || !a->dq || !a->d_k || !a->dv) return false;
+        if ((a->lddo | a->lddq | a->lddk | a->lddv) % 4 || !al16(a->d_o) || !al16(a->p) || (a->dscore && !al16(a->dscore))) return false;
+        if ((reinterpret_cast<uintptr_t>(a->dq) | reinterpret_cast<uintptr_t>(a->d_k) | reinterpret_cast<uintptr_t>(a->dv)) % (4 * eg)) return false;
+    }
+    return true;
+}
+
+int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
+    const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16;
+    typedef void (*fn_t)(ortk_attn_args);
+    const fn_t fn = njt == 1 ? attn16_fwd_kernel<1> : njt == 2 ? attn16_fwd_kernel<2> : njt == 3 ? attn16_fwd_kernel<3> : attn16_fwd_kernel<4>;
+    const size_t lds = fwd16_lds(njt, nw);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, s, *a);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+int attn16_bwd(const ortk_attn_args* a, hipStream_t s) {
+    const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16, Lqp = (int)ortk_align(a->Lq, 32);
+    typedef void (*fn_t)(ortk_attn_args, int);
+    const fn_t fn = njt == 1 ? attn16_bwd_kernel<1> : njt == 2 ? attn16_bwd_kernel<2> : njt == 3 ? attn16_bwd_kernel<3> : attn16_bwd_kernel<4>;
+    const size_t lds = bwd16_lds(njt, Lqp);
+    static bool attr[4] = {false, false, false, false};
+    if (lds > 64 * 1024 && !attr[njt - 1]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr[njt - 1] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, s, *a, Lqp);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace ortk

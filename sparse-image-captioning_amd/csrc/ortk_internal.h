@@ -11,6 +11,11 @@ bool ortk_prof_active();
 int kv_append(const float* qkv, void* cache_k, void* cache_v, int32_t kv_dtype, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax,
               int32_t t, hipStream_t s);
 
+// bf16-MFMA attention (ortk_attn16.hip): whether the call's shapes / layouts are served, and the launchers
+bool attn16_ok(const ortk_attn_args* a, bool bwd);
+int attn16_fwd(const ortk_attn_args* a, hipStream_t s);
+int attn16_bwd(const ortk_attn_args* a, hipStream_t s);
+
 struct BeamState {
     int32_t B, b, L, V, eos;
     int64_t ldv;

@@ -446,7 +446,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
         const EncOff& e = o.enc[l]; const EncPtrs& b = bufs[l];
         TRY(ln_fwd(c, x, e.n0a, e.n0b, b.y1, A, b.st1, Me));
         TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Me, am.n * d, d));
-        ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.q = b.qkv; a.k = b.qkv + am.k * d; a.v = b.qkv + am.v * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
         a.kmask = masks; a.bias = logbias + (int64_t)l * B * H * S * S; a.p = b.P;
         a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
@@ -561,7 +561,7 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         TRY(ln_fwd(cx, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
         TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Md, am.n * d, d));
-        ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = cx.prec;
         a.q = b.qkv; a.k = b.qkv + am.k * d; a.v = b.qkv + am.v * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
         a.kmask = w.keymask; a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.causal_period = T;
         a.drop_p = cx.p_drop(); a.drop_seed = cx.sub(dop(l, 0));
@@ -591,7 +591,7 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         if (l == 0 && c.use_side) TRY(c.wait_ev(prefix_done)); else TRY(self_part(c, l, x));
-        ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.q = b.qc; a.ldq = d; a.k = w.ckv + o.ckv_slot[l] * cw; a.v = a.k + cv; a.ldk = a.ldv = U * cw;
         a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
@@ -709,7 +709,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(drop_bwd(c, dx2, gt_cur, Md * d, dop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
-        ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.q = b.qc; a.ldq = d; a.k = w.ckv + o.ckv_slot[l] * cw; a.v = a.k + cv; a.ldk = a.ldv = U * cw;
         a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         a.d_o = w.gy; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
@@ -724,7 +724,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(drop_bwd(c, dx, gt_cur, Md * d, dop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Md, d, d));
-        std::memset(&a, 0, sizeof(a));
+        std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.q = b.qkv; a.k = b.qkv + amd.k * d; a.v = b.qkv + amd.v * d; a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
@@ -775,7 +775,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(drop_bwd(c, dx2, gt_cur, Me * d, eop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Me, d, d));
-        ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.q = b.qkv; a.k = b.qkv + ame.k * d; a.v = b.qkv + ame.v * d; a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
@@ -952,7 +952,7 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             const DecOff& e = o.dec[l];
             TRY(ln_fwd(c, x, e.n0a, e.n0b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.wqkv, P + e.bqkv, w.qkv, ORTK_F32, 3 * d, rows, am.n * d, d));
-            ortk_attn_args a; std::memset(&a, 0, sizeof(a));
+            ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
             a.k_new = w.qkv + am.k * d; a.v_new = w.qkv + am.v * d; a.ld_new = 3 * d;    // this position's K / V join the cache inside the kernel
             a.q = w.qkv; a.ldq = 3 * d; a.k = reinterpret_cast<const float*>(w.cache_k[l]); a.v = reinterpret_cast<const float*>(w.cache_v[l]);
             a.kv_dtype = w.kvdt; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
@@ -963,7 +963,7 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             std::swap(x, xn);
             TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
-            std::memset(&a, 0, sizeof(a));
+            std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
             a.q = w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw, w.kvdt));
             a.v = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw + o.cv, w.kvdt)); a.kv_dtype = w.kvdt;
             a.ldk = a.ldv = o.ckv_slots * o.cw;

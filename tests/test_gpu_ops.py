@@ -185,7 +185,7 @@ def test_box_embedding_and_logbias(L):
         assert (dbg[l].cpu() - br[l].grad).abs().max().item() < 2e-2 * br[l].grad.abs().max().item()
 
 
-def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0):
+def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0, precision=0, out_dt=0):
     d = H * dk
     q, k, v = rnd(nkv * Lq, d, seed=seed + 1), rnd(nkv * Lk, d, seed=seed + 2), rnd(nkv * Lk, d, seed=seed + 3)
     kmask = torch.ones(nkv, Lk)
@@ -205,8 +205,17 @@ def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0):
     ref_o = ref.transpose(1, 2).reshape(nkv * Lq, d)
     ref_o.backward(do)
     a = L.AttnArgs()
+    a.precision = precision; a.o_dtype = a.dqkv_dtype = out_dt
+    odt = torch.bfloat16 if out_dt else torch.float32
+    # bf16 operands: error relative to the tensor's scale (the fp32 kernels keep the tight element-wise bound)
+    def close(x, y, rtol, atol):
+        if precision:
+            err = (x.float() - y).abs().max().item()
+            assert err < 2e-2 * max(y.abs().max().item(), 1e-3), err
+        else:
+            torch.testing.assert_close(x, y, rtol=rtol, atol=atol)
     qd, kd, vd, dod = dev(q), dev(k), dev(v), dev(do)
-    o = torch.empty(nkv * Lq, d, device="cuda"); p = torch.empty(nkv, H, Lq, Lk, device="cuda")
+    o = torch.empty(nkv * Lq, d, device="cuda", dtype=odt); p = torch.empty(nkv, H, Lq, Lk, device="cuda")
     a.q, a.k, a.v, a.o = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr()
     a.ldq = a.ldk = a.ldv = a.ldo = d
     km = dev(kmask); a.kmask = km.data_ptr()
@@ -214,17 +223,17 @@ def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0):
         bd = dev(bias); a.bias = bd.data_ptr()
     a.p = p.data_ptr(); a.nkv, a.H, a.Lq, a.Lk, a.dk, a.causal_period = nkv, H, Lq, Lk, dk, causal
     L.check(L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()), "attn_fwd")
-    torch.testing.assert_close(o.cpu(), ref_o.detach(), rtol=1e-4, atol=1e-5)
-    dq, dk_, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    close(o.cpu(), ref_o.detach(), 1e-4, 1e-5)
+    dq, dk_, dv = (torch.empty_like(t, dtype=odt) for t in (qd, kd, vd))
     ds = torch.empty(nkv, H, Lq, Lk, device="cuda")
     a.d_o, a.dq, a.d_k, a.dv, a.dscore = dod.data_ptr(), dq.data_ptr(), dk_.data_ptr(), dv.data_ptr(), ds.data_ptr()
     a.lddo = a.lddq = a.lddk = a.lddv = d
     L.check(L.lib().ortk_attention_bwd(C.byref(a), L.stream_ptr()), "attn_bwd")
-    torch.testing.assert_close(dq.cpu(), qr.grad, rtol=1e-4, atol=2e-5)
-    torch.testing.assert_close(dk_.cpu(), kr.grad, rtol=1e-4, atol=2e-5)
-    torch.testing.assert_close(dv.cpu(), vr.grad, rtol=1e-4, atol=2e-5)
+    close(dq.cpu(), qr.grad, 1e-4, 2e-5)
+    close(dk_.cpu(), kr.grad, 1e-4, 2e-5)
+    close(dv.cpu(), vr.grad, 1e-4, 2e-5)
     if use_bias:
-        torch.testing.assert_close(ds.cpu(), br.grad, rtol=1e-4, atol=2e-5)
+        close(ds.cpu(), br.grad, 1e-4, 2e-5)
 
 
 def test_attention_shapes(L):
@@ -241,6 +250,17 @@ def test_attention_shapes(L):
     _attn_case(L, 6, 8, 1, 36, 64, 0, False, True)       # first beam pass: one row per image
     _attn_case(L, 40, 8, 1, 13, 64, 0, False, False)     # decode self-attention: one row, all 8 heads in one wave
     _attn_case(L, 7, 8, 1, 32, 64, 0, False, True)       # ... longest supported cache, with key mask
+
+
+def test_attention_bf16_operand_kernels(L):
+    """ortk_attn_args.precision = 1: the bf16-MFMA block kernels (ortk_attn16.hip) on the training shapes, against the fp32
+    torch attention at bf16-operand tolerance (2 % of each tensor's scale); fp32 and bf16 outputs."""
+    _attn_case(L, 5, 8, 36, 36, 64, 0, True, True, precision=1)              # encoder box attention: 3 key tiles, k range padded to 64
+    _attn_case(L, 3, 8, 85, 36, 64, 0, False, True, precision=1, out_dt=1)   # cross attention, bf16 O / dQ / dK / dV as in the executor
+    _attn_case(L, 2, 4, 50, 64, 64, 0, True, True, precision=1)              # 4 full key tiles
+    _attn_case(L, 3, 2, 40, 13, 64, 0, False, True, precision=1)             # one key tile, Lk not a multiple of 4 (scalar P rows)
+    _attn_case(L, 2, 8, 51, 17, 64, 17, False, True, precision=1)            # causal period
+    _attn_case(L, 2, 1, 128, 30, 64, 0, True, False, precision=1, out_dt=1)  # 8 waves
 
 
 @pytest.mark.parametrize("H,dk,kvdt", [(8, 64, 0), (8, 64, 1), (4, 16, 0)])
@@ -350,11 +370,13 @@ def test_attention_bf16_kv_cache(L, Lq, Lk, use_idx):
     assert L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()) == -1
 
 
-@pytest.mark.parametrize("nkv,H,Lq,Lk,dk", [(3, 2, 9, 11, 16), (5, 8, 17, 17, 64), (2, 8, 36, 36, 64)])
-def test_attention_dropout_is_consistent_between_fwd_and_bwd(L, nkv, H, Lq, Lk, dk):
+@pytest.mark.parametrize("nkv,H,Lq,Lk,dk,prec", [(3, 2, 9, 11, 16, 0), (5, 8, 17, 17, 64, 0), (2, 8, 36, 36, 64, 0), (2, 8, 36, 36, 64, 1),
+                                                 (2, 8, 85, 36, 64, 1)])
+def test_attention_dropout_is_consistent_between_fwd_and_bwd(L, nkv, H, Lq, Lk, dk, prec):
     d = H * dk
     q, k, v, do = (dev(rnd(nkv * n, d, seed=s)) for n, s in ((Lq, 1), (Lk, 2), (Lk, 3), (Lq, 4)))
     a = L.AttnArgs()
+    a.precision = prec
     o = torch.empty(nkv * Lq, d, device="cuda"); p = torch.empty(nkv, H, Lq, Lk, device="cuda")
     a.q, a.k, a.v, a.o, a.p = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), p.data_ptr()
     a.ldq = a.ldk = a.ldv = a.ldo = d
@@ -367,12 +389,12 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L, nkv, H, Lq, Lk, 
     a.lddo = a.lddq = a.lddk = a.lddv = d
     L.check(L.lib().ortk_attention_bwd(C.byref(a), L.stream_ptr()), "attn_bwd")
     # finite-difference check of dV through the SAME dropout mask: O is linear in V
-    eps = 1e-2
+    eps = 0.5 if prec else 1e-2          # bf16 operands: the step must dwarf the rounding of v + eps
     v2 = v + eps * torch.ones_like(v)
     o2 = torch.empty_like(o); a.v, a.o = v2.data_ptr(), o2.data_ptr()
     L.check(L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()), "attn_fwd")
     lhs = ((o2 - o) * do).sum().item() / eps
-    assert abs(lhs - dv.sum().item()) < 1e-2 * max(1.0, abs(lhs))
+    assert abs(lhs - dv.sum().item()) < (3e-2 if prec else 1e-2) * max(1.0, abs(lhs))
 
 
 def test_embed_xent_softmax_colsum(L):
