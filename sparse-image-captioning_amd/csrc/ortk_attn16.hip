@@ -20,6 +20,7 @@
 //     gathered by the hardware-transposing LDS read; padded k ranges (keys 36 -> 64, queries 85 -> 96, 36 -> 64) are zero
 //     rows / columns of the images.
 // The pitch of 72 bf16 (144 B) makes the 16 rows of a ds_read_b128 service group fall on 16 distinct 16-byte slots.
+#include <cstdlib>
 #include "ortk_common.h"
 
 namespace {
@@ -273,7 +274,9 @@ namespace ortk {
 
 // shapes / layouts these kernels serve (everything else stays with the fp32-MFMA family)
 bool attn16_ok(const ortk_attn_args* a, bool bwd) {
-    if (a->precision != 1 || a->dk != 64 || a->Lk < 1 || a->Lk > 64 || a->Lq <= 32 || a->Lq > 128) return false;
+    static int min_lq = -1;
+    if (min_lq < 0) { const char* e = getenv("ORTK_ATTN16_MINLQ"); min_lq = e ? atoi(e) : 33; }
+    if (a->precision != 1 || a->dk != 64 || a->Lk < 1 || a->Lk > 64 || a->Lq < min_lq || a->Lq > 128) return false;
     if (a->kv_index || a->kv_group_stride > 0 || a->kv_dtype != 0 || a->k_new || a->v_new) return false;
     if ((a->ldq | a->ldk | a->ldv) % 4 || !al16(a->q) || !al16(a->k) || !al16(a->v)) return false;
     if (!bwd) {
