@@ -54,6 +54,11 @@ typedef struct ortk_config {
      * 1 = "kv": K = V = linears.1(key), W_o = linears.2;  2 = "qk": Q = linears.0(query), K = linears.0(key),
      * V = linears.1(value), W_o = linears.2.  Three linears per module in the state_dict, as in the reference. */
     int32_t share_att_enc, share_att_dec;
+    /* 1 = the plain `transformer` model (models/transformer.py:617-665) instead of the relation transformer: encoder self-
+     * attention without geometry bias (no WGs parameters; `boxes` is ignored and may be NULL), region embedding without the
+     * zeroing of padded regions (src_embed = Linear + ReLU + Dropout on every row), and the reference's state_dict names
+     * for that class (`core.src_embed.0.*`, `core.encoder.*`, `core.decoder.*`, `core.tgt_embed.*`, `core.generator.proj.*`). */
+    int32_t no_box;
 } ortk_config;
 
 /* ------------------------------------------------------------------------------------------------

@@ -44,6 +44,10 @@ class OCfg:
         self.bos_token_id, self.eos_token_id, self.unk_token_id, self.pad_token_id = 2, 3, 1, 0
         self.no_box_trigonometric_embedding = False
         self.share_att_encoder = self.share_att_decoder = None      # None | "kv" | "qk" (ACORT)
+        # True: the plain `transformer` model (transformer.py:617-665) — no geometry bias, padded regions embedded like the
+        # others.  ``P`` then still uses this file's names (`att_embed.0.*` for `core.src_embed.0.*`, `model.` for `core.`:
+        # see `plain_state`).
+        self.plain = False
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -146,18 +150,32 @@ def att_embed(P, att_feats: Tensor, att_masks: Tensor) -> Tensor:
 def encode(P, cfg, att_feats: Tensor, boxes: Tensor, att_masks: Tensor) -> Tensor:
     """relation_transformer.py:341-365 (feature prep) + :92-113,148-191 (encoder). Returns memory (B,S,d)."""
     h = cfg.num_heads
-    x = att_embed(P, att_feats, att_masks)
-    emb = box_relational_embedding(boxes, not cfg.no_box_trigonometric_embedding)
+    plain = getattr(cfg, "plain", False)
+    if plain:   # transformer.py:627-629: Linear + ReLU (+ Dropout) on every row; boxes unused
+        x = torch.relu(_linear(P, "att_embed.0", att_feats))
+        emb = None
+    else:
+        x = att_embed(P, att_feats, att_masks)
+        emb = box_relational_embedding(boxes, not cfg.no_box_trigonometric_embedding)
     kmask = (att_masks != 0)[:, None, None, :]  # (B,1,1,S)
     for l in range(cfg.num_layers):
         pre = f"model.encoder.layers.{l}."
         y = layer_norm(x, P[pre + "sublayer.0.norm.a_2"], P[pre + "sublayer.0.norm.b_2"])
         q, k, v, out = project_qkv(P, pre + "self_attn.", getattr(cfg, "share_att_encoder", None), y, y, h)
-        o = attention(q, k, v, kmask, box_logbias(P, l, emb, h))
+        o = attention(q, k, v, kmask, None if plain else box_logbias(P, l, emb, h))
         x = x + _linear(P, out, _merge(o))
         y = layer_norm(x, P[pre + "sublayer.1.norm.a_2"], P[pre + "sublayer.1.norm.b_2"])
         x = x + _linear(P, pre + "feed_forward.w_2", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
     return layer_norm(x, P["model.encoder.norm.a_2"], P["model.encoder.norm.b_2"])
+
+
+def plain_state(state: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """state_dict of the plain `transformer` class (`core.*`) under the names this file indexes."""
+    out = {}
+    for k, v in state.items():
+        k = k.replace("core.src_embed.0.", "att_embed.0.", 1) if k.startswith("core.src_embed.0.") else k
+        out["model." + k[len("core."):] if k.startswith("core.") else k] = v
+    return out
 
 
 def positional_encoding(n_pos: int, d: int) -> Tensor:

@@ -28,7 +28,7 @@ class Config(C.Structure):
                 ("pad_id", C.c_int32), ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("unk_id", C.c_int32),
                 ("box_trig", C.c_int32), ("precision", C.c_int32), ("drop_src", C.c_float), ("drop", C.c_float),
                 ("share_enc", C.c_int32 * 16), ("share_dec", C.c_int32 * 16),
-                ("share_att_enc", C.c_int32), ("share_att_dec", C.c_int32)]
+                ("share_att_enc", C.c_int32), ("share_att_dec", C.c_int32), ("no_box", C.c_int32)]
 
 
 class Batch(C.Structure):

@@ -85,10 +85,12 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
     const int ne = att_mode(c.share_att_enc).n, nd = att_mode(c.share_att_dec).n;
     const bool cqk = c.share_att_dec == 2;     // cross-attention Q and K share linears.0: it lives in the packed K|V block
     o.cw = c.share_att_dec == 1 ? d : 2 * d; o.cv = c.share_att_dec == 1 ? 0 : d;
-    align(); o.att_w = add("att_embed.0.weight", {d, F});
-    align(); o.att_b = add("att_embed.0.bias", {d});
+    const bool plain = c.no_box != 0;
+    const std::string root = plain ? "core." : "model.", emb = plain ? "core.src_embed.0." : "att_embed.0.";
+    align(); o.att_w = add(emb + "weight", {d, F});
+    align(); o.att_b = add(emb + "bias", {d});
     for (int l = 0; l < L; ++l) {
-        const std::string p = "model.encoder.layers." + std::to_string(l);
+        const std::string p = root + "encoder.layers." + std::to_string(l);
         EncOff& e = o.enc[l];
         if (c.share_enc[l] > 0) { e = o.enc[c.share_enc[l] - 1]; continue; }      // the same module: no storage of its own
         align(); e.wqkv = off; for (int i = 0; i < ne; ++i) add(L_(p + ".self_attn", i, "weight"), {d, d});
@@ -96,8 +98,11 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         align(); e.wo = add(L_(p + ".self_attn", ne, "weight"), {d, d});
         align(); e.bo = add(L_(p + ".self_attn", ne, "bias"), {d});
         const int64_t dg = c.box_trig ? 64 : 4;   // relation_transformer.py:131-136
-        align(); e.wg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".weight", {1, dg});
-        align(); e.bg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".bias", {1});
+        e.wg = e.bg = -1;
+        if (!plain) {
+            align(); e.wg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".weight", {1, dg});
+            align(); e.bg = off; for (int h = 0; h < H; ++h) add(p + ".self_attn.WGs." + std::to_string(h) + ".bias", {1});
+        }
         align(); e.w1 = add(p + ".feed_forward.w_1.weight", {ff, d});
         align(); e.b1 = add(p + ".feed_forward.w_1.bias", {ff});
         align(); e.w2 = add(p + ".feed_forward.w_2.weight", {d, ff});
@@ -105,11 +110,11 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         align(); e.n0a = add(p + ".sublayer.0.norm.a_2", {d}); align(); e.n0b = add(p + ".sublayer.0.norm.b_2", {d});
         align(); e.n1a = add(p + ".sublayer.1.norm.a_2", {d}); align(); e.n1b = add(p + ".sublayer.1.norm.b_2", {d});
     }
-    align(); o.enc_na = add("model.encoder.norm.a_2", {d}); align(); o.enc_nb = add("model.encoder.norm.b_2", {d});
+    align(); o.enc_na = add(root + "encoder.norm.a_2", {d}); align(); o.enc_nb = add(root + "encoder.norm.b_2", {d});
     o.ckv_slots = 0;
     for (int l = 0; l < L; ++l) o.ckv_slot[l] = c.share_dec[l] > 0 ? o.ckv_slot[c.share_dec[l] - 1] : o.ckv_slots++;
     for (int l = 0; l < L; ++l) {
-        const std::string p = "model.decoder.layers." + std::to_string(l);
+        const std::string p = root + "decoder.layers." + std::to_string(l);
         DecOff& e = o.dec[l];
         if (c.share_dec[l] > 0) { e = o.dec[c.share_dec[l] - 1]; continue; }
         align(); e.wqkv = off; for (int i = 0; i < nd; ++i) add(L_(p + ".self_attn", i, "weight"), {d, d});
@@ -128,34 +133,34 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
         align(); e.n1a = add(p + ".sublayer.1.norm.a_2", {d}); align(); e.n1b = add(p + ".sublayer.1.norm.b_2", {d});
         align(); e.n2a = add(p + ".sublayer.2.norm.a_2", {d}); align(); e.n2b = add(p + ".sublayer.2.norm.b_2", {d});
     }
-    align(); o.dec_na = add("model.decoder.norm.a_2", {d}); align(); o.dec_nb = add("model.decoder.norm.b_2", {d});
+    align(); o.dec_na = add(root + "decoder.norm.a_2", {d}); align(); o.dec_nb = add(root + "decoder.norm.b_2", {d});
     // cross-attention K / V projections of ALL distinct decoder layers: one (U*cw, d) matrix.  Slice of a layer:
     // [W_k; W_v] (linears.1, .2) | "kv": [W_kv] (linears.1) | "qk": [W_qk; W_v] (linears.0, .1; also the query projection)
     const int c0 = cqk ? 0 : 1, c1 = c.share_att_dec == 1 ? 1 : c0 + 1;
     align(); o.ckv_w = off;
     for (int l = 0; l < L; ++l) {
         if (c.share_dec[l] > 0) continue;
-        const std::string p = "model.decoder.layers." + std::to_string(l) + ".src_attn";
+        const std::string p = root + "decoder.layers." + std::to_string(l) + ".src_attn";
         if (cqk) o.dec[l].cqw = off;
         for (int i = c0; i <= c1; ++i) add(L_(p, i, "weight"), {d, d});
     }
     align(); o.ckv_b = off;
     for (int l = 0; l < L; ++l) {
         if (c.share_dec[l] > 0) continue;
-        const std::string p = "model.decoder.layers." + std::to_string(l) + ".src_attn";
+        const std::string p = root + "decoder.layers." + std::to_string(l) + ".src_attn";
         if (cqk) o.dec[l].cqb = off;
         for (int i = c0; i <= c1; ++i) add(L_(p, i, "bias"), {d});
     }
     if (cqk) for (int l = 0; l < L; ++l) if (c.share_dec[l] > 0) { o.dec[l].cqw = o.dec[c.share_dec[l] - 1].cqw; o.dec[l].cqb = o.dec[c.share_dec[l] - 1].cqb; }
-    align(); o.lut = add("model.tgt_embed.0.lut.weight", {V, d});
+    align(); o.lut = add(root + "tgt_embed.0.lut.weight", {V, d});
     // The generator rows are padded (with zeros that no state_dict entry covers) to a multiple of the GEMM tile:
     // logits are computed for Vp = align(V,128) columns with full tiles; the pad logits are exactly 0, have zero
     // gradient, and are ignored by the soft-max / criterion / decoders, which all take V.
     const int64_t Vp = ortk_align(V, 128);
-    align(); o.gen_w = add("model.generator.proj.weight", {V, d}); off += (Vp - V) * d;
-    align(); o.gen_b = add("model.generator.proj.bias", {V}); off += (Vp - V);
+    align(); o.gen_w = add(root + "generator.proj.weight", {V, d}); off += (Vp - V) * d;
+    align(); o.gen_b = add(root + "generator.proj.bias", {V}); off += (Vp - V);
     align(); o.total = off;
-    o.pe = add("model.tgt_embed.1.pe", {1, PE_ROWS, d});
+    o.pe = add(root + "tgt_embed.1.pe", {1, PE_ROWS, d});
     if (entries) entries->back().kind = 2;
     align(); o.total_all = off;
 }
@@ -427,13 +432,17 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H, A = c.adt;
     const int64_t Me = (int64_t)B * S;
     // att_embed: relu(Linear) on valid regions, zeros elsewhere, dropout (relation_transformer.py:331-333,349-350)
+    // (the plain `transformer` embeds every row, padded regions included: transformer.py:627-629)
+    const bool plain = cfg.no_box != 0;
     TRY(fwd_gemm(c, feats, ORTK_F32, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
-                 nullptr, 0, masks));
+                 nullptr, 0, plain ? nullptr : masks));
     const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS];
     for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; }
     // the geometry bias only depends on the boxes and WG: beside att_embed / the first LayerNorm and QKV projection
     hipEvent_t box_done = nullptr;
-    if (c.use_side) {
+    if (plain) {
+        // no geometry bias
+    } else if (c.use_side) {
         TRY(c.fork());
         TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)g_side.s));
         TRY(c.side_mark(&box_done));
@@ -448,7 +457,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
         TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Me, am.n * d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.q = b.qkv; a.k = b.qkv + am.k * d; a.v = b.qkv + am.v * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
-        a.kmask = masks; a.bias = logbias + (int64_t)l * B * H * S * S; a.p = b.P;
+        a.kmask = masks; a.bias = plain ? nullptr : logbias + (int64_t)l * B * H * S * S; a.p = b.P;
         a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         if (l == 0) TRY(c.wait_ev(box_done));
         TRY(ortk_attention_fwd(&a, (ortk_stream)c.s));
@@ -521,7 +530,7 @@ extern "C" int ortk_arena_entry(const ortk_config* cfg, int32_t index, char* nam
 }
 
 static int check_batch(const ortk_config* cfg, const ortk_batch* b, bool need_seq) {
-    if (!b || !b->att_feats || !b->boxes || !b->att_masks) return ORTK_EINVAL;
+    if (!b || !b->att_feats || (!b->boxes && !cfg->no_box) || !b->att_masks) return ORTK_EINVAL;
     if (b->B < 1 || b->S < 1 || b->S > 128) return ORTK_EINVAL;
     if (need_seq) {
         if (!b->seqs || b->R < 1 || b->T < 1 || b->R % b->B || b->seq_stride < b->T + 1) return ORTK_EINVAL;
@@ -780,7 +789,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, ame.gk * d, A); a.dv = off_elems(w.gqkv, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
-        a.dscore = w.dscore + (int64_t)l * B * H * S * S;
+        a.dscore = cfg->no_box ? nullptr : w.dscore + (int64_t)l * B * H * S * S;
         TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(fold(ame, Me));
@@ -789,7 +798,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, gt_new(), l > 0 ? (int)eop(l - 1, 3) : -1));
     }
     // geometry bias weights
-    {
+    if (!cfg->no_box) {
         const float* P = params;
         const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS]; float* dwg[MAXLAYERS]; float* dbg[MAXLAYERS];
         for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; dwg[l] = G + o.enc[l].wg; dbg[l] = G + o.enc[l].bg; }
@@ -821,7 +830,7 @@ extern "C" int ortk_encode(const ortk_config* cfg, const float* params, const fl
                            const float* att_masks, int32_t B, int32_t S, void* ws, size_t ws_bytes, float* memory_out,
                            ortk_stream stream) {
     if (int e = check_cfg(cfg)) return e;
-    if (!params || !att_feats || !boxes || !att_masks || !ws || !memory_out || B < 1 || S < 1 || S > 128) return ORTK_EINVAL;
+    if (!params || !att_feats || (!boxes && !cfg->no_box) || !att_masks || !ws || !memory_out || B < 1 || S < 1 || S > 128) return ORTK_EINVAL;
     return encode_impl(cfg, params, att_feats, boxes, att_masks, B, S, ws, ws_bytes, memory_out, stream);
 }
 
@@ -985,7 +994,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
                            const float* att_masks, int32_t B, int32_t S, const ortk_decode_opts* op, void* ws, size_t ws_bytes,
                            int64_t* seq_out, float* logprob_out, float* score_out, ortk_stream stream) {
     if (int e = check_cfg(cfg)) return e;
-    if (!params || !att_feats || !boxes || !att_masks || !op || !ws || !seq_out || !logprob_out) return ORTK_EINVAL;
+    if (!params || !att_feats || (!boxes && !cfg->no_box) || !att_masks || !op || !ws || !seq_out || !logprob_out) return ORTK_EINVAL;
     if (B < 1 || S < 1 || S > 128) return ORTK_EINVAL;
     const int K = decode_K(op);
     if (K < 1) return ORTK_EINVAL;   // the reference asserts the same option combinations (transformer.py:509,514)

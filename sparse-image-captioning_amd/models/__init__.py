@@ -31,4 +31,4 @@ def register_into(reference_models_module, suffix="_hip"):
             reference_models_module.MODEL_REGISTRY[key] = cls
 
 
-from . import relation_transformer, relation_transformer_prune  # noqa: E402,F401
+from . import relation_transformer, relation_transformer_prune, transformer  # noqa: E402,F401

@@ -67,8 +67,9 @@ def parse_share_att(value, what):
     return 1 if value == "kv" else 2
 
 
-def make_ccfg(config, precision, drop, train_drop_src=None):
+def make_ccfg(config, precision, drop, train_drop_src=None, no_box=False):
     c = L.Config()
+    c.no_box = 1 if no_box else 0
     get = config.get if hasattr(config, "get") else (lambda k, d=None: getattr(config, k, d))
     c.share_att_enc = parse_share_att(get("share_att_encoder", None), "share_att_encoder")
     c.share_att_dec = parse_share_att(get("share_att_decoder", None), "share_att_decoder")
@@ -81,7 +82,7 @@ def make_ccfg(config, precision, drop, train_drop_src=None):
     c.vocab, c.feat, c.seq_len = int(config.vocab_size), int(config.att_feat_size), int(config.max_seq_length)
     c.pad_id, c.bos_id, c.eos_id, c.unk_id = (int(config.pad_token_id), int(config.bos_token_id),
                                               int(config.eos_token_id), int(config.unk_token_id))
-    c.box_trig = 0 if config.no_box_trigonometric_embedding else 1
+    c.box_trig = 0 if get("no_box_trigonometric_embedding", False) else 1
     c.precision = int(precision)
     c.drop_src = float(config.drop_prob_src if train_drop_src is None else train_drop_src)
     c.drop = float(drop)
@@ -138,6 +139,7 @@ class RelationTransformerModel(CaptionModelBase):
     COLLATE_FN = ObjectRelationBatchLayout
     DROPOUT = 0.1          # make_model(dropout=0.1), relation_transformer.py:306
     MASKED = False
+    NO_BOX = False         # True in the plain `transformer` subclass (models/transformer.py)
 
     def __init__(self, config, precision=None):
         super().__init__()
@@ -150,12 +152,13 @@ class RelationTransformerModel(CaptionModelBase):
         self.att_feat_size, self.vocab_size = config.att_feat_size, config.vocab_size
         self.eos_idx, self.bos_idx = config.eos_token_id, config.bos_token_id
         self.unk_idx, self.pad_idx = config.unk_token_id, config.pad_token_id
-        self.box_trigonometric_embedding = not config.no_box_trigonometric_embedding
+        self.box_trigonometric_embedding = not (config.get("no_box_trigonometric_embedding", False) if hasattr(config, "get")
+                                                else getattr(config, "no_box_trigonometric_embedding", False))
         assert self.num_layers > 0, "num_layers should be greater than 0"
         if precision is None:
             precision = config.get("ortk_precision", 0) if hasattr(config, "get") else 0
         self.precision = {"fp32": 0, "f32": 0, "bf16": 1}.get(precision, precision)
-        self._ccfg = make_ccfg(config, self.precision, self.DROPOUT)
+        self._ccfg = make_ccfg(config, self.precision, self.DROPOUT, no_box=self.NO_BOX)
         self._entries = arena_entries(self._ccfg)
         lib = L.lib()
         self._n_train = lib.ortk_arena_numel(C.byref(self._ccfg))
@@ -197,7 +200,7 @@ class RelationTransformerModel(CaptionModelBase):
         # ACORT layer sharing: a shared position is the SAME module object as the position it shares (as in the reference's
         # ModuleList of repeated modules): state_dict() lists every position, parameters() each tensor once
         for stack, share in (("encoder", self._ccfg.share_enc), ("decoder", self._ccfg.share_dec)):
-            layers = self._modules["model"]._modules[stack]._modules["layers"]
+            layers = self._modules["core" if self.NO_BOX else "model"]._modules[stack]._modules["layers"]
             for l in range(self.num_layers):
                 if share[l] > 0:
                     layers.add_module(str(l), layers._modules[str(share[l] - 1)])
@@ -258,7 +261,7 @@ class RelationTransformerModel(CaptionModelBase):
             elif name.endswith(".b_2"):
                 t.zero_()
             elif len(shape) >= 2:
-                if name.startswith("model."):
+                if name.startswith(("model.", "core.")):     # the plain transformer initialises everything under `core.` (transformer.py:660-664)
                     nn.init.xavier_uniform_(t)
                 else:
                     nn.init.kaiming_uniform_(t, a=math.sqrt(5))

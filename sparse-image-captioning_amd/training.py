@@ -65,7 +65,7 @@ class NativeTrainer:
     # ------------------------------------------------------------------ pieces
     def _batch(self, data, tok_weight):
         m = self.model
-        feats, boxes, masks = m._prepare(data["att_feats"], data["boxes"], data.get("att_masks"))
+        feats, boxes, masks = m._prepare(data["att_feats"], data.get("boxes"), data.get("att_masks"))
         return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight)
 
     def _fwd_bwd(self, batch, norm, train=True):
@@ -127,7 +127,7 @@ class NativeTrainer:
         with torch.no_grad():
             # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
             # token for token what the two calls of utils/training.py:220-237 return, at half the launches
-            seq, _ = m(att_feats=data["att_feats"], boxes=data["boxes"], att_masks=data.get("att_masks"), mode="sample",
+            seq, _ = m(att_feats=data["att_feats"], boxes=data.get("boxes"), att_masks=data.get("att_masks"), mode="sample",
                        opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy"})
         if baseline == "greedy":
             greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()

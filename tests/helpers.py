@@ -102,3 +102,8 @@ def shared_layer_state(cfg, param_names, seed, gen_scale=1.0, eos_bias=0.0, requ
                     if n.startswith(src):
                         state[dst + n[len(src):]] = state[n]
     return state
+
+
+def plain_shapes(g10) -> dict:
+    """Parameter name -> shape of the reference's plain `transformer` model, as recorded in golden G10."""
+    return {str(n): tuple(int(x) for x in str(sh).split(",")) for n, sh in zip(g10["param_names"], g10["param_shapes"])}

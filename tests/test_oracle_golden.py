@@ -347,3 +347,31 @@ def test_share_att_vs_reference_golden(golden, tag, enc, dec):
                 seq, lp, _ = O.beam_search(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"], beam_size=3)
             np.testing.assert_array_equal(seq.numpy(), g9[f"{tag}/decode_b{bs}/seq"])
             close(lp, g9[f"{tag}/decode_b{bs}/logprobs"], 1e-4)
+
+
+def test_plain_transformer_vs_reference_golden(golden):
+    """G10: the plain `transformer` class — no geometry bias, padded regions embedded, `core.*` names."""
+    g10 = golden("g10_tiny_plain_transformer")
+    cfg = _cfg(dict(C.TINY_CFG, plain=True))
+    shapes = H.plain_shapes(g10)
+    assert int(g10["n_params"]) == sum(int(np.prod(v)) for v in shapes.values()) and not any(".WGs." in n for n in shapes)
+    state = H.torch_state(shapes, C.G1_SEED, C.G1_GEN_SCALE, C.G1_EOS_BIAS, requires_grad=True)
+    P = O.plain_state(state)
+    b = H.g1_batch()
+    with torch.no_grad():
+        close(O.encode({k: v.detach() for k, v in P.items()}, cfg, b["att_feats"], None, b["att_masks"]), g10["memory"], 2e-5)
+    logp = O.forward_logp(P, cfg, b["att_feats"], None, b["seqs"], b["att_masks"])
+    close(logp, g10["logp"], 5e-5)
+    loss = O.xe_loss(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - float(g10["xe_loss"])) < 1e-5
+    loss.backward()
+    for n in shapes:
+        ref = g10["grad/" + n]
+        np.testing.assert_allclose(state[n].grad.numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=n)
+    with torch.no_grad():
+        Pd = {k: v.detach() for k, v in P.items()}
+        seq, lp = O.sample_greedy_or_multinomial(Pd, cfg, b["att_feats"], None, b["att_masks"])[:2]
+        np.testing.assert_array_equal(seq.numpy(), g10["decode_b1/seq"])
+        seq, lp, _ = O.beam_search(Pd, cfg, b["att_feats"], None, b["att_masks"], beam_size=3)
+        np.testing.assert_array_equal(seq.numpy(), g10["decode_b3/seq"])
+        close(lp, g10["decode_b3/logprobs"], 1e-4)
