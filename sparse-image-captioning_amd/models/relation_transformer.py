@@ -431,7 +431,8 @@ class RelationTransformerModel(CaptionModelBase):
         o.seed = int(opt.get("seed", self._next_seed())) & 0xFFFFFFFF
         for k in ("group_size",):
             if int(opt.get(k, 1)) != 1:
-                raise NotImplementedError("diverse beam groups (group_size > 1) are not implemented in the HIP path")
+                raise NotImplementedError("diverse beam groups (group_size > 1): the reference's own path raises AttributeError "
+                                          "(caption_model.py:50 calls an undefined self.repeat_tensor); nothing to match")
         o.with_greedy = 1 if (o.num_random_sample > 0 and opt.get("with_greedy", False)) else 0
         if o.num_random_sample > 0:
             assert o.beam_size < 1, f"Beam size must be < 1, saw {o.beam_size}"      # transformer.py:509
