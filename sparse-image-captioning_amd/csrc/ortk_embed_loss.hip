@@ -2,7 +2,7 @@
 //
 // Replaces InputEmbedding + PositionalEncoding (models/transformer.py:383-401), OutputEmbedding's log_softmax
 // (transformer.py:412-413) and LanguageModelCriterion / RewardCriterion (utils/losses.py:15-43).
-#include "ortk_common.h"
+#include "ortk_internal.h"
 
 namespace {
 
@@ -192,6 +192,51 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (__bf16)x[i];
 }
 
+// one 64 x 64 tile of one weight block per workgroup: fp32 (N, K) -> bf16 (K, N) through a padded LDS tile
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ x, __bf16* __restrict__ yt, ortk::WBlockTable tab) {
+    __shared__ float tile[64][65];
+    int bi = 0;
+    {   // the block that owns this tile (tile0 is ascending): binary search
+        int lo = 0, hi = tab.n - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab.b[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        bi = lo;
+    }
+    const ortk::WBlock wb = tab.b[bi];
+    const int tk = (wb.K + 63) >> 6;
+    const int t = (int)blockIdx.x - wb.tile0, n0 = (t / tk) * 64, k0 = (t % tk) * 64;
+    const float* src = x + wb.off;
+    __bf16* dst = yt + wb.off;
+    const int tid = threadIdx.x;
+    const bool vec = (wb.K & 3) == 0 && (wb.off & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
+        const int n = n0 + r, k = k0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < wb.N) {
+            if (vec && k + 3 < wb.K) v = *reinterpret_cast<const float4*>(src + (int64_t)n * wb.K + k);
+            else { float* q = &v.x; for (int e = 0; e < 4; ++e) if (k + e < wb.K) q[e] = src[(int64_t)n * wb.K + k + e]; }
+        }
+        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+    }
+    __syncthreads();
+    const bool vec_o = (wb.N & 7) == 0 && (wb.off & 7) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kr = (tid >> 3) + 32 * i, c = (tid & 7) * 8;
+        const int k = k0 + kr, n = n0 + c;
+        if (k >= wb.K) continue;
+        if (vec_o && n + 7 < wb.N) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)tile[c + e][kr];
+            *reinterpret_cast<bf16x8*>(dst + (int64_t)k * wb.N + n) = o;
+        } else {
+            for (int e = 0; e < 8; ++e) if (n + e < wb.N) dst[(int64_t)k * wb.N + n + e] = (__bf16)tile[c + e][kr];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void add_cols_kernel(const void* __restrict__ x, void* __restrict__ y, int dt, int64_t ld, int64_t rows, int cols) {
     const int64_t n = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -308,6 +353,16 @@ extern "C" int ortk_cast_bf16(const float* x, void* y, int64_t n, ortk_stream st
     ORTK_CHECK_LAUNCH();
     return 0;
 }
+
+namespace ortk {
+int cast_bf16_transposed(const float* x, void* yt, const WBlockTable& t, hipStream_t s) {
+    if (!x || !yt || t.n < 0 || t.n > MAX_WBLOCKS) return ORTK_EINVAL;
+    if (t.n == 0 || t.tiles == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)t.tiles), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(yt), t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace ortk
 
 // y[r, 0..cols) += x[r, 0..cols) for two column blocks of one (rows, ld) matrix (dtype 0 fp32 / 1 bf16)
 extern "C" int ortk_axpy_cols(const void* x, void* y, int32_t dtype, int64_t ld, int64_t rows, int32_t cols, ortk_stream stream) {

@@ -16,6 +16,13 @@ bool attn16_ok(const ortk_attn_args* a, bool bwd);
 int attn16_fwd(const ortk_attn_args* a, hipStream_t s);
 int attn16_bwd(const ortk_attn_args* a, hipStream_t s);
 
+// bf16 TRANSPOSED copies of weight blocks: block i is an (N, K) row-major fp32 matrix at x + off; yt + off receives it as
+// (K, N) row-major bf16 (the data-gradient GEMM dX = dY W then runs in the forward operand layout, on the LDS-DMA kernels)
+struct WBlock { int32_t off, N, K, tile0; };      // tile0: index of the block's first 64 x 64 tile in the launch
+constexpr int MAX_WBLOCKS = 200;
+struct WBlockTable { int32_t n, tiles; WBlock b[MAX_WBLOCKS]; };
+int cast_bf16_transposed(const float* x, void* yt, const WBlockTable& t, hipStream_t s);
+
 struct BeamState {
     int32_t B, b, L, V, eos;
     int64_t ldv;
