@@ -111,7 +111,8 @@ def pmc_traffic(workload, precision, B):
     try:
         for cname, fname in (("FETCH_SIZE", "r01_xe_b256_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_xe_b256_pmc_write_size.csv")):
             for r in csv.DictReader(open(os.path.join(here, "profiles", fname))):
-                fwd = "gemm_bf16_glds_kernel<false, false" in r["kernel"] or "gemm_bf16_dma256_kernel<false, false" in r["kernel"]
+                fwd = ("gemm_bf16_glds_kernel<false, false" in r["kernel"] or "gemm_bf16_dma256_kernel<false, false" in r["kernel"]
+                       or "gemm_bf16_dma64_kernel" in r["kernel"])
                 if fwd and r["counter"] == cname:
                     tot[cname] += float(r["total"]); n[cname] += int(r["launches"])
     except (OSError, KeyError, ValueError):
@@ -241,6 +242,8 @@ def main():
         for k in (key, key + 1, key + 3):
             lib.ortk_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl))
             per_key[k] = (n.value, ms.value, fl.value)
+        by = C.c_double()
+        lib.ortk_prof_collect_bytes(key, C.byref(by))
         lib.ortk_prof_enable(0)
         n0, ms0, fl0 = per_key[key]
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
@@ -248,7 +251,7 @@ def main():
         tot_ms = sum(v[1] for v in per_key.values())
         tot_fl = sum(v[2] for v in per_key.values())
         roofline = {"bound": "mfma",
-                    "kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> (forward X*W^T, LDS-DMA pipeline)" if args.precision == "bf16"
+                    "kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> / gemm_bf16_dma64_kernel (k-contiguous operands: forward X*W^T, and dY*W on transposed bf16 weight copies; LDS-DMA pipeline)" if args.precision == "bf16"
                                else "gemm_f32_kernel<false,false> (forward X*W^T)"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
@@ -256,8 +259,9 @@ def main():
                     "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                                          "ms_per_step": round(tot_ms, 3)},
                     "traffic": pmc_traffic(args.workload, args.precision, B),
+                    "algorithmic_bytes_per_launch": round(by.value / max(n0, 1)),
                     "traffic_note": "HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_xe_b256_pmc_*.csv "
-                                    "(separate rocprofv3 --pmc passes of this command); algorithmic bytes per launch 118.1e6"}
+                                    "(separate rocprofv3 --pmc passes of this command), launch-weighted over the same kernels"}
         if not decode:
             step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3 * (0.05 if sparse else 1.0)
             roofline["whole_step"] = {"algorithmic_tflop": round(step_tflop, 3),

@@ -208,6 +208,8 @@ int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
  * launch stream, summed per kernel instance key = precision*4 + transA*2 + transB.  collect() synchronises. */
 int ortk_prof_enable(int32_t on);
 int ortk_prof_collect(int32_t key, int64_t* launches, double* total_ms, double* total_flops);
+/* algorithmic bytes of the same launches: operands once (A: M x K, B: N x K), the output once, residual / gate rows once */
+int ortk_prof_collect_bytes(int32_t key, double* total_bytes);
 
 /* LayerNorm of transformer.py:338-341: a*(x-mean)/(std_unbiased+eps)+b.  stats (rows,2) = {mean, std}. */
 int ortk_layernorm_fwd(const float* x, const float* a, const float* b, void* y, int32_t y_dtype, float* stats,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),
     "ortk_prof_enable": (_I32, [_I32]),
     "ortk_prof_collect": (_I32, [_I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ortk_prof_collect_bytes": (_I32, [_I32, C.POINTER(C.c_double)]),
     "ortk_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd_drop": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _I32, _F, C.c_uint32, _P]),

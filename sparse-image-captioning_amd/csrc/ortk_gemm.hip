@@ -943,7 +943,7 @@ template <bool TA, bool TB> gemm16_fn pick16(int adt, int bdt, bool fast) {
 // accumulated per kernel instance (precision, transA, transB).  Disabled by default; the timed region of bench.py
 // never runs with it on.  This is the only process-global state in the library.
 namespace {
-struct ProfRec { hipEvent_t a, b; int key; double flops; };
+struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; };
 bool g_prof_on = false;
 std::mutex g_prof_mu;          // decode chunks may be driven by several host threads
 std::vector<ProfRec>* g_prof = nullptr;
@@ -969,6 +969,13 @@ extern "C" int ortk_prof_collect(int32_t key, int64_t* launches, double* total_m
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return ORTK_EINVAL;
         *launches += 1; *total_ms += ms; *total_flops += r.flops;
     }
+    return 0;
+}
+
+extern "C" int ortk_prof_collect_bytes(int32_t key, double* total_bytes) {
+    if (!g_prof || !total_bytes) return ORTK_EINVAL;
+    *total_bytes = 0;
+    for (auto& r : *g_prof) if (r.key == key) *total_bytes += r.bytes;
     return 0;
 }
 
@@ -1001,6 +1008,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     if (g_prof_on) {
         if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return ORTK_EINVAL;
         rec.key = key; rec.flops = 2.0 * p.M * p.N * p.K;
+        rec.bytes = (double)p.M * p.K * ortk_esize(p.a_dtype) + (double)p.N * p.K * ortk_esize(p.b_dtype) +
+                    (double)p.M * p.N * (ortk_esize(p.c_dtype) + (p.resid ? 4 : 0) + (p.gate ? ortk_esize(p.gate_dtype) : 0));
         (void)hipEventRecord(rec.a, s);
     }
     if (!p.precision) {
