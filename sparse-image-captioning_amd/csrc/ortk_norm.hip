@@ -97,13 +97,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < NREG; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
     load_row<VEC, NREG>(a, d, lane, av);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    // Software pipeline over the wave's rows: the loads of row k+1 (x, dy, the residual gradient, the statistics) are in
+    // flight while row k is reduced and stored.  With one row per wave in flight the kernel ran at 2.9 TB/s (5 waves per CU,
+    // ~4 KB each in flight: latency-bound); see DESIGN.md section 7.
+    float xn[NREG], gn[NREG], rn[NREG];
+    float mean_n = 0.f, sd_n = 1.f;
+    auto fetch = [&](int64_t row) {
+        load_row<VEC, NREG>(x + row * d, d, lane, xn);
+        load_row<VEC, NREG>(dy + row * d, d, lane, gn);
+        if (dres) load_row<VEC, NREG>(dres + row * d, d, lane, rn);
+        mean_n = stats[row * 2]; sd_n = stats[row * 2 + 1];
+    };
+    if (r0 + wave < rows && wave < rows_per_block) fetch(r0 + wave);
     for (int rr = wave; rr < rows_per_block; rr += 4) {
         const int64_t row = r0 + rr;
         if (row >= rows) break;
-        float xv[NREG], gv[NREG];
-        load_row<VEC, NREG>(x + row * d, d, lane, xv);
-        load_row<VEC, NREG>(dy + row * d, d, lane, gv);
-        const float mean = stats[row * 2], sd = stats[row * 2 + 1];
+        float xv[NREG], gv[NREG], rv[NREG];
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) { xv[i] = xn[i]; gv[i] = gn[i]; rv[i] = dres ? rn[i] : 0.f; }
+        const float mean = mean_n, sd = sd_n;
+        if (rr + 4 < rows_per_block && row + 4 < rows) fetch(row + 4);
         const float r = 1.f / (sd + eps);
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
@@ -121,7 +134,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const float mg = sg / (float)d;
         const float coef = r * r * sgx / ((float)(d - 1) * sd);
         float* dxr = dx + row * d;
-        const float* res = dres ? dres + row * d : nullptr;
 #pragma unroll
         for (int it = 0; it < C::NIT; ++it) {
             const int c = C::col(lane, it);
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     o.y = r * (gv[it * 4 + 1] - mg) - coef * xv[it * 4 + 1];
                     o.z = r * (gv[it * 4 + 2] - mg) - coef * xv[it * 4 + 2];
                     o.w = r * (gv[it * 4 + 3] - mg) - coef * xv[it * 4 + 3];
-                    if (res) { const float4 t = *reinterpret_cast<const float4*>(res + c); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+                    o.x += rv[it * 4]; o.y += rv[it * 4 + 1]; o.z += rv[it * 4 + 2]; o.w += rv[it * 4 + 3];
                     *reinterpret_cast<float4*>(dxr + c) = o;
                     if (dz) {   // second output: the dropout-masked (and possibly bf16) copy the next out-projection's GEMMs read
                         const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)c;
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     }
                 } else {
                     float o = r * (gv[it] - mg) - coef * xv[it];
-                    if (res) o += res[c];
+                    o += rv[it];
                     dxr[c] = o;
                     if (dz) {
                         const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)c;
