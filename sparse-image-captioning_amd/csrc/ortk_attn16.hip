@@ -71,6 +71,33 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     __bf16* sV = sK + 16 * NJT * P16;               // [64][P16]      rows = key, zero-padded (k of P.V: transposing reads)
     __bf16* sP = sV + 64 * P16 + wave * 16 * P16;   // [16][P16]      this wave's dropped P: rows = query, columns = key 0..63
     float* sMask = reinterpret_cast<float*>(sm16 + (16 * NJT + 64 + 16 * nw) * P16);   // [64]
+    const int lr = lane & 15, lq = lane >> 4;
+    const bool vec_p = (Lk & 3) == 0;               // P / bias rows start 16-byte aligned
+    const int nit = (Lq + 15) >> 4;
+    // The launcher gives every 16-row query tile its own wave (nw = nit).  This wave's Q fragments and bias rows are
+    // requested BEFORE the K / V staging and its barrier, so that the workgroup pays one global round trip, not two.
+    const int it = wave;
+    const int i = it * 16 + lr;                     // this lane's query (operand row and output row)
+    const bool iv = it < nit && i < Lq;
+    const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
+    float4 qraw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qraw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iv) {
+        const float* qp = a.q + ((int64_t)g * Lq + i) * a.ldq + h * DK + 8 * lq;
+        qraw[0] = *reinterpret_cast<const float4*>(qp); qraw[1] = *reinterpret_cast<const float4*>(qp + 4);
+        qraw[2] = *reinterpret_cast<const float4*>(qp + 32); qraw[3] = *reinterpret_cast<const float4*>(qp + 36);
+    }
+    float4 bias4[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int j0 = 16 * jt + 4 * lq;
+        bias4[jt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && iv) {
+            if (vec_p && j0 < Lk) bias4[jt] = *reinterpret_cast<const float4*>(a.bias + prow + j0);
+            else { float* bp = &bias4[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) bp[r] = a.bias[prow + j0 + r]; }
+        }
+    }
     stage_rows(sK, a.k + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
     stage_rows(sV, a.v + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 64, tid, blockDim.x);
     if (tid < 64) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
@@ -78,22 +105,8 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     for (int idx = lane; idx < 16 * 16; idx += 64) *reinterpret_cast<bf16x4*>(sP + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    const int lr = lane & 15, lq = lane >> 4;
-    const bool vec_p = (Lk & 3) == 0;               // P / bias rows start 16-byte aligned
-    const int nit = (Lq + 15) >> 4;
-    for (int it = wave; it < nit; it += nw) {
-        const int i = it * 16 + lr;                 // this lane's query (operand row and output row)
-        const bool iv = i < Lq;
-        bf16x8 qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-            if (iv) {
-                const float* qp = a.q + ((int64_t)g * Lq + i) * a.ldq + h * DK + 32 * ks + 8 * lq;
-                q0 = *reinterpret_cast<const float4*>(qp); q1 = *reinterpret_cast<const float4*>(qp + 4);
-            }
-            qf[ks] = cvt8(q0, q1);
-        }
+    if (it < nit) {
+        const bf16x8 qf[2] = {cvt8(qraw[0], qraw[1]), cvt8(qraw[2], qraw[3])};
         // S^T[j = 16*jt + 4*lq + r][i = lr]
         f32x4 s[NJT];
 #pragma unroll
@@ -102,18 +115,12 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) s[jt] = mma(frag_row(sK, 16 * jt + lr, 32 * ks + 8 * lq), qf[ks], s[jt]);
         }
-        const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
         const int qpos = a.causal_period > 0 ? i % a.causal_period : 0;
         float mx = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
             const int j0 = 16 * jt + 4 * lq;
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias && iv) {
-                if (vec_p && j0 < Lk) b4 = *reinterpret_cast<const float4*>(a.bias + prow + j0);
-                else { float* bp = &b4.x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) bp[r] = a.bias[prow + j0 + r]; }
-            }
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            const float bb[4] = {bias4[jt].x, bias4[jt].y, bias4[jt].z, bias4[jt].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = j0 + r;
@@ -158,7 +165,6 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
             if (NJT > 2) o = mma(frag_tr(sV, 32, 16 * dt, lane), pf1, o);
             if (iv) st_elem4(a.o, ((int64_t)g * Lq + i) * a.ldo + h * DK + 16 * dt + 4 * lq, a.o_dtype, make_float4(o[0], o[1], o[2], o[3]));
         }
-        wsync();
     }
 }
 static size_t fwd16_lds(int njt, int nw) { return (size_t)(16 * njt + 64 + 16 * nw) * P16 * sizeof(__bf16) + 64 * sizeof(float); }
@@ -179,6 +185,24 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
     __bf16* sG = sQ + Lqp * P16;            // [Lqp][P16]     dO: row fragments in phase 1, transposing reads in phase 2
     __bf16* sS = sG + Lqp * P16;            // [Lqp][P16]     dS / sqrt(dk): rows = query, columns = key 0..63
     __bf16* sD = sS + Lqp * P16;            // [Lqp][P16]     dropped P
+    const int lr = lane & 15, lq = lane >> 4;
+    const bool vec_p = (Lk & 3) == 0;
+    const int nit = (Lq + 15) >> 4;
+    // one 16-row query tile per wave (nw = nit); its saved probabilities are requested before the staging barrier
+    const int it = wave;
+    const int i0 = it * 16, i = i0 + lr;
+    const bool iv = it < nit && i < Lq;
+    const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
+    float4 praw[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int j0 = 16 * jt + 4 * lq;
+        praw[jt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iv) {
+            if (vec_p && j0 < Lk) praw[jt] = *reinterpret_cast<const float4*>(a.p + prow + j0);
+            else { float* q = &praw[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) q[r] = a.p[prow + j0 + r]; }
+        }
+    }
     stage_rows(sK, a.k + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 64, tid, blockDim.x);
     stage_rows(sV, a.v + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
     stage_rows(sQ, a.q + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
@@ -188,14 +212,8 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
         *reinterpret_cast<bf16x4*>(sS + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));   // sD follows sS
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    const int lr = lane & 15, lq = lane >> 4;
-    const bool vec_p = (Lk & 3) == 0;
-    const int nit = (Lq + 15) >> 4;
-    for (int it = wave; it < nit; it += nw) {
-        const int i0 = it * 16, i = i0 + lr;
-        const bool iv = i < Lq;
+    if (it < nit) {
         const bf16x8 g0 = frag_row(sG, i, 8 * lq), g1 = frag_row(sG, i, 32 + 8 * lq);
-        const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
         // dP^T[j = 16*jt + 4*lq + r][i = lr]
         f32x4 dp[NJT], pp[NJT];
         float dot = 0.f;
@@ -205,12 +223,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             dp[jt] = mma(frag_row(sV, 16 * jt + lr, 8 * lq), g0, dp[jt]);
             dp[jt] = mma(frag_row(sV, 16 * jt + lr, 32 + 8 * lq), g1, dp[jt]);
             const int j0 = 16 * jt + 4 * lq;
-            float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iv) {
-                if (vec_p && j0 < Lk) p4 = *reinterpret_cast<const float4*>(a.p + prow + j0);
-                else { float* q = &p4.x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) q[r] = a.p[prow + j0 + r]; }
-            }
-            const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+            const float pv[4] = {praw[jt].x, praw[jt].y, praw[jt].z, praw[jt].w};
             float pd[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
