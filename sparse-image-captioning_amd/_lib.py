@@ -71,7 +71,7 @@ class AttnArgs(C.Structure):
                 ("lddo", C.c_int64), ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64),
                 ("o_dtype", C.c_int32), ("dqkv_dtype", C.c_int32), ("kv_dtype", C.c_int32),
                 ("k_new", C.c_void_p), ("v_new", C.c_void_p), ("ld_new", C.c_int64), ("bwd_part", C.c_int32),
-                ("precision", C.c_int32)]
+                ("precision", C.c_int32), ("qkv_dtype", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _U32, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t

@@ -1151,7 +1151,8 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a_in, ortk_stream stream
             a->k_new = a->v_new = nullptr;
         }
     }
-    if (attn_impl() == 0 && ortk::attn16_ok(a, false)) return ortk::attn16_fwd(a, ortk_s(stream));   // mixed precision, block shapes
+    if ((attn_impl() == 0 || a->qkv_dtype) && ortk::attn16_ok(a, false)) return ortk::attn16_fwd(a, ortk_s(stream));   // mixed precision
+    if (a->qkv_dtype) return ORTK_EINVAL;          // bf16 Q / K / V are only understood by the bf16-operand kernels
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1229,8 +1230,9 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
     if (a->kv_dtype != 0 || a->bwd_part < 0 || a->bwd_part > 2) return ORTK_EINVAL;
     if (!a->p || !a->d_o || !a->dq || !a->d_k || !a->dv || a->kv_index || a->kv_group_stride) return ORTK_EINVAL;
     if (a->nkv == 0) return 0;
-    if (attn_impl() == 0 && ortk::attn16_ok(a, true))           // mixed precision, block shapes: one kernel does both parts
+    if ((attn_impl() == 0 || a->qkv_dtype) && ortk::attn16_ok(a, true))     // mixed precision: one kernel does both parts
         return a->bwd_part == 2 ? 0 : ortk::attn16_bwd(a, ortk_s(stream));
+    if (a->qkv_dtype) return ORTK_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

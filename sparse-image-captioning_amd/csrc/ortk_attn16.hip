@@ -49,7 +49,7 @@ __device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
 }
 __device__ __forceinline__ f32x4 mma(bf16x8 x, bf16x8 y, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc, 0, 0, 0); }
 
-// rows [0, rows) of a (.., 64)-column fp32 matrix slice -> bf16 image; rows [rows, rows_pad) are zeroed
+// rows [0, rows) of a (.., 64)-column matrix slice (fp32 or bf16 in memory) -> bf16 image; rows [rows, rows_pad) are zeroed
 __device__ __forceinline__ void stage_rows(__bf16* img, const float* src, int64_t ld, int rows, int rows_pad, int tid, int nthr) {
     for (int idx = tid; idx < rows_pad * 16; idx += nthr) {
         const int r = idx >> 4, c = (idx & 15) * 4;
@@ -58,11 +58,23 @@ __device__ __forceinline__ void stage_rows(__bf16* img, const float* src, int64_
         *reinterpret_cast<bf16x4*>(img + r * P16 + c) = cvt4(v);
     }
 }
+__device__ __forceinline__ void stage_rows(__bf16* img, const __bf16* src, int64_t ld, int rows, int rows_pad, int tid, int nthr) {
+    for (int idx = tid; idx < rows_pad * 8; idx += nthr) {
+        const int r = idx >> 3, c = (idx & 7) * 8;
+        bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < rows) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)r * ld + c);
+        *reinterpret_cast<bf16x8*>(img + r * P16 + c) = v;
+    }
+}
+// 8 consecutive elements of a global row as an MFMA fragment
+__device__ __forceinline__ bf16x8 ld_frag(const float* p) { return cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)); }
+__device__ __forceinline__ bf16x8 ld_frag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // ------------------------------------------------------------------------------------------------ forward
 // One workgroup per (group g, head h); one wave per 16-row query tile.  NJT = key tiles (Lk <= 16 * NJT <= 64).
-template <int NJT>
+template <int NJT, typename TQ>
 __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
+    const TQ* aq = reinterpret_cast<const TQ*>(a.q); const TQ* ak = reinterpret_cast<const TQ*>(a.k); const TQ* av = reinterpret_cast<const TQ*>(a.v);
     extern __shared__ __attribute__((aligned(16))) __bf16 sm16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
@@ -80,13 +92,10 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     const int i = it * 16 + lr;                     // this lane's query (operand row and output row)
     const bool iv = it < nit && i < Lq;
     const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
-    float4 qraw[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) qraw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bf16x8 qf[2] = {(bf16x8){0, 0, 0, 0, 0, 0, 0, 0}, (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}};
     if (iv) {
-        const float* qp = a.q + ((int64_t)g * Lq + i) * a.ldq + h * DK + 8 * lq;
-        qraw[0] = *reinterpret_cast<const float4*>(qp); qraw[1] = *reinterpret_cast<const float4*>(qp + 4);
-        qraw[2] = *reinterpret_cast<const float4*>(qp + 32); qraw[3] = *reinterpret_cast<const float4*>(qp + 36);
+        const TQ* qp = aq + ((int64_t)g * Lq + i) * a.ldq + h * DK + 8 * lq;
+        qf[0] = ld_frag(qp); qf[1] = ld_frag(qp + 32);
     }
     float4 bias4[NJT];
 #pragma unroll
@@ -98,15 +107,14 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
             else { float* bp = &bias4[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) bp[r] = a.bias[prow + j0 + r]; }
         }
     }
-    stage_rows(sK, a.k + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
-    stage_rows(sV, a.v + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 64, tid, blockDim.x);
+    stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
+    stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 64, tid, blockDim.x);
     if (tid < 64) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
     // key columns 16*NJT .. 63 of the P image are never written below: zero them once
     for (int idx = lane; idx < 16 * 16; idx += 64) *reinterpret_cast<bf16x4*>(sP + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     if (it < nit) {
-        const bf16x8 qf[2] = {cvt8(qraw[0], qraw[1]), cvt8(qraw[2], qraw[3])};
         // S^T[j = 16*jt + 4*lq + r][i = lr]
         f32x4 s[NJT];
 #pragma unroll
@@ -173,8 +181,9 @@ static size_t fwd16_lds(int njt, int nw) { return (size_t)(16 * njt + 64 + 16 * 
 // Phase 1 (wave = 16-row query tile): dP^T = V dO^T, dS = P (dP - rowsum(P dP)), dQ = dS K / sqrt(dk); dS / sqrt(dk) and the
 // dropped P go to workgroup-wide images.  Phase 2 (the 2 x NJT x 4 output tiles shared by the waves): dK = dS^T Q / sqrt(dk),
 // dV = Pd^T dO over all query rows of the group.  Lqp = query rows padded to a multiple of 32 (k range of phase 2).
-template <int NJT>
+template <int NJT, typename TQ>
 __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int Lqp) {
+    const TQ* aq = reinterpret_cast<const TQ*>(a.q); const TQ* ak = reinterpret_cast<const TQ*>(a.k); const TQ* av = reinterpret_cast<const TQ*>(a.v);
     extern __shared__ __attribute__((aligned(16))) __bf16 sm16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
@@ -203,9 +212,9 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             else { float* q = &praw[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) q[r] = a.p[prow + j0 + r]; }
         }
     }
-    stage_rows(sK, a.k + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 64, tid, blockDim.x);
-    stage_rows(sV, a.v + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
-    stage_rows(sQ, a.q + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
+    stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 64, tid, blockDim.x);
+    stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
+    stage_rows(sQ, aq + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
     stage_rows(sG, a.d_o + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
     // dS / P images: the key columns 16*NJT .. 63 and the query rows past the last wave tile are never written below
     for (int idx = tid; idx < 2 * Lqp * 16; idx += blockDim.x)
@@ -286,12 +295,15 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 namespace ortk {
 
 // shapes / layouts these kernels serve (everything else stays with the fp32-MFMA family)
+bool attn16_shape_ok(int Lq, int Lk, int dk) { return dk == 64 && Lk >= 1 && Lk <= 64 && Lq >= 1 && Lq <= 128; }
+
 bool attn16_ok(const ortk_attn_args* a, bool bwd) {
+    // fp32 inputs: only the block shapes (the register-only kernels keep the short ones); bf16 inputs: every served shape
     static int min_lq = -1;
     if (min_lq < 0) { const char* e = getenv("ORTK_ATTN16_MINLQ"); min_lq = e ? atoi(e) : 33; }
-    if (a->precision != 1 || a->dk != 64 || a->Lk < 1 || a->Lk > 64 || a->Lq < min_lq || a->Lq > 128) return false;
+    if (a->precision != 1 || !attn16_shape_ok(a->Lq, a->Lk, a->dk) || (a->qkv_dtype == 0 && a->Lq < min_lq)) return false;
     if (a->kv_index || a->kv_group_stride > 0 || a->kv_dtype != 0 || a->k_new || a->v_new) return false;
-    if ((a->ldq | a->ldk | a->ldv) % 4 || !al16(a->q) || !al16(a->k) || !al16(a->v)) return false;
+    if ((a->ldq | a->ldk | a->ldv) % (a->qkv_dtype ? 8 : 4) || !al16(a->q) || !al16(a->k) || !al16(a->v)) return false;
     if (!bwd) {
         const int64_t eo = a->o_dtype == ORTK_BF16 ? 2 : 4;
         if (a->ldo % 4 || (reinterpret_cast<uintptr_t>(a->o) % (4 * eo)) || (a->p && !al16(a->p)) || (a->bias && !al16(a->bias))) return false;
@@ -307,7 +319,9 @@ bool attn16_ok(const ortk_attn_args* a, bool bwd) {
 int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
     const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16;
     typedef void (*fn_t)(ortk_attn_args);
-    const fn_t fn = njt == 1 ? attn16_fwd_kernel<1> : njt == 2 ? attn16_fwd_kernel<2> : njt == 3 ? attn16_fwd_kernel<3> : attn16_fwd_kernel<4>;
+    const fn_t fn = a->qkv_dtype
+        ? (njt == 1 ? attn16_fwd_kernel<1, __bf16> : njt == 2 ? attn16_fwd_kernel<2, __bf16> : njt == 3 ? attn16_fwd_kernel<3, __bf16> : attn16_fwd_kernel<4, __bf16>)
+        : (njt == 1 ? attn16_fwd_kernel<1, float> : njt == 2 ? attn16_fwd_kernel<2, float> : njt == 3 ? attn16_fwd_kernel<3, float> : attn16_fwd_kernel<4, float>);
     const size_t lds = fwd16_lds(njt, nw);
     hipLaunchKernelGGL(fn, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, s, *a);
     ORTK_CHECK_LAUNCH();
@@ -317,12 +331,15 @@ int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
 int attn16_bwd(const ortk_attn_args* a, hipStream_t s) {
     const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16, Lqp = (int)ortk_align(a->Lq, 32);
     typedef void (*fn_t)(ortk_attn_args, int);
-    const fn_t fn = njt == 1 ? attn16_bwd_kernel<1> : njt == 2 ? attn16_bwd_kernel<2> : njt == 3 ? attn16_bwd_kernel<3> : attn16_bwd_kernel<4>;
+    const fn_t fn = a->qkv_dtype
+        ? (njt == 1 ? attn16_bwd_kernel<1, __bf16> : njt == 2 ? attn16_bwd_kernel<2, __bf16> : njt == 3 ? attn16_bwd_kernel<3, __bf16> : attn16_bwd_kernel<4, __bf16>)
+        : (njt == 1 ? attn16_bwd_kernel<1, float> : njt == 2 ? attn16_bwd_kernel<2, float> : njt == 3 ? attn16_bwd_kernel<3, float> : attn16_bwd_kernel<4, float>);
     const size_t lds = bwd16_lds(njt, Lqp);
-    static bool attr[4] = {false, false, false, false};
-    if (lds > 64 * 1024 && !attr[njt - 1]) {
+    static bool attr[8] = {false, false, false, false, false, false, false, false};
+    const int ai = njt - 1 + (a->qkv_dtype ? 4 : 0);
+    if (lds > 64 * 1024 && !attr[ai]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr[njt - 1] = true;
+        attr[ai] = true;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, s, *a, Lqp);
     ORTK_CHECK_LAUNCH();

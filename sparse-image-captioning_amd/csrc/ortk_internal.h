@@ -12,6 +12,7 @@ int kv_append(const float* qkv, void* cache_k, void* cache_v, int32_t kv_dtype, 
               int32_t t, hipStream_t s);
 
 // bf16-MFMA attention (ortk_attn16.hip): whether the call's shapes / layouts are served, and the launchers
+bool attn16_shape_ok(int Lq, int Lk, int dk);
 bool attn16_ok(const ortk_attn_args* a, bool bwd);
 int attn16_fwd(const ortk_attn_args* a, hipStream_t s);
 int attn16_bwd(const ortk_attn_args* a, hipStream_t s);

@@ -178,20 +178,23 @@ struct Bump {
 };
 
 // Buffers marked (A) hold MFMA operands only: bf16 in mixed precision (cfg.precision = 1), fp32 otherwise.
+// Buffers marked (Q) — the projected Q / K / V, which only feed the attention products — are bf16 in mixed precision when
+// the attention of their stack is served by the bf16-operand kernels (TrainWS.qdt_*), fp32 otherwise.
 struct EncBuf {   // per encoder layer
-    void *y1 /*A*/; float* qkv; float* P; void* o /*A*/; float* xm; void* y2 /*A*/; void* h /*A*/; float* xout; float *st1, *st2;
+    void *y1 /*A*/; void* qkv /*Q*/; float* P; void* o /*A*/; float* xm; void* y2 /*A*/; void* h /*A*/; float* xout; float *st1, *st2;
 };
 struct DecBuf {   // per decoder layer
-    void* y1 /*A*/; float* qkv; float* Ps; void* o1 /*A*/; float* xm1; void* y2 /*A*/; float* qc; float* Pc; void* o2 /*A*/;
+    void* y1 /*A*/; void* qkv /*Q*/; float* Ps; void* o1 /*A*/; float* xm1; void* y2 /*A*/; void* qc /*Q*/; float* Pc; void* o2 /*A*/;
     float* xm2; void* y3 /*A*/; void* h /*A*/; float* xout; float *st1, *st2, *st3;
 };
 struct TrainWS {
     int64_t Me, Md, ldv; int adt;
+    int qdt_enc, qdt_self, qdt_cross;       // element type of the (Q) buffers of the three attention stacks
     void* w16;                              // bf16 working copy of the weight arena (mixed precision)
     void* w16t;                             // ... and of every weight block TRANSPOSED (operand of the data-gradient GEMMs)
     float *x0, *logbias, *dscore; void* mem /*A*/; float* st_mem;
     EncBuf enc[MAXLAYERS];
-    float *dx0, *keymask, *ckv; void* dec_out /*A*/; float *st_out, *logits; void* dlogits /*A; aliases logits in fp32*/;
+    float *dx0, *keymask; void* ckv /*Q*/; void* dec_out /*A*/; float *st_out, *logits; void* dlogits /*A; aliases logits in fp32*/;
     DecBuf dec[MAXLAYERS];
     // backward temporaries
     float *ga, *gb, *gy; void *gt /*A*/, *gt2 /*A*/, *gt3 /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
@@ -207,6 +210,11 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     const size_t es = ortk_esize(w.adt);
     Bump b{reinterpret_cast<char*>(base), 0};
     auto act = [&](int64_t n) { return b.take_bytes((size_t)n * es); };
+    const int dk_ = (int)(d / H);
+    w.qdt_enc = (c.precision && attn16_shape_ok(S, S, dk_)) ? ORTK_BF16 : ORTK_F32;
+    w.qdt_self = (c.precision && attn16_shape_ok(T, T, dk_)) ? ORTK_BF16 : ORTK_F32;
+    w.qdt_cross = (c.precision && attn16_shape_ok((int)(spi * T), S, dk_)) ? ORTK_BF16 : ORTK_F32;
+    auto qbuf = [&](int64_t n, int dt) { return b.take_bytes((size_t)n * ortk_esize(dt)); };
     Offsets o; build_layout(c, o, nullptr);
     w.w16 = c.precision ? b.take_bytes((size_t)o.total * 2) : nullptr;
     w.w16t = c.precision ? b.take_bytes((size_t)o.total * 2) : nullptr;
@@ -215,19 +223,19 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     w.dscore = b.take<float>(L * B * H * S * S);
     for (int l = 0; l < L; ++l) {
         EncBuf& e = w.enc[l];
-        e.y1 = act(Me * d); e.qkv = b.take<float>(Me * 3 * d); e.P = b.take<float>((int64_t)B * H * S * S);
+        e.y1 = act(Me * d); e.qkv = qbuf(Me * 3 * d, w.qdt_enc); e.P = b.take<float>((int64_t)B * H * S * S);
         e.o = act(Me * d); e.xm = b.take<float>(Me * d); e.y2 = act(Me * d);
         e.h = act(Me * ff); e.xout = b.take<float>(Me * d);
         e.st1 = b.take<float>(Me * 2); e.st2 = b.take<float>(Me * 2);
     }
     w.mem = act(Me * d); w.st_mem = b.take<float>(Me * 2);
     w.dx0 = b.take<float>(Md * d); w.keymask = b.take<float>(Md);
-    w.ckv = b.take<float>(Me * L * 2 * d);
+    w.ckv = qbuf(Me * L * 2 * d, w.qdt_cross);
     for (int l = 0; l < L; ++l) {
         DecBuf& e = w.dec[l];
-        e.y1 = act(Md * d); e.qkv = b.take<float>(Md * 3 * d); e.Ps = b.take<float>((int64_t)R * H * T * T);
+        e.y1 = act(Md * d); e.qkv = qbuf(Md * 3 * d, w.qdt_self); e.Ps = b.take<float>((int64_t)R * H * T * T);
         e.o1 = act(Md * d); e.xm1 = b.take<float>(Md * d); e.y2 = act(Md * d);
-        e.qc = b.take<float>(Md * d); e.Pc = b.take<float>((int64_t)B * H * spi * T * S);
+        e.qc = qbuf(Md * d, w.qdt_cross); e.Pc = b.take<float>((int64_t)B * H * spi * T * S);
         e.o2 = act(Md * d); e.xm2 = b.take<float>(Md * d); e.y3 = act(Md * d);
         e.h = act(Md * ff); e.xout = b.take<float>(Md * d);
         e.st1 = b.take<float>(Md * 2); e.st2 = b.take<float>(Md * 2); e.st3 = b.take<float>(Md * 2);
@@ -433,12 +441,12 @@ enum Op : uint32_t { OP_SRC = 1, OP_EMB = 2, OP_ENC = 16, OP_DEC = 16 + 16 * MAX
 static inline uint32_t eop(int l, int k) { return OP_ENC + 16 * l + k; }
 static inline uint32_t dop(int l, int k) { return OP_DEC + 16 * l + k; }
 
-struct EncPtrs { void* y1; float* qkv; float* P; void* o; float* xm; void* y2; void* h; float* xout; float *st1, *st2; };
+struct EncPtrs { void* y1; void* qkv; float* P; void* o; float* xm; void* y2; void* h; float* xout; float *st1, *st2; };
 
 // encoder stack; `bufs[l]` may alias between layers when nothing has to be kept for a backward pass.
 // `mem` receives the final LayerNorm in dtype `mem_dt`.
 static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, const float* boxes, const float* masks, int B, int S,
-                           float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem) {
+                           float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem, int qdt = ORTK_F32) {
     const ortk_config& cfg = *c.cfg;
     const float* P = c.P;
     const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H, A = c.adt;
@@ -466,9 +474,10 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     for (int l = 0; l < L; ++l) {
         const EncOff& e = o.enc[l]; const EncPtrs& b = bufs[l];
         TRY(ln_fwd(c, x, e.n0a, e.n0b, b.y1, A, b.st1, Me));
-        TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Me, am.n * d, d));
-        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
-        a.q = b.qkv; a.k = b.qkv + am.k * d; a.v = b.qkv + am.v * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
+        TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, qdt, 3 * d, Me, am.n * d, d));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec; a.qkv_dtype = qdt;
+        a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, am.k * d, qdt); a.v = (const float*)off_elems(b.qkv, am.v * d, qdt);
+        a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
         a.kmask = masks; a.bias = plain ? nullptr : logbias + (int64_t)l * B * H * S * S; a.p = b.P;
         a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         if (l == 0) TRY(c.wait_ev(box_done));
@@ -583,15 +592,16 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     auto self_part = [&](const Ctx& cx, int l, const float* x) -> int {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         TRY(ln_fwd(cx, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
-        TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, ORTK_F32, 3 * d, Md, am.n * d, d));
-        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = cx.prec;
-        a.q = b.qkv; a.k = b.qkv + am.k * d; a.v = b.qkv + am.v * d; a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
+        TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, w.qdt_self, 3 * d, Md, am.n * d, d));
+        ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = cx.prec; a.qkv_dtype = w.qdt_self;
+        a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, am.k * d, w.qdt_self); a.v = (const float*)off_elems(b.qkv, am.v * d, w.qdt_self);
+        a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
         a.kmask = w.keymask; a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.causal_period = T;
         a.drop_p = cx.p_drop(); a.drop_seed = cx.sub(dop(l, 0));
         TRY(ortk_attention_fwd(&a, (ortk_stream)cx.s));
         TRY(fwd_gemm(cx, b.o1, A, d, e.wo, P + e.bo, b.xm1, ORTK_F32, d, Md, d, d, false, cx.p_drop(), cx.sub(dop(l, 1)), x, d));
         TRY(ln_fwd(cx, b.xm1, e.n1a, e.n1b, b.y2, A, b.st2, Md));
-        TRY(fwd_gemm(cx, b.y2, A, d, e.cqw, P + e.cqb, b.qc, ORTK_F32, d, Md, d, d));
+        TRY(fwd_gemm(cx, b.y2, A, d, e.cqw, P + e.cqb, b.qc, w.qdt_cross, d, Md, d, d));
         return 0;
     };
     // The token side of decoder layer 0 (embedding, self-attention sublayer, cross-attention query) does not depend on the
@@ -600,7 +610,7 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     if (c.use_side) {
         TRY(c.fork());                     // the side stream sees the bf16 weight copy
     }
-    TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem));
+    TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc));
     {
         const Ctx cx = c.use_side ? c.on_side() : c;
         TRY(ortk_embed_fwd(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, R, T, 0, d, cfg->pad_id, c.p_drop(),
@@ -609,13 +619,15 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     }
     // decoder
     const int U = o.ckv_slots;            // distinct decoder layers: one K|V slice each in the packed projection
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, ORTK_F32, U * cw, Me, (int)(U * cw), d));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.qdt_cross, U * cw, Me, (int)(U * cw), d));
     const float* x = w.dx0;
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         if (l == 0 && c.use_side) TRY(c.wait_ev(prefix_done)); else TRY(self_part(c, l, x));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
-        a.q = b.qc; a.ldq = d; a.k = w.ckv + o.ckv_slot[l] * cw; a.v = a.k + cv; a.ldk = a.ldv = U * cw;
+        a.qkv_dtype = w.qdt_cross; a.q = (const float*)b.qc; a.ldq = d;
+        a.k = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw, w.qdt_cross); a.v = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw + cv, w.qdt_cross);
+        a.ldk = a.ldv = U * cw;
         a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         TRY(ortk_attention_fwd(&a, stream));
@@ -734,7 +746,9 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
-        a.q = b.qc; a.ldq = d; a.k = w.ckv + o.ckv_slot[l] * cw; a.v = a.k + cv; a.ldk = a.ldv = U * cw;
+        a.qkv_dtype = w.qdt_cross; a.q = (const float*)b.qc; a.ldq = d;
+        a.k = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw, w.qdt_cross); a.v = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw + cv, w.qdt_cross);
+        a.ldk = a.ldv = U * cw;
         a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         a.d_o = w.gy; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
         a.d_k = off_elems(w.gkv, gslot[l] * cw, A); a.dv = off_elems(w.gkv, gslot[l] * cw + gdv, A);
@@ -749,7 +763,8 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Md, d, d));
         std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
-        a.q = b.qkv; a.k = b.qkv + amd.k * d; a.v = b.qkv + amd.v * d; a.ldq = a.ldk = a.ldv = 3 * d;
+        a.qkv_dtype = w.qdt_self; a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, amd.k * d, w.qdt_self);
+        a.v = (const float*)off_elems(b.qkv, amd.v * d, w.qdt_self); a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, amd.gk * d, A); a.dv = off_elems(w.gqkv, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
@@ -800,7 +815,8 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Me, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
-        a.q = b.qkv; a.k = b.qkv + ame.k * d; a.v = b.qkv + ame.v * d; a.ldq = a.ldk = a.ldv = 3 * d;
+        a.qkv_dtype = w.qdt_enc; a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, ame.k * d, w.qdt_enc);
+        a.v = (const float*)off_elems(b.qkv, ame.v * d, w.qdt_enc); a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, ame.gk * d, A); a.dv = off_elems(w.gqkv, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;

@@ -185,7 +185,7 @@ def test_box_embedding_and_logbias(L):
         assert (dbg[l].cpu() - br[l].grad).abs().max().item() < 2e-2 * br[l].grad.abs().max().item()
 
 
-def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0, precision=0, out_dt=0):
+def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0, precision=0, out_dt=0, in_dt=0):
     d = H * dk
     q, k, v = rnd(nkv * Lq, d, seed=seed + 1), rnd(nkv * Lk, d, seed=seed + 2), rnd(nkv * Lk, d, seed=seed + 3)
     kmask = torch.ones(nkv, Lk)
@@ -215,6 +215,9 @@ def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0, precis
         else:
             torch.testing.assert_close(x, y, rtol=rtol, atol=atol)
     qd, kd, vd, dod = dev(q), dev(k), dev(v), dev(do)
+    if in_dt:       # bf16 Q / K / V rows (the executor's packed projections in mixed precision)
+        qd, kd, vd = qd.bfloat16(), kd.bfloat16(), vd.bfloat16()
+        a.qkv_dtype = 1
     o = torch.empty(nkv * Lq, d, device="cuda", dtype=odt); p = torch.empty(nkv, H, Lq, Lk, device="cuda")
     a.q, a.k, a.v, a.o = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr()
     a.ldq = a.ldk = a.ldv = a.ldo = d
@@ -261,6 +264,17 @@ def test_attention_bf16_operand_kernels(L):
     _attn_case(L, 3, 2, 40, 13, 64, 0, False, True, precision=1)             # one key tile, Lk not a multiple of 4 (scalar P rows)
     _attn_case(L, 2, 8, 51, 17, 64, 17, False, True, precision=1)            # causal period
     _attn_case(L, 2, 1, 128, 30, 64, 0, True, False, precision=1, out_dt=1)  # 8 waves
+    # bf16 Q / K / V in memory (qkv_dtype = 1): the three stacks of the training step
+    _attn_case(L, 5, 8, 36, 36, 64, 0, True, True, precision=1, out_dt=1, in_dt=1)
+    _attn_case(L, 3, 8, 85, 36, 64, 0, False, True, precision=1, out_dt=1, in_dt=1)
+    _attn_case(L, 7, 8, 17, 17, 64, 17, False, True, precision=1, out_dt=1, in_dt=1)     # decoder self-attention: one 16-row tile + 1 row
+    _attn_case(L, 4, 2, 9, 5, 64, 9, False, False, precision=1, in_dt=1)                  # a single partial tile
+    a = L.AttnArgs()                                                                      # shapes the bf16 kernels do not take: loud
+    a.qkv_dtype, a.precision = 1, 1
+    t = torch.zeros(4 * 200, 64, device="cuda", dtype=torch.bfloat16); o = torch.zeros(4 * 200, 64, device="cuda")
+    a.q = a.k = a.v = t.data_ptr(); a.o = o.data_ptr(); a.ldq = a.ldk = a.ldv = a.ldo = 64
+    a.nkv, a.H, a.Lq, a.Lk, a.dk = 4, 1, 200, 200, 64
+    assert L.lib().ortk_attention_fwd(C.byref(a), L.stream_ptr()) != 0
 
 
 @pytest.mark.parametrize("H,dk,kvdt", [(8, 64, 0), (8, 64, 1), (4, 16, 0)])
