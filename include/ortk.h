@@ -268,8 +268,9 @@ typedef struct ortk_attn_args {
     /* 0 = fp32 products (v_mfma_f32_16x16x4_f32: the parity mode); 1 = the operands of the four products are rounded to bf16
      * (fp32 accumulation, fp32 soft-max; served for dk = 64, Lk <= 64, 32 < Lq <= 128 — other shapes run the fp32 kernels) */
     int32_t precision;
-    /* 1 = q, k, v point to bf16 rows (ldq / ldk / ldv in elements, multiples of 8; 16-byte aligned): the packed projection
-     * outputs of the mixed-precision training step, which only ever feed these products.  Served by the bf16-operand kernels
+    /* 1 = q, k, v — and, in the backward, d_o — point to bf16 rows (leading dimensions in elements, multiples of 8; 16-byte
+     * aligned): the packed projection outputs (and the out-projection's input gradient) of the mixed-precision training
+     * step, which only ever feed these products.  Served by the bf16-operand kernels
      * only (precision = 1, dk = 64, Lk <= 64, Lq <= 128); anything else returns ORTK_EINVAL. */
     int32_t qkv_dtype;
 } ortk_attn_args;

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
     stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 64, tid, blockDim.x);
     stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
     stage_rows(sQ, aq + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
-    stage_rows(sG, a.d_o + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
+    stage_rows(sG, reinterpret_cast<const TQ*>(a.d_o) + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
     // dS / P images: the key columns 16*NJT .. 63 and the query rows past the last wave tile are never written below
     for (int idx = tid; idx < 2 * Lqp * 16; idx += blockDim.x)
         *reinterpret_cast<bf16x4*>(sS + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));   // sD follows sS
@@ -310,7 +310,7 @@ bool attn16_ok(const ortk_attn_args* a, bool bwd) {
     } else {
         const int64_t eg = a->dqkv_dtype == ORTK_BF16 ? 2 : 4;
         if (!a->p || !a->d_o || !a->dq || !a->d_k || !a->dv) return false;
-        if ((a->lddo | a->lddq | a->lddk | a->lddv) % 4 || !al16(a->d_o) || !al16(a->p) || (a->dscore && !al16(a->dscore))) return false;
+        if ((a->lddo % (a->qkv_dtype ? 8 : 4)) || (a->lddq | a->lddk | a->lddv) % 4 || !al16(a->d_o) || !al16(a->p) || (a->dscore && !al16(a->dscore))) return false;
         if ((reinterpret_cast<uintptr_t>(a->dq) | reinterpret_cast<uintptr_t>(a->d_k) | reinterpret_cast<uintptr_t>(a->dv)) % (4 * eg)) return false;
     }
     return true;

@@ -197,7 +197,7 @@ struct TrainWS {
     float *dx0, *keymask; void* ckv /*Q*/; void* dec_out /*A*/; float *st_out, *logits; void* dlogits /*A; aliases logits in fp32*/;
     DecBuf dec[MAXLAYERS];
     // backward temporaries
-    float *ga, *gb, *gy; void *gt /*A*/, *gt2 /*A*/, *gt3 /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
+    float *ga, *gb, *gy; void* gdo /*Q: dO of an attention backward*/; void *gt /*A*/, *gt2 /*A*/, *gt3 /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
     size_t bytes;
 };
 
@@ -244,6 +244,7 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     w.logits = b.take<float>(Md * w.ldv);
     w.dlogits = c.precision ? act(Md * w.ldv) : (void*)w.logits;
     w.ga = b.take<float>(Mx * d); w.gb = b.take<float>(Mx * d); w.gy = b.take<float>(Mx * d);
+    w.gdo = c.precision ? act(Mx * d) : nullptr;
     w.gt = act(Mx * d); w.gt2 = act(Mx * d); w.gt3 = act(Mx * d); w.gqkv = act(Mx * 3 * d); w.gh = act(Mx * ff); w.gkv = act(Me * L * 2 * d);
     w.scalar = b.take<float>(64);
     w.bytes = (b.off + 255) & ~(size_t)255;
@@ -744,13 +745,15 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         // cross-attention sublayer
         TRY(drop_bwd(c, dx2, gt_cur, Md * d, dop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
-        TRY(dgrad_gemm(c, dt, dtt, d, e.cow, w.gy, ORTK_F32, d, Md, d, d));
+        // the out-projection's input gradient only feeds the attention backward's products: bf16 beside bf16 Q / K / V
+        void* dO = w.qdt_cross ? w.gdo : (void*)w.gy;
+        TRY(dgrad_gemm(c, dt, dtt, d, e.cow, dO, w.qdt_cross, d, Md, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.qkv_dtype = w.qdt_cross; a.q = (const float*)b.qc; a.ldq = d;
         a.k = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw, w.qdt_cross); a.v = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw + cv, w.qdt_cross);
         a.ldk = a.ldv = U * cw;
         a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
-        a.d_o = w.gy; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
+        a.d_o = (const float*)dO; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
         a.d_k = off_elems(w.gkv, gslot[l] * cw, A); a.dv = off_elems(w.gkv, gslot[l] * cw + gdv, A);
         a.lddk = a.lddv = ldg;
         TRY(c.before_write(gt_cur));
@@ -761,12 +764,13 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         // self-attention sublayer
         TRY(drop_bwd(c, dx, gt_cur, Md * d, dop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
-        TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Md, d, d));
+        dO = w.qdt_self ? w.gdo : (void*)w.gy;
+        TRY(dgrad_gemm(c, dt, dtt, d, e.wo, dO, w.qdt_self, d, Md, d, d));
         std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.qkv_dtype = w.qdt_self; a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, amd.k * d, w.qdt_self);
         a.v = (const float*)off_elems(b.qkv, amd.v * d, w.qdt_self); a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
-        a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
+        a.d_o = (const float*)dO; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, amd.gk * d, A); a.dv = off_elems(w.gqkv, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
@@ -813,12 +817,13 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me, gt_new(), eop(l, 1)));
         TRY(drop_bwd(c, dx2, gt_cur, Me * d, eop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
-        TRY(dgrad_gemm(c, dt, dtt, d, e.wo, w.gy, ORTK_F32, d, Me, d, d));
+        void* dOe = w.qdt_enc ? w.gdo : (void*)w.gy;
+        TRY(dgrad_gemm(c, dt, dtt, d, e.wo, dOe, w.qdt_enc, d, Me, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.qkv_dtype = w.qdt_enc; a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, ame.k * d, w.qdt_enc);
         a.v = (const float*)off_elems(b.qkv, ame.v * d, w.qdt_enc); a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
-        a.d_o = w.gy; a.lddo = d; a.dqkv_dtype = A;
+        a.d_o = (const float*)dOe; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, ame.gk * d, A); a.dv = off_elems(w.gqkv, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         a.dscore = cfg->no_box ? nullptr : w.dscore + (int64_t)l * B * H * S * S;
         TRY(c.before_write(w.gqkv));

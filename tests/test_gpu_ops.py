@@ -216,7 +216,7 @@ def _attn_case(L, nkv, H, Lq, Lk, dk, causal, use_bias, use_mask, seed=0, precis
             torch.testing.assert_close(x, y, rtol=rtol, atol=atol)
     qd, kd, vd, dod = dev(q), dev(k), dev(v), dev(do)
     if in_dt:       # bf16 Q / K / V rows (the executor's packed projections in mixed precision)
-        qd, kd, vd = qd.bfloat16(), kd.bfloat16(), vd.bfloat16()
+        qd, kd, vd, dod = qd.bfloat16(), kd.bfloat16(), vd.bfloat16(), dod.bfloat16()      # ... and the backward's dO
         a.qkv_dtype = 1
     o = torch.empty(nkv * Lq, d, device="cuda", dtype=odt); p = torch.empty(nkv, H, Lq, Lk, device="cuda")
     a.q, a.k, a.v, a.o = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr()
