@@ -114,3 +114,41 @@ G1_INPUTS = dict(seed=77, n_img=3, n_reg=12, feat=TINY_CFG["att_feat_size"], voc
 G2_SEED = 8888
 G2_INPUTS = dict(seed=99, n_img=4, n_reg=36, feat=2048, vocab=10001, spi=5, ragged=False)
 G3_KEEP = 0.3
+
+
+# ---- collate fixture (G12): synthetic feature / box files + a stand-in tokenizer, shared by make_golden_collate.py and the tests ----
+class StubTokenizer:
+    """Stands in for the reference's tokenizers (out of scope): words -> ids by a fixed arithmetic rule."""
+
+    def __init__(self, vocab=97, bos=2, eos=3):
+        self.vocab, self.bos, self.eos = vocab, bos, eos
+
+    def encode(self, text, add_bos_eos=True, max_seq_length=18):
+        ids = [4 + (sum(ord(c) * (i + 1) for i, c in enumerate(w)) % (self.vocab - 4)) for w in text.split()]
+        if add_bos_eos:
+            ids = [self.bos] + ids[:max_seq_length - 2] + [self.eos]
+        return ids[:max_seq_length]
+
+
+COLLATE_WORDS = "a an the man woman dog cat sits stands on in near table street grass with red blue small large ball hat".split()
+
+
+def make_collate_fixture(root, seed=4242, n_img=5, feat=16):
+    """Writes <root>/att/<id>.npy ((n, feat) or (1, n, feat)) and <root>/box/<id>.npy ((n, 4)) with n in 3..12 and returns the
+    list of dataset items (image_path, image_id, caption, all_captions, all_gts) a reference DataLoader would hand to the collate."""
+    import os
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "att"), exist_ok=True)
+    os.makedirs(os.path.join(root, "box"), exist_ok=True)
+    items = []
+    for i in range(n_img):
+        n = int(rs.randint(3, 13))
+        att = rs.standard_normal((n, feat)).astype(np.float32)
+        if i % 2:
+            att = att[None]                                     # some files carry a leading axis (collate.py:109-110 reshapes)
+        np.save(os.path.join(root, "att", f"{100 + i}.npy"), att)
+        np.save(os.path.join(root, "box", f"{100 + i}.npy"), rs.uniform(0, 1, (n, 4)).astype(np.float64 if i == 2 else np.float32))
+        ncap = int(rs.randint(1, 5))
+        caps = [" ".join(rs.choice(COLLATE_WORDS, size=int(rs.randint(3, 25)))) for _ in range(ncap)]
+        items.append((f"/images/{100 + i}.jpg", 100 + i, caps[0], caps, [c.split() for c in caps]))
+    return items

@@ -358,6 +358,32 @@ def test_plain_transformer_vs_reference_golden(P, golden):
     assert abs(LanguageModelCriterion()(lb, b["seqs"][:, 1:], b["masks"][:, 1:]).item() - float(g10["xe_loss"])) < 0.05
 
 
+def test_collated_batch_feeds_the_model(P, tmp_path):
+    """Files -> ObjectRelationCollate (native padding, pinned tensors) -> .cuda(non_blocking) -> model(**data): log-probs
+    equal the oracle's on the same tensors (ragged 3..12 regions, captions of different lengths)."""
+    import random
+    from sparse_image_captioning_amd.data import ObjectRelationCollate
+    from sparse_image_captioning_amd.utils.config import Config
+    cfgd = dict(C.TINY_CFG)
+    root = str(tmp_path)
+    items = C.make_collate_fixture(root, feat=cfgd["att_feat_size"])
+    ccfg = Config(input_att_dir=root + "/att", input_rel_box_dir=root + "/box", seq_per_img=2, max_seq_length=cfgd["max_seq_length"],
+                  dataset_dir=root)
+    random.seed(7)
+    # every image contributes exactly seq_per_img captions here (the model needs rows = images x captions per image)
+    items = [(p_, i_, c_, (caps * 2)[:2], g_) for p_, i_, c_, caps, g_ in items]
+    data = ObjectRelationCollate(ccfg, C.StubTokenizer(vocab=cfgd["vocab_size"]))(items)
+    assert data["att_feats"].is_pinned() and data["seqs"].dtype == torch.long
+    dev = {k: (v.cuda(non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+    state = H.g1_state()
+    m = _model(P, "relation_transformer", cfgd, state).eval()
+    # the reference's training step calls model(**data) with the collate's dict (utils/training.py:190-206)
+    logp = m(**{k: dev[k] for k in ("att_feats", "att_masks", "boxes", "seqs")})
+    ocfg = O.OCfg(**{k: v for k, v in cfgd.items() if not k.startswith("prune")})
+    ref = O.forward_logp(state, ocfg, data["att_feats"], data["boxes"], data["seqs"], data["att_masks"])
+    close(logp, ref.numpy(), 1e-4)
+
+
 def test_non_trigonometric_box_embedding_vs_reference_golden(P, golden):
     """`no_box_trigonometric_embedding`: WG is Linear(4, 1) on the raw log-ratios (relation_transformer.py:131-136,243-256)."""
     from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
