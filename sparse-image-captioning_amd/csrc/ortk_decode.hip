@@ -252,44 +252,52 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
         }
         __syncthreads();
     }
-    // histories, ancestry table, next tokens: thread q handles new beam q
+    // histories, ancestry table, next tokens.  Every copy is spread over the whole workgroup: one thread per beam walking
+    // its t history entries and t+1 ancestry entries was a chain of ~50 dependent global round trips (the tail of this kernel
+    // grew with t and dominated it: 118 us per step at 1 024 images x 5 beams).
+    const int64_t row0 = (int64_t)img * b;
+    for (int idx = tid; idx < b * t; idx += 256) {
+        const int q = idx / t, u = idx - q * t;
+        const int parent = win_i[q] / V;
+        const int64_t nrow = row0 + q, prow = row0 + parent;
+        st.seq[nxt][nrow * L + u] = st.seq[cur][prow * L + u];
+        st.tok_lp[nxt][nrow * L + u] = st.tok_lp[cur][prow * L + u];
+    }
+    for (int idx = tid; idx < b * (t + 1); idx += 256) {
+        const int q = idx / (t + 1), u = idx - q * (t + 1);
+        const int parent = win_i[q] / V;
+        const int64_t srow = t == 0 ? img : row0 + parent;
+        st.kvidx[nxt][(row0 + q) * (t + 2) + u] = st.kvidx[cur][srow * (t + 1) + u];   // ancestors' cache rows
+    }
+    __shared__ int end_slot[MAXB];
     if (tid < b) {
         const int q = tid;
         const int ix = win_i[q];
         const int parent = ix / V, tok = ix - parent * V;
-        const int64_t nrow = (int64_t)img * b + q, prow = (int64_t)img * b + parent;
+        const int64_t nrow = row0 + q, prow = row0 + parent;
         const int64_t srow = t == 0 ? img : prow;
-        for (int u = 0; u < t; ++u) {
-            st.seq[nxt][nrow * L + u] = st.seq[cur][prow * L + u];
-            st.tok_lp[nxt][nrow * L + u] = st.tok_lp[cur][prow * L + u];
-        }
         st.seq[nxt][nrow * L + t] = tok;
         const int pq = t == 0 ? 0 : parent;
         st.tok_lp[nxt][nrow * L + t] = FUSED ? (logp[srow * st.ldv + tok] * scale - row_mx[pq]) - row_lse[pq] : logp[srow * st.ldv + tok];
         st.it[nrow] = tok;
-        // keys of the next pass: ancestors' cache rows, then this beam's own slot at time t+1
-        const int32_t* src = st.kvidx[cur] + srow * (t + 1);
-        int32_t* dst = st.kvidx[nxt] + nrow * (t + 2);
-        for (int u = 0; u <= t; ++u) dst[u] = src[u];
-        dst[t + 1] = (int32_t)(nrow * st.tmax + t + 1);
+        st.kvidx[nxt][nrow * (t + 2) + t + 1] = (int32_t)(nrow * st.tmax + t + 1);      // this beam's own slot at time t+1
     }
-    __syncthreads();
-    // finished hypotheses (sequential per image: insertion order matters for the final stable sort)
+    // finished hypotheses: slots are handed out sequentially per image (insertion order matters for the final stable
+    // sort), the copies run in parallel afterwards
+    const int cap = b * L;
     if (tid == 0) {
         int cnt = st.done_cnt[img];
-        const int cap = b * L;
         for (int q = 0; q < b; ++q) {
-            const int64_t nrow = (int64_t)img * b + q;
-            const int tok = st.seq[nxt][nrow * L + t];
+            const int64_t nrow = row0 + q;
+            const int ix = win_i[q];
+            const int tok = ix - (ix / V) * V;
             float cum = win_v[q];
             const bool end = tok == st.eos || t == L - 1;
+            end_slot[q] = -1;
             if (end) {
                 if (cnt < cap) {
                     const int64_t base = ((int64_t)img * cap + cnt);
-                    for (int u = 0; u <= t; ++u) {
-                        st.done_seq[base * L + u] = st.seq[nxt][nrow * L + u];
-                        st.done_lp[base * L + u] = st.tok_lp[nxt][nrow * L + u];
-                    }
+                    end_slot[q] = cnt;
                     st.done_len[base] = t + 1;
                     st.done_p[base] = length_pen(st.length_penalty, st.length_alpha, t + 1, (double)cum);
                     ++cnt;
@@ -299,6 +307,14 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
             st.cum[nrow] = cum;
         }
         st.done_cnt[img] = cnt;
+    }
+    __syncthreads();          // end_slot, and the histories written above, are visible to the whole workgroup
+    for (int idx = tid; idx < b * (t + 1); idx += 256) {
+        const int q = idx / (t + 1), u = idx - q * (t + 1);
+        if (end_slot[q] < 0) continue;
+        const int64_t base = (int64_t)img * cap + end_slot[q], nrow = row0 + q;
+        st.done_seq[base * L + u] = st.seq[nxt][nrow * L + u];
+        st.done_lp[base * L + u] = st.tok_lp[nxt][nrow * L + u];
     }
 }
 
