@@ -414,6 +414,65 @@ __global__ __launch_bounds__(256) void sample_step_kernel(SampleState st, const 
     }
 }
 
+// Same step on RAW generator logits: the row stays in registers (one read), its log-soft-max statistics are taken with the
+// reductions of log_softmax_kernel (bit-identical log-probabilities), then the arg-max / Gumbel-max runs on
+// logp = (logit - max) - lse.  Saves the separate log-soft-max pass (read + write of rows x V fp32 per step).
+template <int NPT>
+__global__ __launch_bounds__(256) void sample_step_fused_kernel(SampleState st, const float* __restrict__ logits, int t) {
+    __shared__ float sh_red[4];
+    __shared__ float red_v[4], red_l[4];
+    __shared__ int red_i[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lp = logits + (int64_t)row * st.ldv;
+    float z[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) { const int v = tid + 256 * u; z[u] = v < st.V ? lp[v] : 0.f; }
+    const int prev = (st.decoding_constraint && t > 0) ? (int)st.seq[(int64_t)row * st.L + t - 1] : -1;
+    const bool is_greedy = st.greedy_stride > 0 && row % st.greedy_stride == 0;
+    const bool samp = st.sample && !is_greedy;
+    const int64_t grow = st.row_offset + row;
+    const int hrow = (int)(st.greedy_stride > 0 ? grow - grow / st.greedy_stride - 1 : grow);
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) if (tid + 256 * u < st.V) m = fmaxf(m, z[u]);
+    const float mx = blk_max(m, sh_red);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) if (tid + 256 * u < st.V) sum += expf(z[u] - mx);
+    sum = blk_sum(sum, sh_red);
+    const float lse = logf(sum);
+    float mv = -INFINITY, ml = 0.f; int mi = 0x7FFFFFFF;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int v = tid + 256 * u;
+        if (v >= st.V || v == prev) continue;
+        const float l = (z[u] - mx) - lse;
+        float x = l;
+        if (samp) x = x / st.temperature + gumbel(st.seed, t, hrow, v);
+        if (better(x, v, mv, mi)) { mv = x; mi = v; ml = l; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mv, o, 64), ol = __shfl_xor(ml, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (better(ov, oi, mv, mi)) { mv = ov; mi = oi; ml = ol; }
+    }
+    if (lane == 0) { red_v[wave] = mv; red_i[wave] = mi; red_l[wave] = ml; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w], red_i[w], mv, mi)) { mv = red_v[w]; mi = red_i[w]; ml = red_l[w]; }
+        const int unf = st.unfinished[row];
+        st.it[row] = mi;
+        st.seq[(int64_t)row * st.L + t] = unf ? mi : 0;
+        st.lp[(int64_t)row * st.L + t] = ml;
+        const int now = unf && (mi != st.eos);
+        st.unfinished[row] = now;
+        int32_t* last = st.last_step + (is_greedy ? 1 : 0);
+        if (unf && !now) atomicMax(last, t);
+        if (now && t == st.L - 1) atomicMax(last, t);
+    }
+}
+
 __global__ void sample_finalize_kernel(SampleState st) {
     const int64_t n = (int64_t)st.rows * st.L;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -474,8 +533,14 @@ int sample_init(const SampleState& st, int32_t bos, hipStream_t s) {
     ORTK_CHECK_LAUNCH();
     return 0;
 }
-int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s) {
+int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused) {
     if (st.rows == 0) return 0;
+    if (fused) {       // `logp` holds raw logits (V <= 10 240: the caller checks sample_step_can_fuse)
+        if (st.V > 256 * 40) return ORTK_EINVAL;
+        hipLaunchKernelGGL(sample_step_fused_kernel<40>, dim3((unsigned)st.rows), dim3(256), 0, s, st, logp, t);
+        ORTK_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(sample_step_kernel, dim3((unsigned)st.rows), dim3(256), 0, s, st, logp, t);
     ORTK_CHECK_LAUNCH();
     return 0;

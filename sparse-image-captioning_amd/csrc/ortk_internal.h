@@ -62,7 +62,8 @@ struct SampleState {
     int64_t row_offset;       // index of row 0 in the full batch (chunked decoding): the Gumbel hash is keyed by the global row
 };
 int sample_init(const SampleState& st, int32_t bos, hipStream_t s);
-int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s);
+// fused = true: `logp` holds raw logits (V <= 10 240) and the log-soft-max is taken inside the step
+int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false);
 int sample_finalize(const SampleState& st, hipStream_t s);
 
 int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
