@@ -33,6 +33,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.ortk_version() == 1
 
 
+def test_every_header_under_include_is_fully_exported():
+    """All C-ABI headers (device path, SCST scorer, batch padding): each declared ortk_* function is a symbol of libortk.so."""
+    import glob
+    import sparse_image_captioning_amd as P
+    lib = P._lib.lib()
+    headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    assert [os.path.basename(h) for h in headers] == ["ortk.h", "ortk_data.h", "ortk_scorer.h"]
+    for h in headers:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names = sorted(set(re.findall(r"\b(ortk_[a-z0-9_]+)\s*\(", src)))
+        assert names, h
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in {os.path.basename(h)} but not exported by libortk.so"
+
+
 def test_struct_sizes_match_header():
     """sizeof() of the ctypes mirrors == what the C compiler lays out (checked by compiling a tiny C program)."""
     import subprocess, tempfile
