@@ -158,9 +158,12 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
                 if (vec_p && j0 < Lk) *reinterpret_cast<float4*>(a.p + prow + j0) = make_float4(p[0], p[1], p[2], p[3]);
                 else for (int r = 0; r < 4; ++r) if (j0 + r < Lk) a.p[prow + j0 + r] = p[r];
             }
-            if (a.drop_p > 0.f)
+            if (a.drop_p > 0.f) {
+                bool kp[4];
+                ortk_keep4(a.drop_seed, (uint64_t)(prow + j0), a.drop_p, kp);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] = ortk_keep(a.drop_seed, (uint64_t)(prow + j0 + r), a.drop_p) ? p[r] * inv_keep : 0.f;
+                for (int r = 0; r < 4; ++r) p[r] = kp[r] ? p[r] * inv_keep : 0.f;
+            }
             *reinterpret_cast<bf16x4*>(sP + lr * P16 + j0) = cvt4(make_float4(p[0], p[1], p[2], p[3]));
         }
         wsync();
@@ -234,10 +237,12 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             const int j0 = 16 * jt + 4 * lq;
             const float pv[4] = {praw[jt].x, praw[jt].y, praw[jt].z, praw[jt].w};
             float pd[4];
+            bool kp[4] = {true, true, true, true};
+            if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)(prow + j0), a.drop_p, kp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool valid = iv && j0 + r < Lk;
-                const bool keep = valid && (a.drop_p > 0.f ? ortk_keep(a.drop_seed, (uint64_t)(prow + j0 + r), a.drop_p) : true);
+                const bool keep = valid && kp[r];
                 const float d = keep ? dp[jt][r] * inv_keep : 0.f;
                 pd[r] = keep ? pv[r] * inv_keep : 0.f;
                 pp[jt][r] = valid ? pv[r] : 0.f; dp[jt][r] = d; dot += pp[jt][r] * d;

@@ -65,10 +65,33 @@ __host__ __device__ static inline uint32_t ortk_mix32(uint32_t x) {
 // uniform in (0,1) with 24 random bits
 __host__ __device__ static inline float ortk_u01(uint32_t h) { return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-// dropout keep decision for element `idx` of the tensor keyed by `seed`
+// Dropout keep decisions.  Four consecutive elements (idx & ~3 .. +3) share ONE hash evaluation: 64 bits = four 16-bit
+// fields, element idx keeps iff its field >= floor(p * 65536) (drop probability within 1.6e-5 of p).  A kernel that owns an
+// aligned group of four (GEMM epilogues, LayerNorm backward, the bf16 attention kernels) calls ortk_keep4 — one 32-bit mix
+// plus one multiply-xorshift round per four elements instead of one mix and an int->float conversion per element (the
+// per-element form cost 25 us of the 100-us FFN up-projection); every other site evaluates the same function per element.
+__device__ static inline uint2 ortk_keep_bits(uint32_t seed, uint64_t group) {
+    const uint32_t h = ortk_mix32((uint32_t)group * 0x9E3779B1u + (uint32_t)(group >> 32) * 0x85EBCA77u + seed);
+    uint32_t g = (h ^ 0x68E31DA4u) * 0xB5297A4Du;
+    g ^= g >> 15;
+    return make_uint2(h, g);
+}
+__device__ static inline uint32_t ortk_keep_thr(float p) { return (uint32_t)(p * 65536.f); }
 __device__ static inline bool ortk_keep(uint32_t seed, uint64_t idx, float p) {
-    uint32_t h = ortk_mix32((uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x85EBCA77u + seed);
-    return ortk_u01(h) >= p;
+    const uint2 b = ortk_keep_bits(seed, idx >> 2);
+    const uint32_t w = (idx & 2) ? b.y : b.x;
+    return ((w >> ((idx & 1) * 16)) & 0xFFFFu) >= ortk_keep_thr(p);
+}
+// k[r] = ortk_keep(seed, idx0 + r, p), r = 0..3
+__device__ static inline void ortk_keep4(uint32_t seed, uint64_t idx0, float p, bool (&k)[4]) {
+    if ((idx0 & 3) == 0) {
+        const uint2 b = ortk_keep_bits(seed, idx0 >> 2);
+        const uint32_t thr = ortk_keep_thr(p);
+        k[0] = (b.x & 0xFFFFu) >= thr; k[1] = (b.x >> 16) >= thr; k[2] = (b.y & 0xFFFFu) >= thr; k[3] = (b.y >> 16) >= thr;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) k[r] = ortk_keep(seed, idx0 + r, p);
+    }
 }
 __host__ static inline uint32_t ortk_subseed(uint64_t seed, uint32_t op) {
     return ortk_mix32((uint32_t)seed ^ ortk_mix32((uint32_t)(seed >> 32) + 0x632BE5ABu) ^ (op * 0x9E3779B1u + 0x7F4A7C15u));

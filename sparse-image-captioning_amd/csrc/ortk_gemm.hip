@@ -116,12 +116,14 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
             const float rr[4] = {res[j].x, res[j].y, res[j].z, res[j].w};
             const float gg[4] = {gat[j].x, gat[j].y, gat[j].z, gat[j].w};
             float v[4];
+            bool kp[4] = {true, true, true, true};
+            if (e.drop_p > 0.f) ortk_keep4(e.drop_seed, (uint64_t)m * (uint64_t)e.N + n0, e.drop_p, kp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = acc[i][j][r] + bb[r];
                 if (e.relu) x = fmaxf(x, 0.f);
                 x *= rs;
-                if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, (uint64_t)m * (uint64_t)e.N + (n0 + r), e.drop_p) ? x * inv_keep : 0.f;
+                if (e.drop_p > 0.f) x = kp[r] ? x * inv_keep : 0.f;
                 if (e.gate) x = gg[r] > 0.f ? x * e.gate_scale : 0.f;
                 v[r] = x + rr[r];
             }

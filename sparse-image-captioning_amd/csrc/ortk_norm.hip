@@ -150,10 +150,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                         const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)c;
                         const float ik = 1.f / (1.f - drop_p);
                         float4 z;
-                        z.x = (drop_p > 0.f && !ortk_keep(drop_seed, i0, drop_p)) ? 0.f : o.x * ik;
-                        z.y = (drop_p > 0.f && !ortk_keep(drop_seed, i0 + 1, drop_p)) ? 0.f : o.y * ik;
-                        z.z = (drop_p > 0.f && !ortk_keep(drop_seed, i0 + 2, drop_p)) ? 0.f : o.z * ik;
-                        z.w = (drop_p > 0.f && !ortk_keep(drop_seed, i0 + 3, drop_p)) ? 0.f : o.w * ik;
+                        bool kp[4] = {true, true, true, true};
+                        if (drop_p > 0.f) ortk_keep4(drop_seed, i0, drop_p, kp);
+                        z.x = kp[0] ? o.x * ik : 0.f;
+                        z.y = kp[1] ? o.y * ik : 0.f;
+                        z.z = kp[2] ? o.z * ik : 0.f;
+                        z.w = kp[3] ? o.w * ik : 0.f;
                         st_elem4(dz, (int64_t)i0, dz_dt, z);
                     }
                 } else {
