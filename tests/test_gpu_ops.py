@@ -577,7 +577,8 @@ def test_spmm_csr_vs_dense(L, xdt, M, N, K, sp):
         assert err < tol, (relu, use_res, ydt, err)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (1280, 512, 2048), (384, 256, 192), (2048, 2048, 192), (4096, 1024, 64), (4096, 2560, 192), (3328, 3072, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (1280, 512, 2048), (384, 256, 192), (2048, 2048, 192), (4096, 1024, 64), (4096, 2560, 192), (3328, 3072, 64),
+                                   (4480, 2560, 512), (5376, 512, 128)])
 def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
     """Full-tile bf16 x bf16 shapes take the LDS-DMA pipelined kernel (swizzled images, 4-stage ring): all three operand
     layouts, fused epilogue, split-K accumulation and fused column sums — against fp32 matmuls of the same bf16 values
@@ -600,6 +601,13 @@ def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
     gemm(L, A16, B16, M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1, C=C16, c_dtype=1, bias=dev(bias), relu=1, resid=dev(resid))
     refe = (ref + bias.double()).clamp_min(0) + resid.double()
     assert (C16.float().cpu().double() - refe).abs().max().item() < 1e-2 * max(sc, 1.0)
+    # dropout epilogue (grouped hash): reproducible, right keep rate, kept entries scaled
+    d1 = gemm(L, A16, B16, M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1, drop_p=0.2, drop_seed=99)
+    d2 = gemm(L, A16, B16, M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1, drop_p=0.2, drop_seed=99)
+    assert torch.equal(d1, d2)
+    keptm = d1.cpu() != 0
+    assert abs(keptm.float().mean().item() - 0.8) < 0.02
+    assert ((d1.cpu().double() - ref / 0.8).abs()[keptm]).max().item() < 2e-3 * sc
     # split-K accumulation on top of existing content + fused column sums of A
     for sk in (1, 2, 3):
         Cacc = torch.ones(M, N, device="cuda"); csum = torch.full((M,), 2.0, device="cuda")
