@@ -580,15 +580,17 @@ typedef __attribute__((address_space(1))) const void glb_void;
 
 // issue this wave's share (2 wave-instructions) of one operand tile of TM rows / columns (128: 8 instructions over
 // 4 waves; 256: 16 instructions over 8 waves)
+// rmax: last valid row of an [m][k] operand (a partial last row tile re-reads it; its results are dropped by the epilogue)
 template <bool T, int TM>
-__device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane) {
+__device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane,
+                                          int rmax = 0x7FFFFFFF) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int inst = wave * 2 + u;
         const __bf16* g;
         if (!T) {
             const int r = inst * 16 + (lane >> 2), c = (lane & 3) ^ swz_mk(r);
-            g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+            g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
         } else {
             constexpr int CPR = TM / 8;                       // 16-byte chunks per k-row
             const int f = inst * 64 + lane, kr = f / CPR, c = (f % CPR) ^ swz_km(kr);
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
 
     auto issue = [&](int t) {
         __bf16* st = smem16 + (size_t)(t & (NS - 1)) * 2 * IMG;
-        glds_tile<TA, TM>(Ap, p.lda, mb, k_begin + t * GBK, st, wave, lane);
+        glds_tile<TA, TM>(Ap, p.lda, mb, k_begin + t * GBK, st, wave, lane, TA ? 0x7FFFFFFF : p.M - 1);
         glds_tile<TB, TM>(Bp, p.ldb, nb, k_begin + t * GBK, st + IMG, wave, lane);
     };
     for (int t = 0; t < NS - 1 && t < T; ++t) issue(t);
@@ -692,11 +694,16 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
         __syncthreads();      // the staged C tile reuses the ring
         epilogue_staged<true>(e, reinterpret_cast<float*>(smem16), mb, nb, wm, wn, lane, wave,
                               *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]));
-    } else {
+    } else if (mb + TM <= p.M) {
 #pragma unroll
         for (int hh = 0; hh < MI / 4; ++hh)
             epilogue_tile<true>(e, mb + wm * (16 * MI) + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
                                 *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+    } else {              // partial last row tile (forward layout, ragged M): bounds-checked stores
+#pragma unroll
+        for (int hh = 0; hh < MI / 4; ++hh)
+            epilogue_tile<false>(e, mb + wm * (16 * MI) + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
+                                 *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
     }
 }
 constexpr size_t GLDS_LDS_BYTES = GLDS_RING_BYTES > 128 * CP * sizeof(float) ? GLDS_RING_BYTES : 128 * CP * sizeof(float);
@@ -712,14 +719,15 @@ constexpr size_t GLDS_LDS_BYTES_BIG = (size_t)GNS * 2 * 256 * GBK * sizeof(__bf1
 constexpr int HBK = 64;
 
 template <bool T>
-__device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane) {
+__device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane,
+                                            int rmax = 0x7FFFFFFF) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int inst = wave * 4 + u;                         // 32 wave-instructions of 1 KB per 256 x 64 operand tile
         const __bf16* g;
         if (!T) {
             const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
-            g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+            g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
         } else {
             const int f = inst * 64 + lane, kr = f >> 5, c = (f & 31) ^ swz_km(kr);     // 32 chunks per 512-byte k-row
             g = base + (int64_t)(k0 + kr) * ld + tile0 + c * 8;
@@ -730,12 +738,13 @@ __device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int
 
 // one 1-KB piece (wave-instruction) of a 256 x 64 operand tile: piece index u = 0..3 of this wave
 template <bool T>
-__device__ __forceinline__ void glds_piece64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane, int u) {
+__device__ __forceinline__ void glds_piece64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane, int u,
+                                             int rmax = 0x7FFFFFFF) {
     const int inst = wave * 4 + u;
     const __bf16* g;
     if (!T) {
         const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
-        g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+        g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
     } else {
         const int f = inst * 64 + lane, kr = f >> 5, c = (f & 31) ^ swz_km(kr);
         g = base + (int64_t)(k0 + kr) * ld + tile0 + c * 8;
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto issue = [&](int t) {
         __bf16* st = smem16 + (size_t)(t & 1) * 2 * IMG;
-        glds_tile64<TA>(Ap, p.lda, mb, k_begin + t * HBK, st, wave, lane);
+        glds_tile64<TA>(Ap, p.lda, mb, k_begin + t * HBK, st, wave, lane, TA ? 0x7FFFFFFF : p.M - 1);
         glds_tile64<TB>(Bp, p.ldb, nb, k_begin + t * HBK, st + IMG, wave, lane);
     };
     if (T > 0) issue(0);
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
             for (int i = 0; i < 8; ++i) {
                 if (next && (i & 1) == 0) {
                     const int u = ks * 4 + (i >> 1);               // 0..7: pieces 0-3 of A, then 0-3 of B
-                    if (u < 4) glds_piece64<TA>(Ap, p.lda, mb, nk0, nst, wave, lane, u);
+                    if (u < 4) glds_piece64<TA>(Ap, p.lda, mb, nk0, nst, wave, lane, u, TA ? 0x7FFFFFFF : p.M - 1);
                     else       glds_piece64<TB>(Bp, p.ldb, nb, nk0, nst + IMG, wave, lane, u - 4);
                 }
 #pragma unroll
@@ -817,10 +826,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
+    if (mb + 256 <= p.M) {
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-        epilogue_tile<true>(e, mb + wm * 128 + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
-                            *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+        for (int hh = 0; hh < 2; ++hh)
+            epilogue_tile<true>(e, mb + wm * 128 + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
+                                *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+    } else {              // partial last row tile (ragged M)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            epilogue_tile<false>(e, mb + wm * 128 + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
+                                 *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+    }
 }
 constexpr size_t DMA256_LDS_BYTES = (size_t)2 * 2 * 256 * HBK * sizeof(__bf16);   // 128 KB
 
@@ -854,17 +870,17 @@ __global__ __launch_bounds__(256, NS > 4 ? 1 : NS == 4 ? 2 : 3) void gemm_bf16_d
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one 1-KB piece = 8 rows of 128 bytes; this wave moves pieces 2*wave, 2*wave + 1 of each operand image
-    auto piece = [&](const __bf16* base, int64_t ld, int tile0, int k0, __bf16* img, int inst) {
+    auto piece = [&](const __bf16* base, int64_t ld, int tile0, int k0, __bf16* img, int inst, int rmax) {
         const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
-        const __bf16* g = base + (int64_t)(tile0 + r) * ld + k0 + c * 8;
+        const __bf16* g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
         __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
     };
     auto issue = [&](int t) {
         __bf16* st = smem16 + (size_t)(t % NS) * 2 * IMG;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) piece(Ap, p.lda, mb, t * HBK, st, wave * 2 + u);
+        for (int u = 0; u < 2; ++u) piece(Ap, p.lda, mb, t * HBK, st, wave * 2 + u, p.M - 1);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) piece(Bp, p.ldb, nb, t * HBK, st + IMG, wave * 2 + u);
+        for (int u = 0; u < 2; ++u) piece(Bp, p.ldb, nb, t * HBK, st + IMG, wave * 2 + u, 0x7FFFFFFF);
     };
     // The epilogue's operands (bias, residual rows) are requested FIRST, ahead of the operand stages, instead of after the
     // K loop: one fetch round trip less on a kernel that is a handful of round trips long (being the oldest loads they
@@ -876,8 +892,8 @@ __global__ __launch_bounds__(256, NS > 4 ? 1 : NS == 4 ? 2 : 3) void gemm_bf16_d
         bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            res4[i][j] = p.resid ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)(mrow0 + 16 * i) * p.ldr + ncol0 + 16 * j)
-                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+            res4[i][j] = (p.resid && mrow0 + 16 * i < p.M) ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)(mrow0 + 16 * i) * p.ldr + ncol0 + 16 * j)
+                                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int t = 0; t < NS - 1 && t < T; ++t) issue(t);
     for (int t = 0; t < T; ++t) {
@@ -922,7 +938,8 @@ __global__ __launch_bounds__(256, NS > 4 ? 1 : NS == 4 ? 2 : 3) void gemm_bf16_d
                 if (p.relu) x = fmaxf(x, 0.f);
                 v[r] = x + res4[i][j][r];
             }
-            st_elem4(p.C, (int64_t)(mrow0 + 16 * i) * p.ldc + ncol0 + 16 * j, p.c_dtype, make_float4(v[0], v[1], v[2], v[3]));
+            if (mrow0 + 16 * i < p.M)        // (a partial last row tile: ragged M)
+                st_elem4(p.C, (int64_t)(mrow0 + 16 * i) * p.ldc + ncol0 + 16 * j, p.c_dtype, make_float4(v[0], v[1], v[2], v[3]));
         }
 }
 constexpr size_t DMA64_STAGE_BYTES = (size_t)2 * 64 * HBK * sizeof(__bf16);   // 16 KB
@@ -1024,10 +1041,17 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     } else {
         auto al = [](const void* q, size_t a_) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) % a_) == 0; };
         const size_t ea = ortk_esize(p.a_dtype), eb = ortk_esize(p.b_dtype), ec = ortk_esize(p.c_dtype), eg = ortk_esize(p.gate_dtype);
-        const bool fast = p.M % BM == 0 && p.N % BN == 0 && p.K > 0 && p.K % BK16 == 0 && kchunk % BK16 == 0 &&
-                          al(p.A, 16) && al(p.B, 16) && (p.lda * ea) % 16 == 0 && (p.ldb * eb) % 16 == 0 &&
-                          al(p.C, 4 * ec) && (p.ldc % 4) == 0 && al(p.bias, 16) && al(p.resid, 16) && (p.ldr % 4) == 0 &&
-                          al(p.gate, 4 * eg) && (p.ldg % 4) == 0;
+        // everything the unguarded kernels assume, except the row count: full column / K tiles and vector alignment
+        const bool fast_nk = p.N % BN == 0 && p.K > 0 && p.K % BK16 == 0 && kchunk % BK16 == 0 &&
+                             al(p.A, 16) && al(p.B, 16) && (p.lda * ea) % 16 == 0 && (p.ldb * eb) % 16 == 0 &&
+                             al(p.C, 4 * ec) && (p.ldc % 4) == 0 && al(p.bias, 16) && al(p.resid, 16) && (p.ldr % 4) == 0 &&
+                             al(p.gate, 4 * eg) && (p.ldg % 4) == 0;
+        const bool fast = fast_nk && p.M % BM == 0;
+        // The forward-layout LDS-DMA kernels also take a RAGGED row count (M = images x regions, captions x positions, images x
+        // beams: whatever the batch is): the operand rows of the partial last row tile are clamped to M - 1 and only that tile
+        // runs the bounds-checked epilogue.  (Without this every batch size that is not a multiple of 128 images fell back to
+        // the guarded register-staged kernel: 13.4 ms per XE step at 127 images against 9.0 ms at 128.)
+        const bool fast4 = fast_nk && key == 4 && !p.accumulate;
         static int impl = -1;   // experiments: 1 = register-staged kernel only, 2 = 128^2 DMA tiles only, 3 = 256^2 whenever legal
         if (impl < 0) { const char* ev = getenv("ORTK_GEMM_IMPL"); impl = ev ? atoi(ev) : 0; }
         // Measured in the XE step (bench.py, ms/step): register-staged kernel everywhere 17.9; DMA kernels everywhere
@@ -1041,9 +1065,9 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         // 163 -> 178, 21760x1536x512 87 -> 106).
         static int t64 = -2;    // ORTK_GEMM_T64: use them while the 128 x 128 grid has at most this many workgroups (-1 = never)
         if (t64 == -2) { const char* ev = getenv("ORTK_GEMM_T64"); t64 = ev ? atoi(ev) : 640; }
-        if (fast && key == 4 && impl != 1 && !p.accumulate && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.K % HBK == 0 &&
+        if (fast4 && impl != 1 && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.K % HBK == 0 &&
             p.drop_p == 0.f && !p.gate && !p.rowscale && (int64_t)tilesM * tilesN <= t64 && p.N <= 2048) {
-            const int tm = p.M / 64, tn = p.N / 64;
+            const int tm = (int)ortk_cdiv(p.M, 64), tn = p.N / 64;
             const bool one = (int64_t)tm * tn <= 256 + 64;          // one workgroup per CU: the whole K = 512 panel in flight
             gemm16_fn g = one ? gemm_bf16_dma64_kernel<8> : gemm_bf16_dma64_kernel<3>;    // else three per CU
             const size_t lds = (one ? 8 : 3) * DMA64_STAGE_BYTES;
@@ -1057,16 +1081,16 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             ORTK_CHECK_LAUNCH();
             return 0;
         }
-        if (fast && impl != 1 && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0) {
+        if ((fast || fast4) && impl != 1 && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0) {
             // 256 x 256 tiles when they still give enough workgroups (and no split-K accumulation, which needs the
             // staged 128 x 128 epilogue); impl 2 = small tiles only, impl 3 = big tiles whenever legal
-            const int64_t big_blocks = (int64_t)(p.M / 256) * (p.N / 256);
+            const int64_t big_blocks = (int64_t)ortk_cdiv(p.M, 256) * (p.N / 256);
             // measured (scratch/gemm_shapes.py): the big tile wins whenever its grid fills >= 60 % of the CU slots of its
             // last round (170 blocks: 29.6 vs 33.7 us; 510: 58 vs 72 us) and loses on short grids (72 blocks: 26 vs 17 us;
             // 288 blocks = 1.1 rounds: 50 vs 44 us)
             const int64_t rounds = (big_blocks + 255) / 256;
             const bool fills = big_blocks * 10 >= rounds * 256 * 6;
-            const bool big = !p.accumulate && p.M % 256 == 0 && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
+            const bool big = !p.accumulate && (p.M % 256 == 0 || fast4) && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
             // 8-deep ring for grids of at most one workgroup per CU (decode-time projections): measured SLOWER in the
             // 1024-image decode (36.9 vs 35.8 ms) -> experiment only (ORTK_GEMM_IMPL=5)
             const bool deep = !big && (int64_t)tilesM * tilesN * splitk <= 256 && impl == 5;
@@ -1091,9 +1115,9 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA256_LDS_BYTES);
                     a2[g2i] = true;
                 }
-                hipLaunchKernelGGL(g2, dim3((unsigned)big_blocks), dim3(512), DMA256_LDS_BYTES, s, p, p.M / 256, p.N / 256, kchunk);
+                hipLaunchKernelGGL(g2, dim3((unsigned)big_blocks), dim3(512), DMA256_LDS_BYTES, s, p, (int)ortk_cdiv(p.M, 256), p.N / 256, kchunk);
             }
-            else if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, p.M / 256, p.N / 256, kchunk);
+            else if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, (int)ortk_cdiv(p.M, 256), p.N / 256, kchunk);
             else          hipLaunchKernelGGL(gf, grid, block, lds, s, p, tilesM, tilesN, kchunk);
             if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
             ORTK_CHECK_LAUNCH();

@@ -578,7 +578,9 @@ def test_spmm_csr_vs_dense(L, xdt, M, N, K, sp):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (1280, 512, 2048), (384, 256, 192), (2048, 2048, 192), (4096, 1024, 64), (4096, 2560, 192), (3328, 3072, 64),
-                                   (4480, 2560, 512), (5376, 512, 128)])
+                                   (4480, 2560, 512), (5376, 512, 128),
+                                   # ragged row counts (any batch size): LDS-DMA kernels with a clamped, bounds-checked last row tile
+                                   (1000, 512, 512), (37, 1536, 512), (4500, 2560, 192), (10795, 512, 512), (21590, 512, 128), (635, 2048, 512)])
 def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
     """Full-tile bf16 x bf16 shapes take the LDS-DMA pipelined kernel (swizzled images, 4-stage ring): all three operand
     layouts, fused epilogue, split-K accumulation and fused column sums — against fp32 matmuls of the same bf16 values
