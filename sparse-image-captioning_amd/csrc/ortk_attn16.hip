@@ -30,17 +30,26 @@ constexpr int DK = 64;
 
 __device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+// Key-indexed geometry for NJT key tiles (Lk <= 16 * NJT <= 128): KJ = key range as a k dimension (multiple of 32, zero-
+// padded), PJ = pitch of the [query][key] images (KJ + 8: the same 16-distinct-slots property as P16 for its row length).
+template <int NJT> struct KeyGeo {
+    static constexpr int KJ = NJT <= 2 ? 32 : NJT <= 4 ? 64 : NJT <= 6 ? 96 : 128;
+    static constexpr int PJ = NJT <= 4 ? P16 : 136;
+};
+
 // [index = row][k = k0 .. k0+7]: 8 consecutive elements of an image row
+template <int PITCH = P16>
 __device__ __forceinline__ bf16x8 frag_row(const __bf16* img, int row, int k0) {
-    return *reinterpret_cast<const bf16x8*>(img + row * P16 + k0);
+    return *reinterpret_cast<const bf16x8*>(img + row * PITCH + k0);
 }
 // [index = x0 + lr][k = k0 + 8*lq .. +7] where k runs along the image ROWS: two transposing reads of 4 rows x 16 columns
+template <int PITCH = P16>
 __device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int k0, int x0, int lane) {
     const int lr = lane & 15, lq = lane >> 4;
-    const __bf16* p = img + (k0 + 8 * lq + (lr >> 2)) * P16 + x0 + 4 * (lane & 3);
+    const __bf16* p = img + (k0 + 8 * lq + (lr >> 2)) * PITCH + x0 + 4 * (lane & 3);
     typedef bf16x4 __attribute__((address_space(3))) * lds4;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + 4 * P16));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + 4 * PITCH));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x4 cvt4(float4 v) { return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w}; }
@@ -71,7 +80,7 @@ __device__ __forceinline__ bf16x8 ld_frag(const float* p) { return cvt8(*reinter
 __device__ __forceinline__ bf16x8 ld_frag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // ------------------------------------------------------------------------------------------------ forward
-// One workgroup per (group g, head h); one wave per 16-row query tile.  NJT = key tiles (Lk <= 16 * NJT <= 64).
+// One workgroup per (group g, head h); one wave per 16-row query tile.  NJT = key tiles (Lk <= 16 * NJT <= 128).
 template <int NJT, typename TQ>
 __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     const TQ* aq = reinterpret_cast<const TQ*>(a.q); const TQ* ak = reinterpret_cast<const TQ*>(a.k); const TQ* av = reinterpret_cast<const TQ*>(a.v);
@@ -79,10 +88,11 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
     const int Lk = a.Lk, Lq = a.Lq;
+    constexpr int KJ = KeyGeo<NJT>::KJ, PJ = KeyGeo<NJT>::PJ;
     __bf16* sK = sm16;                              // [16*NJT][P16]  rows = key            (row fragments)
-    __bf16* sV = sK + 16 * NJT * P16;               // [64][P16]      rows = key, zero-padded (k of P.V: transposing reads)
-    __bf16* sP = sV + 64 * P16 + wave * 16 * P16;   // [16][P16]      this wave's dropped P: rows = query, columns = key 0..63
-    float* sMask = reinterpret_cast<float*>(sm16 + (16 * NJT + 64 + 16 * nw) * P16);   // [64]
+    __bf16* sV = sK + 16 * NJT * P16;               // [KJ][P16]      rows = key, zero-padded (k of P.V: transposing reads)
+    __bf16* sP = sV + KJ * P16 + wave * 16 * PJ;    // [16][PJ]       this wave's dropped P: rows = query, columns = key 0..KJ-1
+    float* sMask = reinterpret_cast<float*>(sm16 + (16 * NJT + KJ) * P16 + 16 * nw * PJ);   // [128]
     const int lr = lane & 15, lq = lane >> 4;
     const bool vec_p = (Lk & 3) == 0;               // P / bias rows start 16-byte aligned
     const int nit = (Lq + 15) >> 4;
@@ -108,10 +118,11 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
         }
     }
     stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
-    stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 64, tid, blockDim.x);
-    if (tid < 64) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
-    // key columns 16*NJT .. 63 of the P image are never written below: zero them once
-    for (int idx = lane; idx < 16 * 16; idx += 64) *reinterpret_cast<bf16x4*>(sP + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));
+    stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, KJ, tid, blockDim.x);
+    if (tid < 128) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
+    // key columns 16*NJT .. KJ-1 of the P image are never written below: zero the image once
+    for (int idx = lane; idx < 16 * (KJ / 4); idx += 64)
+        *reinterpret_cast<bf16x4*>(sP + (idx / (KJ / 4)) * PJ + (idx % (KJ / 4)) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     if (it < nit) {
@@ -164,21 +175,27 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] = kp[r] ? p[r] * inv_keep : 0.f;
             }
-            *reinterpret_cast<bf16x4*>(sP + lr * P16 + j0) = cvt4(make_float4(p[0], p[1], p[2], p[3]));
+            *reinterpret_cast<bf16x4*>(sP + lr * PJ + j0) = cvt4(make_float4(p[0], p[1], p[2], p[3]));
         }
         wsync();
         // O^T[d = 16*dt + 4*lq + r][i = lr] = sum_j V[j][d] Pd[i][j]
-        const bf16x8 pf0 = frag_row(sP, lr, 8 * lq), pf1 = frag_row(sP, lr, 32 + 8 * lq);
+        bf16x8 pf[KJ / 32];
+#pragma unroll
+        for (int ks = 0; ks < KJ / 32; ++ks) pf[ks] = frag_row<PJ>(sP, lr, 32 * ks + 8 * lq);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-            o = mma(frag_tr(sV, 0, 16 * dt, lane), pf0, o);
-            if (NJT > 2) o = mma(frag_tr(sV, 32, 16 * dt, lane), pf1, o);
+#pragma unroll
+            for (int ks = 0; ks < KJ / 32; ++ks) o = mma(frag_tr(sV, 32 * ks, 16 * dt, lane), pf[ks], o);
             if (iv) st_elem4(a.o, ((int64_t)g * Lq + i) * a.ldo + h * DK + 16 * dt + 4 * lq, a.o_dtype, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
-static size_t fwd16_lds(int njt, int nw) { return (size_t)(16 * njt + 64 + 16 * nw) * P16 * sizeof(__bf16) + 64 * sizeof(float); }
+static int key_kj(int njt) { return njt <= 2 ? 32 : njt <= 4 ? 64 : njt <= 6 ? 96 : 128; }
+static int key_pj(int njt) { return njt <= 4 ? P16 : 136; }
+static size_t fwd16_lds(int njt, int nw) {
+    return ((size_t)(16 * njt + key_kj(njt)) * P16 + (size_t)16 * nw * key_pj(njt)) * sizeof(__bf16) + 128 * sizeof(float);
+}
 
 // ------------------------------------------------------------------------------------------------ backward
 // Phase 1 (wave = 16-row query tile): dP^T = V dO^T, dS = P (dP - rowsum(P dP)), dQ = dS K / sqrt(dk); dS / sqrt(dk) and the
@@ -191,12 +208,13 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
     const int Lk = a.Lk, Lq = a.Lq;
-    __bf16* sK = sm16;                      // [64][P16]      rows = key, zero-padded   (k of dS.K: transposing reads)
-    __bf16* sV = sK + 64 * P16;             // [16*NJT][P16]  rows = key                (row fragments of dP^T = V dO^T)
+    constexpr int KJ = KeyGeo<NJT>::KJ, PJ = KeyGeo<NJT>::PJ;
+    __bf16* sK = sm16;                      // [KJ][P16]      rows = key, zero-padded   (k of dS.K: transposing reads)
+    __bf16* sV = sK + KJ * P16;             // [16*NJT][P16]  rows = key                (row fragments of dP^T = V dO^T)
     __bf16* sQ = sV + 16 * NJT * P16;       // [Lqp][P16]     rows = query              (k of dS^T Q: transposing reads)
     __bf16* sG = sQ + Lqp * P16;            // [Lqp][P16]     dO: row fragments in phase 1, transposing reads in phase 2
-    __bf16* sS = sG + Lqp * P16;            // [Lqp][P16]     dS / sqrt(dk): rows = query, columns = key 0..63
-    __bf16* sD = sS + Lqp * P16;            // [Lqp][P16]     dropped P
+    __bf16* sS = sG + Lqp * P16;            // [Lqp][PJ]      dS / sqrt(dk): rows = query, columns = key 0..KJ-1
+    __bf16* sD = sS + Lqp * PJ;             // [Lqp][PJ]      dropped P
     const int lr = lane & 15, lq = lane >> 4;
     const bool vec_p = (Lk & 3) == 0;
     const int nit = (Lq + 15) >> 4;
@@ -215,13 +233,13 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             else { float* q = &praw[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) q[r] = a.p[prow + j0 + r]; }
         }
     }
-    stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 64, tid, blockDim.x);
+    stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, KJ, tid, blockDim.x);
     stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
     stage_rows(sQ, aq + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
     stage_rows(sG, reinterpret_cast<const TQ*>(a.d_o) + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
     // dS / P images: the key columns 16*NJT .. 63 and the query rows past the last wave tile are never written below
-    for (int idx = tid; idx < 2 * Lqp * 16; idx += blockDim.x)
-        *reinterpret_cast<bf16x4*>(sS + (idx >> 4) * P16 + (idx & 15) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));   // sD follows sS
+    for (int idx = tid; idx < 2 * Lqp * (KJ / 4); idx += blockDim.x)
+        *reinterpret_cast<bf16x4*>(sS + (idx / (KJ / 4)) * PJ + (idx % (KJ / 4)) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));   // sD follows sS
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     if (it < nit) {
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
                 pd[r] = keep ? pv[r] * inv_keep : 0.f;
                 pp[jt][r] = valid ? pv[r] : 0.f; dp[jt][r] = d; dot += pp[jt][r] * d;
             }
-            *reinterpret_cast<bf16x4*>(sD + i * P16 + j0) = cvt4(make_float4(pd[0], pd[1], pd[2], pd[3]));
+            *reinterpret_cast<bf16x4*>(sD + i * PJ + j0) = cvt4(make_float4(pd[0], pd[1], pd[2], pd[3]));
         }
         dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
@@ -260,16 +278,18 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
                 if (vec_p && j0 < Lk) *reinterpret_cast<float4*>(a.dscore + prow + j0) = make_float4(ds[0], ds[1], ds[2], ds[3]);
                 else for (int r = 0; r < 4; ++r) if (j0 + r < Lk) a.dscore[prow + j0 + r] = ds[r];
             }
-            *reinterpret_cast<bf16x4*>(sS + i * P16 + j0) = cvt4(make_float4(ds[0] * 0.125f, ds[1] * 0.125f, ds[2] * 0.125f, ds[3] * 0.125f));
+            *reinterpret_cast<bf16x4*>(sS + i * PJ + j0) = cvt4(make_float4(ds[0] * 0.125f, ds[1] * 0.125f, ds[2] * 0.125f, ds[3] * 0.125f));
         }
         wsync();
         // dQ^T[d = 16*dt + 4*lq + r][i = lr] = sum_j K[j][d] dSs[i][j]
-        const bf16x8 s0 = frag_row(sS, i, 8 * lq), s1 = frag_row(sS, i, 32 + 8 * lq);
+        bf16x8 sf[KJ / 32];
+#pragma unroll
+        for (int ks = 0; ks < KJ / 32; ++ks) sf[ks] = frag_row<PJ>(sS, i, 32 * ks + 8 * lq);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc = mma(frag_tr(sK, 0, 16 * dt, lane), s0, acc);
-            if (NJT > 2) acc = mma(frag_tr(sK, 32, 16 * dt, lane), s1, acc);
+#pragma unroll
+            for (int ks = 0; ks < KJ / 32; ++ks) acc = mma(frag_tr(sK, 32 * ks, 16 * dt, lane), sf[ks], acc);
             if (iv) st_elem4(a.dq, ((int64_t)g * Lq + i) * a.lddq + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, make_float4(acc[0], acc[1], acc[2], acc[3]));
         }
     }
@@ -281,7 +301,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
         const __bf16* sA = which == 0 ? sS : sD;      // [query][key]
         const __bf16* sB = which == 0 ? sQ : sG;      // [query][feature]
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < Lqp; k0 += 32) acc = mma(frag_tr(sB, k0, 16 * dt, lane), frag_tr(sA, k0, 16 * jt, lane), acc);
+        for (int k0 = 0; k0 < Lqp; k0 += 32) acc = mma(frag_tr(sB, k0, 16 * dt, lane), frag_tr<PJ>(sA, k0, 16 * jt, lane), acc);
         const int j = 16 * jt + lr;
         if (j < Lk) {
             const int64_t row = (int64_t)g * Lk + j;
@@ -291,7 +311,9 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
         }
     }
 }
-static size_t bwd16_lds(int njt, int Lqp) { return (size_t)(64 + 16 * njt + 4 * Lqp) * P16 * sizeof(__bf16); }
+static size_t bwd16_lds(int njt, int Lqp) {
+    return ((size_t)(key_kj(njt) + 16 * njt + 2 * Lqp) * P16 + (size_t)2 * Lqp * key_pj(njt)) * sizeof(__bf16);
+}
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -300,13 +322,14 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 namespace ortk {
 
 // shapes / layouts these kernels serve (everything else stays with the fp32-MFMA family)
-bool attn16_shape_ok(int Lq, int Lk, int dk) { return dk == 64 && Lk >= 1 && Lk <= 64 && Lq >= 1 && Lq <= 128; }
+bool attn16_shape_ok(int Lq, int Lk, int dk) { return dk == 64 && Lk >= 1 && Lk <= 128 && Lq >= 1 && Lq <= 128; }
 
 bool attn16_ok(const ortk_attn_args* a, bool bwd) {
     // fp32 inputs: only the block shapes (the register-only kernels keep the short ones); bf16 inputs: every served shape
     static int min_lq = -1;
     if (min_lq < 0) { const char* e = getenv("ORTK_ATTN16_MINLQ"); min_lq = e ? atoi(e) : 33; }
-    if (a->precision != 1 || !attn16_shape_ok(a->Lq, a->Lk, a->dk) || (a->qkv_dtype == 0 && a->Lq < min_lq)) return false;
+    // (short query blocks over at most 48 keys stay with the register-only kernels; past 48 keys those do not apply)
+    if (a->precision != 1 || !attn16_shape_ok(a->Lq, a->Lk, a->dk) || (a->qkv_dtype == 0 && a->Lq < min_lq && a->Lk <= 48)) return false;
     if (a->kv_index || a->kv_group_stride > 0 || a->kv_dtype != 0 || a->k_new || a->v_new) return false;
     if ((a->ldq | a->ldk | a->ldv) % (a->qkv_dtype ? 8 : 4) || !al16(a->q) || !al16(a->k) || !al16(a->v)) return false;
     if (!bwd) {
@@ -321,13 +344,33 @@ bool attn16_ok(const ortk_attn_args* a, bool bwd) {
     return true;
 }
 
+typedef void (*fwd16_fn)(ortk_attn_args);
+typedef void (*bwd16_fn)(ortk_attn_args, int);
+template <typename TQ> static fwd16_fn pick_fwd(int njt) {
+    switch (njt) {
+        case 1: return attn16_fwd_kernel<1, TQ>; case 2: return attn16_fwd_kernel<2, TQ>; case 3: return attn16_fwd_kernel<3, TQ>;
+        case 4: return attn16_fwd_kernel<4, TQ>; case 5: return attn16_fwd_kernel<5, TQ>; case 6: return attn16_fwd_kernel<6, TQ>;
+        case 7: return attn16_fwd_kernel<7, TQ>; default: return attn16_fwd_kernel<8, TQ>;
+    }
+}
+template <typename TQ> static bwd16_fn pick_bwd(int njt) {
+    switch (njt) {
+        case 1: return attn16_bwd_kernel<1, TQ>; case 2: return attn16_bwd_kernel<2, TQ>; case 3: return attn16_bwd_kernel<3, TQ>;
+        case 4: return attn16_bwd_kernel<4, TQ>; case 5: return attn16_bwd_kernel<5, TQ>; case 6: return attn16_bwd_kernel<6, TQ>;
+        case 7: return attn16_bwd_kernel<7, TQ>; default: return attn16_bwd_kernel<8, TQ>;
+    }
+}
+
 int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
     const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16;
-    typedef void (*fn_t)(ortk_attn_args);
-    const fn_t fn = a->qkv_dtype
-        ? (njt == 1 ? attn16_fwd_kernel<1, __bf16> : njt == 2 ? attn16_fwd_kernel<2, __bf16> : njt == 3 ? attn16_fwd_kernel<3, __bf16> : attn16_fwd_kernel<4, __bf16>)
-        : (njt == 1 ? attn16_fwd_kernel<1, float> : njt == 2 ? attn16_fwd_kernel<2, float> : njt == 3 ? attn16_fwd_kernel<3, float> : attn16_fwd_kernel<4, float>);
+    const fwd16_fn fn = a->qkv_dtype ? pick_fwd<__bf16>(njt) : pick_fwd<float>(njt);
     const size_t lds = fwd16_lds(njt, nw);
+    static bool attr[16] = {};
+    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0);
+    if (lds > 64 * 1024 && !attr[ai]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr[ai] = true;
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, s, *a);
     ORTK_CHECK_LAUNCH();
     return 0;
@@ -335,13 +378,11 @@ int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
 
 int attn16_bwd(const ortk_attn_args* a, hipStream_t s) {
     const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16, Lqp = (int)ortk_align(a->Lq, 32);
-    typedef void (*fn_t)(ortk_attn_args, int);
-    const fn_t fn = a->qkv_dtype
-        ? (njt == 1 ? attn16_bwd_kernel<1, __bf16> : njt == 2 ? attn16_bwd_kernel<2, __bf16> : njt == 3 ? attn16_bwd_kernel<3, __bf16> : attn16_bwd_kernel<4, __bf16>)
-        : (njt == 1 ? attn16_bwd_kernel<1, float> : njt == 2 ? attn16_bwd_kernel<2, float> : njt == 3 ? attn16_bwd_kernel<3, float> : attn16_bwd_kernel<4, float>);
+    const bwd16_fn fn = a->qkv_dtype ? pick_bwd<__bf16>(njt) : pick_bwd<float>(njt);
     const size_t lds = bwd16_lds(njt, Lqp);
-    static bool attr[8] = {false, false, false, false, false, false, false, false};
-    const int ai = njt - 1 + (a->qkv_dtype ? 4 : 0);
+    if (lds > 160 * 1024) return ORTK_EINVAL;
+    static bool attr[16] = {};
+    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0);
     if (lds > 64 * 1024 && !attr[ai]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr[ai] = true;

@@ -269,6 +269,12 @@ def test_attention_bf16_operand_kernels(L):
     _attn_case(L, 3, 8, 85, 36, 64, 0, False, True, precision=1, out_dt=1, in_dt=1)
     _attn_case(L, 7, 8, 17, 17, 64, 17, False, True, precision=1, out_dt=1, in_dt=1)     # decoder self-attention: one 16-row tile + 1 row
     _attn_case(L, 4, 2, 9, 5, 64, 9, False, False, precision=1, in_dt=1)                  # a single partial tile
+    # 65-128 keys (ragged region counts up to 100 per image): wider [query][key] images, 3-4 k-steps over the keys
+    _attn_case(L, 2, 8, 100, 100, 64, 0, True, True, precision=1, out_dt=1, in_dt=1)     # encoder self-attention with 100 regions
+    _attn_case(L, 2, 8, 85, 100, 64, 0, False, True, precision=1, out_dt=1, in_dt=1)     # cross attention over 100 regions
+    _attn_case(L, 1, 2, 128, 128, 64, 0, True, False, precision=1, in_dt=1)               # the largest shape
+    _attn_case(L, 2, 4, 70, 77, 64, 0, True, True, precision=1)                           # fp32 inputs, Lk not a multiple of 4
+    _attn_case(L, 6, 8, 5, 60, 64, 0, False, True, precision=1)                           # decode cross-attention: 5 beams x 60 regions (fp32 rows)
     a = L.AttnArgs()                                                                      # shapes the bf16 kernels do not take: loud
     a.qkv_dtype, a.precision = 1, 1
     t = torch.zeros(4 * 200, 64, device="cuda", dtype=torch.bfloat16); o = torch.zeros(4 * 200, 64, device="cuda")
