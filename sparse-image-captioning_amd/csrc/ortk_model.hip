@@ -926,9 +926,10 @@ namespace ortk {
 struct DecodeWS {
     int64_t ldv; int adt;
     void* w16;
-    float *x0, *logbias; void* mem /*A*/; float* st; void* ckv /*kvdt*/;
+    float *x0, *logbias; void* mem /*A*/; float* st; void* ckv /*ckvdt*/;
     EncPtrs enc;                       // one set of encoder buffers, reused by every layer
-    float *xa, *xb; void* y /*A*/; float* qkv; void* o /*A*/; float* q; void* h /*A*/; float* logits;
+    float *xa, *xb; void* y /*A*/; float* qkv; void* o /*A*/; void* q /*ckvdt when xq16*/; void* h /*A*/; float* logits;
+    int ckvdt, xq16;                   // projected memory dtype; 1 = cross-attention through the bf16-operand kernels (bf16 query too)
     void *cache_k[MAXLAYERS], *cache_v[MAXLAYERS]; int kvdt;   // K/V caches + projected memory: bf16 in mixed precision when the
                                                                // decode attention kernels take them (kv16), fp32 otherwise
     int64_t* it; int32_t *unfinished, *last_step;
@@ -940,6 +941,10 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
     w.kvdt = (c.precision && H == 8 && d == 512 && S > 8 && S <= 48 && T <= 32 && K <= 16) ? ORTK_BF16 : ORTK_F32;
     const size_t kves = ortk_esize(w.kvdt);
+    // more than 48 regions (ragged 10-100 bottom-up features): the cross-attention of a step runs in the bf16-operand block
+    // kernel on bf16 projected memory and a bf16 query; the self-attention caches stay as the row kernel wants them
+    w.xq16 = (c.precision && w.kvdt == ORTK_F32 && S > 48 && attn16_shape_ok(K, S, (int)(d / H))) ? 1 : 0;
+    w.ckvdt = w.xq16 ? ORTK_BF16 : w.kvdt;
     const int64_t Me = (int64_t)B * S, rows = (int64_t)B * K;
     w.ldv = ortk_align(c.vocab, 128);
     w.adt = c.precision ? ORTK_BF16 : ORTK_F32;
@@ -953,9 +958,9 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.enc.xm = b.take<float>(Me * d); w.enc.y2 = act(Me * d); w.enc.h = act(Me * ff);
     w.enc.xout = w.x0; w.enc.st1 = b.take<float>(Me * 2); w.enc.st2 = w.enc.st1;
     w.mem = b.take_bytes((size_t)Me * d * 4); w.st = b.take<float>(std::max(Me, rows) * 2);
-    w.ckv = b.take_bytes((size_t)(Me * L * 2 * d) * kves);
+    w.ckv = b.take_bytes((size_t)(Me * L * 2 * d) * ortk_esize(w.ckvdt));
     w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = act(rows * d);
-    w.qkv = b.take<float>(rows * 3 * d); w.o = act(rows * d); w.q = b.take<float>(rows * d);
+    w.qkv = b.take<float>(rows * 3 * d); w.o = act(rows * d); w.q = b.take<float>(rows * d);      // (fp32-sized; holds bf16 when xq16)
     w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
@@ -1002,10 +1007,11 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
 // the keys of a row are its own slots 0..t unless the beam ancestry table kvidx is given), attends to the projected
 // memory of the row's group (`per_group` consecutive rows share one), and leaves the generator logits in b.logits.
 struct StepBufs {
-    const int64_t* it; float *xa, *xb; void* y; float* qkv; void* o; float* q; void* h; float* logits; float* st; int64_t ldv;
+    const int64_t* it; float *xa, *xb; void* y; float* qkv; void* o; void* q; void* h; float* logits; float* st; int64_t ldv;
     const void* ckv; const float* att_masks;
     void* cache_k[MAXLAYERS]; void* cache_v[MAXLAYERS];
-    int kvdt;      // element type of ckv / cache_k / cache_v
+    int kvdt;      // element type of cache_k / cache_v
+    int ckvdt = ORTK_F32, xq16 = 0;   // element type of ckv; 1 = bf16 cross-attention query + bf16-operand kernel
 };
 static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64_t rows, int groups, int per_group, int /*row_mult*/,
                         int S, int T, int t, const int32_t* kvidx) {
@@ -1032,10 +1038,11 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             TRY(fwd_gemm(c, w.o, A, d, e.wo, P + e.bo, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
             std::swap(x, xn);
             TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
-            TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, ORTK_F32, d, rows, d, d));
+            TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, w.xq16 ? ORTK_BF16 : ORTK_F32, d, rows, d, d));
             std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
-            a.q = w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw, w.kvdt));
-            a.v = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw + o.cv, w.kvdt)); a.kv_dtype = w.kvdt;
+            a.q = (const float*)w.q; a.ldq = d; a.k = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw, w.ckvdt));
+            a.v = reinterpret_cast<const float*>(off_elems(w.ckv, o.ckv_slot[l] * o.cw + o.cv, w.ckvdt));
+            if (w.xq16) a.qkv_dtype = 1; else a.kv_dtype = w.ckvdt;
             a.ldk = a.ldv = o.ckv_slots * o.cw;
             a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
             TRY(ortk_attention_fwd(&a, stream));
@@ -1077,7 +1084,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     EncPtrs ep[MAXLAYERS];
     for (int l = 0; l < L; ++l) ep[l] = w.enc;
     TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.kvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
+    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
 
     const int64_t rows_full = (int64_t)B * K;
     BeamState bs; std::memset(&bs, 0, sizeof(bs));
@@ -1107,7 +1114,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         const int per_img = first_beam ? 1 : K;
         const int row_mult = first_beam ? K : 1;
         StepBufs sb{w.it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, w.ckv, att_masks};
-        sb.kvdt = w.kvdt;
+        sb.kvdt = w.kvdt; sb.ckvdt = w.ckvdt; sb.xq16 = w.xq16;
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
         TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
