@@ -136,6 +136,7 @@ def main():
                     help="sparse_decode: CSR gather products (ortk_spmm_csr) instead of MFMA GEMMs on zero-filled weights; "
                          "measured slower than bf16 MFMA at 95 %% unstructured sparsity (DESIGN.md section 7)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 256; decode 1024)")
+    ap.add_argument("--max-seq-length", type=int, default=18, help="caption length incl. BOS/EOS (18 = BASELINE; the ACORT commands use 26)")
     ap.add_argument("--regions", type=int, default=36, help="regions per image (36 = BASELINE; real bottom-up features have 10-100)")
     ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,7 +165,7 @@ def main():
     B = args.batch or (1024 if decode else 256)
     spi, S = 5, args.regions
     # ORT pruning / SCST commands use drop_prob_src 0.1 (resources/commands_pruning.sh:240,265); dense XE default 0.5
-    config = ort_config(drop_prob_src=0.5, prune_type="supermask")
+    config = ort_config(drop_prob_src=0.5, prune_type="supermask", max_seq_length=args.max_seq_length)
     torch.manual_seed(8888)     # identical weights (and dropout / mask streams) on every rank
     name = "relation_transformer_prune" if args.workload == "sparse_xe" else "relation_transformer"
     model = pkg.get_model(name)(config, precision=args.precision)
