@@ -266,13 +266,13 @@ typedef struct ortk_attn_args {
      * split does everything in part 1 and nothing in part 2). */
     int32_t bwd_part;
     /* 0 = fp32 products (v_mfma_f32_16x16x4_f32: the parity mode); 1 = the operands of the four products are rounded to bf16
-     * (fp32 accumulation, fp32 soft-max; served for dk = 64, Lk <= 128, Lq <= 128 — other shapes, and short query blocks over
+     * (fp32 accumulation, fp32 soft-max; served for dk = 64 or 32, Lk <= 128, Lq <= 128 — other shapes, and short query blocks over
      * at most 48 fp32 keys, run the fp32 kernels) */
     int32_t precision;
     /* 1 = q, k, v — and, in the backward, d_o — point to bf16 rows (leading dimensions in elements, multiples of 8; 16-byte
      * aligned): the packed projection outputs (and the out-projection's input gradient) of the mixed-precision training
      * step, which only ever feed these products.  Served by the bf16-operand kernels
-     * only (precision = 1, dk = 64, Lk <= 128, Lq <= 128); anything else returns ORTK_EINVAL. */
+     * only (precision = 1, dk = 64 or 32, Lk <= 128, Lq <= 128); anything else returns ORTK_EINVAL. */
     int32_t qkv_dtype;
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);

@@ -25,8 +25,7 @@
 
 namespace {
 
-constexpr int P16 = 72;                 // bf16 elements per image row
-constexpr int DK = 64;
+constexpr int P16 = 72;                 // bf16 elements per row of an image with up to 64 columns (keys, or the 64 features of a head)
 
 __device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
@@ -59,20 +58,25 @@ __device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
 __device__ __forceinline__ f32x4 mma(bf16x8 x, bf16x8 y, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc, 0, 0, 0); }
 
 // rows [0, rows) of a (.., 64)-column matrix slice (fp32 or bf16 in memory) -> bf16 image; rows [rows, rows_pad) are zeroed
+// (DKT = features per head: 64 or 32; image pitch DKT + 8)
+template <int DKT>
 __device__ __forceinline__ void stage_rows(__bf16* img, const float* src, int64_t ld, int rows, int rows_pad, int tid, int nthr) {
-    for (int idx = tid; idx < rows_pad * 16; idx += nthr) {
-        const int r = idx >> 4, c = (idx & 15) * 4;
+    constexpr int CPR = DKT / 4;
+    for (int idx = tid; idx < rows_pad * CPR; idx += nthr) {
+        const int r = idx / CPR, c = (idx % CPR) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + c);
-        *reinterpret_cast<bf16x4*>(img + r * P16 + c) = cvt4(v);
+        *reinterpret_cast<bf16x4*>(img + r * (DKT + 8) + c) = cvt4(v);
     }
 }
+template <int DKT>
 __device__ __forceinline__ void stage_rows(__bf16* img, const __bf16* src, int64_t ld, int rows, int rows_pad, int tid, int nthr) {
-    for (int idx = tid; idx < rows_pad * 8; idx += nthr) {
-        const int r = idx >> 3, c = (idx & 7) * 8;
+    constexpr int CPR = DKT / 8;
+    for (int idx = tid; idx < rows_pad * CPR; idx += nthr) {
+        const int r = idx / CPR, c = (idx % CPR) * 8;
         bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         if (r < rows) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)r * ld + c);
-        *reinterpret_cast<bf16x8*>(img + r * P16 + c) = v;
+        *reinterpret_cast<bf16x8*>(img + r * (DKT + 8) + c) = v;
     }
 }
 // 8 consecutive elements of a global row as an MFMA fragment
@@ -81,18 +85,20 @@ __device__ __forceinline__ bf16x8 ld_frag(const __bf16* p) { return *reinterpret
 
 // ------------------------------------------------------------------------------------------------ forward
 // One workgroup per (group g, head h); one wave per 16-row query tile.  NJT = key tiles (Lk <= 16 * NJT <= 128).
-template <int NJT, typename TQ>
+template <int NJT, typename TQ, int DKT>
 __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
+    constexpr int DK = DKT, PD = DKT + 8;           // features per head; pitch of the [row][feature] images
+    const float qscale = DKT == 64 ? 0.125f : 0.17677669529663687f;      // 1 / sqrt(dk)
     const TQ* aq = reinterpret_cast<const TQ*>(a.q); const TQ* ak = reinterpret_cast<const TQ*>(a.k); const TQ* av = reinterpret_cast<const TQ*>(a.v);
     extern __shared__ __attribute__((aligned(16))) __bf16 sm16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
     const int Lk = a.Lk, Lq = a.Lq;
     constexpr int KJ = KeyGeo<NJT>::KJ, PJ = KeyGeo<NJT>::PJ;
-    __bf16* sK = sm16;                              // [16*NJT][P16]  rows = key            (row fragments)
-    __bf16* sV = sK + 16 * NJT * P16;               // [KJ][P16]      rows = key, zero-padded (k of P.V: transposing reads)
-    __bf16* sP = sV + KJ * P16 + wave * 16 * PJ;    // [16][PJ]       this wave's dropped P: rows = query, columns = key 0..KJ-1
-    float* sMask = reinterpret_cast<float*>(sm16 + (16 * NJT + KJ) * P16 + 16 * nw * PJ);   // [128]
+    __bf16* sK = sm16;                              // [16*NJT][PD]   rows = key            (row fragments)
+    __bf16* sV = sK + 16 * NJT * PD;                // [KJ][PD]       rows = key, zero-padded (k of P.V: transposing reads)
+    __bf16* sP = sV + KJ * PD + wave * 16 * PJ;     // [16][PJ]       this wave's dropped P: rows = query, columns = key 0..KJ-1
+    float* sMask = reinterpret_cast<float*>(sm16 + (16 * NJT + KJ) * PD + 16 * nw * PJ);   // [128]
     const int lr = lane & 15, lq = lane >> 4;
     const bool vec_p = (Lk & 3) == 0;               // P / bias rows start 16-byte aligned
     const int nit = (Lq + 15) >> 4;
@@ -102,10 +108,13 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     const int i = it * 16 + lr;                     // this lane's query (operand row and output row)
     const bool iv = it < nit && i < Lq;
     const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
-    bf16x8 qf[2] = {(bf16x8){0, 0, 0, 0, 0, 0, 0, 0}, (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}};
+    bf16x8 qf[DK / 32];
+#pragma unroll
+    for (int ks = 0; ks < DK / 32; ++ks) qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     if (iv) {
         const TQ* qp = aq + ((int64_t)g * Lq + i) * a.ldq + h * DK + 8 * lq;
-        qf[0] = ld_frag(qp); qf[1] = ld_frag(qp + 32);
+#pragma unroll
+        for (int ks = 0; ks < DK / 32; ++ks) qf[ks] = ld_frag(qp + 32 * ks);
     }
     float4 bias4[NJT];
 #pragma unroll
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
             else { float* bp = &bias4[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) bp[r] = a.bias[prow + j0 + r]; }
         }
     }
-    stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
-    stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, KJ, tid, blockDim.x);
+    stage_rows<DK>(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
+    stage_rows<DK>(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, KJ, tid, blockDim.x);
     if (tid < 128) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
     // key columns 16*NJT .. KJ-1 of the P image are never written below: zero the image once
     for (int idx = lane; idx < 16 * (KJ / 4); idx += 64)
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
         for (int jt = 0; jt < NJT; ++jt) {
             s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) s[jt] = mma(frag_row(sK, 16 * jt + lr, 32 * ks + 8 * lq), qf[ks], s[jt]);
+            for (int ks = 0; ks < DK / 32; ++ks) s[jt] = mma(frag_row<PD>(sK, 16 * jt + lr, 32 * ks + 8 * lq), qf[ks], s[jt]);
         }
         const int qpos = a.causal_period > 0 ? i % a.causal_period : 0;
         float mx = -INFINITY;
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
             for (int r = 0; r < 4; ++r) {
                 const int j = j0 + r;
                 const float mk = sMask[j];
-                float x = s[jt][r] * 0.125f;                                      // 1 / sqrt(64)
+                float x = s[jt][r] * qscale;
                 if (mk == 0.f || (a.causal_period > 0 && j > qpos)) x = -1e9f;
                 if (mk < 0.f) x = -INFINITY;                                      // padded key: not part of the row
                 else if (a.bias && iv) x = bb[r] + x;
@@ -183,37 +192,39 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
 #pragma unroll
         for (int ks = 0; ks < KJ / 32; ++ks) pf[ks] = frag_row<PJ>(sP, lr, 32 * ks + 8 * lq);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DK / 16; ++dt) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KJ / 32; ++ks) o = mma(frag_tr(sV, 32 * ks, 16 * dt, lane), pf[ks], o);
+            for (int ks = 0; ks < KJ / 32; ++ks) o = mma(frag_tr<PD>(sV, 32 * ks, 16 * dt, lane), pf[ks], o);
             if (iv) st_elem4(a.o, ((int64_t)g * Lq + i) * a.ldo + h * DK + 16 * dt + 4 * lq, a.o_dtype, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
 static int key_kj(int njt) { return njt <= 2 ? 32 : njt <= 4 ? 64 : njt <= 6 ? 96 : 128; }
 static int key_pj(int njt) { return njt <= 4 ? P16 : 136; }
-static size_t fwd16_lds(int njt, int nw) {
-    return ((size_t)(16 * njt + key_kj(njt)) * P16 + (size_t)16 * nw * key_pj(njt)) * sizeof(__bf16) + 128 * sizeof(float);
+static size_t fwd16_lds(int njt, int nw, int dk) {
+    return ((size_t)(16 * njt + key_kj(njt)) * (dk + 8) + (size_t)16 * nw * key_pj(njt)) * sizeof(__bf16) + 128 * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
 // Phase 1 (wave = 16-row query tile): dP^T = V dO^T, dS = P (dP - rowsum(P dP)), dQ = dS K / sqrt(dk); dS / sqrt(dk) and the
 // dropped P go to workgroup-wide images.  Phase 2 (the 2 x NJT x 4 output tiles shared by the waves): dK = dS^T Q / sqrt(dk),
 // dV = Pd^T dO over all query rows of the group.  Lqp = query rows padded to a multiple of 32 (k range of phase 2).
-template <int NJT, typename TQ>
+template <int NJT, typename TQ, int DKT>
 __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int Lqp) {
+    constexpr int DK = DKT, PD = DKT + 8;
+    const float qscale = DKT == 64 ? 0.125f : 0.17677669529663687f;
     const TQ* aq = reinterpret_cast<const TQ*>(a.q); const TQ* ak = reinterpret_cast<const TQ*>(a.k); const TQ* av = reinterpret_cast<const TQ*>(a.v);
     extern __shared__ __attribute__((aligned(16))) __bf16 sm16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int g = blockIdx.x / a.H, h = blockIdx.x - g * a.H;
     const int Lk = a.Lk, Lq = a.Lq;
     constexpr int KJ = KeyGeo<NJT>::KJ, PJ = KeyGeo<NJT>::PJ;
-    __bf16* sK = sm16;                      // [KJ][P16]      rows = key, zero-padded   (k of dS.K: transposing reads)
-    __bf16* sV = sK + KJ * P16;             // [16*NJT][P16]  rows = key                (row fragments of dP^T = V dO^T)
-    __bf16* sQ = sV + 16 * NJT * P16;       // [Lqp][P16]     rows = query              (k of dS^T Q: transposing reads)
-    __bf16* sG = sQ + Lqp * P16;            // [Lqp][P16]     dO: row fragments in phase 1, transposing reads in phase 2
-    __bf16* sS = sG + Lqp * P16;            // [Lqp][PJ]      dS / sqrt(dk): rows = query, columns = key 0..KJ-1
+    __bf16* sK = sm16;                      // [KJ][PD]       rows = key, zero-padded   (k of dS.K: transposing reads)
+    __bf16* sV = sK + KJ * PD;              // [16*NJT][PD]   rows = key                (row fragments of dP^T = V dO^T)
+    __bf16* sQ = sV + 16 * NJT * PD;        // [Lqp][PD]      rows = query              (k of dS^T Q: transposing reads)
+    __bf16* sG = sQ + Lqp * PD;             // [Lqp][PD]      dO: row fragments in phase 1, transposing reads in phase 2
+    __bf16* sS = sG + Lqp * PD;             // [Lqp][PJ]      dS / sqrt(dk): rows = query, columns = key 0..KJ-1
     __bf16* sD = sS + Lqp * PJ;             // [Lqp][PJ]      dropped P
     const int lr = lane & 15, lq = lane >> 4;
     const bool vec_p = (Lk & 3) == 0;
@@ -233,25 +244,27 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             else { float* q = &praw[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) q[r] = a.p[prow + j0 + r]; }
         }
     }
-    stage_rows(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, KJ, tid, blockDim.x);
-    stage_rows(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
-    stage_rows(sQ, aq + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
-    stage_rows(sG, reinterpret_cast<const TQ*>(a.d_o) + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
+    stage_rows<DK>(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, KJ, tid, blockDim.x);
+    stage_rows<DK>(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
+    stage_rows<DK>(sQ, aq + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
+    stage_rows<DK>(sG, reinterpret_cast<const TQ*>(a.d_o) + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
     // dS / P images: the key columns 16*NJT .. 63 and the query rows past the last wave tile are never written below
     for (int idx = tid; idx < 2 * Lqp * (KJ / 4); idx += blockDim.x)
         *reinterpret_cast<bf16x4*>(sS + (idx / (KJ / 4)) * PJ + (idx % (KJ / 4)) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));   // sD follows sS
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     if (it < nit) {
-        const bf16x8 g0 = frag_row(sG, i, 8 * lq), g1 = frag_row(sG, i, 32 + 8 * lq);
+        bf16x8 gf[DK / 32];
+#pragma unroll
+        for (int ks = 0; ks < DK / 32; ++ks) gf[ks] = frag_row<PD>(sG, i, 32 * ks + 8 * lq);
         // dP^T[j = 16*jt + 4*lq + r][i = lr]
         f32x4 dp[NJT], pp[NJT];
         float dot = 0.f;
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
             dp[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dp[jt] = mma(frag_row(sV, 16 * jt + lr, 8 * lq), g0, dp[jt]);
-            dp[jt] = mma(frag_row(sV, 16 * jt + lr, 32 + 8 * lq), g1, dp[jt]);
+#pragma unroll
+            for (int ks = 0; ks < DK / 32; ++ks) dp[jt] = mma(frag_row<PD>(sV, 16 * jt + lr, 32 * ks + 8 * lq), gf[ks], dp[jt]);
             const int j0 = 16 * jt + 4 * lq;
             const float pv[4] = {praw[jt].x, praw[jt].y, praw[jt].z, praw[jt].w};
             float pd[4];
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
                 if (vec_p && j0 < Lk) *reinterpret_cast<float4*>(a.dscore + prow + j0) = make_float4(ds[0], ds[1], ds[2], ds[3]);
                 else for (int r = 0; r < 4; ++r) if (j0 + r < Lk) a.dscore[prow + j0 + r] = ds[r];
             }
-            *reinterpret_cast<bf16x4*>(sS + i * PJ + j0) = cvt4(make_float4(ds[0] * 0.125f, ds[1] * 0.125f, ds[2] * 0.125f, ds[3] * 0.125f));
+            *reinterpret_cast<bf16x4*>(sS + i * PJ + j0) = cvt4(make_float4(ds[0] * qscale, ds[1] * qscale, ds[2] * qscale, ds[3] * qscale));
         }
         wsync();
         // dQ^T[d = 16*dt + 4*lq + r][i = lr] = sum_j K[j][d] dSs[i][j]
@@ -286,22 +299,23 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
 #pragma unroll
         for (int ks = 0; ks < KJ / 32; ++ks) sf[ks] = frag_row<PJ>(sS, i, 32 * ks + 8 * lq);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DK / 16; ++dt) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KJ / 32; ++ks) acc = mma(frag_tr(sK, 32 * ks, 16 * dt, lane), sf[ks], acc);
+            for (int ks = 0; ks < KJ / 32; ++ks) acc = mma(frag_tr<PD>(sK, 32 * ks, 16 * dt, lane), sf[ks], acc);
             if (iv) st_elem4(a.dq, ((int64_t)g * Lq + i) * a.lddq + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, make_float4(acc[0], acc[1], acc[2], acc[3]));
         }
     }
     __syncthreads();
     // phase 2: tile t = (which, jt, dt): D[d = 16*dt + 4*lq + r][j = 16*jt + lr] = sum_i B[i][d] A[i][j]
-    const int ntiles = 2 * NJT * 4;
+    constexpr int NDT = DK / 16;
+    const int ntiles = 2 * NJT * NDT;
     for (int t = wave; t < ntiles; t += nw) {
-        const int which = t / (NJT * 4), rem = t - which * NJT * 4, jt = rem >> 2, dt = rem & 3;
+        const int which = t / (NJT * NDT), rem = t - which * NJT * NDT, jt = rem / NDT, dt = rem % NDT;
         const __bf16* sA = which == 0 ? sS : sD;      // [query][key]
         const __bf16* sB = which == 0 ? sQ : sG;      // [query][feature]
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < Lqp; k0 += 32) acc = mma(frag_tr(sB, k0, 16 * dt, lane), frag_tr<PJ>(sA, k0, 16 * jt, lane), acc);
+        for (int k0 = 0; k0 < Lqp; k0 += 32) acc = mma(frag_tr<PD>(sB, k0, 16 * dt, lane), frag_tr<PJ>(sA, k0, 16 * jt, lane), acc);
         const int j = 16 * jt + lr;
         if (j < Lk) {
             const int64_t row = (int64_t)g * Lk + j;
@@ -311,8 +325,8 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
         }
     }
 }
-static size_t bwd16_lds(int njt, int Lqp) {
-    return ((size_t)(key_kj(njt) + 16 * njt + 2 * Lqp) * P16 + (size_t)2 * Lqp * key_pj(njt)) * sizeof(__bf16);
+static size_t bwd16_lds(int njt, int Lqp, int dk) {
+    return ((size_t)(key_kj(njt) + 16 * njt + 2 * Lqp) * (dk + 8) + (size_t)2 * Lqp * key_pj(njt)) * sizeof(__bf16);
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -322,7 +336,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 namespace ortk {
 
 // shapes / layouts these kernels serve (everything else stays with the fp32-MFMA family)
-bool attn16_shape_ok(int Lq, int Lk, int dk) { return dk == 64 && Lk >= 1 && Lk <= 128 && Lq >= 1 && Lq <= 128; }
+bool attn16_shape_ok(int Lq, int Lk, int dk) { return (dk == 64 || dk == 32) && Lk >= 1 && Lk <= 128 && Lq >= 1 && Lq <= 128; }
 
 bool attn16_ok(const ortk_attn_args* a, bool bwd) {
     // fp32 inputs: only the block shapes (the register-only kernels keep the short ones); bf16 inputs: every served shape
@@ -346,27 +360,28 @@ bool attn16_ok(const ortk_attn_args* a, bool bwd) {
 
 typedef void (*fwd16_fn)(ortk_attn_args);
 typedef void (*bwd16_fn)(ortk_attn_args, int);
-template <typename TQ> static fwd16_fn pick_fwd(int njt) {
+template <typename TQ, int DKT> static fwd16_fn pick_fwd(int njt) {
     switch (njt) {
-        case 1: return attn16_fwd_kernel<1, TQ>; case 2: return attn16_fwd_kernel<2, TQ>; case 3: return attn16_fwd_kernel<3, TQ>;
-        case 4: return attn16_fwd_kernel<4, TQ>; case 5: return attn16_fwd_kernel<5, TQ>; case 6: return attn16_fwd_kernel<6, TQ>;
-        case 7: return attn16_fwd_kernel<7, TQ>; default: return attn16_fwd_kernel<8, TQ>;
+        case 1: return attn16_fwd_kernel<1, TQ, DKT>; case 2: return attn16_fwd_kernel<2, TQ, DKT>; case 3: return attn16_fwd_kernel<3, TQ, DKT>;
+        case 4: return attn16_fwd_kernel<4, TQ, DKT>; case 5: return attn16_fwd_kernel<5, TQ, DKT>; case 6: return attn16_fwd_kernel<6, TQ, DKT>;
+        case 7: return attn16_fwd_kernel<7, TQ, DKT>; default: return attn16_fwd_kernel<8, TQ, DKT>;
     }
 }
-template <typename TQ> static bwd16_fn pick_bwd(int njt) {
+template <typename TQ, int DKT> static bwd16_fn pick_bwd(int njt) {
     switch (njt) {
-        case 1: return attn16_bwd_kernel<1, TQ>; case 2: return attn16_bwd_kernel<2, TQ>; case 3: return attn16_bwd_kernel<3, TQ>;
-        case 4: return attn16_bwd_kernel<4, TQ>; case 5: return attn16_bwd_kernel<5, TQ>; case 6: return attn16_bwd_kernel<6, TQ>;
-        case 7: return attn16_bwd_kernel<7, TQ>; default: return attn16_bwd_kernel<8, TQ>;
+        case 1: return attn16_bwd_kernel<1, TQ, DKT>; case 2: return attn16_bwd_kernel<2, TQ, DKT>; case 3: return attn16_bwd_kernel<3, TQ, DKT>;
+        case 4: return attn16_bwd_kernel<4, TQ, DKT>; case 5: return attn16_bwd_kernel<5, TQ, DKT>; case 6: return attn16_bwd_kernel<6, TQ, DKT>;
+        case 7: return attn16_bwd_kernel<7, TQ, DKT>; default: return attn16_bwd_kernel<8, TQ, DKT>;
     }
 }
 
 int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
     const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16;
-    const fwd16_fn fn = a->qkv_dtype ? pick_fwd<__bf16>(njt) : pick_fwd<float>(njt);
-    const size_t lds = fwd16_lds(njt, nw);
-    static bool attr[16] = {};
-    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0);
+    const fwd16_fn fn = a->dk == 64 ? (a->qkv_dtype ? pick_fwd<__bf16, 64>(njt) : pick_fwd<float, 64>(njt))
+                                    : (a->qkv_dtype ? pick_fwd<__bf16, 32>(njt) : pick_fwd<float, 32>(njt));
+    const size_t lds = fwd16_lds(njt, nw, a->dk);
+    static bool attr[32] = {};
+    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0) + (a->dk == 64 ? 0 : 16);
     if (lds > 64 * 1024 && !attr[ai]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr[ai] = true;
@@ -378,11 +393,12 @@ int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
 
 int attn16_bwd(const ortk_attn_args* a, hipStream_t s) {
     const int njt = (a->Lk + 15) / 16, nw = (a->Lq + 15) / 16, Lqp = (int)ortk_align(a->Lq, 32);
-    const bwd16_fn fn = a->qkv_dtype ? pick_bwd<__bf16>(njt) : pick_bwd<float>(njt);
-    const size_t lds = bwd16_lds(njt, Lqp);
+    const bwd16_fn fn = a->dk == 64 ? (a->qkv_dtype ? pick_bwd<__bf16, 64>(njt) : pick_bwd<float, 64>(njt))
+                                    : (a->qkv_dtype ? pick_bwd<__bf16, 32>(njt) : pick_bwd<float, 32>(njt));
+    const size_t lds = bwd16_lds(njt, Lqp, a->dk);
     if (lds > 160 * 1024) return ORTK_EINVAL;
-    static bool attr[16] = {};
-    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0);
+    static bool attr[32] = {};
+    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0) + (a->dk == 64 ? 0 : 16);
     if (lds > 64 * 1024 && !attr[ai]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr[ai] = true;

@@ -275,6 +275,11 @@ def test_attention_bf16_operand_kernels(L):
     _attn_case(L, 1, 2, 128, 128, 64, 0, True, False, precision=1, in_dt=1)               # the largest shape
     _attn_case(L, 2, 4, 70, 77, 64, 0, True, True, precision=1)                           # fp32 inputs, Lk not a multiple of 4
     _attn_case(L, 6, 8, 5, 60, 64, 0, False, True, precision=1)                           # decode cross-attention: 5 beams x 60 regions (fp32 rows)
+    # 32-wide heads (d_model 256 with 8 heads: the ACORT-small width)
+    _attn_case(L, 3, 8, 36, 36, 32, 0, True, True, precision=1, out_dt=1, in_dt=1)
+    _attn_case(L, 2, 8, 85, 36, 32, 0, False, True, precision=1, out_dt=1, in_dt=1)
+    _attn_case(L, 5, 8, 25, 25, 32, 25, False, True, precision=1, out_dt=1, in_dt=1)      # causal, T = 25 (max_seq_length 26)
+    _attn_case(L, 2, 4, 100, 100, 32, 0, True, True, precision=1)                         # fp32 rows, 100 keys
     a = L.AttnArgs()                                                                      # shapes the bf16 kernels do not take: loud
     a.qkv_dtype, a.precision = 1, 1
     t = torch.zeros(4 * 200, 64, device="cuda", dtype=torch.bfloat16); o = torch.zeros(4 * 200, 64, device="cuda")
