@@ -17,3 +17,15 @@ for d, ff, extra in ((512, 2048, {}), (256, 1024, {}), (104, 416, {}), (512, 204
     for _ in range(10): tr.xe_step(batch)
     torch.cuda.synchronize()
     print(f"d_model {d} ff {ff} {extra and 'acort-shared' or ''}: {(time.perf_counter()-t0)*100:.2f} ms/step, params {sum(p.numel() for p in m.parameters())/1e6:.1f} M", flush=True)
+
+# decode (beam 5, 256 images) at the same widths
+for d, ff in ((512, 2048), (256, 1024)):
+    cfg = ort_config(d_model=d, dim_feedforward=ff, vocab_size=771, max_seq_length=26)
+    m = P.get_model("relation_transformer")(cfg, precision="bf16").cuda().eval()
+    batch = bench.synth_batch(256, 36, cfg.att_feat_size, cfg.vocab_size, 5, cfg.max_seq_length, 1000, torch.device("cuda"))
+    f = lambda: m(att_feats=batch["att_feats"], boxes=batch["boxes"], att_masks=batch["att_masks"], opt={"beam_size": 5}, mode="sample")
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    print(f"decode d_model {d}: {(time.perf_counter()-t0)*200:.2f} ms per 256 images", flush=True)
