@@ -607,11 +607,13 @@ def test_bf16_path_tolerance_and_fused_loss(P, golden, full_state):
     assert seq5.shape[1] == 5 and int((seq5[:, 0] != 0).sum()) > 0
 
 
-def test_mixed_precision_gradients_track_fp32_gradients(P, full_state):
+@pytest.mark.parametrize("inputs", [C.G2_INPUTS, dict(C.G2_INPUTS, seed=123, n_img=3, n_reg=100, ragged=True)])
+def test_mixed_precision_gradients_track_fp32_gradients(P, full_state, inputs):
     """The mixed-precision step runs a different executor schedule (bf16 operand storage, weight-gradient GEMMs and other
-    off-critical-path kernels on a side stream): every parameter gradient must still point where the fp32 one points."""
+    off-critical-path kernels on a side stream): every parameter gradient must still point where the fp32 one points.
+    Second case: ragged masks over up to 100 regions (the 5-8 key-tile attention kernels, ragged GEMM row counts)."""
     from sparse_image_captioning_amd.training import NativeTrainer
-    b = _cuda(H.torch_batch(C.make_inputs(**C.G2_INPUTS)))
+    b = _cuda(H.torch_batch(C.make_inputs(**inputs)))
     grads = {}
     for prec in (0, "bf16"):
         m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=prec)
