@@ -132,9 +132,10 @@ def main():
     ap.add_argument("--overlap-allreduce", default="auto", choices=("auto", "on", "off"),
                     help="all-reduce the decoder half of the gradients while the encoder half of the backward runs "
                          "(auto: on when more than one rank)")
-    ap.add_argument("--csr-kernels", action="store_true",
-                    help="sparse_decode: CSR gather products (ortk_spmm_csr) instead of MFMA GEMMs on zero-filled weights; "
-                         "measured slower than bf16 MFMA at 95 %% unstructured sparsity (DESIGN.md section 7)")
+    ap.add_argument("--csr-kernels", "--sparse-kernels", dest="csr_kernels", action="store_true",
+                    help="sparse_decode / sparse_xe: sparse products (ortk_spmm_ell, sorted-ELL images rebuilt on the device every "
+                         "call) instead of MFMA GEMMs on zero-filled weights; sparse_xe: forward and data gradients (the weight "
+                         "gradients stay dense: the straight-through mask gradient needs them at every position)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 256; decode 1024)")
     ap.add_argument("--max-seq-length", type=int, default=18, help="caption length incl. BOS/EOS (18 = BASELINE; the ACORT commands use 26)")
     ap.add_argument("--regions", type=int, default=36, help="regions per image (36 = BASELINE; real bottom-up features have 10-100)")
@@ -171,17 +172,18 @@ def main():
     model = pkg.get_model(name)(config, precision=args.precision)
     if sparse:
         with torch.no_grad():
-            if args.workload == "sparse_xe":    # mask logits with round(sigmoid(m)) ~ Bernoulli(0.05): 95 % sparse
+            if args.workload == "sparse_xe":    # mask logits of a converged supermask run: |m| = 6, 5 % positive -> the
+                # Bernoulli(sigmoid(m)) samples of the training step keep 0.05*0.9975 + 0.95*0.0025 = 5.2 % of the weights
                 for _, m in model.all_pruning_masks():
-                    m.copy_(torch.where(torch.rand_like(m) < 0.05, torch.full_like(m, 3.0), torch.full_like(m, -3.0)))
+                    m.copy_(torch.where(torch.rand_like(m) < 0.05, torch.full_like(m, 6.0), torch.full_like(m, -6.0)))
             else:                                # decode: dense class on densified 95 %-pruned weights (eval_model.py:64-88)
                 for n_, p in model.named_parameters():
                     if p.dim() >= 2:
                         p.mul_((torch.rand_like(p) < 0.05).float())
     model = model.to(dev)
-    use_csr = args.workload == "sparse_decode" and args.csr_kernels
-    if use_csr:
-        model.enable_sparse_kernels(0.9)     # CSR sparse products (ortk_spmm_csr) for the >= 90 %-sparse weight blocks
+    use_csr = sparse and args.csr_kernels
+    if use_csr:                              # sparse products (ortk_spmm_ell) for the >= 90 %-sparse weight blocks
+        model.enable_sparse_kernels(0.9, train=args.workload == "sparse_xe")
     batch = synth_batch(B, S, config.att_feat_size, config.vocab_size, spi, config.max_seq_length, 1000 + rank, dev)
 
     if decode:
@@ -281,7 +283,7 @@ def main():
                           "parallelism": f"dp{world}" if world > 1 else "single",
                           "storage": ("fp32 master weights / residual stream / logits; MFMA-operand tensors stored bf16; fp32 accumulate"
                                       if args.precision == "bf16" else "fp32"),
-                          "sparse_kernels": "csr" if use_csr else None},
+                          "sparse_kernels": "sorted-ELL (ortk_spmm_ell)" if use_csr else None},
                "roofline": roofline}
         if not args.no_cpu_baseline and world == 1:
             from sparse_image_captioning_amd.utils.config import ORT_DEFAULTS

@@ -38,6 +38,7 @@ int ortk_device_ok(void);
 /* ------------------------------------------------------------------------------------------------
  * Model geometry — the fields models/transformer.py:418-437 reads from `config`.
  * ---------------------------------------------------------------------------------------------- */
+struct ortk_ell_plan;
 typedef struct ortk_config {
     int32_t d_model, d_ff, n_layers, n_heads;
     int32_t vocab, feat, seq_len;              /* vocab_size, att_feat_size, max_seq_length          */
@@ -59,6 +60,15 @@ typedef struct ortk_config {
      * zeroing of padded regions (src_embed = Linear + ReLU + Dropout on every row), and the reference's state_dict names
      * for that class (`core.src_embed.0.*`, `core.encoder.*`, `core.decoder.*`, `core.tgt_embed.*`, `core.generator.proj.*`). */
     int32_t no_box;
+    /* Execution option, not geometry (may be NULL): sparse plans over blocks of the weight arena for the TRAINING step
+     * (`relation_transformer_prune`: the masked linears of pruning/masked_layer.py:84-110,134-135 as sparse products).
+     * sparse_fwd: blocks = (N,K) weight blocks at their arena offsets; ortk_forward rebuilds it from the effective weights
+     * of the call (s*W: the mask sample of THIS step) and runs those projections with ortk_spmm_ell.  sparse_bwd (mixed
+     * precision only): the same blocks TRANSPOSED ((K,N), same offsets, ld = N): rebuilt by ortk_forward from its
+     * transposed bf16 weight copies, used by ortk_backward for the data gradients dX = dY W~.  The weight gradients stay
+     * dense MFMA products: the straight-through mask gradient needs dLoss/d(s*W) at EVERY position (sampler.py:10-34). */
+    const struct ortk_ell_plan* sparse_fwd;
+    const struct ortk_ell_plan* sparse_bwd;
 } ortk_config;
 
 /* ------------------------------------------------------------------------------------------------
@@ -121,17 +131,57 @@ int64_t ortk_arena_decoder_offset(const ortk_config* cfg);
 
 /* Cached-attention decoding: CachedTransformerBase._generate_captions (models/transformer.py:471-561)
  * + CaptionModel.batch_beam_search (models/caption_model.py:30-226, group_size 1). */
-/* A pruned (N,K) weight block in chunked CSR form (device pointers).  The K axis is cut in chunks of 512 columns:
- * row_ptr has ceil(K/512)*N + 1 entries; the non-zeros of row n whose column lies in chunk c are
- * [row_ptr[c*N+n], row_ptr[c*N+n+1]); col holds the column relative to its chunk; val the fp32 value.
- * Every list is padded with (col 0, val 0.0f) entries to a multiple of 4 entries, and col / val are allocated with
- * 4 spare zero entries behind row_ptr[last] (the kernel reads one 4-entry batch ahead).
- * arena_offset identifies the block inside the parameter arena (ortk_linear_block). */
-typedef struct ortk_csr {
-    const int32_t* row_ptr; const uint16_t* col; const float* val;
+/* ------------------------------------------------------------------------------------------------
+ * Sparse weights: sorted, padded ELL ("SELL-64") images of pruned weight blocks, rebuilt ON THE DEVICE from the
+ * dense (zero-filled) weights of the current call, so there is no host-side cache that could go stale.
+ *
+ * A block is an (N outputs, K inputs) row-major matrix (a torch Linear weight, or — for the data gradient
+ * dX = dY W — its transposed bf16 copy, then N = in_features).  Its N output columns are cut in ranges of 512;
+ * inside a range the columns are ordered by their number of non-zeros (descending) and grouped in chunks of
+ * 64: chunk c = 64 output columns, one per lane, padded to chunk_len[c] entries (a multiple of 4) with zero
+ * entries.  Entry j of lane l of chunk c sits at stream[chunk_ptr[c] + j*64 + l]:
+ *   entry_bytes 4: uint32  = bf16(value) << 16 | slot(k)*16          (mixed precision)
+ *   entry_bytes 8: uint32x2 = { slot(k)*16, fp32 bits of value }     (fp32 parity mode)
+ * slot(k) = (k & ~7) | ((k + (k >> 3)) & 7) is the 16-byte slot of input column k in the kernel's LDS image
+ * of the activation tile (K <= 4095).  perm[c*64 + l] = the output column of lane l (or -1 for a pad lane).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ortk_ell_block {
+    int64_t src_offset;        /* element offset of the dense (N,K) block inside the dense buffer handed to the builder   */
+    int64_t ld;                /* its leading dimension (elements)                                                         */
+    int64_t stream_offset;     /* first entry of this block's region in the stream buffer                                 */
+    int64_t capacity;          /* entries reserved for it (the builder drops what does not fit and raises *overflow)      */
     int32_t N, K;
-    int64_t arena_offset;
-} ortk_csr;
+    int32_t chunk0;            /* index of its first chunk in chunk_ptr / chunk_len / perm (ceil(N/64) chunks)            */
+    int32_t row0;              /* index of its first output column in the builder's count scratch                        */
+} ortk_ell_block;
+
+/* One set of sparse blocks (device buffers owned by the caller; the block table is given twice: host copy for the
+ * launch geometry, device copy for the kernels). */
+typedef struct ortk_ell_plan {
+    const ortk_ell_block* blocks_host; const ortk_ell_block* blocks_dev;
+    int32_t nblocks, entry_bytes;
+    void* stream; int32_t* chunk_ptr; int32_t* chunk_len; int32_t* perm;
+    int32_t* count_scratch;    /* >= sum of N over the blocks                                                             */
+    int32_t* overflow;         /* device int: set to 1 by the builder when a block exceeded its capacity                  */
+    int64_t total_rows;        /* sum of N over the blocks                                                                 */
+} ortk_ell_plan;
+
+/* Build every block of the plan from `dense` (dtype 0 fp32 / 1 bf16): three launches, no host sync. */
+int ortk_ell_build(const ortk_ell_plan* plan, const void* dense, int32_t dtype, ortk_stream stream);
+
+/* Y = epi(X W~^T) for block `block` of a built plan.  Same epilogue as ortk_gemm:
+ *   v = acc + bias[n]; relu; v *= rowscale[m]; dropout(p, seed, index m*N+n); v *= (gate[m,n]>0)*gate_scale; v += resid[m,n].
+ * Replaces F.linear on zero-filled pruned weights (scripts/eval_model.py:64-88) and the masked linears of
+ * pruning/masked_layer.py:84-110,134-135 (forward, and the data gradient with a plan built from W^T). */
+typedef struct ortk_spmm_args {
+    const void* X; void* Y;
+    int64_t ldx, ldy; int64_t M;
+    int32_t x_dtype, y_dtype;
+    const float* bias; const float* rowscale; const float* resid; int64_t ldr;
+    const void* gate; int64_t ldg; int32_t gate_dtype; float gate_scale;
+    int32_t relu; float drop_p; uint32_t drop_seed;
+} ortk_spmm_args;
+int ortk_spmm_ell(const ortk_ell_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream);
 
 typedef struct ortk_decode_opts {
     int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
@@ -141,10 +191,11 @@ typedef struct ortk_decode_opts {
     int32_t length_penalty;       /* 0 none, 1 "wu_<alpha>", 2 "avg_<alpha>"   utils/model_utils.py:121-146 */
     double  length_alpha;
     uint64_t seed;                /* multinomial: Gumbel-max over counter-based uniforms */
-    /* Optional (may be NULL / 0): CSR images of pruned weight blocks (see ortk_linear_block / ortk_spmm_csr).  A
-     * projection whose weight block has an entry here runs as a sparse product instead of a dense GEMM. */
-    const struct ortk_csr* sparse;
-    int32_t n_sparse;
+    /* Optional (may be NULL): sparse plan over blocks of the weight arena (src_offset = arena offset of the block, see
+     * ortk_linear_block).  ortk_decode rebuilds it from the weights of this call and runs every projection that has a
+     * block in it as a sparse product (ortk_spmm_ell) instead of a dense GEMM. */
+    const struct ortk_ell_plan* sparse;
+    int32_t reserved0;
     /* multinomial only: also decode ONE greedy row per image in the same pass (the SCST baseline of
      * utils/training.py:220-237): K = num_random_sample + 1, row 0 of each image is the arg-max decode, rows 1.. are
      * the samples — token for token what two separate calls return, at half the launches. */
@@ -327,13 +378,6 @@ int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw
 /* The weight blocks the executor multiplies by (packed Q|K|V, the all-layer cross-attention K|V block, ...): block i
  * is the (N,K) row-major matrix at arena offset *offset.  Returns the number of blocks when i < 0. */
 int ortk_linear_block(const ortk_config* cfg, int32_t i, int64_t* offset, int32_t* N, int32_t* K);
-/* Y = epi(X W~^T), W~ sparse (ortk_csr): v = sum_j val_j X[m, col_j] + bias[n]; relu; v += resid[m,n].
- * Replaces F.linear on zero-filled pruned weights (scripts/eval_model.py:64-88, pruning/masked_layer.py:134-135).
- * X / Y dtype: 0 fp32, 1 bf16. */
-int ortk_spmm_csr(const ortk_csr* w, const void* X, int32_t x_dtype, int64_t ldx, const float* bias, void* Y,
-                  int32_t y_dtype, int64_t ldy, int64_t M, int32_t relu, const float* resid, int64_t ldr,
-                  ortk_stream stream);
-
 /* count_dev[0] += number of kept entries (round(sigmoid(m)) for mode 0/1, m != 0 for mode 2) in m[0..n). */
 int ortk_mask_count(const float* m, int64_t n, int32_t mode, float* count_dev, ortk_stream stream);
 

@@ -28,7 +28,8 @@ class Config(C.Structure):
                 ("pad_id", C.c_int32), ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("unk_id", C.c_int32),
                 ("box_trig", C.c_int32), ("precision", C.c_int32), ("drop_src", C.c_float), ("drop", C.c_float),
                 ("share_enc", C.c_int32 * 16), ("share_dec", C.c_int32 * 16),
-                ("share_att_enc", C.c_int32), ("share_att_dec", C.c_int32), ("no_box", C.c_int32)]
+                ("share_att_enc", C.c_int32), ("share_att_dec", C.c_int32), ("no_box", C.c_int32),
+                ("sparse_fwd", C.c_void_p), ("sparse_bwd", C.c_void_p)]
 
 
 class Batch(C.Structure):
@@ -37,15 +38,29 @@ class Batch(C.Structure):
                 ("B", C.c_int32), ("S", C.c_int32), ("R", C.c_int32), ("T", C.c_int32)]
 
 
-class Csr(C.Structure):
-    _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
-                ("arena_offset", C.c_int64)]
+class EllBlock(C.Structure):
+    _fields_ = [("src_offset", C.c_int64), ("ld", C.c_int64), ("stream_offset", C.c_int64), ("capacity", C.c_int64),
+                ("N", C.c_int32), ("K", C.c_int32), ("chunk0", C.c_int32), ("row0", C.c_int32)]
+
+
+class EllPlanStruct(C.Structure):
+    _fields_ = [("blocks_host", C.POINTER(EllBlock)), ("blocks_dev", C.c_void_p), ("nblocks", C.c_int32), ("entry_bytes", C.c_int32),
+                ("stream", C.c_void_p), ("chunk_ptr", C.c_void_p), ("chunk_len", C.c_void_p), ("perm", C.c_void_p),
+                ("count_scratch", C.c_void_p), ("overflow", C.c_void_p), ("total_rows", C.c_int64)]
+
+
+class SpmmArgs(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("Y", C.c_void_p), ("ldx", C.c_int64), ("ldy", C.c_int64), ("M", C.c_int64),
+                ("x_dtype", C.c_int32), ("y_dtype", C.c_int32),
+                ("bias", C.c_void_p), ("rowscale", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64),
+                ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_dtype", C.c_int32), ("gate_scale", C.c_float),
+                ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
 
 
 class DecodeOpts(C.Structure):
     _fields_ = [("beam_size", C.c_int32), ("num_random_sample", C.c_int32), ("temperature", C.c_float),
                 ("decoding_constraint", C.c_int32), ("length_penalty", C.c_int32), ("length_alpha", C.c_double),
-                ("seed", C.c_uint64), ("sparse", C.POINTER(Csr)), ("n_sparse", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64)]
+                ("seed", C.c_uint64), ("sparse", C.POINTER(EllPlanStruct)), ("reserved0", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64)]
 
 
 class GemmArgs(C.Structure):
@@ -129,7 +144,8 @@ SIGNATURES = {
     "ortk_decode_step": (_I32, [_CFG, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _SZ, _P, _I64, _P]),
     "ortk_axpy_cols": (_I32, [_P, _P, _I32, _I64, _I64, _I32, _P]),
     "ortk_linear_block": (_I32, [_CFG, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "ortk_spmm_csr": (_I32, [C.POINTER(Csr), _P, _I32, _I64, _P, _P, _I32, _I64, _I64, _I32, _P, _I64, _P]),
+    "ortk_ell_build": (_I32, [C.POINTER(EllPlanStruct), _P, _I32, _P]),
+    "ortk_spmm_ell": (_I32, [C.POINTER(EllPlanStruct), _I32, C.POINTER(SpmmArgs), _P]),
 }
 
 _lib = None

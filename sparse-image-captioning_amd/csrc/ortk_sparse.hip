@@ -1,144 +1,422 @@
-// ortk_sparse.hip — sparse x dense product for >= 90 %-pruned weights:  Y = epi(X . W~^T),  W~ (N,K) in CSR.
+// ortk_sparse.hip — sparse x dense products for pruned weights:  Y = epi(X . W~^T),  W~ (N outputs, K inputs) sparse.
 //
-// The reference runs pruned models as DENSE linears on zero-filled weights (scripts/eval_model.py:64-88,
-// pruning/masked_layer.py:134-135).  At 95 % sparsity only 5 % of those multiply-adds touch a non-zero, so here each
-// output column n gathers just its nnz(n) ~ 0.05 K input columns.
+// The reference multiplies by the zero-filled weight s (.) W in every masked layer (pruning/masked_layer.py:84-110,
+// 134-135) and evaluates pruned checkpoints as DENSE linears on zero-filled weights (scripts/eval_model.py:64-88).  At
+// 95 % sparsity only 5 % of those multiply-adds touch a non-zero.  This file holds
+//   * the device-side builder of the sparse image ("sorted, padded ELL in chunks of 64 output columns", include/ortk.h:
+//     ortk_ell_block / ortk_ell_plan) — three launches over ALL blocks of a plan, no host synchronisation, so a plan is
+//     simply rebuilt from the effective weights of every call (a new Bernoulli mask sample per training step);
+//   * the product kernel.
 //
-// Layout: the K axis is cut in chunks of KC = 512 columns; the CSR is "chunked" (row_ptr has nchunk*N+1 entries,
-// entry c*N+n starts the non-zeros of row n whose column lies in chunk c; col holds the column RELATIVE to its
-// chunk as uint16).  Every (chunk,row) list is padded with (col 0, val 0) entries to a multiple of 4 and the arrays
-// carry 4 spare entries at the end: the kernel streams them as aligned 4-entry batches, one batch ahead of use.  A workgroup owns ROWS consecutive rows of X, stages their current K-chunk in LDS as
-// [row][k] (pitch odd in dwords: lane = row reads are bank-conflict free whatever the gathered column), and its waves
-// walk groups of 16 output columns: the (col, val) stream of a group is wave-uniform (scalar loads), each lane
-// accumulates its row's 16 outputs in registers and writes them as one 64-byte segment.  For K > KC the chunks are
-// processed in sequence by the same workgroup (same threads own the same outputs: plain read-modify-write, no atomics).
-// HBM traffic = X once + Y once (+ 6 bytes per non-zero from L2): activation-bandwidth bound.
+// Product kernel.  A workgroup owns RB consecutive rows of X (16 in mixed precision, 8 in the fp32 parity mode) and one
+// range of 512 output columns.  It stages its X tile in LDS TRANSPOSED, as two planes of [input column k][8 bf16 rows]
+// (16-byte slots; the slot of k is a fixed permutation that makes the staging writes bank-conflict free and is baked into
+// the entries by the builder).  Then LANE = OUTPUT COLUMN: a wave takes one chunk of 64 columns at a time (dynamic, longest
+// chunk first: the builder sorts the columns of a range by their non-zero count), each lane walks the entry list of its
+// own column — one coalesced 256-byte load per step for the wave — and per entry reads the 16 rows of that input column
+// with two ds_read_b128 and does 16 multiply-adds into its 16 row accumulators.  The results go through an fp32 LDS tile
+// in natural column order, so that bias / ReLU / row scale / dropout / gate / residual and the global stores run on
+// whole 1-KB row segments exactly like the dense GEMM epilogue.
+// Bounds: 26 VALU instructions and two 16-byte LDS gathers per 1024 multiply-adds; algorithmic HBM bytes =
+// X once + Y once + 4 bytes per non-zero (the entries are re-read by every row tile, from L2).
 #include "ortk_common.h"
 
 namespace {
 
-constexpr int KC = 512;
-typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+constexpr int RANGE = 512;             // output columns per workgroup = sort range of the format (8 chunks of 64)
+constexpr int OP = RANGE + 4;          // fp32 row pitch of the staged output tile
+constexpr int KMAX = 2048;             // offsets are slot*16 < 65536 and two planes must fit the LDS beside the output tile
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-struct SpmmP {
-    const int32_t* row_ptr; const uint16_t* col; const float* val;
-    const void* X; int64_t ldx; int x_dt;
-    const float* bias; const float* resid; int64_t ldr;
-    void* Y; int64_t ldy; int y_dt;
-    int64_t M; int N, K, relu;
-};
+__host__ __device__ inline int ell_slot(int k) { return (k & ~7) | ((k + (k >> 3)) & 7); }
 
-// XT: element type staged in LDS (float or bf16). ROWS rows per workgroup; a wave serves 64/ROWS column groups at once.
-template <typename XT, int ROWS>
-__global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmP p) {
-    constexpr int EPD = 4 / (int)sizeof(XT);                 // elements per dword
-    constexpr int PITCH = KC + EPD;                           // odd number of dwords
-    constexpr int NQ = 64 / ROWS;                             // column groups per wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    XT* sX = reinterpret_cast<XT*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * ROWS;
-    const int ml = lane % ROWS, q = lane / ROWS;
-    const int64_t m = m0 + ml;
-    const int nchunk = (p.K + KC - 1) / KC;
-    const int ngroups = (p.N + 15) / 16;
-    for (int c = 0; c < nchunk; ++c) {
-        const int k0 = c * KC, kw = min(KC, p.K - k0);
-        __syncthreads();
-        // stage X[m0 .. m0+ROWS)[k0 .. k0+kw) -> sX[row][k]   (coalesced along k)
-        for (int idx = tid; idx < ROWS * (KC / 4); idx += 256) {
-            const int r = idx / (KC / 4), k = (idx - r * (KC / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < p.M) {
-                const int64_t gi = (m0 + r) * p.ldx + k0 + k;
-                if (k + 3 < kw && (gi & 3) == 0) v = ld_elem4(p.X, gi, p.x_dt);
-                else {
-                    if (k < kw) v.x = ld_elem(p.X, gi, p.x_dt);
-                    if (k + 1 < kw) v.y = ld_elem(p.X, gi + 1, p.x_dt);
-                    if (k + 2 < kw) v.z = ld_elem(p.X, gi + 2, p.x_dt);
-                    if (k + 3 < kw) v.w = ld_elem(p.X, gi + 3, p.x_dt);
-                }
-            }
-            XT* dst = sX + r * PITCH + k;
-            dst[0] = (XT)v.x; dst[1] = (XT)v.y; dst[2] = (XT)v.z; dst[3] = (XT)v.w;
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned int)b << 16); }
+__device__ __forceinline__ unsigned int f32_to_bf16_bits(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
+
+// 8 consecutive elements X[row][k0 .. k0+8) as floats, zeros beyond K
+__device__ __forceinline__ void load8(const void* X, int dt, int64_t ld, int64_t row, int k0, int K, float (&v)[8]) {
+    const int64_t i0 = row * ld + k0;
+    if (dt == ORTK_BF16) {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(X) + i0;
+        if (k0 + 8 <= K && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { v[2 * d] = __uint_as_float(t[d] << 16); v[2 * d + 1] = __uint_as_float(t[d] & 0xFFFF0000u); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = k0 + i < K ? bf16_bits_to_f32(p[i]) : 0.f;
         }
-        __syncthreads();
-        const int32_t* rp = p.row_ptr + (int64_t)c * p.N;
-        const bool first = c == 0, last = c == nchunk - 1;
-        for (int ng = wave * NQ + q; ng < ngroups; ng += 4 * NQ) {
-            float acc[16];
-            int r[17];
+    } else {
+        const float* p = reinterpret_cast<const float*>(X) + i0;
+        if (k0 + 8 <= K && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
 #pragma unroll
-            for (int t = 0; t <= 16; ++t) r[t] = rp[min(ng * 16 + t, p.N)];
-            // Rows are padded to multiples of 4 entries (col 0, val 0) and the arrays end with 4 spare entries, so the
-            // stream of the 16 columns is read as aligned 4-entry batches, always one batch ahead of its use.
-            int j = r[0];
-            f32x4 v_next = *reinterpret_cast<const f32x4*>(p.val + j);
-            u16x4 c_next = *reinterpret_cast<const u16x4*>(p.col + j);
-            const XT* xrow = sX + ml * PITCH;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                float a0 = 0.f, a1 = 0.f;
-                while (j < r[t + 1]) {
-                    const f32x4 v = v_next; const u16x4 cc = c_next;
-                    j += 4;
-                    v_next = *reinterpret_cast<const f32x4*>(p.val + j);
-                    c_next = *reinterpret_cast<const u16x4*>(p.col + j);
-                    a0 += v[0] * (float)xrow[cc[0]]; a1 += v[1] * (float)xrow[cc[1]];
-                    a0 += v[2] * (float)xrow[cc[2]]; a1 += v[3] * (float)xrow[cc[3]];
-                }
-                acc[t] = a0 + a1;
-            }
-            if (m < p.M) {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int n = ng * 16 + t;
-                    if (n < p.N) {
-                        float y = acc[t];
-                        const int64_t yi = m * p.ldy + n;
-                        if (first) { if (p.bias) y += p.bias[n]; } else y += ld_elem(p.Y, yi, p.y_dt);
-                        if (last) {
-                            if (p.relu) y = fmaxf(y, 0.f);
-                            if (p.resid) y += p.resid[m * p.ldr + n];
-                        }
-                        st_elem(p.Y, yi, p.y_dt, y);
-                    }
-                }
-            }
+            for (int i = 0; i < 8; ++i) v[i] = k0 + i < K ? p[i] : 0.f;
         }
     }
 }
 
-template <typename XT>
-int launch(const SpmmP& p, hipStream_t s) {
-    constexpr int EPD = 4 / (int)sizeof(XT);
-    const size_t per_row = (size_t)(KC + EPD) * sizeof(XT);
-    // fewer rows per workgroup for small batches so that the grid still covers the 256 CUs
-    const int rows = p.M >= 32768 ? 64 : (p.M >= 8192 ? 32 : 16);
-    const dim3 block(256);
+struct SpmmP {
+    const void* stream; const int32_t* chunk_ptr; const int32_t* chunk_len; const int32_t* perm;   // already at the block's chunk0
+    int32_t N, K, nchunks, nranges;
+    ortk_spmm_args a;
+};
+
+// 4 consecutive fp32 of a row (zero beyond N)
+__device__ __forceinline__ void ld4f(const float* __restrict__ p, int n0, int N, bool vec, float (&o)[4]) {
+    if (vec && n0 + 3 < N) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; return; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = n0 + q < N ? p[q] : 0.f;
+}
+
+// one entry of a bf16 chunk: 16 rows (two planes of 8) += value * X[:, k]
+template <int PB>
+__device__ __forceinline__ void fma_entry16(const unsigned char* planes, unsigned int w, float (&acc)[16]) {
+    const unsigned int off = w & 0xFFFFu;
+    const float val = __uint_as_float(w & 0xFFFF0000u);
+    const u32x4 a = *reinterpret_cast<const u32x4*>(planes + off);
+    const u32x4 b = *reinterpret_cast<const u32x4*>(planes + PB + off);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        acc[2 * d] = fmaf(val, __uint_as_float(a[d] << 16), acc[2 * d]);
+        acc[2 * d + 1] = fmaf(val, __uint_as_float(a[d] & 0xFFFF0000u), acc[2 * d + 1]);
+        acc[8 + 2 * d] = fmaf(val, __uint_as_float(b[d] << 16), acc[8 + 2 * d]);
+        acc[8 + 2 * d + 1] = fmaf(val, __uint_as_float(b[d] & 0xFFFF0000u), acc[8 + 2 * d + 1]);
+    }
+}
+// fp32 parity mode: 8 rows (two planes of 4)
+template <int PB>
+__device__ __forceinline__ void fma_entry8(const unsigned char* planes, u32x2 w, float (&acc)[8]) {
+    const float val = __uint_as_float(w[1]);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(planes + w[0]);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(planes + PB + w[0]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { acc[d] = fmaf(val, a[d], acc[d]); acc[4 + d] = fmaf(val, b[d], acc[4 + d]); }
+}
+
+// XT = __bf16: 4-byte entries, bf16 activation planes, 16 rows per workgroup;  XT = float: 8-byte entries, fp32 planes, 8 rows.
+// KT: compile-time plane capacity (input columns): the second plane is an immediate offset of the first.
+template <typename XT, int KT>
+__global__ __launch_bounds__(256) void spmm_ell_kernel(SpmmP p) {
+    constexpr bool F32 = sizeof(XT) == 4;
+    constexpr int RB = F32 ? 8 : 16;
+    constexpr int NPAIR = RB / 2;
+    constexpr int PB = KT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* planes = smem;
+    float* sOut = reinterpret_cast<float*>(smem + 2 * PB);
+    int* sNext = reinterpret_cast<int*>(sOut + RB * OP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rg = blockIdx.x % p.nranges;
+    const int64_t m0 = (int64_t)(blockIdx.x / p.nranges) * RB;
+    const ortk_spmm_args& a = p.a;
+    if (tid == 0) *sNext = 0;
+    // ---- stage the X tile transposed: plane h, slot(k): rows 8h..8h+7 (bf16) / 4h..4h+3 (fp32) of input column k
+    const int Kp = (p.K + 7) & ~7;
+    for (int task = tid; task < NPAIR * (Kp >> 3); task += 256) {
+        const int pr = task % NPAIR, q = task / NPAIR;
+        const int64_t r0 = min(m0 + 2 * pr, a.M - 1), r1 = min(m0 + 2 * pr + 1, a.M - 1);
+        float x0[8], x1[8];
+        load8(a.X, a.x_dtype, a.ldx, r0, 8 * q, p.K, x0);
+        load8(a.X, a.x_dtype, a.ldx, r1, 8 * q, p.K, x1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int slot = 8 * q + ((i + q) & 7);            // == ell_slot(8 q + i)
+            if (!F32) {
+                const unsigned int w = f32_to_bf16_bits(x0[i]) | (f32_to_bf16_bits(x1[i]) << 16);
+                *reinterpret_cast<unsigned int*>(planes + (pr >> 2) * PB + slot * 16 + (pr & 3) * 4) = w;
+            } else {
+                *reinterpret_cast<f32x2*>(planes + (pr >> 1) * PB + slot * 16 + (pr & 1) * 8) = (f32x2){x0[i], x1[i]};
+            }
+        }
+    }
+    __syncthreads();
+    // ---- lane = output column; chunks of this range are taken longest first
+    const int c_begin = rg * (RANGE / 64), c_end = min(p.nchunks, c_begin + RANGE / 64);
+    for (;;) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(sNext, 1);
+        c = __builtin_amdgcn_readfirstlane(c) + c_begin;
+        if (c >= c_end) break;
+        const int len = p.chunk_len[c];
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        if (len > 0) {
+            if constexpr (!F32) {
+                const unsigned int* e = reinterpret_cast<const unsigned int*>(p.stream) + p.chunk_ptr[c] + lane;
+                unsigned int w0 = e[0], w1 = e[64], w2 = e[128], w3 = e[192];
+                for (int j = 0; j < len; j += 4) {
+                    unsigned int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                    if (j + 4 < len) {
+                        const unsigned int* en = e + (int64_t)(j + 4) * 64;
+                        n0 = en[0]; n1 = en[64]; n2 = en[128]; n3 = en[192];
+                    }
+                    fma_entry16<PB>(planes, w0, acc); fma_entry16<PB>(planes, w1, acc);
+                    fma_entry16<PB>(planes, w2, acc); fma_entry16<PB>(planes, w3, acc);
+                    w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                }
+            } else {
+                const u32x2* e = reinterpret_cast<const u32x2*>(p.stream) + p.chunk_ptr[c] + lane;
+                u32x2 w0 = e[0], w1 = e[64], w2 = e[128], w3 = e[192];
+                for (int j = 0; j < len; j += 4) {
+                    u32x2 n0 = {0u, 0u}, n1 = {0u, 0u}, n2 = {0u, 0u}, n3 = {0u, 0u};
+                    if (j + 4 < len) {
+                        const u32x2* en = e + (int64_t)(j + 4) * 64;
+                        n0 = en[0]; n1 = en[64]; n2 = en[128]; n3 = en[192];
+                    }
+                    fma_entry8<PB>(planes, w0, acc); fma_entry8<PB>(planes, w1, acc);
+                    fma_entry8<PB>(planes, w2, acc); fma_entry8<PB>(planes, w3, acc);
+                    w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                }
+            }
+        }
+        const int col = p.perm[c * 64 + lane];
+        if (col >= 0) {
+            const int nloc = col - rg * RANGE;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) sOut[r * OP + nloc] = acc[r];
+        }
+    }
+    __syncthreads();
+    // ---- epilogue on whole row segments (same order of operations as the dense GEMM epilogue, ortk_gemm.hip)
+    const bool al_b = a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0;
+    const bool al_r = a.resid && (reinterpret_cast<uintptr_t>(a.resid) & 15) == 0 && (a.ldr & 3) == 0;
+    const bool al_g = a.gate && (reinterpret_cast<uintptr_t>(a.gate) & (a.gate_dtype == ORTK_BF16 ? 7 : 15)) == 0 && (a.ldg & 3) == 0;
+    const bool al_y = (reinterpret_cast<uintptr_t>(a.Y) & (a.y_dtype == ORTK_BF16 ? 7 : 15)) == 0 && (a.ldy & 3) == 0;
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    for (int task = tid; task < RB * (RANGE / 4); task += 256) {
+        const int r = task >> 7, c4 = (task & 127) * 4;
+        const int64_t m = m0 + r;
+        const int n0 = rg * RANGE + c4;
+        if (m >= a.M || n0 >= p.N) continue;
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sOut + r * OP + c4);
+        float bb[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.bias) ld4f(a.bias + n0, n0, p.N, al_b, bb);
+        if (a.resid) ld4f(a.resid + m * a.ldr + n0, n0, p.N, al_r, rr);
+        if (a.gate) {
+            if (a.gate_dtype == ORTK_F32) ld4f(reinterpret_cast<const float*>(a.gate) + m * a.ldg + n0, n0, p.N, al_g, gg);
+            else if (al_g && n0 + 3 < p.N) { const float4 t = ld_elem4(a.gate, m * a.ldg + n0, ORTK_BF16); gg[0] = t.x; gg[1] = t.y; gg[2] = t.z; gg[3] = t.w; }
+            else for (int q = 0; q < 4; ++q) if (n0 + q < p.N) gg[q] = ld_elem(a.gate, m * a.ldg + n0 + q, ORTK_BF16);
+        }
+        const float rs = a.rowscale ? a.rowscale[m] : 1.f;
+        bool kp[4] = {true, true, true, true};
+        if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)m * (uint64_t)p.N + n0, a.drop_p, kp);
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = s4[q] + bb[q];
+            if (a.relu) x = fmaxf(x, 0.f);
+            x *= rs;
+            if (a.drop_p > 0.f) x = kp[q] ? x * inv_keep : 0.f;
+            if (a.gate) x = gg[q] > 0.f ? x * a.gate_scale : 0.f;
+            v[q] = x + rr[q];
+        }
+        const int64_t yi = m * a.ldy + n0;
+        if (al_y && n0 + 3 < p.N) st_elem4(a.Y, yi, a.y_dtype, make_float4(v[0], v[1], v[2], v[3]));
+        else for (int q = 0; q < 4; ++q) if (n0 + q < p.N) st_elem(a.Y, yi + q, a.y_dtype, v[q]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ builder
+__device__ __forceinline__ int find_block_by_row(const ortk_ell_block* __restrict__ blocks, int nblocks, int64_t g) {
+    int b = 0;
+    for (int i = 1; i < nblocks; ++i) if ((int64_t)blocks[i].row0 <= g) b = i;     // blocks are ordered by row0
+    return b;
+}
+__device__ __forceinline__ bool elem_nz(const void* base, int dt, int64_t i) {
+    if (dt == ORTK_BF16) return (reinterpret_cast<const unsigned short*>(base)[i] & 0x7FFFu) != 0;
+    return reinterpret_cast<const float*>(base)[i] != 0.f;
+}
+
+// one wave per output column (= row of the dense block): number of non-zeros
+__global__ __launch_bounds__(256) void ell_count_kernel(const ortk_ell_block* __restrict__ blocks, int nblocks, const void* dense, int dt,
+                                                        int32_t* __restrict__ cnt, int64_t total_rows) {
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (g >= total_rows) return;
+    const ortk_ell_block& bk = blocks[find_block_by_row(blocks, nblocks, g)];
+    const int64_t row = bk.src_offset + (g - bk.row0) * bk.ld;
+    int n = 0;
+    const size_t es = dt == ORTK_BF16 ? 2 : 4;
+    const bool vec = (bk.K & 7) == 0 && ((reinterpret_cast<uintptr_t>(dense) + (size_t)row * es) & 15) == 0 && ((bk.ld * es) & 15) == 0;
+    if (vec && dt == ORTK_BF16) {
+        for (int k = lane * 8; k < bk.K; k += 512) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(dense) + row + k);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) n += ((t[d] & 0x7FFFu) != 0) + ((t[d] & 0x7FFF0000u) != 0);
+        }
+    } else if (vec) {
+        for (int k = lane * 4; k < bk.K; k += 256) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dense) + row + k);
+            n += (t[0] != 0.f) + (t[1] != 0.f) + (t[2] != 0.f) + (t[3] != 0.f);
+        }
+    } else {
+        for (int k = lane; k < bk.K; k += 64) n += elem_nz(dense, dt, row + k) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0) cnt[g] = n;
+}
+
+// one workgroup per block: order the columns of every 512-column range by count (descending), chunk lengths, offsets
+__global__ __launch_bounds__(256) void ell_plan_kernel(const ortk_ell_block* __restrict__ blocks, const int32_t* __restrict__ cnt,
+                                                       int32_t* __restrict__ chunk_ptr, int32_t* __restrict__ chunk_len,
+                                                       int32_t* __restrict__ perm, int32_t* overflow) {
+    __shared__ int key[RANGE];
+    __shared__ int lens[256];
+    const ortk_ell_block bk = blocks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int nch = (bk.N + 63) >> 6;
+    for (int n0 = 0; n0 < bk.N; n0 += RANGE) {
+        const int nn = min(RANGE, bk.N - n0);
+        __syncthreads();
+        for (int i = tid; i < RANGE; i += 256) key[i] = i < nn ? cnt[bk.row0 + n0 + i] : -1;
+        __syncthreads();
+        const int slots = min(RANGE, nch * 64 - n0);            // lane slots of this range (the last chunk is padded to 64)
+        for (int i = tid; i < RANGE; i += 256) {
+            if (i < nn) {
+                const int ki = key[i];
+                int rank = 0;
+                for (int j = 0; j < nn; ++j) { const int kj = key[j]; rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0; }
+                perm[(int64_t)bk.chunk0 * 64 + n0 + rank] = n0 + i;
+                if ((rank & 63) == 0) lens[(n0 + rank) >> 6] = (ki + 3) & ~3;
+            } else if (i < slots) {
+                perm[(int64_t)bk.chunk0 * 64 + n0 + i] = -1;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t off = bk.stream_offset;
+        const int64_t end = bk.stream_offset + bk.capacity;
+        for (int c = 0; c < nch; ++c) {
+            int l = lens[c];
+            if (off + (int64_t)l * 64 > end) {
+                l = (int)(((end - off) / 64) & ~(int64_t)3);
+                if (l < 0) l = 0;
+                *overflow = 1;
+            }
+            chunk_ptr[bk.chunk0 + c] = (int32_t)off;
+            chunk_len[bk.chunk0 + c] = l;
+            off += (int64_t)l * 64;
+        }
+    }
+}
+
+// one wave per lane slot of a chunk: compact the non-zeros of its column into entries j*64 + slot, zero-pad to the chunk length
+template <int EB>
+__global__ __launch_bounds__(256) void ell_fill_kernel(const ortk_ell_block* __restrict__ blocks, int nblocks, const void* dense, int dt,
+                                                       const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ chunk_len,
+                                                       const int32_t* __restrict__ perm, void* stream, int64_t total_slots) {
+    const int64_t gs = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (gs >= total_slots) return;
+    int b = 0;
+    for (int i = 1; i < nblocks; ++i) if ((int64_t)blocks[i].chunk0 * 64 <= gs) b = i;       // ordered by chunk0
+    const ortk_ell_block& bk = blocks[b];
+    const int col = perm[gs];
+    if (col < 0) return;
+    const int c = (int)(gs >> 6), slot = (int)(gs & 63);
+    const int64_t start = chunk_ptr[c];
+    const int len = chunk_len[c];
+    const int64_t row = bk.src_offset + (int64_t)col * bk.ld;
+    int j = 0;
+    for (int k0 = 0; k0 < bk.K; k0 += 64) {
+        const int k = k0 + lane;
+        unsigned int bits = 0; bool nz = false;
+        if (k < bk.K) {
+            if (dt == ORTK_BF16) {
+                const unsigned short h = reinterpret_cast<const unsigned short*>(dense)[row + k];
+                nz = (h & 0x7FFFu) != 0;
+                bits = EB == 4 ? (unsigned int)h : ((unsigned int)h << 16);
+            } else {
+                const float f = reinterpret_cast<const float*>(dense)[row + k];
+                nz = f != 0.f;
+                bits = EB == 4 ? f32_to_bf16_bits(f) : __float_as_uint(f);
+            }
+        }
+        const unsigned long long mask = __ballot(nz);
+        const int pos = j + __popcll(mask & ((1ull << lane) - 1ull));
+        if (nz && pos < len) {
+            const int64_t at = start + (int64_t)pos * 64 + slot;
+            if (EB == 4) reinterpret_cast<unsigned int*>(stream)[at] = (bits << 16) | (unsigned int)(ell_slot(k) * 16);
+            else reinterpret_cast<u32x2*>(stream)[at] = (u32x2){(unsigned int)(ell_slot(k) * 16), bits};
+        }
+        j += __popcll(mask);
+    }
+    for (int pos = j + lane; pos < len; pos += 64) {
+        const int64_t at = start + (int64_t)pos * 64 + slot;
+        if (EB == 4) reinterpret_cast<unsigned int*>(stream)[at] = 0u;
+        else reinterpret_cast<u32x2*>(stream)[at] = (u32x2){0u, 0u};
+    }
+}
+
+bool plan_ok(const ortk_ell_plan* p) {
+    return p && p->blocks_host && p->blocks_dev && p->nblocks > 0 && (p->entry_bytes == 4 || p->entry_bytes == 8) && p->stream &&
+           p->chunk_ptr && p->chunk_len && p->perm && p->count_scratch && p->overflow && p->total_rows > 0;
+}
+
+template <typename XT, int KT>
+int launch_spmm(const SpmmP& p, hipStream_t s) {
+    constexpr int RB = sizeof(XT) == 4 ? 8 : 16;
+    const size_t lds = (size_t)2 * KT * 16 + (size_t)RB * OP * sizeof(float) + 16;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_csr_kernel<XT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * per_row));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_csr_kernel<XT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * per_row));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_csr_kernel<XT, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * per_row));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    if (rows == 64) hipLaunchKernelGGL((spmm_csr_kernel<XT, 64>), dim3((unsigned)ortk_cdiv(p.M, 64)), block, 64 * per_row, s, p);
-    else if (rows == 32) hipLaunchKernelGGL((spmm_csr_kernel<XT, 32>), dim3((unsigned)ortk_cdiv(p.M, 32)), block, 32 * per_row, s, p);
-    else hipLaunchKernelGGL((spmm_csr_kernel<XT, 16>), dim3((unsigned)ortk_cdiv(p.M, 16)), block, 16 * per_row, s, p);
+    const int64_t tiles = ortk_cdiv(p.a.M, RB);
+    hipLaunchKernelGGL((spmm_ell_kernel<XT, KT>), dim3((unsigned)(tiles * p.nranges)), dim3(256), lds, s, p);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
 
 }  // namespace
 
-extern "C" int ortk_spmm_csr(const ortk_csr* w, const void* X, int32_t x_dtype, int64_t ldx, const float* bias, void* Y,
-                             int32_t y_dtype, int64_t ldy, int64_t M, int32_t relu, const float* resid, int64_t ldr,
-                             ortk_stream stream) {
-    if (!w || !w->row_ptr || !w->col || !w->val || !X || !Y || M < 0 || w->N < 1 || w->K < 1) return ORTK_EINVAL;
-    if ((x_dtype != ORTK_F32 && x_dtype != ORTK_BF16) || (y_dtype != ORTK_F32 && y_dtype != ORTK_BF16)) return ORTK_EINVAL;
-    if (M == 0) return 0;
-    SpmmP p{w->row_ptr, w->col, w->val, X, ldx, x_dtype, bias, resid, ldr, Y, ldy, y_dtype, M, w->N, w->K, relu};
-    // bf16 activations stay bf16 in LDS; fp32 activations stay fp32 (parity mode)
-    return x_dtype == ORTK_BF16 ? launch<__bf16>(p, ortk_s(stream)) : launch<float>(p, ortk_s(stream));
+extern "C" int ortk_ell_build(const ortk_ell_plan* plan, const void* dense, int32_t dtype, ortk_stream stream) {
+    if (!plan_ok(plan) || !dense || (dtype != ORTK_F32 && dtype != ORTK_BF16)) return ORTK_EINVAL;
+    int64_t rows = 0, slots = 0;
+    for (int i = 0; i < plan->nblocks; ++i) {
+        const ortk_ell_block& b = plan->blocks_host[i];
+        if (b.N < 1 || b.N > 16384 || b.K < 1 || b.K > KMAX || b.ld < b.K || b.capacity < 0) return ORTK_EINVAL;
+        if (b.row0 != rows || (int64_t)b.chunk0 * 64 != slots) return ORTK_EINVAL;      // packed, in table order
+        rows += b.N; slots += ortk_cdiv(b.N, 64) * 64;
+    }
+    if (rows != plan->total_rows) return ORTK_EINVAL;
+    hipStream_t s = ortk_s(stream);
+    hipLaunchKernelGGL(ell_count_kernel, dim3((unsigned)ortk_cdiv(rows, 4)), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, dense, dtype,
+                       plan->count_scratch, rows);
+    hipLaunchKernelGGL(ell_plan_kernel, dim3((unsigned)plan->nblocks), dim3(256), 0, s, plan->blocks_dev, plan->count_scratch,
+                       plan->chunk_ptr, plan->chunk_len, plan->perm, plan->overflow);
+    if (plan->entry_bytes == 4)
+        hipLaunchKernelGGL(ell_fill_kernel<4>, dim3((unsigned)ortk_cdiv(slots, 4)), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, dense,
+                           dtype, plan->chunk_ptr, plan->chunk_len, plan->perm, plan->stream, slots);
+    else
+        hipLaunchKernelGGL(ell_fill_kernel<8>, dim3((unsigned)ortk_cdiv(slots, 4)), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, dense,
+                           dtype, plan->chunk_ptr, plan->chunk_len, plan->perm, plan->stream, slots);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_spmm_ell(const ortk_ell_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream) {
+    if (!plan_ok(plan) || !a || block < 0 || block >= plan->nblocks || !a->X || !a->Y || a->M < 0) return ORTK_EINVAL;
+    auto dt_ok = [](int d) { return d == ORTK_F32 || d == ORTK_BF16; };
+    if (!dt_ok(a->x_dtype) || !dt_ok(a->y_dtype) || !dt_ok(a->gate_dtype)) return ORTK_EINVAL;
+    if (a->M == 0) return 0;
+    const ortk_ell_block& b = plan->blocks_host[block];
+    if (b.K > KMAX) return ORTK_EINVAL;
+    SpmmP p;
+    p.stream = plan->stream; p.chunk_ptr = plan->chunk_ptr + b.chunk0; p.chunk_len = plan->chunk_len + b.chunk0;
+    p.perm = plan->perm + (int64_t)b.chunk0 * 64;
+    p.N = b.N; p.K = b.K; p.nchunks = (int)ortk_cdiv(b.N, 64); p.nranges = (int)ortk_cdiv(b.N, RANGE);
+    p.a = *a;
+    hipStream_t s = ortk_s(stream);
+    const bool small = b.K <= 512;
+    if (plan->entry_bytes == 4) return small ? launch_spmm<__bf16, 512>(p, s) : launch_spmm<__bf16, 2048>(p, s);
+    return small ? launch_spmm<float, 512>(p, s) : launch_spmm<float, 2048>(p, s);
 }

@@ -233,6 +233,9 @@ class RelationTransformerModel(CaptionModelBase):
             setattr(self, attr, t)
         self._bind()
         self._ws_cache = {}
+        self._plans = None                 # sparse plans live on the old device
+        self._ccfg.sparse_fwd = None
+        self._ccfg.sparse_bwd = None
         for par in self.parameters():
             if par.grad is not None:
                 par.grad = fn(par.grad)
@@ -293,26 +296,47 @@ class RelationTransformerModel(CaptionModelBase):
         """The arena tensor behind the last ``_eff_params_ptr`` call."""
         return self._flat
 
-    def enable_sparse_kernels(self, min_sparsity=0.9):
-        """Decode with CSR sparse products (``ortk_spmm_csr``) for every weight block whose fraction of zeros is
-        >= ``min_sparsity`` (pass ``None`` to go back to dense GEMMs).  Same results as the reference's
-        dense-on-zero-filled-weights evaluation (scripts/eval_model.py:64-88) up to fp32 summation order."""
+    def enable_sparse_kernels(self, min_sparsity=0.9, train=False):
+        """Run every weight block whose fraction of zeros is >= ``min_sparsity`` as a sparse product (``ortk_spmm_ell``)
+        instead of a dense GEMM on the zero-filled weight; ``None`` goes back to dense GEMMs.  Same results as the reference's
+        dense-on-zero-filled-weights flow (scripts/eval_model.py:64-88, pruning/masked_layer.py:134-135) up to fp32 summation
+        order.  Decoding (``mode="sample"``) always uses the plan; ``train=True`` also routes the teacher-forced forward and —
+        in mixed precision — the data gradients of the backward through it (the weight gradients stay dense: the
+        straight-through mask gradient needs them at every position).  The sparse images are rebuilt on the device inside
+        every call from that call's effective weights; only the block selection and the buffer capacities are fixed here
+        (from the CURRENT eval-mode weights) — see :meth:`check_sparse_overflow`."""
         self._sparse_min = min_sparsity
-        self._sparse_tab = None
+        self._sparse_train = bool(train) and min_sparsity is not None
+        self._plans = None
+        self._ccfg.sparse_fwd = None
+        self._ccfg.sparse_bwd = None
+        if min_sparsity is not None and self._flat.is_cuda:
+            self._sparse_plans()
 
-    def _sparse_table(self):
-        """CSR table for the CURRENT effective weights (rebuilt when the weights or masks change)."""
+    def _sparse_plans(self):
+        """(forward plan, backward plan) or (None, None); created on first use after enable / a device move."""
         if getattr(self, "_sparse_min", None) is None:
-            return None
-        eff = self._eff_params_tensor()
-        mflat = getattr(self, "_mask_flat", None)
-        key = (self._flat.data_ptr(), self._flat._version, None if mflat is None else mflat._version)
-        tab = getattr(self, "_sparse_tab", None)
-        if tab is None or tab[0] != key:
-            from ..sparse import SparseTable
-            tab = (key, SparseTable(self._ccfg, eff, self._sparse_min))
-            self._sparse_tab = tab
-        return tab[1]
+            return None, None
+        if getattr(self, "_plans", None) is None:
+            from ..sparse import make_plans
+            L.require_gpu()
+            self._eff_params_ptr(False, 0)
+            eff = self._eff_params_tensor()
+            pf, pb = make_plans(self._ccfg, eff, self._sparse_min, self.precision, backward=self._sparse_train)
+            if pf is not None:       # validate the capacities against the weights they were planned from
+                pf.build(eff[:self._n_train].bfloat16() if self.precision else eff)
+                pf.check_overflow()
+            self._plans = (pf, pb)
+            if self._sparse_train:
+                self._ccfg.sparse_fwd = C.cast(pf.ref(), C.c_void_p) if pf is not None else None
+                self._ccfg.sparse_bwd = C.cast(pb.ref(), C.c_void_p) if pb is not None else None
+        return self._plans
+
+    def check_sparse_overflow(self):
+        """Host sync: raises if a sparse image built since the last check had to drop entries."""
+        for pl in self._sparse_plans():
+            if pl is not None:
+                pl.check_overflow()
 
     def _next_seed(self):
         self._seed_counter += 1
@@ -367,6 +391,7 @@ class RelationTransformerModel(CaptionModelBase):
     # ------------------------------------------------------------------ teacher forcing
     def _run_forward(self, batch, train, seed, want_logp, cache_ws):
         lib = L.lib()
+        self._sparse_plans()       # (re)attach the training plans to the config after enable / a device move
         nbytes = lib.ortk_train_workspace_bytes(C.byref(self._ccfg), batch.B, batch.S, batch.R, batch.T)
         ws = self._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, cache_ws)
         logp, ldv = None, 0
@@ -447,9 +472,9 @@ class RelationTransformerModel(CaptionModelBase):
         lp = torch.empty(B, K, self.seq_length, device=dev)
         score = torch.empty(B, K, device=dev)
         pptr = self._eff_params_ptr(False, 0)
-        tab = self._sparse_table()
-        if tab is not None and tab.n:
-            o.sparse, o.n_sparse = tab.array, tab.n
+        plan = self._sparse_plans()[0]
+        if plan is not None:
+            o.sparse = plan.ref()
         beam = o.beam_size > 1 and o.num_random_sample <= 0
         # Images are independent: `opt["decode_streams"] = n` decodes the batch as n chunks on n streams, each driven by its
         # own host thread (ctypes releases the GIL) — same tokens as one call (the Gumbel hash takes the global row).

@@ -1,9 +1,12 @@
-"""CSR images of pruned weight blocks for the sparse decode path (``ortk_spmm_csr``).
+"""Sparse plans for pruned weight blocks (``include/ortk.h``: ``ortk_ell_plan``).
 
-The reference evaluates pruned checkpoints as dense linears on zero-filled weights (``scripts/eval_model.py:64-88``:
-COO state dict -> ``densify_state_dict`` -> dense model).  Here the zero pattern is turned into a chunked CSR once
-per weight version (plumbing: torch index ops on the device), and every projection whose block is sparse enough is
-multiplied by ``ortk_spmm_csr`` inside ``ortk_decode``.  Layout: see ``include/ortk.h`` (``ortk_csr``).
+The reference multiplies by the zero-filled weight ``s * W`` in every masked layer (``pruning/masked_layer.py:84-110,
+134-135``) and evaluates pruned checkpoints as dense linears on zero-filled weights (``scripts/eval_model.py:64-88``).
+Here a *plan* names the weight blocks that are sparse enough and owns the device buffers of their sorted-ELL images; the
+images themselves are (re)built on the device inside ``ortk_forward`` / ``ortk_decode`` from the effective weights of that
+very call, so nothing on the host can go stale when the weights, the masks or the mask sample change.
+
+This module only does plumbing: block selection (one-off, at ``enable_sparse_kernels``), buffer sizes, ctypes tables.
 """
 import ctypes as C
 
@@ -11,61 +14,133 @@ import torch
 
 from . import _lib as L
 
-CHUNK = 512   # K columns per chunk; must match KC in csrc/ortk_sparse.hip
-PAD = 4       # every (chunk,row) entry list is padded to a multiple of PAD entries
+KMAX = 2048      # input columns one product launch takes (csrc/ortk_sparse.hip); wider blocks are cut along their inputs
 
 
-def csr_from_dense(w):
-    """(N, K) device tensor -> (row_ptr int32 [nchunk*N+1], col int16 [n] (relative to chunk), val fp32 [n]);
-    lists padded to multiples of PAD with (0, 0.0) entries, PAD spare entries at the end (include/ortk.h: ortk_csr)."""
-    N, K = w.shape
-    nch = (K + CHUNK - 1) // CHUNK
-    wp = w
-    if nch * CHUNK != K:
-        wp = torch.zeros(N, nch * CHUNK, dtype=w.dtype, device=w.device)
-        wp[:, :K] = w
-    wc = wp.view(N, nch, CHUNK).permute(1, 0, 2).reshape(nch * N, CHUNK)   # chunk-major rows
-    nz = wc != 0
-    counts = nz.sum(1)
-    padded = (counts + PAD - 1) // PAD * PAD
-    row_ptr = torch.zeros(nch * N + 1, dtype=torch.int64, device=w.device)
-    row_ptr[1:] = padded.cumsum(0)
-    idx = nz.nonzero()                       # sorted by (row, col)
-    first = counts.cumsum(0) - counts        # rank of each row's first non-zero in `idx`
-    rank = torch.arange(idx.size(0), device=w.device) - first[idx[:, 0]]
-    dest = row_ptr[idx[:, 0]] + rank
-    total = int(row_ptr[-1]) + PAD           # spare batch at the end (read-ahead)
-    col = torch.zeros(total, dtype=torch.int16, device=w.device)
-    val = torch.zeros(total, dtype=torch.float32, device=w.device)
-    col[dest] = idx[:, 1].to(torch.int16)
-    val[dest] = wc[idx[:, 0], idx[:, 1]].float()
-    return row_ptr.to(torch.int32), col, val
+def linear_blocks(ccfg):
+    """[(arena offset, N, K)] of every weight matrix the executor multiplies by (packed projections count once)."""
+    lib = L.lib()
+    n = lib.ortk_linear_block(C.byref(ccfg), -1, None, None, None)
+    if n < 0:
+        L.check(n, "ortk_linear_block")
+    out, seen = [], set()
+    off, N, K = C.c_int64(), C.c_int32(), C.c_int32()
+    for i in range(n):
+        L.check(lib.ortk_linear_block(C.byref(ccfg), i, C.byref(off), C.byref(N), C.byref(K)), "ortk_linear_block")
+        key = (off.value, N.value, K.value)
+        if key not in seen:                       # ACORT layer sharing lists a shared block once per position
+            seen.add(key)
+            out.append(key)
+    return out
 
 
-class SparseTable:
-    """Owns the CSR tensors and the ctypes ``ortk_csr`` array handed to ``ortk_decode``."""
+class EllPlan:
+    """One ``ortk_ell_plan``: a set of (N outputs, K inputs) blocks of a dense buffer + the device buffers of their images.
 
-    def __init__(self, ccfg, flat, min_sparsity=0.9):
-        lib = L.lib()
-        n = lib.ortk_linear_block(C.byref(ccfg), -1, None, None, None)
-        if n < 0:
-            L.check(n, "ortk_linear_block")
-        self.blocks, self._keep = [], []
-        ents = []
-        off, N, K = C.c_int64(), C.c_int32(), C.c_int32()
-        for i in range(n):
-            L.check(lib.ortk_linear_block(C.byref(ccfg), i, C.byref(off), C.byref(N), C.byref(K)), "ortk_linear_block")
-            w = flat[off.value: off.value + N.value * K.value].view(N.value, K.value)
-            sparsity = 1.0 - float((w != 0).float().mean())
-            if sparsity < min_sparsity:
-                continue
-            rp, col, val = csr_from_dense(w)
-            self._keep += [rp, col, val]
-            ents.append(L.Csr(L.ptr(rp), L.ptr(col), L.ptr(val), N.value, K.value, off.value))
-            self.blocks.append({"offset": off.value, "N": N.value, "K": K.value, "nnz": int((val != 0).sum()), "sparsity": sparsity})
-        self.n = len(ents)
-        self.array = (L.Csr * max(self.n, 1))(*ents)
+    ``blocks``: list of dicts ``offset, N, K, ld`` (element offset / leading dimension inside the dense buffer the builder
+    will be given) and ``capacity`` (entries).  ``entry_bytes`` 4 = bf16 value + slot (mixed precision), 8 = fp32 value."""
+
+    def __init__(self, blocks, entry_bytes, device):
+        assert blocks, "a sparse plan needs at least one block"
+        self.blocks = blocks
+        self.entry_bytes = entry_bytes
+        n = len(blocks)
+        self._host = (L.EllBlock * n)()
+        rows = chunks = entries = 0
+        for i, b in enumerate(blocks):
+            assert 1 <= b["K"] <= KMAX and 1 <= b["N"] <= 16384
+            h = self._host[i]
+            h.src_offset, h.ld, h.N, h.K = b["offset"], b["ld"], b["N"], b["K"]
+            h.stream_offset, h.capacity = entries, b["capacity"]
+            h.chunk0, h.row0 = chunks, rows
+            rows += b["N"]
+            chunks += (b["N"] + 63) // 64
+            entries += b["capacity"]
+        assert entries < 2 ** 31, "entry offsets are 32-bit"
+        raw = bytes(self._host)
+        self._dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.stream = torch.zeros(max(entries, 1) * entry_bytes // 4, dtype=torch.int32, device=device)
+        self.chunk_ptr = torch.zeros(chunks, dtype=torch.int32, device=device)
+        self.chunk_len = torch.zeros(chunks, dtype=torch.int32, device=device)
+        self.perm = torch.full((chunks * 64,), -1, dtype=torch.int32, device=device)
+        self.count = torch.zeros(rows, dtype=torch.int32, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self.n, self.total_rows, self.total_chunks, self.total_entries = n, rows, chunks, entries
+        p = L.EllPlanStruct()
+        p.blocks_host = C.cast(self._host, C.POINTER(L.EllBlock))
+        p.blocks_dev = self._dev.data_ptr()
+        p.nblocks, p.entry_bytes = n, entry_bytes
+        p.stream, p.chunk_ptr, p.chunk_len = self.stream.data_ptr(), self.chunk_ptr.data_ptr(), self.chunk_len.data_ptr()
+        p.perm, p.count_scratch, p.overflow = self.perm.data_ptr(), self.count.data_ptr(), self.overflow.data_ptr()
+        p.total_rows = rows
+        self.struct = p
+
+    def ref(self):
+        return C.pointer(self.struct)
+
+    def build(self, dense):
+        """(Re)build every image from ``dense`` (fp32 or bf16 device tensor) — what ortk_forward / ortk_decode do themselves;
+        exposed for the operator-level tests and tools."""
+        dt = {torch.float32: 0, torch.bfloat16: 1}[dense.dtype]
+        L.check(L.lib().ortk_ell_build(self.ref(), L.ptr(dense), dt, L.stream_ptr()), "ortk_ell_build")
+
+    def spmm(self, block, args):
+        L.check(L.lib().ortk_spmm_ell(self.ref(), block, C.byref(args), L.stream_ptr()), "ortk_spmm_ell")
+
+    def check_overflow(self):
+        """Host sync: raises if the last build dropped entries (a block denser than the capacity it was planned with)."""
+        if int(self.overflow.item()):
+            raise L.OrtkError("sparse plan overflow: a weight block has more non-zeros than the capacity reserved at "
+                              "enable_sparse_kernels(); call it again with a lower min_sparsity")
 
     @property
     def nnz(self):
-        return sum(b["nnz"] for b in self.blocks)
+        """Non-zeros counted by the last build (host sync)."""
+        return int(self.count.sum().item())
+
+
+def capacity_for(N, K, max_density):
+    """Entries reserved for an (N, K) block: the sorted chunks pad each group of 64 columns to its longest member (about
+    +15 % at K = 512 / 5 % density, +5 % at K = 2048) and to a multiple of 4."""
+    return int(max_density * N * K * 1.3) + 4 * 64 * ((N + 63) // 64)
+
+
+def select_blocks(ccfg, eff, min_sparsity):
+    """Blocks of the arena ``eff`` whose fraction of zeros is >= ``min_sparsity`` (host syncs: one-off)."""
+    out = []
+    for off, N, K in linear_blocks(ccfg):
+        w = eff[off: off + N * K]
+        sparsity = 1.0 - float(torch.count_nonzero(w)) / (N * K)
+        if sparsity >= min_sparsity:
+            out.append({"offset": off, "N": N, "K": K, "sparsity": sparsity})
+    return out
+
+
+def make_plans(ccfg, eff, min_sparsity, precision, backward=False):
+    """(forward plan, backward plan | None) for the blocks of ``eff`` that are sparse enough.
+
+    Forward: the (N, K) weight blocks at their arena offsets.  Backward (mixed precision only): the same blocks transposed
+    — (K outputs, N inputs), leading dimension N, at the same offsets of the transposed bf16 copy the executor keeps for its
+    data-gradient GEMMs; a block with more than KMAX inputs (the generator: 10 112) is cut into KMAX-wide pieces that the
+    executor accumulates.  The region embedding (block 0) has no input gradient."""
+    sel = select_blocks(ccfg, eff, min_sparsity)
+    if not sel:
+        return None, None
+    dens = 1.0 - min_sparsity
+    eb = 4 if precision else 8
+    first = linear_blocks(ccfg)[0][0]
+    fwd = [dict(offset=b["offset"], N=b["N"], K=b["K"], ld=b["K"], capacity=capacity_for(b["N"], b["K"], dens), sparsity=b["sparsity"])
+           for b in sel if b["K"] <= KMAX]
+    plan_f = EllPlan(fwd, eb, eff.device) if fwd else None
+    plan_b = None
+    if backward and precision:
+        bwd = []
+        for b in sel:
+            if b["offset"] == first:
+                continue
+            for k0 in range(0, b["N"], KMAX):            # inputs of the transposed block = outputs of the weight
+                kw = min(KMAX, b["N"] - k0)
+                bwd.append(dict(offset=b["offset"] + k0, N=b["K"], K=kw, ld=b["N"], capacity=capacity_for(b["K"], kw, dens),
+                                sparsity=b["sparsity"]))
+        plan_b = EllPlan(bwd, 4, eff.device) if bwd else None
+    return plan_f, plan_b

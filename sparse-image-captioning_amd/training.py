@@ -72,6 +72,7 @@ class NativeTrainer:
         """forward + fused criterion + backward into self.grads; returns the device loss scalar."""
         m, lib = self.model, L.lib()
         seed = m._next_seed() if train else 0
+        m._sparse_plans()          # sparse training plans (enable_sparse_kernels(train=True)) ride on the config
         nbytes = lib.ortk_train_workspace_bytes(C.byref(m._ccfg), batch.B, batch.S, batch.R, batch.T)
         ws = m._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, True)
         pptr = m._eff_params_ptr(train, seed)

@@ -554,38 +554,133 @@ def test_bf16_storage_paths(L):
     torch.testing.assert_close(acc.cpu(), C16.float().cpu().sum(0), rtol=1e-3, atol=1e-2)
 
 
+def _ell_slot(k):
+    return (k & ~7) | ((k + (k >> 3)) & 7)
+
+
+def _ell_to_dense(plan, bi):
+    """Decode block `bi` of a built plan back to a dense (N, K) fp32 matrix (inverse of the device builder)."""
+    blk = plan.blocks[bi]
+    N, K = blk["N"], blk["K"]
+    c0, nch = plan._host[bi].chunk0, (N + 63) // 64
+    cp, cl = plan.chunk_ptr.cpu().numpy(), plan.chunk_len.cpu().numpy()
+    perm = plan.perm.cpu().numpy()
+    st = plan.stream.cpu().numpy().view(np.uint32)
+    inv = {_ell_slot(k): k for k in range(((K + 7) // 8) * 8)}
+    W = np.zeros((N, K), np.float32)
+    seen = set()
+    for c in range(nch):
+        ln, base = int(cl[c0 + c]), int(cp[c0 + c])
+        assert ln % 4 == 0
+        for lane in range(64):
+            col = int(perm[(c0 + c) * 64 + lane])
+            if col < 0:
+                continue
+            assert col not in seen and c * 64 // 512 == col // 512          # every column once, inside its 512-column range
+            seen.add(col)
+            for j in range(ln):
+                if plan.entry_bytes == 4:
+                    w = int(st[base + j * 64 + lane])
+                    off, val = w & 0xFFFF, np.array([w & 0xFFFF0000], np.uint32).view(np.float32)[0]
+                else:
+                    off = int(st[2 * (base + j * 64 + lane)])
+                    val = st[2 * (base + j * 64 + lane) + 1:2 * (base + j * 64 + lane) + 2].view(np.float32)[0]
+                if val != 0:
+                    assert off % 16 == 0 and W[col, inv[off // 16]] == 0
+                    W[col, inv[off // 16]] = val
+    assert seen == set(range(N))
+    return W
+
+
+@pytest.mark.parametrize("eb", [4, 8])
+@pytest.mark.parametrize("N,K,sp", [(130, 70, 0.8), (512, 512, 0.95), (1536, 512, 0.95), (600, 2048, 0.97), (5, 3, 0.5)])
+def test_ell_builder_round_trip(L, eb, N, K, sp):
+    """The device builder (count / order / fill) reproduces the non-zeros of the dense block exactly: columns ordered by
+    count inside each 512-column range, chunks padded to multiples of 4, two blocks in one plan, fp32 and bf16 sources."""
+    from sparse_image_captioning_amd.sparse import EllPlan, capacity_for
+    g = torch.Generator().manual_seed(N + K)
+    Ws = []
+    for i in range(2):
+        W = rnd(N, K, seed=1 + i, scale=0.2) * (torch.rand(N, K, generator=g) >= sp).float()
+        W[N // 2] = 0.0                               # an empty column list
+        Ws.append(W)
+    dense = torch.cat([Ws[0].reshape(-1), torch.zeros(37), Ws[1].reshape(-1)])
+    off1 = N * K + 37
+    blocks = [dict(offset=0, N=N, K=K, ld=K, capacity=capacity_for(N, K, 1.3 * (1 - sp) + 0.05)),
+              dict(offset=off1, N=N, K=K, ld=K, capacity=capacity_for(N, K, 1.3 * (1 - sp) + 0.05))]
+    plan = EllPlan(blocks, eb, "cuda")
+    for src in (dev(dense), dev(dense).bfloat16()):
+        plan.stream.fill_(-1)
+        plan.build(src)
+        plan.check_overflow()
+        for bi in range(2):
+            want = Ws[bi] if (eb == 8 and src.dtype == torch.float32) else Ws[bi].bfloat16().float()
+            got = _ell_to_dense(plan, bi)
+            np.testing.assert_array_equal(got, want.numpy())
+            cnt = plan.count.cpu().numpy()[bi * N:(bi + 1) * N]
+            np.testing.assert_array_equal(cnt, (Ws[bi] != 0).sum(1).numpy())
+    # a plan that is too small raises instead of silently dropping weights
+    small = EllPlan([dict(offset=0, N=N, K=K, ld=K, capacity=64)], eb, "cuda")
+    small.build(dev(dense))
+    if int((Ws[0] != 0).sum()) > 64:
+        with pytest.raises(Exception):
+            small.check_overflow()
+
+
 @pytest.mark.parametrize("xdt", [0, 1])
+@pytest.mark.parametrize("eb", [4, 8])
 @pytest.mark.parametrize("M,N,K,sp", [(300, 130, 70, 0.8), (5120, 512, 512, 0.95), (100, 512, 2048, 0.95), (33, 2048, 512, 0.9),
-                                      (40000, 64, 600, 0.97), (1, 5, 3, 0.5), (9000, 48, 1030, 0.9)])
-def test_spmm_csr_vs_dense(L, xdt, M, N, K, sp):
-    """ortk_spmm_csr == F.linear on the zero-filled weight (scripts/eval_model.py:64-88 flow), with the fused
-    bias / ReLU / residual epilogue, fp32 and bf16 activations, K spanning several 512-column chunks."""
-    from sparse_image_captioning_amd.sparse import csr_from_dense
+                                      (4000, 64, 600, 0.97), (1, 5, 3, 0.5), (900, 48, 1030, 0.9), (77, 1100, 512, 0.95)])
+def test_spmm_ell_vs_dense(L, xdt, eb, M, N, K, sp):
+    """ortk_spmm_ell == F.linear on the zero-filled weight (scripts/eval_model.py:64-88, masked_layer.py:134-135) with the
+    GEMM's fused epilogue (bias / ReLU / row scale / dropout / gate / residual), fp32 and bf16 activations and outputs, ragged
+    row counts, column counts that are not multiples of 4, 64 or 512."""
+    from sparse_image_captioning_amd.sparse import EllPlan, capacity_for
     g = torch.Generator().manual_seed(M + N + K)
     W = rnd(N, K, seed=1, scale=0.2) * (torch.rand(N, K, generator=g) >= sp).float()
-    W[N // 2] = 0.0                                   # an empty row
-    X, bias, resid = rnd(M, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    W[N // 2] = 0.0
+    X, bias, resid, rows = rnd(M, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4), torch.rand(M, generator=g)
+    gate = rnd(M, N, seed=5)
     Xd = dev(X.bfloat16() if xdt else X)
-    Xr = Xd.float().cpu()
-    rp, col, val = csr_from_dense(dev(W))
-    assert int((val != 0).sum()) == int((W != 0).sum()) and int(rp[-1]) + 4 == val.numel() == col.numel()
-    assert int((rp % 4 != 0).sum()) == 0
-    for relu, use_res, ydt in [(0, False, 0), (1, True, 0), (1, False, 1)]:
-        ref = Xr.double() @ W.double().t() + bias.double()
+    plan = EllPlan([dict(offset=0, N=N, K=K, ld=K, capacity=capacity_for(N, K, 1.3 * (1 - sp) + 0.05))], eb, "cuda")
+    plan.build(dev(W))
+    plan.check_overflow()
+    Wr = (W if eb == 8 else W.bfloat16().float()).double()
+    Xr = (Xd.float().cpu() if eb == 8 else Xd.float().cpu().bfloat16().float()).double()
+    for relu, use_res, ydt, use_rs, use_gate, drop in [(0, False, 0, False, False, 0.0), (1, True, 0, True, False, 0.0),
+                                                       (1, False, 1, False, False, 0.0), (0, True, 0, False, True, 0.25)]:
+        Y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if ydt else torch.float32)
+        a = L.SpmmArgs()
+        a.X, a.Y, a.ldx, a.ldy, a.M, a.x_dtype, a.y_dtype = Xd.data_ptr(), Y.data_ptr(), K, N, M, xdt, ydt
+        keep = [dev(bias), dev(resid), dev(rows), dev(gate)]
+        a.bias, a.relu = keep[0].data_ptr(), relu
+        if use_res:
+            a.resid, a.ldr = keep[1].data_ptr(), N
+        if use_rs:
+            a.rowscale = keep[2].data_ptr()
+        if use_gate:
+            a.gate, a.ldg, a.gate_dtype, a.gate_scale = keep[3].data_ptr(), N, 0, 1.5
+        a.drop_p, a.drop_seed = drop, 1234
+        plan.spmm(0, a)
+        ref = Xr @ Wr.t() + bias.double()
         if relu:
             ref = ref.clamp_min(0)
+        if use_rs:
+            ref = ref * rows.double()[:, None]
+        got = Y.float().cpu().double()
+        assert torch.isfinite(got).all()
+        if drop > 0:          # the keep pattern is the GEMM's (ortk_keep): compare through the same kernel family
+            Yg = gemm(L, dev(Xd.float()), dev(W), M, N, K, bias=dev(bias + 100.0), drop_p=drop, drop_seed=1234)
+            kept = (Yg != 0).cpu()
+            ref = torch.where(kept, ref / (1 - drop), torch.zeros_like(ref))
+            assert 0.6 < kept.float().mean().item() < 0.9 or M * N < 100
+        if use_gate:
+            ref = torch.where(gate > 0, ref * 1.5, torch.zeros_like(ref))
         if use_res:
             ref = ref + resid.double()
-        Y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if ydt else torch.float32)
-        csr = L.Csr(L.ptr(rp), L.ptr(col), L.ptr(val), N, K, 0)
-        r = dev(resid)
-        L.check(L.lib().ortk_spmm_csr(C.byref(csr), L.ptr(Xd), xdt, K, L.ptr(dev(bias)), L.ptr(Y), ydt, N, M, relu,
-                                      L.ptr(r) if use_res else None, N, L.stream_ptr()), "ortk_spmm_csr")
-        got = Y.float().cpu().double()
         tol = 2e-2 if ydt else 2e-5
-        assert torch.isfinite(got).all()
         err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
-        assert err < tol, (relu, use_res, ydt, err)
+        assert err < tol, (relu, use_res, ydt, use_rs, use_gate, drop, err)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (1280, 512, 2048), (384, 256, 192), (2048, 2048, 192), (4096, 1024, 64), (4096, 2560, 192), (3328, 3072, 64),
