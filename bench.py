@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the ORT hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 from a plain shell: this process starts N ranks with
+                                                            torch.distributed.run before touching the GPU; under
+                                                            torch.distributed.run it is one of the ranks)
 
 Default workload = BASELINE.json configs[1]: ORT dense, bf16 MFMA, 256 images x 5 captions x 36 regions x 2048-d per
 GPU, teacher-forcing XE.  One "step" = zero_grad -> forward (dropout on) -> fused criterion -> backward ->
@@ -123,6 +125,37 @@ def pmc_traffic(workload, precision, B):
     return round(kb * 1024)
 
 
+def launch_command(n, argv, port):
+    """The driver's own launch line (one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required by RCCL on this driver
+    return subprocess.call(launch_command(n, argv, port), env=env)
+
+
+def selftest(rank, world, args):
+    """No GPU: checks the launch path end to end (ranks start, rendezvous, collective, ONE JSON line from rank 0)."""
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": t.item(), "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,18 +174,28 @@ def main():
     ap.add_argument("--regions", type=int, default=36, help="regions per image (36 = BASELINE; real bottom-up features have 10-100)")
     ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest", action="store_true",
+                    help="launcher check without a GPU: the ranks form a gloo group, all-reduce their rank ids and rank 0 "
+                         "prints one JSON line (tests/test_dist_cpu.py)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no HIP
+        # call, no torch.cuda.*): the ranks are CHILD processes, this one only relays their exit code.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest:
+        return selftest(rank, world, args)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     import sparse_image_captioning_amd as pkg

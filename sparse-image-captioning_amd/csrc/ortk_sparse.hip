@@ -13,12 +13,15 @@
 // (16-byte slots; the slot of k is a fixed permutation that makes the staging writes bank-conflict free and is baked into
 // the entries by the builder).  Then LANE = OUTPUT COLUMN: a wave takes one chunk of 64 columns at a time (dynamic, longest
 // chunk first: the builder sorts the columns of a range by their non-zero count), each lane walks the entry list of its
-// own column — one coalesced 256-byte load per step for the wave — and per entry reads the 16 rows of that input column
-// with two ds_read_b128 and does 16 multiply-adds into its 16 row accumulators.  The results go through an fp32 LDS tile
+// own column — coalesced 512-byte loads of entry PAIRS for the wave — and per pair reads the 16 rows of the two input columns
+// with four ds_read_b128, re-pairs the bf16 halves (v_perm_b32: (x[r,k1], x[r,k2])) and accumulates both products of a row
+// with ONE v_dot2c_f32_bf16 against the packed weight pair: no bf16 -> fp32 conversions (the first version spent 16 of its
+// 26 VALU instructions per entry on them and ran VALU-bound at 8 G products/ms; PMC: profiles/r02_spmm_*).  The results go through an fp32 LDS tile
 // in natural column order, so that bias / ReLU / row scale / dropout / gate / residual and the global stores run on
 // whole 1-KB row segments exactly like the dense GEMM epilogue.
-// Bounds: 26 VALU instructions and two 16-byte LDS gathers per 1024 multiply-adds; algorithmic HBM bytes =
+// Bounds: 34 VALU instructions and four 16-byte LDS gathers per 2048 multiply-adds; algorithmic HBM bytes =
 // X once + Y once + 4 bytes per non-zero (the entries are re-read by every row tile, from L2).
+#include <algorithm>
 #include "ortk_common.h"
 
 namespace {
@@ -73,19 +76,32 @@ __device__ __forceinline__ void ld4f(const float* __restrict__ p, int n0, int N,
     for (int q = 0; q < 4; ++q) o[q] = n0 + q < N ? p[q] : 0.f;
 }
 
-// one entry of a bf16 chunk: 16 rows (two planes of 8) += value * X[:, k]
+// one PAIR of entries of a bf16 chunk: e = {off1 | off2 << 16, bf16 w1 | bf16 w2 << 16}; 16 rows (two planes of 8):
+// acc[r] += w1 * X[r, k1] + w2 * X[r, k2]   (v_dot2c_f32_bf16: fp32 accumulate of the two exact bf16 products)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ float dot2(unsigned int x, unsigned int w, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x), __builtin_bit_cast(bf16x2, w), c, false);
+}
+// The gathers of a pair and its arithmetic are separate steps so that the loop can keep the NEXT pairs' gathers in flight
+// under the arithmetic of the current ones (PMC of the un-pipelined loop: LDS 50 % busy, VALU 47 % busy, and the two added
+// up to the run time — every wave of a CU gathered, then every wave computed).
+struct PairRows { u32x4 a0, a1, b0, b1; };
 template <int PB>
-__device__ __forceinline__ void fma_entry16(const unsigned char* planes, unsigned int w, float (&acc)[16]) {
-    const unsigned int off = w & 0xFFFFu;
-    const float val = __uint_as_float(w & 0xFFFF0000u);
-    const u32x4 a = *reinterpret_cast<const u32x4*>(planes + off);
-    const u32x4 b = *reinterpret_cast<const u32x4*>(planes + PB + off);
+__device__ __forceinline__ PairRows gather_pair(const unsigned char* planes, unsigned int offs) {
+    const unsigned int o1 = offs & 0xFFFFu, o2 = offs >> 16;
+    PairRows g;
+    g.a0 = *reinterpret_cast<const u32x4*>(planes + o1); g.a1 = *reinterpret_cast<const u32x4*>(planes + PB + o1);
+    g.b0 = *reinterpret_cast<const u32x4*>(planes + o2); g.b1 = *reinterpret_cast<const u32x4*>(planes + PB + o2);
+    return g;
+}
+__device__ __forceinline__ void fma_pair16(const PairRows& g, unsigned int w, float (&acc)[16]) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        acc[2 * d] = fmaf(val, __uint_as_float(a[d] << 16), acc[2 * d]);
-        acc[2 * d + 1] = fmaf(val, __uint_as_float(a[d] & 0xFFFF0000u), acc[2 * d + 1]);
-        acc[8 + 2 * d] = fmaf(val, __uint_as_float(b[d] << 16), acc[8 + 2 * d]);
-        acc[8 + 2 * d + 1] = fmaf(val, __uint_as_float(b[d] & 0xFFFF0000u), acc[8 + 2 * d + 1]);
+        // dword d of a plane read = rows (2d, 2d+1) of that input column: lo halves -> row 2d, hi halves -> row 2d+1
+        acc[2 * d] = dot2(__builtin_amdgcn_perm(g.b0[d], g.a0[d], 0x05040100u), w, acc[2 * d]);
+        acc[2 * d + 1] = dot2(__builtin_amdgcn_perm(g.b0[d], g.a0[d], 0x07060302u), w, acc[2 * d + 1]);
+        acc[8 + 2 * d] = dot2(__builtin_amdgcn_perm(g.b1[d], g.a1[d], 0x05040100u), w, acc[8 + 2 * d]);
+        acc[8 + 2 * d + 1] = dot2(__builtin_amdgcn_perm(g.b1[d], g.a1[d], 0x07060302u), w, acc[8 + 2 * d + 1]);
     }
 }
 // fp32 parity mode: 8 rows (two planes of 4)
@@ -100,8 +116,12 @@ __device__ __forceinline__ void fma_entry8(const unsigned char* planes, u32x2 w,
 
 // XT = __bf16: 4-byte entries, bf16 activation planes, 16 rows per workgroup;  XT = float: 8-byte entries, fp32 planes, 8 rows.
 // KT: compile-time plane capacity (input columns): the second plane is an immediate offset of the first.
-template <typename XT, int KT>
-__global__ __launch_bounds__(256) void spmm_ell_kernel(SpmmP p) {
+// NT: threads per workgroup (512 on short grids: one chunk per wave instead of two halves the latency of a workgroup).
+// A workgroup stages its X tile once and then walks `rpw` consecutive 512-column ranges (long grids: the staging and the
+// redundant X reads are shared by up to 4 ranges).
+constexpr int MAXRPW = 32;
+template <typename XT, int KT, int NT>
+__global__ __launch_bounds__(NT) void spmm_ell_kernel(SpmmP p, int rpw, int ngroups) {
     constexpr bool F32 = sizeof(XT) == 4;
     constexpr int RB = F32 ? 8 : 16;
     constexpr int NPAIR = RB / 2;
@@ -111,114 +131,159 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(SpmmP p) {
     float* sOut = reinterpret_cast<float*>(smem + 2 * PB);
     int* sNext = reinterpret_cast<int*>(sOut + RB * OP);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int rg = blockIdx.x % p.nranges;
-    const int64_t m0 = (int64_t)(blockIdx.x / p.nranges) * RB;
+    const int rg0 = (blockIdx.x % ngroups) * rpw;
+    const int64_t m0 = (int64_t)(blockIdx.x / ngroups) * RB;
     const ortk_spmm_args& a = p.a;
-    if (tid == 0) *sNext = 0;
+    if (tid < MAXRPW) sNext[tid] = 0;
     // ---- stage the X tile transposed: plane h, slot(k): rows 8h..8h+7 (bf16) / 4h..4h+3 (fp32) of input column k
     const int Kp = (p.K + 7) & ~7;
-    for (int task = tid; task < NPAIR * (Kp >> 3); task += 256) {
-        const int pr = task % NPAIR, q = task / NPAIR;
-        const int64_t r0 = min(m0 + 2 * pr, a.M - 1), r1 = min(m0 + 2 * pr + 1, a.M - 1);
-        float x0[8], x1[8];
-        load8(a.X, a.x_dtype, a.ldx, r0, 8 * q, p.K, x0);
-        load8(a.X, a.x_dtype, a.ldx, r1, 8 * q, p.K, x1);
+    const bool xfast = !F32 && a.x_dtype == ORTK_BF16 && (p.K & 7) == 0 && (a.ldx & 7) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+    if (xfast) {
+        // bf16 rows straight into bf16 planes: the two rows of a pair are interleaved with byte permutes, no float round trip
+        const unsigned short* X16 = reinterpret_cast<const unsigned short*>(a.X);
+        for (int task = tid; task < NPAIR * (Kp >> 3); task += NT) {
+            const int pr = task % NPAIR, q = task / NPAIR;
+            const int64_t r0 = min(m0 + 2 * pr, a.M - 1), r1 = min(m0 + 2 * pr + 1, a.M - 1);
+            const u32x4 t0 = *reinterpret_cast<const u32x4*>(X16 + r0 * a.ldx + 8 * q);
+            const u32x4 t1 = *reinterpret_cast<const u32x4*>(X16 + r1 * a.ldx + 8 * q);
+            unsigned char* dst = planes + (pr >> 2) * PB + (pr & 3) * 4 + 8 * q * 16;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int slot = 8 * q + ((i + q) & 7);            // == ell_slot(8 q + i)
-            if (!F32) {
-                const unsigned int w = f32_to_bf16_bits(x0[i]) | (f32_to_bf16_bits(x1[i]) << 16);
-                *reinterpret_cast<unsigned int*>(planes + (pr >> 2) * PB + slot * 16 + (pr & 3) * 4) = w;
-            } else {
-                *reinterpret_cast<f32x2*>(planes + (pr >> 1) * PB + slot * 16 + (pr & 1) * 8) = (f32x2){x0[i], x1[i]};
+            for (int i = 0; i < 8; ++i) {
+                const unsigned int w = __builtin_amdgcn_perm(t1[i >> 1], t0[i >> 1], (i & 1) ? 0x07060302u : 0x05040100u);
+                *reinterpret_cast<unsigned int*>(dst + ((i + q) & 7) * 16) = w;          // slot 8 q + ((i + q) & 7) == ell_slot(8 q + i)
+            }
+        }
+    } else {
+        for (int task = tid; task < NPAIR * (Kp >> 3); task += NT) {
+            const int pr = task % NPAIR, q = task / NPAIR;
+            const int64_t r0 = min(m0 + 2 * pr, a.M - 1), r1 = min(m0 + 2 * pr + 1, a.M - 1);
+            float x0[8], x1[8];
+            load8(a.X, a.x_dtype, a.ldx, r0, 8 * q, p.K, x0);
+            load8(a.X, a.x_dtype, a.ldx, r1, 8 * q, p.K, x1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int slot = 8 * q + ((i + q) & 7);            // == ell_slot(8 q + i)
+                if (!F32) {
+                    const unsigned int w = f32_to_bf16_bits(x0[i]) | (f32_to_bf16_bits(x1[i]) << 16);
+                    *reinterpret_cast<unsigned int*>(planes + (pr >> 2) * PB + slot * 16 + (pr & 3) * 4) = w;
+                } else {
+                    *reinterpret_cast<f32x2*>(planes + (pr >> 1) * PB + slot * 16 + (pr & 1) * 8) = (f32x2){x0[i], x1[i]};
+                }
             }
         }
     }
     __syncthreads();
-    // ---- lane = output column; chunks of this range are taken longest first
-    const int c_begin = rg * (RANGE / 64), c_end = min(p.nchunks, c_begin + RANGE / 64);
-    for (;;) {
-        int c = 0;
-        if (lane == 0) c = atomicAdd(sNext, 1);
-        c = __builtin_amdgcn_readfirstlane(c) + c_begin;
-        if (c >= c_end) break;
-        const int len = p.chunk_len[c];
-        float acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-        if (len > 0) {
-            if constexpr (!F32) {
-                const unsigned int* e = reinterpret_cast<const unsigned int*>(p.stream) + p.chunk_ptr[c] + lane;
-                unsigned int w0 = e[0], w1 = e[64], w2 = e[128], w3 = e[192];
-                for (int j = 0; j < len; j += 4) {
-                    unsigned int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-                    if (j + 4 < len) {
-                        const unsigned int* en = e + (int64_t)(j + 4) * 64;
-                        n0 = en[0]; n1 = en[64]; n2 = en[128]; n3 = en[192];
-                    }
-                    fma_entry16<PB>(planes, w0, acc); fma_entry16<PB>(planes, w1, acc);
-                    fma_entry16<PB>(planes, w2, acc); fma_entry16<PB>(planes, w3, acc);
-                    w0 = n0; w1 = n1; w2 = n2; w3 = n3;
-                }
-            } else {
-                const u32x2* e = reinterpret_cast<const u32x2*>(p.stream) + p.chunk_ptr[c] + lane;
-                u32x2 w0 = e[0], w1 = e[64], w2 = e[128], w3 = e[192];
-                for (int j = 0; j < len; j += 4) {
-                    u32x2 n0 = {0u, 0u}, n1 = {0u, 0u}, n2 = {0u, 0u}, n3 = {0u, 0u};
-                    if (j + 4 < len) {
-                        const u32x2* en = e + (int64_t)(j + 4) * 64;
-                        n0 = en[0]; n1 = en[64]; n2 = en[128]; n3 = en[192];
-                    }
-                    fma_entry8<PB>(planes, w0, acc); fma_entry8<PB>(planes, w1, acc);
-                    fma_entry8<PB>(planes, w2, acc); fma_entry8<PB>(planes, w3, acc);
-                    w0 = n0; w1 = n1; w2 = n2; w3 = n3;
-                }
-            }
-        }
-        const int col = p.perm[c * 64 + lane];
-        if (col >= 0) {
-            const int nloc = col - rg * RANGE;
-#pragma unroll
-            for (int r = 0; r < RB; ++r) sOut[r * OP + nloc] = acc[r];
-        }
-    }
-    __syncthreads();
-    // ---- epilogue on whole row segments (same order of operations as the dense GEMM epilogue, ortk_gemm.hip)
-    const bool al_b = a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0;
-    const bool al_r = a.resid && (reinterpret_cast<uintptr_t>(a.resid) & 15) == 0 && (a.ldr & 3) == 0;
+    const bool al_b = !a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0;
+    const bool al_r = !a.resid || ((reinterpret_cast<uintptr_t>(a.resid) & 15) == 0 && (a.ldr & 3) == 0);
     const bool al_g = a.gate && (reinterpret_cast<uintptr_t>(a.gate) & (a.gate_dtype == ORTK_BF16 ? 7 : 15)) == 0 && (a.ldg & 3) == 0;
     const bool al_y = (reinterpret_cast<uintptr_t>(a.Y) & (a.y_dtype == ORTK_BF16 ? 7 : 15)) == 0 && (a.ldy & 3) == 0;
+    // lean epilogue: bias / ReLU / residual only, everything vector-aligned, whole groups of 4 columns
+    const bool lean = !a.gate && a.drop_p == 0.f && !a.rowscale && al_b && al_r && al_y && (p.N & 3) == 0;
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    for (int task = tid; task < RB * (RANGE / 4); task += 256) {
-        const int r = task >> 7, c4 = (task & 127) * 4;
-        const int64_t m = m0 + r;
-        const int n0 = rg * RANGE + c4;
-        if (m >= a.M || n0 >= p.N) continue;
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sOut + r * OP + c4);
-        float bb[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.bias) ld4f(a.bias + n0, n0, p.N, al_b, bb);
-        if (a.resid) ld4f(a.resid + m * a.ldr + n0, n0, p.N, al_r, rr);
-        if (a.gate) {
-            if (a.gate_dtype == ORTK_F32) ld4f(reinterpret_cast<const float*>(a.gate) + m * a.ldg + n0, n0, p.N, al_g, gg);
-            else if (al_g && n0 + 3 < p.N) { const float4 t = ld_elem4(a.gate, m * a.ldg + n0, ORTK_BF16); gg[0] = t.x; gg[1] = t.y; gg[2] = t.z; gg[3] = t.w; }
-            else for (int q = 0; q < 4; ++q) if (n0 + q < p.N) gg[q] = ld_elem(a.gate, m * a.ldg + n0 + q, ORTK_BF16);
-        }
-        const float rs = a.rowscale ? a.rowscale[m] : 1.f;
-        bool kp[4] = {true, true, true, true};
-        if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)m * (uint64_t)p.N + n0, a.drop_p, kp);
-        float v[4];
+    for (int ri = 0; ri < rpw; ++ri) {
+        const int rg = rg0 + ri;
+        if (rg >= p.nranges) break;
+        // ---- lane = output column; chunks of this range are taken longest first
+        const int c_begin = rg * (RANGE / 64), c_end = min(p.nchunks, c_begin + RANGE / 64);
+        for (;;) {
+            int c = 0;
+            if (lane == 0) c = atomicAdd(sNext + ri, 1);
+            c = __builtin_amdgcn_readfirstlane(c) + c_begin;
+            if (c >= c_end) break;
+            const int len = p.chunk_len[c];
+            float acc[RB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x = s4[q] + bb[q];
-            if (a.relu) x = fmaxf(x, 0.f);
-            x *= rs;
-            if (a.drop_p > 0.f) x = kp[q] ? x * inv_keep : 0.f;
-            if (a.gate) x = gg[q] > 0.f ? x * a.gate_scale : 0.f;
-            v[q] = x + rr[q];
+            for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+            if (len > 0) {
+                if constexpr (!F32) {
+                    // entry pairs (8 bytes) of lane l: pair jp at (chunk_ptr / 2 + jp * 64 + l); len is a multiple of 8 entries
+                    const u32x2* e = reinterpret_cast<const u32x2*>(p.stream) + (p.chunk_ptr[c] >> 1) + lane;
+                    u32x2 w0 = e[0], w1 = e[64], w2 = e[128], w3 = e[192];
+                    PairRows ga = gather_pair<PB>(planes, w0[0]), gb = gather_pair<PB>(planes, w1[0]);
+                    for (int j = 0; j < len; j += 8) {
+                        const bool more = j + 8 < len;
+                        u32x2 n0 = {0u, 0u}, n1 = {0u, 0u}, n2 = {0u, 0u}, n3 = {0u, 0u};
+                        if (more) {
+                            const u32x2* en = e + (int64_t)((j + 8) >> 1) * 64;
+                            n0 = en[0]; n1 = en[64]; n2 = en[128]; n3 = en[192];
+                        }
+                        const PairRows gc = gather_pair<PB>(planes, w2[0]), gd = gather_pair<PB>(planes, w3[0]);
+                        fma_pair16(ga, w0[1], acc); fma_pair16(gb, w1[1], acc);
+                        // (a zero pair gathers slot 0: harmless, and keeps the loop body branch-free apart from the stream load)
+                        ga = gather_pair<PB>(planes, n0[0]); gb = gather_pair<PB>(planes, n1[0]);
+                        fma_pair16(gc, w2[1], acc); fma_pair16(gd, w3[1], acc);
+                        w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                    }
+                } else {
+                    const u32x2* e = reinterpret_cast<const u32x2*>(p.stream) + p.chunk_ptr[c] + lane;
+                    u32x2 w0 = e[0], w1 = e[64], w2 = e[128], w3 = e[192];
+                    for (int j = 0; j < len; j += 4) {
+                        u32x2 n0 = {0u, 0u}, n1 = {0u, 0u}, n2 = {0u, 0u}, n3 = {0u, 0u};
+                        if (j + 4 < len) {
+                            const u32x2* en = e + (int64_t)(j + 4) * 64;
+                            n0 = en[0]; n1 = en[64]; n2 = en[128]; n3 = en[192];
+                        }
+                        fma_entry8<PB>(planes, w0, acc); fma_entry8<PB>(planes, w1, acc);
+                        fma_entry8<PB>(planes, w2, acc); fma_entry8<PB>(planes, w3, acc);
+                        w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                    }
+                }
+            }
+            const int col = p.perm[c * 64 + lane];
+            if (col >= 0) {
+                const int nloc = col - rg * RANGE;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) sOut[r * OP + nloc] = acc[r];
+            }
         }
-        const int64_t yi = m * a.ldy + n0;
-        if (al_y && n0 + 3 < p.N) st_elem4(a.Y, yi, a.y_dtype, make_float4(v[0], v[1], v[2], v[3]));
-        else for (int q = 0; q < 4; ++q) if (n0 + q < p.N) st_elem(a.Y, yi + q, a.y_dtype, v[q]);
+        __syncthreads();
+        // ---- epilogue on whole row segments (same order of operations as the dense GEMM epilogue, ortk_gemm.hip)
+        if (lean) {
+            for (int task = tid; task < RB * (RANGE / 4); task += NT) {
+                const int r = task >> 7, c4 = (task & 127) * 4;
+                const int64_t m = m0 + r;
+                const int n0 = rg * RANGE + c4;
+                if (m >= a.M || n0 >= p.N) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(sOut + r * OP + c4);
+                if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0);
+                if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + m * a.ldr + n0);
+                st_elem4(a.Y, m * a.ldy + n0, a.y_dtype, make_float4(v[0], v[1], v[2], v[3]));
+            }
+        } else {
+            for (int task = tid; task < RB * (RANGE / 4); task += NT) {
+                const int r = task >> 7, c4 = (task & 127) * 4;
+                const int64_t m = m0 + r;
+                const int n0 = rg * RANGE + c4;
+                if (m >= a.M || n0 >= p.N) continue;
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sOut + r * OP + c4);
+                float bb[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.bias) ld4f(a.bias + n0, n0, p.N, al_b, bb);
+                if (a.resid) ld4f(a.resid + m * a.ldr + n0, n0, p.N, al_r, rr);
+                if (a.gate) {
+                    if (a.gate_dtype == ORTK_F32) ld4f(reinterpret_cast<const float*>(a.gate) + m * a.ldg + n0, n0, p.N, al_g, gg);
+                    else if (al_g && n0 + 3 < p.N) { const float4 t = ld_elem4(a.gate, m * a.ldg + n0, ORTK_BF16); gg[0] = t.x; gg[1] = t.y; gg[2] = t.z; gg[3] = t.w; }
+                    else for (int q = 0; q < 4; ++q) if (n0 + q < p.N) gg[q] = ld_elem(a.gate, m * a.ldg + n0 + q, ORTK_BF16);
+                }
+                const float rs = a.rowscale ? a.rowscale[m] : 1.f;
+                bool kp[4] = {true, true, true, true};
+                if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)m * (uint64_t)p.N + n0, a.drop_p, kp);
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = s4[q] + bb[q];
+                    if (a.relu) x = fmaxf(x, 0.f);
+                    x *= rs;
+                    if (a.drop_p > 0.f) x = kp[q] ? x * inv_keep : 0.f;
+                    if (a.gate) x = gg[q] > 0.f ? x * a.gate_scale : 0.f;
+                    v[q] = x + rr[q];
+                }
+                const int64_t yi = m * a.ldy + n0;
+                if (al_y && n0 + 3 < p.N) st_elem4(a.Y, yi, a.y_dtype, make_float4(v[0], v[1], v[2], v[3]));
+                else for (int q = 0; q < 4; ++q) if (n0 + q < p.N) st_elem(a.Y, yi + q, a.y_dtype, v[q]);
+            }
+        }
+        if (ri + 1 < rpw) __syncthreads();       // the next range's chunks overwrite the output tile
     }
 }
 
@@ -266,7 +331,7 @@ __global__ __launch_bounds__(256) void ell_count_kernel(const ortk_ell_block* __
 // one workgroup per block: order the columns of every 512-column range by count (descending), chunk lengths, offsets
 __global__ __launch_bounds__(256) void ell_plan_kernel(const ortk_ell_block* __restrict__ blocks, const int32_t* __restrict__ cnt,
                                                        int32_t* __restrict__ chunk_ptr, int32_t* __restrict__ chunk_len,
-                                                       int32_t* __restrict__ perm, int32_t* overflow) {
+                                                       int32_t* __restrict__ perm, int32_t* overflow, int gran) {
     __shared__ int key[RANGE];
     __shared__ int lens[256];
     const ortk_ell_block bk = blocks[blockIdx.x];
@@ -284,7 +349,7 @@ __global__ __launch_bounds__(256) void ell_plan_kernel(const ortk_ell_block* __r
                 int rank = 0;
                 for (int j = 0; j < nn; ++j) { const int kj = key[j]; rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0; }
                 perm[(int64_t)bk.chunk0 * 64 + n0 + rank] = n0 + i;
-                if ((rank & 63) == 0) lens[(n0 + rank) >> 6] = (ki + 3) & ~3;
+                if ((rank & 63) == 0) lens[(n0 + rank) >> 6] = (ki + gran - 1) & ~(gran - 1);
             } else if (i < slots) {
                 perm[(int64_t)bk.chunk0 * 64 + n0 + i] = -1;
             }
@@ -297,7 +362,7 @@ __global__ __launch_bounds__(256) void ell_plan_kernel(const ortk_ell_block* __r
         for (int c = 0; c < nch; ++c) {
             int l = lens[c];
             if (off + (int64_t)l * 64 > end) {
-                l = (int)(((end - off) / 64) & ~(int64_t)3);
+                l = (int)(((end - off) / 64) & ~(int64_t)(gran - 1));
                 if (l < 0) l = 0;
                 *overflow = 1;
             }
@@ -343,16 +408,22 @@ __global__ __launch_bounds__(256) void ell_fill_kernel(const ortk_ell_block* __r
         const unsigned long long mask = __ballot(nz);
         const int pos = j + __popcll(mask & ((1ull << lane) - 1ull));
         if (nz && pos < len) {
-            const int64_t at = start + (int64_t)pos * 64 + slot;
-            if (EB == 4) reinterpret_cast<unsigned int*>(stream)[at] = (bits << 16) | (unsigned int)(ell_slot(k) * 16);
-            else reinterpret_cast<u32x2*>(stream)[at] = (u32x2){(unsigned int)(ell_slot(k) * 16), bits};
+            if (EB == 4) {     // pair pos/2 of this lane: halfwords {off(even), off(odd), w(even), w(odd)}
+                unsigned short* q = reinterpret_cast<unsigned short*>(stream) + ((start >> 1) + (int64_t)(pos >> 1) * 64 + slot) * 4 + (pos & 1);
+                q[0] = (unsigned short)(ell_slot(k) * 16); q[2] = (unsigned short)bits;
+            } else {
+                reinterpret_cast<u32x2*>(stream)[start + (int64_t)pos * 64 + slot] = (u32x2){(unsigned int)(ell_slot(k) * 16), bits};
+            }
         }
         j += __popcll(mask);
     }
     for (int pos = j + lane; pos < len; pos += 64) {
-        const int64_t at = start + (int64_t)pos * 64 + slot;
-        if (EB == 4) reinterpret_cast<unsigned int*>(stream)[at] = 0u;
-        else reinterpret_cast<u32x2*>(stream)[at] = (u32x2){0u, 0u};
+        if (EB == 4) {
+            unsigned short* q = reinterpret_cast<unsigned short*>(stream) + ((start >> 1) + (int64_t)(pos >> 1) * 64 + slot) * 4 + (pos & 1);
+            q[0] = 0; q[2] = 0;
+        } else {
+            reinterpret_cast<u32x2*>(stream)[start + (int64_t)pos * 64 + slot] = (u32x2){0u, 0u};
+        }
     }
 }
 
@@ -364,14 +435,20 @@ bool plan_ok(const ortk_ell_plan* p) {
 template <typename XT, int KT>
 int launch_spmm(const SpmmP& p, hipStream_t s) {
     constexpr int RB = sizeof(XT) == 4 ? 8 : 16;
-    const size_t lds = (size_t)2 * KT * 16 + (size_t)RB * OP * sizeof(float) + 16;
+    const size_t lds = (size_t)2 * KT * 16 + (size_t)RB * OP * sizeof(float) + MAXRPW * sizeof(int);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int64_t tiles = ortk_cdiv(p.a.M, RB);
-    hipLaunchKernelGGL((spmm_ell_kernel<XT, KT>), dim3((unsigned)(tiles * p.nranges)), dim3(256), lds, s, p);
+    // long grids: a workgroup walks up to 4 ranges (X staged once); short grids: one range per workgroup and 8 waves
+    const int rpw = tiles * p.nranges > 2048 ? std::min(4, p.nranges) : 1;
+    const int ngroups = (int)ortk_cdiv(p.nranges, rpw);
+    const dim3 grid((unsigned)(tiles * ngroups));
+    if (tiles * ngroups <= 640) hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 512>), grid, dim3(512), lds, s, p, rpw, ngroups);
+    else hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 256>), grid, dim3(256), lds, s, p, rpw, ngroups);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
@@ -383,7 +460,7 @@ extern "C" int ortk_ell_build(const ortk_ell_plan* plan, const void* dense, int3
     int64_t rows = 0, slots = 0;
     for (int i = 0; i < plan->nblocks; ++i) {
         const ortk_ell_block& b = plan->blocks_host[i];
-        if (b.N < 1 || b.N > 16384 || b.K < 1 || b.K > KMAX || b.ld < b.K || b.capacity < 0) return ORTK_EINVAL;
+        if (b.N < 1 || b.N > 16384 || b.K < 1 || b.K > KMAX || b.ld < b.K || b.capacity < 0 || ((b.stream_offset | b.capacity) & 1)) return ORTK_EINVAL;
         if (b.row0 != rows || (int64_t)b.chunk0 * 64 != slots) return ORTK_EINVAL;      // packed, in table order
         rows += b.N; slots += ortk_cdiv(b.N, 64) * 64;
     }
@@ -392,7 +469,7 @@ extern "C" int ortk_ell_build(const ortk_ell_plan* plan, const void* dense, int3
     hipLaunchKernelGGL(ell_count_kernel, dim3((unsigned)ortk_cdiv(rows, 4)), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, dense, dtype,
                        plan->count_scratch, rows);
     hipLaunchKernelGGL(ell_plan_kernel, dim3((unsigned)plan->nblocks), dim3(256), 0, s, plan->blocks_dev, plan->count_scratch,
-                       plan->chunk_ptr, plan->chunk_len, plan->perm, plan->overflow);
+                       plan->chunk_ptr, plan->chunk_len, plan->perm, plan->overflow, plan->entry_bytes == 4 ? 8 : 4);
     if (plan->entry_bytes == 4)
         hipLaunchKernelGGL(ell_fill_kernel<4>, dim3((unsigned)ortk_cdiv(slots, 4)), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, dense,
                            dtype, plan->chunk_ptr, plan->chunk_len, plan->perm, plan->stream, slots);

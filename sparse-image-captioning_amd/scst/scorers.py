@@ -113,6 +113,7 @@ class CaptionScorer:
         self.vocab = _Vocab()
         self.native = NativeScorer(4, 6.0, nthreads)
         self._df_loaded = False
+        self._df_space = None        # "words": the df table is keyed by word n-grams (the reference's pickles); "ids": by token ids
 
     # ---- document frequencies (ciderD_scorer.py:82-88)
     def _load_df(self):
@@ -129,9 +130,20 @@ class CaptionScorer:
             with open(path, "rb") as f:
                 table = pickle.load(f, encoding="latin1")
         grams, counts = [], []
+        kinds = set()
         for ngram, cnt in table["document_frequency"].items():
-            grams.append(self.vocab.ids(" ".join(ngram)))
+            if all(isinstance(t, (int, np.integer)) for t in ngram):     # a table cooked in token-id space: ids are used as they are
+                kinds.add("ids")
+                if any(int(t) < 0 or int(t) >= 65534 for t in ngram):
+                    raise ValueError("token ids of a document-frequency table must be < 65534")
+                grams.append([int(t) for t in ngram])
+            else:                                                        # the reference's pickles: whitespace words
+                kinds.add("words")
+                grams.append(self.vocab.ids(" ".join(ngram)))
             counts.append(float(cnt))
+        if len(kinds) > 1:
+            raise ValueError("document-frequency table mixes word and token-id n-grams")
+        self._df_space = kinds.pop() if kinds else None
         self.native.set_df(grams, counts, float(table["ref_len"]))
 
     @staticmethod
@@ -192,9 +204,29 @@ class CaptionScorer:
             sc_baseline = (np.repeat(sums, ns) - sc_sample) / (ns - 1)
         return sc_sample, sc_baseline
 
-    def score_sequences(self, ref_ids, sample_seq, greedy_seq=None, eos_idx=3, pad_idx=0):
-        """Token tensors straight from the model: ``sample_seq`` (N, ns, L) and ``greedy_seq`` (N, 1, L) int arrays
-        (cut at the first EOS / PAD), ``ref_ids[i]`` = list of id lists."""
+    def score_sequences(self, refs, sample_seq, greedy_seq=None, eos_idx=3, pad_idx=0, decode=None):
+        """Token tensors straight from the model: ``sample_seq`` (N, ns, L) and ``greedy_seq`` (N, 1, L) int arrays.
+
+        The n-grams must live in the SAME space as the document-frequency table.  The reference scores decoded strings
+        (utils/training.py:239-250: ``tokenizer.decode`` then whitespace words), and its df pickles are keyed by words, so:
+
+        * ``decode`` given (a callable ``ids -> sentence``, e.g. ``tokenizer.decode``): every row is decoded and scored
+          through the string path — exactly the reference's flow; ``refs[i]`` = list of reference STRINGS (``gts``);
+        * no ``decode``: rows are cut at the first EOS / PAD and scored as raw token ids; ``refs[i]`` = list of id lists.
+          Only valid when the document frequencies are in token-id space too — ``"corpus"`` mode or a table with integer
+          n-grams; with a word-keyed table this raises instead of silently looking up unrelated n-grams."""
+        s = np.asarray(sample_seq.cpu() if hasattr(sample_seq, "cpu") else sample_seq)
+        g = None if greedy_seq is None else np.asarray(greedy_seq.cpu() if hasattr(greedy_seq, "cpu") else greedy_seq)
+        if decode is not None:
+            sample = [[decode(r) for r in img] for img in s]
+            base = None if g is None else [[decode(img[0])] for img in g]
+            return self(refs, sample, base)
+        self._load_df()
+        if self._df_space == "words":
+            raise ValueError("score_sequences without `decode`: the document-frequency table is keyed by words, token ids would "
+                             "look up unrelated n-grams; pass decode=tokenizer.decode (the reference's flow), use a table cooked "
+                             "in token-id space, or 'corpus' document frequencies")
+
         def cut(row):
             out = []
             for t in row:
@@ -203,10 +235,6 @@ class CaptionScorer:
                     break
                 out.append(t)
             return out
-        s = np.asarray(sample_seq.cpu() if hasattr(sample_seq, "cpu") else sample_seq)
         sample = [[cut(r) for r in img] for img in s]
-        base = None
-        if greedy_seq is not None:
-            g = np.asarray(greedy_seq.cpu() if hasattr(greedy_seq, "cpu") else greedy_seq)
-            base = [[cut(img[0])] for img in g]
-        return self.score_ids(ref_ids, sample, base)
+        base = None if g is None else [[cut(img[0])] for img in g]
+        return self.score_ids(refs, sample, base)

@@ -101,8 +101,9 @@ class EllPlan:
 
 def capacity_for(N, K, max_density):
     """Entries reserved for an (N, K) block: the sorted chunks pad each group of 64 columns to its longest member (about
-    +15 % at K = 512 / 5 % density, +5 % at K = 2048) and to a multiple of 4."""
-    return int(max_density * N * K * 1.3) + 4 * 64 * ((N + 63) // 64)
+    +15 % at K = 512 / 5 % density, +5 % at K = 2048) and to a multiple of 8 entries (4 in the fp32 format)."""
+    n = int(max_density * N * K * 1.3) + 8 * 64 * ((N + 63) // 64)
+    return (n + 63) // 64 * 64
 
 
 def select_blocks(ccfg, eff, min_sparsity):

@@ -49,6 +49,18 @@ class NativeTrainer:
                 self.dm = torch.zeros(n, device=self.dev)
                 self.mm = torch.zeros(n, device=self.dev)
                 self.mv = torch.zeros(n, device=self.dev)
+                # Only the ACTIVE masks are in the reference's mask-logit optimizer group (train_n_prune_transformer.py:67-82:
+                # `model.active_pruning_masks()`); logits inside `prune_mask_freeze_scope` never move.  Here the group is the whole
+                # mask arena, so the gradient of every frozen position is zeroed before the exchange and the update (a zero
+                # gradient from step 1 on keeps Adam's moments and therefore the logit exactly unchanged).
+                self.mask_active = None
+                if model.mask_freeze_scope is not None:
+                    act = torch.zeros(n, device=self.dev)
+                    names = {k for k, _ in model.active_pruning_masks()}
+                    for e in model.named_weight_entries():
+                        if e["kind"] == 1 and (e["name"] + "_pruning_mask") in names:
+                            act[e["offset"]:e["offset"] + e["numel"]] = 1.0
+                    self.mask_active = act
             self.sparsity_target = sparsity_target
             # scripts/train_n_prune_transformer.py:306-312: weight = max(5, 1.5 / (1 - target)) unless given
             self.sparsity_weight = sparsity_weight if (sparsity_weight is not None and sparsity_weight >= 0) else (
@@ -142,12 +154,14 @@ class NativeTrainer:
         return loss, reward, seq, greedy
 
     @staticmethod
-    def scorer_reward_fn(scorer, ref_ids, eos_idx=3, pad_idx=0):
-        """``reward_fn`` for :meth:`scst_step` from a :class:`..scst.CaptionScorer` and the images' reference captions
-        (lists of token-id lists): reward = score(sample) - score(baseline), as ``compute_scst_loss`` does
-        (utils/training.py:251-254)."""
+    def scorer_reward_fn(scorer, refs, eos_idx=3, pad_idx=0, decode=None):
+        """``reward_fn`` for :meth:`scst_step` from a :class:`..scst.CaptionScorer` and the images' reference captions:
+        reward = score(sample) - score(baseline), as ``compute_scst_loss`` does (utils/training.py:239-254).  With
+        ``decode`` (``tokenizer.decode``) the rows are decoded to strings and ``refs`` are the reference strings (``gts``) —
+        the reference's flow, required for its word-keyed df pickles; without it ``refs`` are token-id lists and the scorer's
+        document frequencies must be in token-id space (see ``CaptionScorer.score_sequences``)."""
         def fn(seq, greedy):
-            sc_sample, sc_baseline = scorer.score_sequences(ref_ids, seq, greedy, eos_idx=eos_idx, pad_idx=pad_idx)
+            sc_sample, sc_baseline = scorer.score_sequences(refs, seq, greedy, eos_idx=eos_idx, pad_idx=pad_idx, decode=decode)
             return torch.from_numpy(sc_sample - sc_baseline).float()
         return fn
 
@@ -160,6 +174,7 @@ class NativeTrainer:
         batch = self._batch(data, tok_weight)
         seed = self._fwd_bwd(batch, self.norm_dev, train)
         loss = self.loss_dev.clone()
+        parallel.reduce_scalar_sum(loss)            # every rank's partial is already divided by the GLOBAL normaliser
         lr = self.rate()
         if self.masked:
             coef = None
@@ -175,6 +190,8 @@ class NativeTrainer:
             L.check(L.lib().ortk_mask_bwd(L.ptr(self.grads), L.ptr(m._flat), L.ptr(m._mask_flat), L.ptr(self.grads),
                                           L.ptr(self.dm) if self.train_masks else None, m._n_train, m._mode(train),
                                           m._mask_seed(seed), L.ptr(coef), L.stream_ptr()), "ortk_mask_bwd")
+            if self.train_masks and self.mask_active is not None:
+                self.dm.mul_(self.mask_active)
         self._allreduce()
         self._adam(m._flat[:m._n_train], self.grads, self.m, self.v, lr, self.eps)
         if self.masked and self.train_masks:

@@ -76,3 +76,29 @@ def test_shard_batch_single_process():
     assert torch.equal(s["seqs"], data["seqs"][20:30])
     with pytest.raises(AssertionError):
         parallel.shard_batch(data, 0, 4)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` from a plain shell (the form the driver's scaling run uses when WORLD_SIZE is unset) starts N
+    ranks itself — torch.distributed.run children, rendezvous on 127.0.0.1 — and rank 0 prints ONE JSON line with n_gpus = N.
+    Checked without a GPU through the gloo self-test of the same launch path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"selftest": True, "n_gpus": 2, "rank_sum": 3.0, "steps": 3, "warmup": 1}
+    # a mismatch between --gpus and the group size is refused, not silently run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--selftest"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "20"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "20"]

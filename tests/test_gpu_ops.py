@@ -571,7 +571,7 @@ def _ell_to_dense(plan, bi):
     seen = set()
     for c in range(nch):
         ln, base = int(cl[c0 + c]), int(cp[c0 + c])
-        assert ln % 4 == 0
+        assert ln % (8 if plan.entry_bytes == 4 else 4) == 0 and base % 2 == 0
         for lane in range(64):
             col = int(perm[(c0 + c) * 64 + lane])
             if col < 0:
@@ -579,9 +579,11 @@ def _ell_to_dense(plan, bi):
             assert col not in seen and c * 64 // 512 == col // 512          # every column once, inside its 512-column range
             seen.add(col)
             for j in range(ln):
-                if plan.entry_bytes == 4:
-                    w = int(st[base + j * 64 + lane])
-                    off, val = w & 0xFFFF, np.array([w & 0xFFFF0000], np.uint32).view(np.float32)[0]
+                if plan.entry_bytes == 4:      # pairs: uint2 {off(even) | off(odd) << 16, bf16 w(even) | w(odd) << 16}
+                    at = 2 * (base // 2 + (j // 2) * 64 + lane)
+                    sh = 16 * (j & 1)
+                    off = (int(st[at]) >> sh) & 0xFFFF
+                    val = np.array([((int(st[at + 1]) >> sh) & 0xFFFF) << 16], np.uint32).view(np.float32)[0]
                 else:
                     off = int(st[2 * (base + j * 64 + lane)])
                     val = st[2 * (base + j * 64 + lane) + 1:2 * (base + j * 64 + lane) + 2].view(np.float32)[0]
