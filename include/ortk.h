@@ -38,7 +38,7 @@ int ortk_device_ok(void);
 /* ------------------------------------------------------------------------------------------------
  * Model geometry — the fields models/transformer.py:418-437 reads from `config`.
  * ---------------------------------------------------------------------------------------------- */
-struct ortk_ell_plan;
+struct ortk_sparse_plan;
 typedef struct ortk_config {
     int32_t d_model, d_ff, n_layers, n_heads;
     int32_t vocab, feat, seq_len;              /* vocab_size, att_feat_size, max_seq_length          */
@@ -63,12 +63,12 @@ typedef struct ortk_config {
     /* Execution option, not geometry (may be NULL): sparse plans over blocks of the weight arena for the TRAINING step
      * (`relation_transformer_prune`: the masked linears of pruning/masked_layer.py:84-110,134-135 as sparse products).
      * sparse_fwd: blocks = (N,K) weight blocks at their arena offsets; ortk_forward rebuilds it from the effective weights
-     * of the call (s*W: the mask sample of THIS step) and runs those projections with ortk_spmm_ell.  sparse_bwd (mixed
+     * of the call (s*W: the mask sample of THIS step) and runs those projections with ortk_spmm.  sparse_bwd (mixed
      * precision only): the same blocks TRANSPOSED ((K,N), same offsets, ld = N): rebuilt by ortk_forward from its
      * transposed bf16 weight copies, used by ortk_backward for the data gradients dX = dY W~.  The weight gradients stay
      * dense MFMA products: the straight-through mask gradient needs dLoss/d(s*W) at EVERY position (sampler.py:10-34). */
-    const struct ortk_ell_plan* sparse_fwd;
-    const struct ortk_ell_plan* sparse_bwd;
+    const struct ortk_sparse_plan* sparse_fwd;
+    const struct ortk_sparse_plan* sparse_bwd;
 } ortk_config;
 
 /* ------------------------------------------------------------------------------------------------
@@ -132,42 +132,63 @@ int64_t ortk_arena_decoder_offset(const ortk_config* cfg);
 /* Cached-attention decoding: CachedTransformerBase._generate_captions (models/transformer.py:471-561)
  * + CaptionModel.batch_beam_search (models/caption_model.py:30-226, group_size 1). */
 /* ------------------------------------------------------------------------------------------------
- * Sparse weights: sorted, padded ELL ("SELL-64") images of pruned weight blocks, rebuilt ON THE DEVICE from the
- * dense (zero-filled) weights of the current call, so there is no host-side cache that could go stale.
+ * Sparse weights.  A *plan* names pruned weight blocks and owns the device buffers of their sparse images; the images are
+ * rebuilt ON THE DEVICE from the dense (zero-filled) weights of the current call (ortk_sparse_build: no host sync), so
+ * there is no host-side cache that could go stale.  A block is an (N outputs, K inputs) row-major matrix: a torch Linear
+ * weight, or — for the data gradient dX = dY W — its transposed bf16 copy (then N = in_features).
  *
- * A block is an (N outputs, K inputs) row-major matrix (a torch Linear weight, or — for the data gradient
- * dX = dY W — its transposed bf16 copy, then N = in_features).  Its N output columns are cut in ranges of 512;
- * inside a range the columns are ordered by their number of non-zeros (descending) and grouped in chunks of
- * 64: chunk c = 64 output columns, one per lane, padded to chunk_len[c] entries (a multiple of 4) with zero
- * entries.  Entry j of lane l of chunk c sits at stream[chunk_ptr[c] + j*64 + l]:
- *   entry_bytes 4: uint32  = bf16(value) << 16 | slot(k)*16          (mixed precision)
- *   entry_bytes 8: uint32x2 = { slot(k)*16, fp32 bits of value }     (fp32 parity mode)
- * slot(k) = (k & ~7) | ((k + (k >> 3)) & 7) is the 16-byte slot of input column k in the kernel's LDS image
- * of the activation tile (K <= 4095).  perm[c*64 + l] = the output column of lane l (or -1 for a pad lane).
+ * format ORTK_SP_GU16 (mixed precision; the fast path): "group union".  The outputs are cut in groups of 16 columns
+ *   (one MFMA tile) and the inputs in chunks of 512.  For each (group g, chunk c) — slot = slot0 + g*nchunks + c — the image
+ *   holds the UNION of the input columns in which any of the 16 outputs has a non-zero, as up to 16 k-steps of 32 columns:
+ *     nsteps[slot]            number of k-steps
+ *     kofs[(slot*16 + s)*64 + lane]   the two LDS rows (chunk-relative input columns, lo / hi 16 bits) whose addresses lane
+ *                             `lane` supplies to the two transposing LDS reads of step s
+ *     wfrag[((slot*16 + s)*64 + lane)*8 + j]  bf16 weights in MFMA operand order: output 16g + (lane & 15), union entry
+ *                             8*(lane >> 4) + j of the step
+ *   The product is then a DENSE bf16 MFMA over the compacted K (56 % of K at 95 % sparsity, 33 % at 97.5 %), its activation
+ *   operand gathered from an LDS tile by ds_read_b64_tr_b16.  Entry e of a step takes an input column with
+ *   k mod 8 == ((e & 7) + 4*((e >> 3) & 1)) & 7 (zero-weight dummies pad the residue classes): the gathers are then
+ *   bank-conflict free.  Worst-case sized (16 steps per slot): nothing can overflow.
+ * format ORTK_SP_ELL32 (fp32 parity mode) / ORTK_SP_ELL16: sorted, padded ELL.  The N output columns are cut in ranges of
+ *   512; inside a range they are ordered by their number of non-zeros (descending) and grouped in chunks of 64: chunk c =
+ *   64 output columns, one per lane, padded to chunk_len[c] entries.  ELL32: entry j of lane l of chunk c =
+ *   stream[chunk_ptr[c] + j*64 + l] = uint32x2 { slot(k)*16, fp32 bits of the value } (chunk_len multiple of 4).  ELL16:
+ *   entry PAIRS uint32x2 { off_even | off_odd << 16, bf16 w_even | w_odd << 16 } at stream[chunk_ptr[c]/2 + (j/2)*64 + l]
+ *   (chunk_len multiple of 8).  slot(k) = (k & ~7) | ((k + (k >> 3)) & 7) is the 16-byte slot of input column k in the
+ *   kernel's LDS image (K <= 2048).  perm[c*64 + l] = the output column of lane l (-1 = pad lane).  Capacity-planned: the
+ *   builder drops what does not fit and raises *overflow.
  * ---------------------------------------------------------------------------------------------- */
-typedef struct ortk_ell_block {
+#define ORTK_SP_ELL32 0
+#define ORTK_SP_ELL16 1
+#define ORTK_SP_GU16  2
+typedef struct ortk_sparse_block {
     int64_t src_offset;        /* element offset of the dense (N,K) block inside the dense buffer handed to the builder   */
     int64_t ld;                /* its leading dimension (elements)                                                         */
-    int64_t stream_offset;     /* first entry of this block's region in the stream buffer                                 */
-    int64_t capacity;          /* entries reserved for it (the builder drops what does not fit and raises *overflow)      */
+    int64_t stream_offset;     /* ELL: first entry of this block's region in the stream buffer                            */
+    int64_t capacity;          /* ELL: entries reserved for it                                                            */
     int32_t N, K;
-    int32_t chunk0;            /* index of its first chunk in chunk_ptr / chunk_len / perm (ceil(N/64) chunks)            */
-    int32_t row0;              /* index of its first output column in the builder's count scratch                        */
-} ortk_ell_block;
+    int32_t chunk0;            /* ELL: index of its first chunk (ceil(N/64) chunks);  GU16: slot0, its first (group, chunk) slot
+                                  (ceil(N/16) * ceil(K/512) slots)                                                        */
+    int32_t row0;              /* ELL: index of its first output column in the builder's count scratch                   */
+} ortk_sparse_block;
 
 /* One set of sparse blocks (device buffers owned by the caller; the block table is given twice: host copy for the
  * launch geometry, device copy for the kernels). */
-typedef struct ortk_ell_plan {
-    const ortk_ell_block* blocks_host; const ortk_ell_block* blocks_dev;
-    int32_t nblocks, entry_bytes;
-    void* stream; int32_t* chunk_ptr; int32_t* chunk_len; int32_t* perm;
-    int32_t* count_scratch;    /* >= sum of N over the blocks                                                             */
-    int32_t* overflow;         /* device int: set to 1 by the builder when a block exceeded its capacity                  */
-    int64_t total_rows;        /* sum of N over the blocks                                                                 */
-} ortk_ell_plan;
+typedef struct ortk_sparse_plan {
+    const ortk_sparse_block* blocks_host; const ortk_sparse_block* blocks_dev;
+    int32_t nblocks, format;
+    void* stream;              /* ELL: entries;  GU16: wfrag (bf16, total_slots*16*64*8)                                  */
+    int32_t* chunk_ptr;        /* ELL: per chunk; GU16: kofs (uint32, total_slots*16*64)                                  */
+    int32_t* chunk_len;        /* ELL: per chunk; GU16: nsteps (per slot)                                                 */
+    int32_t* perm;             /* ELL: per lane slot; GU16: per block, the maximum of its nsteps (written by the builder: the
+                                  product kernel runs every group of a block for that many k-steps, branch-free)           */
+    int32_t* count_scratch;    /* ELL: >= total_rows; GU16: non-zeros per slot (statistics)                               */
+    int32_t* overflow;         /* device int: set to 1 by the ELL builder when a block exceeded its capacity              */
+    int64_t total_rows;        /* ELL: sum of N over the blocks; GU16: total number of slots                              */
+} ortk_sparse_plan;
 
-/* Build every block of the plan from `dense` (dtype 0 fp32 / 1 bf16): three launches, no host sync. */
-int ortk_ell_build(const ortk_ell_plan* plan, const void* dense, int32_t dtype, ortk_stream stream);
+/* Build every block of the plan from `dense` (dtype 0 fp32 / 1 bf16): no host sync. */
+int ortk_sparse_build(const ortk_sparse_plan* plan, const void* dense, int32_t dtype, ortk_stream stream);
 
 /* Y = epi(X W~^T) for block `block` of a built plan.  Same epilogue as ortk_gemm:
  *   v = acc + bias[n]; relu; v *= rowscale[m]; dropout(p, seed, index m*N+n); v *= (gate[m,n]>0)*gate_scale; v += resid[m,n].
@@ -181,7 +202,7 @@ typedef struct ortk_spmm_args {
     const void* gate; int64_t ldg; int32_t gate_dtype; float gate_scale;
     int32_t relu; float drop_p; uint32_t drop_seed;
 } ortk_spmm_args;
-int ortk_spmm_ell(const ortk_ell_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream);
+int ortk_spmm(const ortk_sparse_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream);
 
 typedef struct ortk_decode_opts {
     int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
@@ -193,8 +214,8 @@ typedef struct ortk_decode_opts {
     uint64_t seed;                /* multinomial: Gumbel-max over counter-based uniforms */
     /* Optional (may be NULL): sparse plan over blocks of the weight arena (src_offset = arena offset of the block, see
      * ortk_linear_block).  ortk_decode rebuilds it from the weights of this call and runs every projection that has a
-     * block in it as a sparse product (ortk_spmm_ell) instead of a dense GEMM. */
-    const struct ortk_ell_plan* sparse;
+     * block in it as a sparse product (ortk_spmm) instead of a dense GEMM. */
+    const struct ortk_sparse_plan* sparse;
     int32_t reserved0;
     /* multinomial only: also decode ONE greedy row per image in the same pass (the SCST baseline of
      * utils/training.py:220-237): K = num_random_sample + 1, row 0 of each image is the arg-max decode, rows 1.. are

@@ -38,13 +38,16 @@ class Batch(C.Structure):
                 ("B", C.c_int32), ("S", C.c_int32), ("R", C.c_int32), ("T", C.c_int32)]
 
 
+SP_ELL32, SP_ELL16, SP_GU16 = 0, 1, 2     # ortk_sparse_plan.format
+
+
 class EllBlock(C.Structure):
     _fields_ = [("src_offset", C.c_int64), ("ld", C.c_int64), ("stream_offset", C.c_int64), ("capacity", C.c_int64),
                 ("N", C.c_int32), ("K", C.c_int32), ("chunk0", C.c_int32), ("row0", C.c_int32)]
 
 
 class EllPlanStruct(C.Structure):
-    _fields_ = [("blocks_host", C.POINTER(EllBlock)), ("blocks_dev", C.c_void_p), ("nblocks", C.c_int32), ("entry_bytes", C.c_int32),
+    _fields_ = [("blocks_host", C.POINTER(EllBlock)), ("blocks_dev", C.c_void_p), ("nblocks", C.c_int32), ("format", C.c_int32),
                 ("stream", C.c_void_p), ("chunk_ptr", C.c_void_p), ("chunk_len", C.c_void_p), ("perm", C.c_void_p),
                 ("count_scratch", C.c_void_p), ("overflow", C.c_void_p), ("total_rows", C.c_int64)]
 
@@ -144,8 +147,8 @@ SIGNATURES = {
     "ortk_decode_step": (_I32, [_CFG, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _SZ, _P, _I64, _P]),
     "ortk_axpy_cols": (_I32, [_P, _P, _I32, _I64, _I64, _I32, _P]),
     "ortk_linear_block": (_I32, [_CFG, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "ortk_ell_build": (_I32, [C.POINTER(EllPlanStruct), _P, _I32, _P]),
-    "ortk_spmm_ell": (_I32, [C.POINTER(EllPlanStruct), _I32, C.POINTER(SpmmArgs), _P]),
+    "ortk_sparse_build": (_I32, [C.POINTER(EllPlanStruct), _P, _I32, _P]),
+    "ortk_spmm": (_I32, [C.POINTER(EllPlanStruct), _I32, C.POINTER(SpmmArgs), _P]),
 }
 
 _lib = None

@@ -285,8 +285,8 @@ struct Ctx {
     const float* P;          // fp32 parameter arena (biases, LayerNorm, embeddings, and weights in fp32 mode)
     const void* W16;         // bf16 weight arena (mixed precision) or nullptr
     int adt;                 // dtype of (A) buffers
-    const ortk_ell_plan* ell_f = nullptr;        // optional sparse plan over (N,K) weight blocks: forward-layout products
-    const ortk_ell_plan* ell_b = nullptr;        // ... over their transposed copies: data-gradient products (mixed precision)
+    const ortk_sparse_plan* ell_f = nullptr;        // optional sparse plan over (N,K) weight blocks: forward-layout products
+    const ortk_sparse_plan* ell_b = nullptr;        // ... over their transposed copies: data-gradient products (mixed precision)
     const void* W16T = nullptr;                  // transposed bf16 weight blocks (training workspaces, mixed precision)
     bool use_side = false;                       // backward only: weight-gradient GEMMs on g_side
     struct Pend { const void* buf; hipEvent_t done; };
@@ -327,10 +327,10 @@ struct Ctx {
     }
     // block of `plan` that is the (N outputs, K inputs) matrix at arena offset `off`, or -1
     // (with share_att "qk" a (d,d) projection starts where the K|V block does: the shape is part of the key)
-    static int ell_block(const ortk_ell_plan* plan, int64_t off, int N, int K) {
+    static int ell_block(const ortk_sparse_plan* plan, int64_t off, int N, int K) {
         if (!plan) return -1;
         for (int i = 0; i < plan->nblocks; ++i) {
-            const ortk_ell_block& b = plan->blocks_host[i];
+            const ortk_sparse_block& b = plan->blocks_host[i];
             if (b.src_offset == off && b.N == N && b.K == K) return i;
         }
         return -1;
@@ -356,7 +356,7 @@ static int fwd_gemm(const Ctx& c, const void* X, int xdt, int64_t ldx, int64_t w
             ortk_spmm_args sa; std::memset(&sa, 0, sizeof(sa));
             sa.X = X; sa.x_dtype = xdt; sa.ldx = ldx; sa.Y = Y; sa.y_dtype = ydt; sa.ldy = ldy; sa.M = M;
             sa.bias = bias; sa.rowscale = rowscale; sa.resid = resid; sa.ldr = ldr; sa.relu = relu; sa.drop_p = drop; sa.drop_seed = seed;
-            return ortk_spmm_ell(c.ell_f, blk, &sa, (ortk_stream)c.s);
+            return ortk_spmm(c.ell_f, blk, &sa, (ortk_stream)c.s);
         }
     }
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
@@ -376,13 +376,13 @@ static int dgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, int6
     if (c.prec && c.W16T && whole_block) {
         // W~^T as a sparse plan block: (Kin outputs, Nout inputs) at the same offset
         constexpr int KMAX = 2048;          // inputs one sparse product launch takes (ortk_sparse.hip)
-        const int blk = Nout <= KMAX ? Ctx::ell_block(c.ell_b, woff, Kin, Nout) : -1;
+        const int blk = Ctx::ell_block(c.ell_b, woff, Kin, Nout);      // (ELL plans hold wide blocks as pieces: below)
         if (blk >= 0) {
             ortk_spmm_args sa; std::memset(&sa, 0, sizeof(sa));
             sa.X = dY; sa.x_dtype = dydt; sa.ldx = lddy; sa.Y = dX; sa.y_dtype = dxdt; sa.ldy = lddx; sa.M = M;
             sa.gate = gate; sa.gate_dtype = gdt; sa.ldg = ldg; sa.gate_scale = gate_scale;
             TRY(c.before_write(dX));
-            return ortk_spmm_ell(c.ell_b, blk, &sa, (ortk_stream)c.s);
+            return ortk_spmm(c.ell_b, blk, &sa, (ortk_stream)c.s);
         }
         if (Nout > KMAX && !gate && dxdt == ORTK_F32 && c.ell_b) {
             // more inputs than one launch takes (the generator: 10 112 logit columns): the plan holds the block cut into
@@ -395,7 +395,7 @@ static int dgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, int6
                     ortk_spmm_args sa; std::memset(&sa, 0, sizeof(sa));
                     sa.X = off_elems(dY, k0, dydt); sa.x_dtype = dydt; sa.ldx = lddy; sa.Y = dX; sa.y_dtype = ORTK_F32; sa.ldy = lddx; sa.M = M;
                     if (k0) { sa.resid = reinterpret_cast<const float*>(dX); sa.ldr = lddx; }
-                    TRY(ortk_spmm_ell(c.ell_b, Ctx::ell_block(c.ell_b, woff + k0, Kin, std::min(KMAX, Nout - k0)), &sa, (ortk_stream)c.s));
+                    TRY(ortk_spmm(c.ell_b, Ctx::ell_block(c.ell_b, woff + k0, Kin, std::min(KMAX, Nout - k0)), &sa, (ortk_stream)c.s));
                 }
                 return 0;
             }
@@ -622,10 +622,10 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
     // sparse plans are rebuilt from THIS call's effective weights (a new mask sample per step): no stale images
     if (cfg->sparse_fwd) {
-        TRY(ortk_ell_build(cfg->sparse_fwd, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
+        TRY(ortk_sparse_build(cfg->sparse_fwd, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
         c.ell_f = cfg->sparse_fwd;
     }
-    if (cfg->sparse_bwd && cfg->precision) TRY(ortk_ell_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, stream));
+    if (cfg->sparse_bwd && cfg->precision) TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, stream));
     const float* P = params;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
@@ -1122,7 +1122,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     TRY(make_w16(cfg, o, params, w.w16, stream));
     Ctx c{cfg, s, cfg->precision, 0, false, params, w.w16, w.adt};
     if (op->sparse) {
-        TRY(ortk_ell_build(op->sparse, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
+        TRY(ortk_sparse_build(op->sparse, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
         c.ell_f = op->sparse;
     }
     const float* P = params;

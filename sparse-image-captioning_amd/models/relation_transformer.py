@@ -297,7 +297,7 @@ class RelationTransformerModel(CaptionModelBase):
         return self._flat
 
     def enable_sparse_kernels(self, min_sparsity=0.9, train=False):
-        """Run every weight block whose fraction of zeros is >= ``min_sparsity`` as a sparse product (``ortk_spmm_ell``)
+        """Run every weight block whose fraction of zeros is >= ``min_sparsity`` as a sparse product (``ortk_spmm``)
         instead of a dense GEMM on the zero-filled weight; ``None`` goes back to dense GEMMs.  Same results as the reference's
         dense-on-zero-filled-weights flow (scripts/eval_model.py:64-88, pruning/masked_layer.py:134-135) up to fp32 summation
         order.  Decoding (``mode="sample"``) always uses the plan; ``train=True`` also routes the teacher-forced forward and —

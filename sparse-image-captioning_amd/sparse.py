@@ -1,20 +1,25 @@
-"""Sparse plans for pruned weight blocks (``include/ortk.h``: ``ortk_ell_plan``).
+"""Sparse plans for pruned weight blocks (``include/ortk.h``: ``ortk_sparse_plan``).
 
 The reference multiplies by the zero-filled weight ``s * W`` in every masked layer (``pruning/masked_layer.py:84-110,
 134-135``) and evaluates pruned checkpoints as dense linears on zero-filled weights (``scripts/eval_model.py:64-88``).
-Here a *plan* names the weight blocks that are sparse enough and owns the device buffers of their sorted-ELL images; the
+Here a *plan* names the weight blocks that are sparse enough and owns the device buffers of their sparse images; the
 images themselves are (re)built on the device inside ``ortk_forward`` / ``ortk_decode`` from the effective weights of that
 very call, so nothing on the host can go stale when the weights, the masks or the mask sample change.
+
+Formats (``_lib.SP_*``): ``SP_GU16`` — group-union MFMA images, the mixed-precision fast path; ``SP_ELL32`` — sorted ELL with
+fp32 values, the fp32 parity mode; ``SP_ELL16`` — sorted ELL with bf16 pairs (VALU kernel, kept for comparison).
 
 This module only does plumbing: block selection (one-off, at ``enable_sparse_kernels``), buffer sizes, ctypes tables.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
 
-KMAX = 2048      # input columns one product launch takes (csrc/ortk_sparse.hip); wider blocks are cut along their inputs
+KMAX = 2048      # ELL: input columns one product launch takes (csrc/ortk_sparse.hip); wider blocks are cut along their inputs
+GKC, GSTEPS = 512, 16     # GU16: input columns per chunk, k-steps reserved per (group, chunk) slot
 
 
 def linear_blocks(ccfg):
@@ -34,45 +39,60 @@ def linear_blocks(ccfg):
     return out
 
 
-class EllPlan:
-    """One ``ortk_ell_plan``: a set of (N outputs, K inputs) blocks of a dense buffer + the device buffers of their images.
+class SparsePlan:
+    """One ``ortk_sparse_plan``: a set of (N outputs, K inputs) blocks of a dense buffer + the device buffers of their images.
 
     ``blocks``: list of dicts ``offset, N, K, ld`` (element offset / leading dimension inside the dense buffer the builder
-    will be given) and ``capacity`` (entries).  ``entry_bytes`` 4 = bf16 value + slot (mixed precision), 8 = fp32 value."""
+    will be given) and, for the ELL formats, ``capacity`` (entries)."""
 
-    def __init__(self, blocks, entry_bytes, device):
+    def __init__(self, blocks, fmt, device):
         assert blocks, "a sparse plan needs at least one block"
         self.blocks = blocks
-        self.entry_bytes = entry_bytes
+        self.format = fmt
         n = len(blocks)
         self._host = (L.EllBlock * n)()
-        rows = chunks = entries = 0
+        rows = chunks = entries = slots = 0
         for i, b in enumerate(blocks):
-            assert 1 <= b["K"] <= KMAX and 1 <= b["N"] <= 16384
             h = self._host[i]
             h.src_offset, h.ld, h.N, h.K = b["offset"], b["ld"], b["N"], b["K"]
-            h.stream_offset, h.capacity = entries, b["capacity"]
-            h.chunk0, h.row0 = chunks, rows
-            rows += b["N"]
-            chunks += (b["N"] + 63) // 64
-            entries += b["capacity"]
-        assert entries < 2 ** 31, "entry offsets are 32-bit"
-        raw = bytes(self._host)
-        self._dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        self.stream = torch.zeros(max(entries, 1) * entry_bytes // 4, dtype=torch.int32, device=device)
-        self.chunk_ptr = torch.zeros(chunks, dtype=torch.int32, device=device)
-        self.chunk_len = torch.zeros(chunks, dtype=torch.int32, device=device)
-        self.perm = torch.full((chunks * 64,), -1, dtype=torch.int32, device=device)
-        self.count = torch.zeros(rows, dtype=torch.int32, device=device)
-        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
-        self.n, self.total_rows, self.total_chunks, self.total_entries = n, rows, chunks, entries
+            if fmt == L.SP_GU16:
+                assert b["K"] <= GKC or b["N"] <= 512, "GU16: blocks with more than 512 inputs may have at most 512 outputs"
+                h.chunk0 = slots
+                slots += ((b["N"] + 15) // 16) * ((b["K"] + GKC - 1) // GKC)
+            else:
+                assert 1 <= b["K"] <= KMAX and 1 <= b["N"] <= 16384
+                h.stream_offset, h.capacity = entries, b["capacity"]
+                h.chunk0, h.row0 = chunks, rows
+                rows += b["N"]
+                chunks += (b["N"] + 63) // 64
+                entries += b["capacity"]
+        self._dev = torch.frombuffer(bytearray(bytes(self._host)), dtype=torch.uint8).to(device)
+        z = lambda k, dt=torch.int32: torch.zeros(max(int(k), 1), dtype=dt, device=device)
+        if fmt == L.SP_GU16:
+            self.stream = z(slots * GSTEPS * 64 * 8, torch.bfloat16)       # wfrag
+            self.chunk_ptr = z(slots * GSTEPS * 64)                         # kofs
+            self.chunk_len = z(slots)                                       # nsteps
+            self.perm = z(n)                                                # per-block maximum of nsteps
+            self.count = z(slots)                                           # non-zeros per slot
+            self.overflow = z(1)
+            total = slots
+        else:
+            assert entries < 2 ** 31, "entry offsets are 32-bit"
+            self.stream = z(entries * (4 if fmt == L.SP_ELL16 else 8) // 4)
+            self.chunk_ptr, self.chunk_len = z(chunks), z(chunks)
+            self.perm = torch.full((max(chunks, 1) * 64,), -1, dtype=torch.int32, device=device)
+            self.count = z(rows)
+            self.overflow = z(1)
+            total = rows
+        self.n, self.total_rows = n, total
         p = L.EllPlanStruct()
         p.blocks_host = C.cast(self._host, C.POINTER(L.EllBlock))
         p.blocks_dev = self._dev.data_ptr()
-        p.nblocks, p.entry_bytes = n, entry_bytes
+        p.nblocks, p.format = n, fmt
         p.stream, p.chunk_ptr, p.chunk_len = self.stream.data_ptr(), self.chunk_ptr.data_ptr(), self.chunk_len.data_ptr()
-        p.perm, p.count_scratch, p.overflow = self.perm.data_ptr(), self.count.data_ptr(), self.overflow.data_ptr()
-        p.total_rows = rows
+        p.perm = self.perm.data_ptr() if self.perm is not None else None
+        p.count_scratch, p.overflow = self.count.data_ptr(), self.overflow.data_ptr()
+        p.total_rows = total
         self.struct = p
 
     def ref(self):
@@ -82,13 +102,14 @@ class EllPlan:
         """(Re)build every image from ``dense`` (fp32 or bf16 device tensor) — what ortk_forward / ortk_decode do themselves;
         exposed for the operator-level tests and tools."""
         dt = {torch.float32: 0, torch.bfloat16: 1}[dense.dtype]
-        L.check(L.lib().ortk_ell_build(self.ref(), L.ptr(dense), dt, L.stream_ptr()), "ortk_ell_build")
+        L.check(L.lib().ortk_sparse_build(self.ref(), L.ptr(dense), dt, L.stream_ptr()), "ortk_sparse_build")
 
     def spmm(self, block, args):
-        L.check(L.lib().ortk_spmm_ell(self.ref(), block, C.byref(args), L.stream_ptr()), "ortk_spmm_ell")
+        L.check(L.lib().ortk_spmm(self.ref(), block, C.byref(args), L.stream_ptr()), "ortk_spmm")
 
     def check_overflow(self):
-        """Host sync: raises if the last build dropped entries (a block denser than the capacity it was planned with)."""
+        """Host sync: raises if the last build dropped entries (ELL: a block denser than the capacity it was planned with;
+        the GU16 format is worst-case sized and cannot overflow)."""
         if int(self.overflow.item()):
             raise L.OrtkError("sparse plan overflow: a weight block has more non-zeros than the capacity reserved at "
                               "enable_sparse_kernels(); call it again with a lower min_sparsity")
@@ -100,7 +121,7 @@ class EllPlan:
 
 
 def capacity_for(N, K, max_density):
-    """Entries reserved for an (N, K) block: the sorted chunks pad each group of 64 columns to its longest member (about
+    """ELL: entries reserved for an (N, K) block: the sorted chunks pad each group of 64 columns to its longest member (about
     +15 % at K = 512 / 5 % density, +5 % at K = 2048) and to a multiple of 8 entries (4 in the fp32 format)."""
     n = int(max_density * N * K * 1.3) + 8 * 64 * ((N + 63) // 64)
     return (n + 63) // 64 * 64
@@ -117,31 +138,46 @@ def select_blocks(ccfg, eff, min_sparsity):
     return out
 
 
-def make_plans(ccfg, eff, min_sparsity, precision, backward=False):
+def default_format(precision):
+    if not precision:
+        return L.SP_ELL32
+    # Measured on MI355X (scratch/spmm_bench.py): the VALU kernel on sorted ELL is the faster of the two
+    # on the decode shapes and on the 2048-input blocks, the MFMA kernel on group unions on the widest outputs; neither beats
+    # the dense MFMA GEMM at 95 %.  ELL16 is the default, ORTK_SPARSE_FORMAT=gu16 selects the other.
+    return {"ell16": L.SP_ELL16, "gu16": L.SP_GU16}[os.environ.get("ORTK_SPARSE_FORMAT", "ell16").lower()]
+
+
+def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None):
     """(forward plan, backward plan | None) for the blocks of ``eff`` that are sparse enough.
 
     Forward: the (N, K) weight blocks at their arena offsets.  Backward (mixed precision only): the same blocks transposed
     — (K outputs, N inputs), leading dimension N, at the same offsets of the transposed bf16 copy the executor keeps for its
-    data-gradient GEMMs; a block with more than KMAX inputs (the generator: 10 112) is cut into KMAX-wide pieces that the
-    executor accumulates.  The region embedding (block 0) has no input gradient."""
+    data-gradient GEMMs (ELL: a block with more than KMAX inputs — the generator: 10 112 — is cut into KMAX-wide pieces that
+    the executor accumulates).  The region embedding (block 0) has no input gradient."""
     sel = select_blocks(ccfg, eff, min_sparsity)
     if not sel:
         return None, None
+    fmt = default_format(precision) if fmt is None else fmt
     dens = 1.0 - min_sparsity
-    eb = 4 if precision else 8
     first = linear_blocks(ccfg)[0][0]
+    gu = fmt == L.SP_GU16
+    ok = (lambda N, K: K <= GKC or N <= 512) if gu else (lambda N, K: K <= KMAX)
     fwd = [dict(offset=b["offset"], N=b["N"], K=b["K"], ld=b["K"], capacity=capacity_for(b["N"], b["K"], dens), sparsity=b["sparsity"])
-           for b in sel if b["K"] <= KMAX]
-    plan_f = EllPlan(fwd, eb, eff.device) if fwd else None
+           for b in sel if ok(b["N"], b["K"])]
+    plan_f = SparsePlan(fwd, fmt, eff.device) if fwd else None
     plan_b = None
     if backward and precision:
         bwd = []
         for b in sel:
             if b["offset"] == first:
                 continue
+            if gu:
+                if ok(b["K"], b["N"]):
+                    bwd.append(dict(offset=b["offset"], N=b["K"], K=b["N"], ld=b["N"], sparsity=b["sparsity"]))
+                continue
             for k0 in range(0, b["N"], KMAX):            # inputs of the transposed block = outputs of the weight
                 kw = min(KMAX, b["N"] - k0)
                 bwd.append(dict(offset=b["offset"] + k0, N=b["K"], K=kw, ld=b["N"], capacity=capacity_for(b["K"], kw, dens),
                                 sparsity=b["sparsity"]))
-        plan_b = EllPlan(bwd, 4, eff.device) if bwd else None
+        plan_b = SparsePlan(bwd, fmt if gu else L.SP_ELL16, eff.device) if bwd else None
     return plan_f, plan_b

@@ -571,7 +571,7 @@ def _ell_to_dense(plan, bi):
     seen = set()
     for c in range(nch):
         ln, base = int(cl[c0 + c]), int(cp[c0 + c])
-        assert ln % (8 if plan.entry_bytes == 4 else 4) == 0 and base % 2 == 0
+        assert ln % (8 if plan.format == 1 else 4) == 0 and base % 2 == 0
         for lane in range(64):
             col = int(perm[(c0 + c) * 64 + lane])
             if col < 0:
@@ -579,7 +579,7 @@ def _ell_to_dense(plan, bi):
             assert col not in seen and c * 64 // 512 == col // 512          # every column once, inside its 512-column range
             seen.add(col)
             for j in range(ln):
-                if plan.entry_bytes == 4:      # pairs: uint2 {off(even) | off(odd) << 16, bf16 w(even) | w(odd) << 16}
+                if plan.format == 1:      # ELL16 pairs: uint2 {off(even) | off(odd) << 16, bf16 w(even) | w(odd) << 16}
                     at = 2 * (base // 2 + (j // 2) * 64 + lane)
                     sh = 16 * (j & 1)
                     off = (int(st[at]) >> sh) & 0xFFFF
@@ -594,12 +594,67 @@ def _ell_to_dense(plan, bi):
     return W
 
 
+def _gu_to_dense(plan, bi):
+    """Decode block `bi` of a built GU16 plan back to a dense (N, K) matrix, checking the invariants of the format: the 4
+    address lanes of an entry agree, entries obey the residue rule that makes the LDS gathers conflict-free, every
+    non-zero appears exactly once, dummies carry zero weights."""
+    blk = plan.blocks[bi]
+    N, K = blk["N"], blk["K"]
+    slot0, G, nkc = plan._host[bi].chunk0, (N + 15) // 16, (K + 511) // 512
+    wf = plan.stream.float().cpu().numpy().reshape(-1, 16, 64, 8)
+    ko = plan.chunk_ptr.cpu().numpy().view(np.uint32).reshape(-1, 16, 64)
+    ns = plan.chunk_len.cpu().numpy()
+    W = np.zeros((((N + 15) // 16) * 16, K), np.float32)
+    for g in range(G):
+        for kc in range(nkc):
+            slot = slot0 + g * nkc + kc
+            S = int(ns[slot])
+            assert 0 <= S <= 16
+            for s in range(S):
+                for lg in range(4):
+                    for j in range(8):
+                        ks = {(int(ko[slot, s, lg * 16 + 4 * (j & 3) + p]) >> (16 * (j >> 2))) & 0xFFFF for p in range(4)}
+                        assert len(ks) == 1
+                        krel = ks.pop()
+                        e = 8 * lg + j
+                        assert krel % 8 == ((e & 7) + 4 * ((e >> 3) & 1)) & 7 and krel < 512
+                        col = wf[slot, s, lg * 16:(lg + 1) * 16, j]
+                        if np.any(col != 0):
+                            k = kc * 512 + krel
+                            assert k < K and not np.any(W[16 * g:16 * g + 16, k] != 0)
+                            W[16 * g:16 * g + 16, k] = col
+    assert not np.any(W[N:] != 0)
+    return W[:N]
+
+
+@pytest.mark.parametrize("N,K,sp", [(130, 70, 0.8), (512, 512, 0.95), (1536, 512, 0.975), (512, 2048, 0.95), (5, 3, 0.5), (48, 1030, 0.9)])
+def test_gu16_builder_round_trip(L, N, K, sp):
+    """The GU16 builder (one wave per group of 16 outputs and chunk of 512 inputs) reproduces the bf16 weights exactly,
+    from fp32 and bf16 sources, two blocks in one plan; format invariants checked by the decoder above."""
+    from sparse_image_captioning_amd.sparse import SparsePlan
+    g = torch.Generator().manual_seed(N + K)
+    Ws = []
+    for i in range(2):
+        W = rnd(N, K, seed=1 + i, scale=0.2) * (torch.rand(N, K, generator=g) >= sp).float()
+        W[N // 2] = 0.0
+        Ws.append(W)
+    dense = torch.cat([Ws[0].reshape(-1), torch.zeros(40), Ws[1].reshape(-1)])
+    plan = SparsePlan([dict(offset=0, N=N, K=K, ld=K), dict(offset=N * K + 40, N=N, K=K, ld=K)], L.SP_GU16, "cuda")
+    for src in (dev(dense), dev(dense).bfloat16()):
+        plan.stream.fill_(7.0); plan.chunk_ptr.fill_(-1)
+        plan.build(src)
+        for bi in range(2):
+            np.testing.assert_array_equal(_gu_to_dense(plan, bi), Ws[bi].bfloat16().float().numpy())
+        assert plan.nnz == sum(int((w.bfloat16() != 0).sum()) for w in Ws)
+
+
 @pytest.mark.parametrize("eb", [4, 8])
 @pytest.mark.parametrize("N,K,sp", [(130, 70, 0.8), (512, 512, 0.95), (1536, 512, 0.95), (600, 2048, 0.97), (5, 3, 0.5)])
 def test_ell_builder_round_trip(L, eb, N, K, sp):
     """The device builder (count / order / fill) reproduces the non-zeros of the dense block exactly: columns ordered by
     count inside each 512-column range, chunks padded to multiples of 4, two blocks in one plan, fp32 and bf16 sources."""
-    from sparse_image_captioning_amd.sparse import EllPlan, capacity_for
+    from sparse_image_captioning_amd.sparse import SparsePlan, capacity_for
+    fmt = L.SP_ELL16 if eb == 4 else L.SP_ELL32
     g = torch.Generator().manual_seed(N + K)
     Ws = []
     for i in range(2):
@@ -610,7 +665,7 @@ def test_ell_builder_round_trip(L, eb, N, K, sp):
     off1 = N * K + 37
     blocks = [dict(offset=0, N=N, K=K, ld=K, capacity=capacity_for(N, K, 1.3 * (1 - sp) + 0.05)),
               dict(offset=off1, N=N, K=K, ld=K, capacity=capacity_for(N, K, 1.3 * (1 - sp) + 0.05))]
-    plan = EllPlan(blocks, eb, "cuda")
+    plan = SparsePlan(blocks, fmt, "cuda")
     for src in (dev(dense), dev(dense).bfloat16()):
         plan.stream.fill_(-1)
         plan.build(src)
@@ -622,7 +677,7 @@ def test_ell_builder_round_trip(L, eb, N, K, sp):
             cnt = plan.count.cpu().numpy()[bi * N:(bi + 1) * N]
             np.testing.assert_array_equal(cnt, (Ws[bi] != 0).sum(1).numpy())
     # a plan that is too small raises instead of silently dropping weights
-    small = EllPlan([dict(offset=0, N=N, K=K, ld=K, capacity=64)], eb, "cuda")
+    small = SparsePlan([dict(offset=0, N=N, K=K, ld=K, capacity=64)], fmt, "cuda")
     small.build(dev(dense))
     if int((Ws[0] != 0).sum()) > 64:
         with pytest.raises(Exception):
@@ -630,21 +685,23 @@ def test_ell_builder_round_trip(L, eb, N, K, sp):
 
 
 @pytest.mark.parametrize("xdt", [0, 1])
-@pytest.mark.parametrize("eb", [4, 8])
+@pytest.mark.parametrize("fmt", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K,sp", [(300, 130, 70, 0.8), (5120, 512, 512, 0.95), (100, 512, 2048, 0.95), (33, 2048, 512, 0.9),
-                                      (4000, 64, 600, 0.97), (1, 5, 3, 0.5), (900, 48, 1030, 0.9), (77, 1100, 512, 0.95)])
-def test_spmm_ell_vs_dense(L, xdt, eb, M, N, K, sp):
-    """ortk_spmm_ell == F.linear on the zero-filled weight (scripts/eval_model.py:64-88, masked_layer.py:134-135) with the
+                                      (4000, 64, 600, 0.97), (1, 5, 3, 0.5), (900, 48, 1030, 0.9), (77, 1100, 512, 0.95),
+                                      (9000, 512, 1536, 0.95), (40000, 96, 512, 0.9)])
+def test_spmm_vs_dense(L, xdt, fmt, M, N, K, sp):
+    """ortk_spmm (all three formats) == F.linear on the zero-filled weight (scripts/eval_model.py:64-88, masked_layer.py:134-135) with the
     GEMM's fused epilogue (bias / ReLU / row scale / dropout / gate / residual), fp32 and bf16 activations and outputs, ragged
     row counts, column counts that are not multiples of 4, 64 or 512."""
-    from sparse_image_captioning_amd.sparse import EllPlan, capacity_for
+    from sparse_image_captioning_amd.sparse import SparsePlan, capacity_for
+    eb = 8 if fmt == L.SP_ELL32 else 4                         # 8: fp32 values and activations; 4: bf16
     g = torch.Generator().manual_seed(M + N + K)
     W = rnd(N, K, seed=1, scale=0.2) * (torch.rand(N, K, generator=g) >= sp).float()
     W[N // 2] = 0.0
     X, bias, resid, rows = rnd(M, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4), torch.rand(M, generator=g)
     gate = rnd(M, N, seed=5)
     Xd = dev(X.bfloat16() if xdt else X)
-    plan = EllPlan([dict(offset=0, N=N, K=K, ld=K, capacity=capacity_for(N, K, 1.3 * (1 - sp) + 0.05))], eb, "cuda")
+    plan = SparsePlan([dict(offset=0, N=N, K=K, ld=K, capacity=capacity_for(N, K, 1.3 * (1 - sp) + 0.05))], fmt, "cuda")
     plan.build(dev(W))
     plan.check_overflow()
     Wr = (W if eb == 8 else W.bfloat16().float()).double()

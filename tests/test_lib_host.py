@@ -56,7 +56,7 @@ def test_struct_sizes_match_header():
     #include <stdio.h>
     #include "ortk.h"
     int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ortk_config), sizeof(ortk_batch), sizeof(ortk_decode_opts),
-                           sizeof(ortk_gemm_args), sizeof(ortk_attn_args), sizeof(ortk_ell_block), sizeof(ortk_ell_plan),
+                           sizeof(ortk_gemm_args), sizeof(ortk_attn_args), sizeof(ortk_sparse_block), sizeof(ortk_sparse_plan),
                            sizeof(ortk_spmm_args)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
