@@ -100,29 +100,48 @@ def cpu_baseline(workload, cfg_dict, seconds=12.0):
                       f"oracle/ort_oracle.py on torch CPU fp32, {cores} threads"}
 
 
+PMC_TAG = "r02"      # profiles/<tag>_xe_b256_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
+
+
 def pmc_traffic(workload, precision, B):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command (profiles/README.md):
     2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction for 16-B/lane streaming reads), launch-weighted over the kernel's
-    instances.  None for workloads / sizes without a committed PMC profile."""
+    instances.  Returns (bytes | None, note): None for workloads / sizes without a committed PMC profile, and — loudly —
+    when the committed CSVs do not contain the kernels this build launches (a stale profile is not a measurement)."""
     if workload != "xe" or precision != "bf16" or B != 256:
-        return None
+        return None, "no PMC pass committed for this workload / size"
     import csv
     here = os.path.dirname(os.path.abspath(__file__))
+    want = ("gemm_bf16_glds_kernel<false, false", "gemm_bf16_dma256_kernel<false, false", "gemm_bf16_dma64_kernel")
     tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     n = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+    seen = set()
+    files = [f"{PMC_TAG}_xe_b256_pmc_fetch_size.csv", f"{PMC_TAG}_xe_b256_pmc_write_size.csv"]
     try:
-        for cname, fname in (("FETCH_SIZE", "r01_xe_b256_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_xe_b256_pmc_write_size.csv")):
+        for cname, fname in zip(("FETCH_SIZE", "WRITE_SIZE"), files):
             for r in csv.DictReader(open(os.path.join(here, "profiles", fname))):
-                fwd = ("gemm_bf16_glds_kernel<false, false" in r["kernel"] or "gemm_bf16_dma256_kernel<false, false" in r["kernel"]
-                       or "gemm_bf16_dma64_kernel" in r["kernel"])
-                if fwd and r["counter"] == cname:
+                hit = [w for w in want if w in r["kernel"]]
+                if hit and r["counter"] == cname:
+                    seen.add(hit[0])
                     tot[cname] += float(r["total"]); n[cname] += int(r["launches"])
-    except (OSError, KeyError, ValueError):
-        return None
-    if not n["FETCH_SIZE"] or not n["WRITE_SIZE"]:
-        return None
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"profiles/{files[0]} / {files[1]} unreadable ({type(e).__name__}): no traffic figure"
+    if not n["FETCH_SIZE"] or not n["WRITE_SIZE"] or "gemm_bf16_dma256_kernel<false, false" not in seen:
+        return None, f"STALE: profiles/{PMC_TAG}_xe_b256_pmc_*.csv do not contain the forward-layout GEMM kernels of this build"
     kb = 2.0 * tot["FETCH_SIZE"] / n["FETCH_SIZE"] + tot["WRITE_SIZE"] / n["WRITE_SIZE"]
-    return round(kb * 1024)
+    return round(kb * 1024), (f"HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from profiles/{PMC_TAG}_xe_b256_pmc_*.csv "
+                              "(separate rocprofv3 --pmc passes of this command), launch-weighted over the same kernels")
+
+
+# Parity evidence carried by the timed mode (tests/, -m gpu; bars in the test sources)
+PARITY = {
+    "fp32": "XE loss within 1e-4 of the reference goldens (observed 2e-6), every gradient within 2e-4*scale, greedy / beam-3 / "
+            "beam-5 tokens exact (tests/test_gpu_model.py: *_vs_reference_golden, full size: test_full_size_config1_*)",
+    "bf16": "timed mode: bf16 MFMA operands, fp32 accumulate / soft-max / LayerNorm / residual / optimizer; XE loss within "
+            "2e-2, gradients within 5 % relative L2 of the fp32 path (test_mixed_precision_gradients_track_fp32_gradients), "
+            "teacher-forced log-prob error of the decode <= 0.1 over 64 images (test_bf16_decode_logprob_bound), bench-size "
+            "determinism / permutation / fused-criterion properties (test_xe_step_at_bench_size_properties)",
+}
 
 
 def launch_command(n, argv, port):
@@ -297,25 +316,44 @@ def main():
         ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
         tot_ms = sum(v[1] for v in per_key.values())
         tot_fl = sum(v[2] for v in per_key.values())
-        roofline = {"bound": "mfma",
-                    "kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> / gemm_bf16_dma64_kernel (k-contiguous operands: forward X*W^T, and dY*W on transposed bf16 weight copies; LDS-DMA pipeline)" if args.precision == "bf16"
-                               else "gemm_f32_kernel<false,false> (forward X*W^T)"),
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
-                    "algorithmic_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3),
-                    "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
-                                         "ms_per_step": round(tot_ms, 3)},
-                    "traffic": pmc_traffic(args.workload, args.precision, B),
-                    "algorithmic_bytes_per_launch": round(by.value / max(n0, 1)),
-                    "traffic_note": "HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_xe_b256_pmc_*.csv "
-                                    "(separate rocprofv3 --pmc passes of this command), launch-weighted over the same kernels"}
+        traffic, traffic_note = pmc_traffic(args.workload, args.precision, B)
+        gemm = {"kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> / gemm_bf16_dma64_kernel (k-contiguous operands: forward X*W^T, and dY*W on transposed bf16 weight copies; LDS-DMA pipeline)" if args.precision == "bf16"
+                           else "gemm_f32_kernel<false,false> (forward X*W^T)"),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
+                "algorithmic_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3),
+                "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
+                                     "ms_per_step": round(tot_ms, 3)},
+                "traffic": traffic, "algorithmic_bytes_per_launch": round(by.value / max(n0, 1)), "traffic_note": traffic_note}
+        if decode or use_csr:
+            # the 95 %-sparse step and the cached decode are HBM-bound.  Algorithmic bytes: decode =
+            # 25.7 MB per image (self-KV reads 10.5 + cross-KV 8.0 + logits 7.2) + the weights once per step (18 steps:
+            # 110.9 MB dense bf16, or 4 bytes per non-zero); sparse XE step = activations of the dense step (the bytes
+            # ortk_prof_collect_bytes sums over the GEMM launches of one step) with 4 bytes per non-zero for the weights.
+            nnz_bytes = 2.77e6 * 4
+            if decode:
+                algo = B * 25.7e6 + config.max_seq_length * (nnz_bytes if sparse else 110.9e6)
+            else:
+                algo = by.value + 3 * nnz_bytes
+            gbs = algo / (ms_per_step * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "whole step (all launches): the path is bandwidth-bound as a whole",
+                        "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                        "algorithmic_bytes_per_step": round(algo), "traffic": None,
+                        "dense_gemm_launches_of_the_step": gemm}
+        else:
+            roofline = dict(gemm, bound="mfma")
+            roofline = {k: roofline[k] for k in ["bound"] + [k for k in gemm]}
         if not decode:
-            step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3 * (0.05 if sparse else 1.0)
-            roofline["whole_step"] = {"algorithmic_tflop": round(step_tflop, 3),
+            # dense-equivalent work of the step (6.354 GFLOP forward per image, x3).  For sparse_xe this is the work
+            # the masked DENSE GEMMs execute (and the weight gradients always do); the sparse products touch 5 % of it.
+            step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3
+            roofline["whole_step"] = {"dense_equivalent_tflop": round(step_tflop, 3),
                                       "achieved_tflops": round(step_tflop / (ms_per_step * 1e-3), 2),
                                       "frac_of_peak": round(step_tflop / (ms_per_step * 1e-3) / peak, 4)}
         cfgname = {"xe": "ORT dense, batch 256 images x 5 captions, teacher-forcing XE fwd+bwd+Adam (BASELINE configs[1])",
-                   "sparse_xe": "ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; masked dense GEMM)",
+                   "sparse_xe": ("ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; forward and data "
+                                 "gradients as sparse products, weight gradients dense)" if use_csr else
+                                 "ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; masked dense GEMM)"),
                    "scst": "ORT dense SCST: greedy + 5 multinomial rollouts + teacher-forced update (BASELINE configs[3])",
                    "decode": "ORT dense, cached-KV beam-5 decode, 1024 images",
                    "sparse_decode": "ORT 95% sparse, cached-KV beam-5 decode, 1024 images (BASELINE configs[4])"}[args.workload]
@@ -326,8 +364,8 @@ def main():
                           "parallelism": f"dp{world}" if world > 1 else "single",
                           "storage": ("fp32 master weights / residual stream / logits; MFMA-operand tensors stored bf16; fp32 accumulate"
                                       if args.precision == "bf16" else "fp32"),
-                          "sparse_kernels": "sorted-ELL (ortk_spmm_ell)" if use_csr else None},
-               "roofline": roofline}
+                          "sparse_kernels": os.environ.get("ORTK_SPARSE_FORMAT", "ell16") + " (ortk_spmm)" if use_csr else None},
+               "roofline": roofline, "parity": PARITY}
         if not args.no_cpu_baseline and world == 1:
             from sparse_image_captioning_amd.utils.config import ORT_DEFAULTS
             out["cpu_baseline"] = cpu_baseline(args.workload, dict(ORT_DEFAULTS))

@@ -7,5 +7,5 @@ for r in rows:
     key = (name, r["Counter_Name"])
     agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
 print("kernel,counter,launches,mean_per_launch,total")
-for (name, c), (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+for (name, c), (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:200]:
     print(f'"{name}",{c},{n},{tot/n:.1f},{tot:.1f}')

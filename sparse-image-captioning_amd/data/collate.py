@@ -42,8 +42,9 @@ def _lib():
 
 
 def _empty(shape, dtype):
-    """Pinned when a GPU is there to copy to (the batch's only consumer), pageable otherwise."""
-    pin = torch.cuda.device_count() > 0
+    """Pinned when a GPU is there to copy to AND this is the main process; pageable inside a DataLoader worker (the batch is
+    copied into shared memory on its way back, so pinning there is lost work — use DataLoader(pin_memory=True) instead)."""
+    pin = torch.cuda.device_count() > 0 and torch.utils.data.get_worker_info() is None
     try:
         return torch.empty(shape, dtype=dtype, pin_memory=pin)
     except RuntimeError:
@@ -84,102 +85,109 @@ def pad_seqs(seqs, pad=0):
 
 
 class ListDataset(torch.utils.data.Dataset):
-    """Basically a `list` (collate.py:31-41)."""
+    """A list behind the Dataset protocol (what the reference's loaders wrap, collate.py:31-41)."""
 
     def __init__(self, data):
         self.data = data
 
-    def __getitem__(self, index):
-        return self.data[index]
-
     def __len__(self):
         return len(self.data)
 
+    def __getitem__(self, index):
+        return self.data[index]
 
-class UpDownCollate:
-    """collate.py:77-188."""
+
+def _load_features(path):
+    """(..., F) array on disk -> (regions, F) float32."""
+    arr = np.load(path)
+    return np.asarray(arr, dtype=np.float32).reshape(-1, arr.shape[-1])
+
+
+def _load_boxes(path):
+    return np.asarray(np.load(path), dtype=np.float32)
+
+
+class _RegionBatcher:
+    """Shared machinery of the two collate classes below.
+
+    A subclass lists its per-image region arrays in ``SOURCES``: ``(batch key, config attribute holding the directory,
+    default sub-directory of <dataset_dir>/bu, loader, emit a validity mask?)``.  One call turns a list of dataset items
+    ``(image_path, image_id, caption, all_captions, gts)`` into the batch dict of the reference's collate functions
+    (data/collate.py:119-169, 202-216): for every source the arrays ``<dir>/<image_id>.npy`` zero-padded to the longest image
+    of the batch, plus ``seq_per_img`` captions per image drawn with ``random.sample`` in item order (same draws as the
+    reference for a seeded ``random``), tokenised and padded with 0."""
+
+    SOURCES = ()
 
     def __init__(self, config, tokenizer, cache_dict=None):
-        self.config = config
-        self.tokenizer = tokenizer
-        import multiprocessing.managers as mp
-        self.cache_dict = cache_dict if isinstance(cache_dict, mp.DictProxy) else None
+        self.config, self.tokenizer = config, tokenizer
+        from multiprocessing.managers import DictProxy
+        # only a Manager().dict() is shared between DataLoader workers; anything else would silently be a per-worker copy
+        self.cache_dict = cache_dict if isinstance(cache_dict, DictProxy) else None
         if self.cache_dict is not None:
-            logger.info(f"{self.__class__.__name__}: Using multiprocessing cache dict.")
-        if self.config.input_att_dir is None:
-            self.config.input_att_dir = self.join_default_bu_dir("cocobu_att")
-        assert self.config.seq_per_img > 0, "`self.config.seq_per_img` should be greater than 0"
+            logger.info("%s: region arrays are cached in a multiprocessing dict", type(self).__name__)
+        for _, attr, subdir, _, _ in self.SOURCES:
+            if getattr(config, attr, None) is None:
+                setattr(config, attr, self.join_default_bu_dir(subdir))
+        assert config.seq_per_img > 0, "`self.config.seq_per_img` should be greater than 0"
 
     def join_default_bu_dir(self, dirname):
         return os.path.join(self.config.dataset_dir, "bu", dirname)
 
-    def _cache_data(self, key, key_value_fn):
-        if self.cache_dict is None:
-            return key_value_fn(key)
+    def _fetch(self, path, loader):
+        """Load through the shared cache; new entries are only added while more than max(20 %, cache_min_free_ram) of the
+        host memory is free (the reference's guard, collate.py:93-107)."""
+        cache = self.cache_dict
+        if cache is None:
+            return loader(path)
+        if path in cache:
+            return cache[path]
+        arr = loader(path)
         try:
-            data = self.cache_dict[key]
-        except KeyError:
-            data = key_value_fn(key)
-            try:
-                import psutil
-                vm = psutil.virtual_memory()
-                free = vm.available / vm.total
-            except Exception:   # pragma: no cover
-                free = 1.0
-            if free > max(0.2, getattr(self.config, "cache_min_free_ram", 0.2)):
-                self.cache_dict[key] = data
-        return data
-
-    @staticmethod
-    def _get_att_feats(path):
-        data = np.load(path)
-        return data.reshape(-1, data.shape[-1]).astype("float32")
+            import psutil
+            vm = psutil.virtual_memory()
+            headroom = vm.available / vm.total
+        except Exception:   # pragma: no cover
+            headroom = 1.0
+        if headroom > max(0.2, getattr(self.config, "cache_min_free_ram", 0.2)):
+            cache[path] = arr
+        return arr
 
     def __call__(self, batch):
-        config = self.config
-        image_paths, image_ids, captions, all_captions, all_gts = zip(*batch)
-        att_feats = [self._cache_data(os.path.join(config.input_att_dir, f"{imgid}.npy"), self._get_att_feats) for imgid in image_ids]
-        labels = [
-            np.asarray(self.tokenizer.encode(_, add_bos_eos=True, max_seq_length=config.max_seq_length), dtype=np.int64)
-            for gt in all_captions
-            for _ in random.sample(gt, min(config.seq_per_img, len(gt)))
-        ]
-        feats, att_masks = pad_rows(att_feats, want_mask=True)
-        seqs, masks = pad_seqs(labels, 0)
-        return {"att_feats": feats, "att_masks": att_masks, "seqs": seqs, "masks": masks, "gts": all_gts,
-                "image_paths": image_paths, "image_ids": image_ids}
+        cfg = self.config
+        image_paths, image_ids, _captions, all_captions, all_gts = zip(*batch)
+        out = {}
+        for key, attr, _, loader, with_mask in self.SOURCES:
+            folder = getattr(cfg, attr)
+            arrays = [self._fetch(os.path.join(folder, f"{i}.npy"), loader) for i in image_ids]
+            if with_mask:
+                out[key], out["att_masks"] = pad_rows(arrays, want_mask=True)
+            else:
+                out[key] = pad_rows(arrays)
+        token_rows = []
+        for caps in all_captions:                      # item order, then sample order: the reference's comprehension
+            for text in random.sample(caps, min(cfg.seq_per_img, len(caps))):
+                ids = self.tokenizer.encode(text, add_bos_eos=True, max_seq_length=cfg.max_seq_length)
+                token_rows.append(np.asarray(ids, dtype=np.int64))
+        out["seqs"], out["masks"] = pad_seqs(token_rows, 0)
+        out["gts"], out["image_paths"], out["image_ids"] = all_gts, image_paths, image_ids
+        return out
 
-    @staticmethod
-    def add_argparse_args(parser):
-        parser.add_argument("--max_seq_length", type=int, default=18, help="int: Maximum sequence length including <BOS> and <EOS>.")
-        parser.add_argument("--seq_per_img", type=int, default=5, help="Number of captions to sample for each image during training.")
-        parser.add_argument("--input_att_dir", type=str, default=None,
-                            help="str: path to the directory containing the preprocessed att feats")
+    @classmethod
+    def add_argparse_args(cls, parser):
+        """The reference's data flags (names and defaults are the contract: collate.py:171-188, 218-227)."""
+        parser.add_argument("--max_seq_length", type=int, default=18, help="caption length limit, <BOS> and <EOS> included")
+        parser.add_argument("--seq_per_img", type=int, default=5, help="captions drawn per image and training step")
+        for _, attr, subdir, _, _ in cls.SOURCES:
+            parser.add_argument("--" + attr, type=str, default=None,
+                                help=f"directory of the per-image <image_id>.npy arrays (default: <dataset_dir>/bu/{subdir})")
 
 
-class ObjectRelationCollate(UpDownCollate):
-    """collate.py:191-227."""
+class UpDownCollate(_RegionBatcher):
+    """Bottom-up region features only (reference ``UpDownCollate``, collate.py:77-188)."""
+    SOURCES = (("att_feats", "input_att_dir", "cocobu_att", _load_features, True),)
 
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        if self.config.input_rel_box_dir is None:
-            self.config.input_rel_box_dir = self.join_default_bu_dir("cocobu_box_relative")
 
-    @staticmethod
-    def _get_boxes(path):
-        return np.load(path).astype("float32")
-
-    def __call__(self, batch):
-        config = self.config
-        image_ids = list(zip(*batch))[1]
-        data = super().__call__(batch)
-        boxes = [self._cache_data(os.path.join(config.input_rel_box_dir, f"{imgid}.npy"), self._get_boxes) for imgid in image_ids]
-        data["boxes"] = pad_rows(boxes)
-        return data
-
-    @staticmethod
-    def add_argparse_args(parser):
-        UpDownCollate.add_argparse_args(parser)
-        parser.add_argument("--input_rel_box_dir", type=str, default=None,
-                            help="str: this directory contains the bounding boxes in relative coordinates "
-                                 "for the corresponding image features in --input_att_dir")
+class ObjectRelationCollate(_RegionBatcher):
+    """Region features + relative boxes (reference ``ObjectRelationCollate``, collate.py:191-227)."""
+    SOURCES = UpDownCollate.SOURCES + (("boxes", "input_rel_box_dir", "cocobu_box_relative", _load_boxes, False),)

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import register_model
 from .. import _lib as L
+from ..data.collate import ObjectRelationCollate
 
 
 class _Node(nn.Module):
@@ -23,17 +24,6 @@ class _Node(nn.Module):
 
     def forward(self, *a, **k):  # pragma: no cover
         raise RuntimeError("structural node: compute happens in RelationTransformerModel")
-
-
-class ObjectRelationBatchLayout:
-    """Documents the batch dict the model consumes (reference ``data/collate.py:119-169,202-216``); the data
-    side (feature files, tokenizer) is out of scope, so this is NOT a collate function."""
-    KEYS = ("att_feats", "att_masks", "boxes", "seqs", "masks")
-
-    @staticmethod
-    def add_argparse_args(parser):
-        parser.add_argument("--seq_per_img", type=int, default=5)
-        parser.add_argument("--max_seq_length", type=int, default=18)
 
 
 def parse_share_layer(value, n_layers, what):
@@ -136,7 +126,7 @@ class CaptionModelBase(nn.Module):
 
 @register_model("relation_transformer")
 class RelationTransformerModel(CaptionModelBase):
-    COLLATE_FN = ObjectRelationBatchLayout
+    COLLATE_FN = ObjectRelationCollate     # what the caller builds its data loaders from (utils/training.py:78-81)
     DROPOUT = 0.1          # make_model(dropout=0.1), relation_transformer.py:306
     MASKED = False
     NO_BOX = False         # True in the plain `transformer` subclass (models/transformer.py)
@@ -634,7 +624,7 @@ class RelationTransformerModel(CaptionModelBase):
     @staticmethod
     def add_argparse_args(parser):
         """Model flags of transformer.py:563-614 and relation_transformer.py:414-426."""
-        ObjectRelationBatchLayout.add_argparse_args(parser)
+        RelationTransformerModel.COLLATE_FN.add_argparse_args(parser)      # the data flags, as the reference does (relation_transformer.py:417)
         parser.add_argument("--d_model", type=int, default=512)
         parser.add_argument("--dim_feedforward", type=int, default=2048)
         parser.add_argument("--num_layers", type=int, default=6)

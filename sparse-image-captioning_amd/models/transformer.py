@@ -13,22 +13,13 @@ Call contract (transformer.py:666-676,705-710): ``model(att_feats=, att_masks=, 
 import torch
 
 from . import register_model
+from ..data.collate import UpDownCollate
 from .relation_transformer import RelationTransformerModel
-
-
-class UpDownBatchLayout:
-    """Batch dict of the reference's ``UpDownCollate`` (data/collate.py:119-169): no boxes."""
-    KEYS = ("att_feats", "att_masks", "seqs", "masks")
-
-    @staticmethod
-    def add_argparse_args(parser):
-        parser.add_argument("--seq_per_img", type=int, default=5)
-        parser.add_argument("--max_seq_length", type=int, default=18)
 
 
 @register_model("transformer")
 class TransformerModel(RelationTransformerModel):
-    COLLATE_FN = UpDownBatchLayout
+    COLLATE_FN = UpDownCollate     # no boxes in the batch dict (data/collate.py:77-188)
     NO_BOX = True
 
     def _prepare(self, att_feats, boxes, att_masks):

@@ -67,3 +67,31 @@ def test_pad_rows_edge_cases():
     assert seqs.tolist() == [[2, 5, 3, 0, 0], [2, 3, 0, 0, 0], [2, 9, 9, 9, 3]] and m.sum().item() == 10
     with pytest.raises(AssertionError):
         pad_rows([np.zeros((2, 3), np.float32), np.zeros((2, 4), np.float32)])
+
+
+def test_collate_fn_of_every_registered_model_is_constructible_like_the_caller_does():
+    """utils/training.py:78-81 builds the loaders with ``model_cls.COLLATE_FN(config=..., tokenizer=..., cache_dict=...)``;
+    ``register_into`` puts the classes (with that attribute) into the reference's registry."""
+    import types
+    import sparse_image_captioning_amd as P
+    from sparse_image_captioning_amd.data.collate import ObjectRelationCollate, UpDownCollate
+    cfg = types.SimpleNamespace(dataset_dir="/data", input_att_dir=None, input_rel_box_dir=None, seq_per_img=5, max_seq_length=18)
+    want = {"relation_transformer": ObjectRelationCollate, "relation_transformer_prune": ObjectRelationCollate, "transformer": UpDownCollate}
+    for name, cls in want.items():
+        model_cls = P.get_model(name)
+        assert model_cls.COLLATE_FN is cls
+        c = model_cls.COLLATE_FN(config=cfg, tokenizer=object(), cache_dict=None)
+        assert callable(c) and cfg.input_att_dir == "/data/bu/cocobu_att"
+    assert cfg.input_rel_box_dir == "/data/bu/cocobu_box_relative"
+    ref = types.SimpleNamespace(MODEL_REGISTRY={"relation_transformer": "theirs"})
+    P.models.register_into(ref)
+    assert ref.MODEL_REGISTRY["relation_transformer"] == "theirs"
+    assert ref.MODEL_REGISTRY["relation_transformer_hip"].COLLATE_FN is ObjectRelationCollate
+    assert ref.MODEL_REGISTRY["transformer_hip"].COLLATE_FN is UpDownCollate
+    import argparse
+    ap = argparse.ArgumentParser()
+    P.get_model("relation_transformer").add_argparse_args(ap)
+    ns = ap.parse_args([])
+    assert ns.seq_per_img == 5 and ns.max_seq_length == 18 and ns.input_rel_box_dir is None and ns.d_model == 512
+    with __import__("pytest").raises(ValueError):
+        P.get_model("nope")
