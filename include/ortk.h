@@ -396,6 +396,12 @@ int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, floa
 int ortk_mask_apply(const float* w, const float* m, float* w_eff, int64_t n, int32_t mode, uint32_t seed, ortk_stream stream);
 int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw, float* dm, int64_t n, int32_t mode,
                   uint32_t seed, const float* extra_coef_dev, ortk_stream stream);
+/* Mode 1 with EXPLICIT uniforms draws[i] in [0,1) in place of the counter hash: s = draws[i] < sigmoid(m[i]), torch.bernoulli's
+ * definition for a given uniform (pruning/sampler.py:10-17) — lets a caller (and the parity tests, with the reference's own
+ * draws) reproduce a given Bernoulli mask sample in the forward and in the straight-through backward. */
+int ortk_mask_apply_draws(const float* w, const float* m, const float* draws, float* w_eff, int64_t n, ortk_stream stream);
+int ortk_mask_bwd_draws(const float* dw_eff, const float* w, const float* m, const float* draws, float* dw, float* dm, int64_t n,
+                        const float* extra_coef_dev, ortk_stream stream);
 /* The weight blocks the executor multiplies by (packed Q|K|V, the all-layer cross-attention K|V block, ...): block i
  * is the (N,K) row-major matrix at arena offset *offset.  Returns the number of blocks when i < 0. */
 int ortk_linear_block(const ortk_config* cfg, int32_t i, int64_t* offset, int32_t* N, int32_t* K);

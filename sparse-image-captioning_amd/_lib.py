@@ -142,6 +142,8 @@ SIGNATURES = {
     "ortk_mask_apply": (_I32, [_P, _P, _P, _I64, _I32, _U32, _P]),
     "ortk_mask_bwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _U32, _P, _P]),
     "ortk_mask_count": (_I32, [_P, _I64, _I32, _P, _P]),
+    "ortk_mask_apply_draws": (_I32, [_P, _P, _P, _P, _I64, _P]),
+    "ortk_mask_bwd_draws": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "ortk_decode_step_workspace_bytes": (_SZ, [_CFG, _I32]),
     "ortk_project_memory": (_I32, [_CFG, _P, _P, _I64, _P, _SZ, _P, _P]),
     "ortk_decode_step": (_I32, [_CFG, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _SZ, _P, _I64, _P]),

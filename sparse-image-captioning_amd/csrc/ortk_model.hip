@@ -11,6 +11,8 @@
 //   * bias / ReLU / dropout / residual are GEMM epilogues; the criterion never materialises log-probs.
 #include <string>
 #include <vector>
+#include <mutex>
+#include <utility>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -265,10 +267,8 @@ struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[64];
     int next = 0;
-    bool ok = false, tried = false;
+    bool ok = false;
     bool init() {
-        if (tried) return ok;
-        tried = true;
         const char* e = getenv("ORTK_SIDE_STREAM");
         if (e && atoi(e) == 0) return false;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
@@ -278,7 +278,21 @@ struct SideStream {
     }
     hipEvent_t take() { hipEvent_t e = ev[next]; next = (next + 1) & 63; return e; }
 };
-static SideStream g_side;
+// One side stream (and event ring) per (device, caller stream): two models stepping from two host threads on two streams
+// never share one — the C-ABI's "thread-safe per stream" holds for the executor too.  Created on first use, kept for the
+// life of the process (a handful of entries: one per stream a host ever trains on).
+static SideStream* side_for(hipStream_t caller) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, hipStream_t>, SideStream*>> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : table) if (e.first.first == dev && e.first.second == caller) return e.second->ok ? e.second : nullptr;
+    SideStream* ss = new SideStream();
+    ss->init();
+    table.push_back({{dev, caller}, ss});
+    return ss->ok ? ss : nullptr;
+}
 
 struct Ctx {
     const ortk_config* cfg; hipStream_t s; int prec; uint64_t seed; bool train;
@@ -288,7 +302,8 @@ struct Ctx {
     const ortk_sparse_plan* ell_f = nullptr;        // optional sparse plan over (N,K) weight blocks: forward-layout products
     const ortk_sparse_plan* ell_b = nullptr;        // ... over their transposed copies: data-gradient products (mixed precision)
     const void* W16T = nullptr;                  // transposed bf16 weight blocks (training workspaces, mixed precision)
-    bool use_side = false;                       // backward only: weight-gradient GEMMs on g_side
+    bool use_side = false;                       // weight-gradient GEMMs (and other independent work) on `side`
+    SideStream* side = nullptr;                  // the side stream of this call's (device, caller stream)
     struct Pend { const void* buf; hipEvent_t done; };
     mutable Pend pend[8] = {};                   // buffers a forked, not yet joined wgrad reads
     mutable hipEvent_t last_done = nullptr;
@@ -307,19 +322,19 @@ struct Ctx {
     // generic fork / mark / wait for other independent work (forward: geometry bias, cross-attention K/V projection;
     // backward: token-embedding and geometry-bias gradients)
     int fork() const {                                   // the side stream waits for everything queued on `s` so far
-        hipEvent_t e = g_side.take();
-        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(g_side.s, e, 0) != hipSuccess) return ORTK_EINVAL;
+        hipEvent_t e = side->take();
+        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(side->s, e, 0) != hipSuccess) return ORTK_EINVAL;
         return 0;
     }
     int side_mark(hipEvent_t* out) const {               // completion point of the work queued on the side stream so far
-        hipEvent_t e = g_side.take();
-        if (hipEventRecord(e, g_side.s) != hipSuccess) return ORTK_EINVAL;
+        hipEvent_t e = side->take();
+        if (hipEventRecord(e, side->s) != hipSuccess) return ORTK_EINVAL;
         last_done = e;
         if (out) *out = e;
         return 0;
     }
     int wait_ev(hipEvent_t e) const { return (e && hipStreamWaitEvent(s, e, 0) != hipSuccess) ? ORTK_EINVAL : 0; }
-    Ctx on_side() const { Ctx t = *this; t.s = g_side.s; t.use_side = false; return t; }
+    Ctx on_side() const { Ctx t = *this; t.s = side->s; t.use_side = false; return t; }
     int join() const {                                   // everything forked so far (the side stream runs in order)
         if (last_done) { if (hipStreamWaitEvent(s, last_done, 0) != hipSuccess) return ORTK_EINVAL; last_done = nullptr; }
         for (auto& p : pend) p.buf = nullptr;
@@ -428,11 +443,11 @@ static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, cons
     a.splitk = (int)std::max<int64_t>(1, std::min(sk, max_sk));
     if (c.prec) a.colsum = db;             // bias gradient fused into the wgrad kernel (bf16-MFMA path)
     if (c.use_side) {
-        hipEvent_t ready = g_side.take(), done = g_side.take();
-        if (hipEventRecord(ready, c.s) != hipSuccess || hipStreamWaitEvent(g_side.s, ready, 0) != hipSuccess) return ORTK_EINVAL;
-        TRY(ortk_gemm(&a, (ortk_stream)g_side.s));
-        if (db && !c.prec) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)g_side.s));
-        if (hipEventRecord(done, g_side.s) != hipSuccess) return ORTK_EINVAL;
+        hipEvent_t ready = c.side->take(), done = c.side->take();
+        if (hipEventRecord(ready, c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, ready, 0) != hipSuccess) return ORTK_EINVAL;
+        TRY(ortk_gemm(&a, (ortk_stream)c.side->s));
+        if (db && !c.prec) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)c.side->s));
+        if (hipEventRecord(done, c.side->s) != hipSuccess) return ORTK_EINVAL;
         c.reads(dY, done);
         return 0;
     }
@@ -504,7 +519,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
         // no geometry bias
     } else if (c.use_side) {
         TRY(c.fork());
-        TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)g_side.s));
+        TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.side->s));
         TRY(c.side_mark(&box_done));
     } else {
         TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s));
@@ -631,7 +646,8 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const int64_t Me = w.Me, Md = w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
-    c.use_side = c.adt == ORTK_BF16 && !ortk_prof_active() && g_side.init();
+    c.side = (c.adt == ORTK_BF16 && !ortk_prof_active()) ? side_for(c.s) : nullptr;
+    c.use_side = c.side != nullptr;
     const AttMode am = att_mode(cfg->share_att_dec);
     const int64_t cw = o.cw, cv = o.cv;
     // Self-attention sublayer (and the cross-attention query projection) of decoder layer l, on context `cx`'s stream.
@@ -741,7 +757,8 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
     c.W16T = w.w16t;
     if (cfg->precision) c.ell_b = cfg->sparse_bwd;      // built by the forward of this step from the transposed bf16 copies
-    c.use_side = c.adt == ORTK_BF16 && !ortk_prof_active() && g_side.init();
+    c.side = (c.adt == ORTK_BF16 && !ortk_prof_active()) ? side_for(c.s) : nullptr;
+    c.use_side = c.side != nullptr;
     float* G = grads;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
@@ -829,7 +846,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     // the embedding gradient (atomics into the 5 M-element table) only feeds the optimizer: beside the K/V projection GEMMs
     if (c.use_side) {
         TRY(c.fork());
-        TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), (ortk_stream)g_side.s));
+        TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), (ortk_stream)c.side->s));
         hipEvent_t e_done = nullptr;
         TRY(c.side_mark(&e_done));
         c.reads(dx, e_done);               // dx (w.ga / w.gb) is rewritten by the encoder half
@@ -887,7 +904,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         // only feeds the optimizer: beside the att_embed gradient
         if (c.use_side) {
             TRY(c.fork());
-            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, (ortk_stream)g_side.s));
+            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, (ortk_stream)c.side->s));
             TRY(c.side_mark(nullptr));
         } else {
             TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, stream));

@@ -42,29 +42,33 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // sample of element i under `mode`
-__device__ __forceinline__ float mask_sample(float m, int mode, uint32_t seed, uint64_t i) {
+// `draws` (optional, mode 1 only): explicit uniforms u[i] instead of the counter hash — the Bernoulli sample is then
+// u[i] < sigmoid(m[i]), exactly torch.bernoulli's definition for a given uniform (parity tests inject the reference's draws)
+__device__ __forceinline__ float mask_sample(float m, int mode, uint32_t seed, uint64_t i, const float* __restrict__ draws) {
     if (mode == 2) return m;
     const float pr = sigmoidf_(m);
     if (mode == 0) return rintf(pr);  // round-half-to-even like torch.round (logit 0 -> 0.5 -> 0)
+    if (draws) return draws[i] < pr ? 1.f : 0.f;
     const uint32_t h = ortk_mix32((uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32) * 0x85EBCA77u + seed);
     return ortk_u01(h) < pr ? 1.f : 0.f;
 }
 
 __global__ __launch_bounds__(256) void mask_apply_kernel(const float* __restrict__ w, const float* __restrict__ m,
-                                                         float* __restrict__ we, int64_t n, int mode, uint32_t seed) {
+                                                         float* __restrict__ we, int64_t n, int mode, uint32_t seed,
+                                                         const float* __restrict__ draws) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        we[i] = mask_sample(m[i], mode, seed, (uint64_t)i) * w[i];
+        we[i] = mask_sample(m[i], mode, seed, (uint64_t)i, draws) * w[i];
 }
 
 __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__ dwe, const float* __restrict__ w,
                                                        const float* __restrict__ m, float* __restrict__ dw, float* __restrict__ dm,
                                                        int64_t n, int mode, uint32_t seed,
-                                                       const float* __restrict__ extra_coef) {
+                                                       const float* __restrict__ extra_coef, const float* __restrict__ draws) {
     // extra_coef[0] = d(sparsity loss)/d(sample), the same for every mask element (pruning/prune.py:228-269)
     const float ec = extra_coef ? extra_coef[0] : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float g = dwe[i], mi = m[i];
-        const float s = mask_sample(mi, mode, seed, (uint64_t)i);
+        const float s = mask_sample(mi, mode, seed, (uint64_t)i, draws);
         if (dm) {
             float ds = g * w[i] + ec;                  // d/ds of (s*w) + sparsity-loss term
             if (mode != 2) { const float pr = sigmoidf_(mi); ds *= pr * (1.f - pr); }
@@ -107,7 +111,15 @@ extern "C" int ortk_mask_apply(const float* w, const float* m, float* w_eff, int
                                ortk_stream stream) {
     if (!w || !m || !w_eff || n < 0 || mode < 0 || mode > 2) return ORTK_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mask_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), w, m, w_eff, n, mode, seed);
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), w, m, w_eff, n, mode, seed, (const float*)nullptr);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_mask_apply_draws(const float* w, const float* m, const float* draws, float* w_eff, int64_t n, ortk_stream stream) {
+    if (!w || !m || !draws || !w_eff || n < 0) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), w, m, w_eff, n, 1, 0u, draws);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
@@ -116,7 +128,17 @@ extern "C" int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m
                              uint32_t seed, const float* extra_coef_dev, ortk_stream stream) {
     if (!dw_eff || !w || !m || !dw || n < 0 || mode < 0 || mode > 2) return ORTK_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), dw_eff, w, m, dw, dm, n, mode, seed, extra_coef_dev);
+    hipLaunchKernelGGL(mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), dw_eff, w, m, dw, dm, n, mode, seed, extra_coef_dev,
+                       (const float*)nullptr);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_mask_bwd_draws(const float* dw_eff, const float* w, const float* m, const float* draws, float* dw, float* dm,
+                                   int64_t n, const float* extra_coef_dev, ortk_stream stream) {
+    if (!dw_eff || !w || !m || !draws || !dw || n < 0) return ORTK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), dw_eff, w, m, dw, dm, n, 1, 0u, extra_coef_dev, draws);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -71,9 +71,38 @@ class RelationTransformerModel(PruningMixin, _Dense):
             self._weff = torch.empty_like(self._flat)
         if self._n_all > self._n_train:
             self._weff[self._n_train:].copy_(self._flat[self._n_train:])   # the `pe` buffer
-        L.check(lib.ortk_mask_apply(L.ptr(self._flat), L.ptr(self._mask_flat), L.ptr(self._weff), self._n_train,
-                                    self._mode(train), self._mask_seed(seed), L.stream_ptr()), "ortk_mask_apply")
+        draws = self._draws(train)
+        if draws is not None:
+            L.check(lib.ortk_mask_apply_draws(L.ptr(self._flat), L.ptr(self._mask_flat), L.ptr(draws), L.ptr(self._weff), self._n_train,
+                                              L.stream_ptr()), "ortk_mask_apply_draws")
+        else:
+            L.check(lib.ortk_mask_apply(L.ptr(self._flat), L.ptr(self._mask_flat), L.ptr(self._weff), self._n_train,
+                                        self._mode(train), self._mask_seed(seed), L.stream_ptr()), "ortk_mask_apply")
         return L.ptr(self._weff)
+
+    def set_mask_draws(self, draws):
+        """Explicit uniforms for the training-mode Bernoulli sample (``None`` = the counter hash): a dict ``mask name -> array``
+        with the mask's shape (or a flat arena-sized tensor).  The sample of a mask element is ``u < sigmoid(logit)``
+        (pruning/sampler.py:10-17 for a given uniform), in the forward and in the straight-through backward."""
+        if draws is None:
+            self._mask_draws = None
+            return
+        if isinstance(draws, dict):
+            flat = torch.zeros(self._n_train)
+            for e in self.named_weight_entries():
+                key = e["name"] + "_pruning_mask"
+                if e["kind"] == 1 and key in draws:
+                    flat[e["offset"]:e["offset"] + e["numel"]] = torch.as_tensor(draws[key], dtype=torch.float32).reshape(-1)
+            draws = flat
+        self._mask_draws = draws.to(self._flat.device).float().contiguous()
+
+    def _draws(self, train):
+        d = getattr(self, "_mask_draws", None)
+        if d is None or not train or not self._supermask:
+            return None
+        if d.device != self._flat.device:
+            d = self._mask_draws = d.to(self._flat.device)
+        return d
 
     def _eff_params_tensor(self):
         return self._weff
@@ -91,9 +120,14 @@ class RelationTransformerModel(PruningMixin, _Dense):
             sparsity_coef, self._sparsity_coef = self._sparsity_coef, None
         need_dm = self._supermask or self.mask_type == prune.SNIP
         dm = torch.zeros(self._n_train, device=gflat.device) if need_dm else None
-        L.check(lib.ortk_mask_bwd(L.ptr(gflat), L.ptr(self._flat), L.ptr(self._mask_flat), L.ptr(gflat), L.ptr(dm),
-                                  self._n_train, self._mode(train), self._mask_seed(seed), L.ptr(sparsity_coef),
-                                  L.stream_ptr()), "ortk_mask_bwd")
+        draws = self._draws(train)
+        if draws is not None:
+            L.check(lib.ortk_mask_bwd_draws(L.ptr(gflat), L.ptr(self._flat), L.ptr(self._mask_flat), L.ptr(draws), L.ptr(gflat), L.ptr(dm),
+                                            self._n_train, L.ptr(sparsity_coef), L.stream_ptr()), "ortk_mask_bwd_draws")
+        else:
+            L.check(lib.ortk_mask_bwd(L.ptr(gflat), L.ptr(self._flat), L.ptr(self._mask_flat), L.ptr(gflat), L.ptr(dm),
+                                      self._n_train, self._mode(train), self._mask_seed(seed), L.ptr(sparsity_coef),
+                                      L.stream_ptr()), "ortk_mask_bwd")
         out = []
         for e in self.named_weight_entries():
             sl = slice(e["offset"], e["offset"] + e["numel"])

@@ -187,9 +187,15 @@ class NativeTrainer:
                     coef, m._sparsity_coef = m._sparsity_coef, None
                     if self.world > 1:
                         coef = coef / self.world     # identical on every rank; the all-reduce below sums it back
-            L.check(L.lib().ortk_mask_bwd(L.ptr(self.grads), L.ptr(m._flat), L.ptr(m._mask_flat), L.ptr(self.grads),
-                                          L.ptr(self.dm) if self.train_masks else None, m._n_train, m._mode(train),
-                                          m._mask_seed(seed), L.ptr(coef), L.stream_ptr()), "ortk_mask_bwd")
+            draws = m._draws(train)
+            if draws is not None:
+                L.check(L.lib().ortk_mask_bwd_draws(L.ptr(self.grads), L.ptr(m._flat), L.ptr(m._mask_flat), L.ptr(draws), L.ptr(self.grads),
+                                                    L.ptr(self.dm) if self.train_masks else None, m._n_train, L.ptr(coef),
+                                                    L.stream_ptr()), "ortk_mask_bwd_draws")
+            else:
+                L.check(L.lib().ortk_mask_bwd(L.ptr(self.grads), L.ptr(m._flat), L.ptr(m._mask_flat), L.ptr(self.grads),
+                                              L.ptr(self.dm) if self.train_masks else None, m._n_train, m._mode(train),
+                                              m._mask_seed(seed), L.ptr(coef), L.stream_ptr()), "ortk_mask_bwd")
             if self.train_masks and self.mask_active is not None:
                 self.dm.mul_(self.mask_active)
         self._allreduce()

@@ -671,6 +671,64 @@ def test_prune_binary_masks_vs_reference_golden(P, golden, mtype):
         assert abs(logp.double().abs().sum().item() - float(g3[f"{mtype}/logp_sum_abs"])) / float(g3[f"{mtype}/logp_sum_abs"]) < 1e-5
 
 
+def test_supermask_train_mode_and_mask_optimizer_vs_reference_golden(P, golden):
+    """Train-mode supermask parity ON THE HIP PATH with the reference's own Bernoulli draws (ortk_mask_apply_draws /
+    ortk_mask_bwd_draws): (a) golden G3 train/* — sampled forward, loss, gradients through the straight-through sampler
+    (pruning/sampler.py:10-17, masked_layer.py:97-104); (b) golden G13 — two native training steps with the reference's two
+    optimizer groups (scripts/train_n_prune_transformer.py:67-82: weights under Noam-Adam, ACTIVE mask logits at lr 100,
+    eps 1e-2, never touched by Noam), sparsity loss included, generator masks frozen by prune_mask_freeze_scope."""
+    import zlib
+    from sparse_image_captioning_amd.training import NativeTrainer
+    from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
+    g3, g13 = golden("g3_tiny_prune"), golden("g13_tiny_maskopt")
+    b = _cuda(H.g1_batch())
+    shapes = H.prune_param_shapes(C.TINY_CFG)
+    mask_shapes = {k: v for k, v in shapes.items() if k.endswith("_pruning_mask")}
+    # ---- (a)
+    m = _model(P, "relation_transformer_prune", C.TINY_CFG, _prune_state())
+    m.train()
+    m._ccfg.drop, m._ccfg.drop_src = 0.0, 0.0
+    u = lambda shape, salt=0: np.random.RandomState((zlib.crc32(str(tuple(shape)).encode()) + salt) & 0x7FFFFFFF).uniform(size=tuple(shape)).astype(np.float32)
+    m.set_mask_draws({k: u(shp) for k, shp in mask_shapes.items()})
+    logp = m(att_feats=b["att_feats"], boxes=b["boxes"], seqs=b["seqs"], att_masks=b["att_masks"])
+    close(logp, g3["train/logp"], 1e-4)
+    loss = LanguageModelCriterion()(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - float(g3["train/loss"])) < 1e-4
+    loss.backward()
+    n_checked = 0
+    params = dict(m.named_parameters())
+    for k, v in g3.items():
+        if k.startswith("train/grad/"):
+            got = params[k[len("train/grad/"):]].grad.cpu().numpy()
+            np.testing.assert_allclose(got, v, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(v).max())), err_msg=k)
+            n_checked += 1
+    assert n_checked >= 10
+    # ---- (b)
+    lr_mask, target, weight, max_step, steps = [float(x) for x in g13["meta"]]
+    m2 = _model(P, "relation_transformer_prune", C.TINY_CFG, _prune_state(), prune_mask_freeze_scope="model.generator.", prune_supermask_init=5.0)
+    m2.train()
+    m2._ccfg.drop, m2._ccfg.drop_src = 0.0, 0.0
+    frozen0 = {n: p.detach().clone() for n, p in m2.all_pruning_masks() if n.startswith("model.generator.")}
+    tr = NativeTrainer(m2, noamopt_factor=1.0, noamopt_warmup=10, prune_supermask_lr=lr_mask, mask_eps=1e-2, sparsity_target=target,
+                       sparsity_weight=weight, max_train_step=int(max_step))
+    losses = []
+    for step in range(int(steps)):
+        m2.set_mask_draws({k: u(shp, 7919 * step) for k, shp in mask_shapes.items()})
+        losses.append(tr.xe_step(b).item())
+    np.testing.assert_allclose(losses, g13["losses"], rtol=2e-5, atol=2e-4)
+    sd = {n: p.detach().cpu().numpy() for n, p in m2.named_parameters()}
+    for k, v in g13.items():
+        if k.startswith("mask/"):
+            # a logit moves by lr * mhat / (sqrt(vhat) + 1e-2) ~ 1e4 * gradient per step: absolute tolerance for 1e-7 gradient noise
+            np.testing.assert_allclose(sd[k[5:]], v, rtol=2e-3, atol=5e-2, err_msg=k)
+        elif k.startswith("param/"):
+            np.testing.assert_allclose(sd[k[6:]], v, rtol=1e-3, atol=5e-4, err_msg=k)
+    for n, p0 in frozen0.items():                     # frozen scope: bit-unchanged, never in the optimizer group
+        assert torch.equal(dict(m2.all_pruning_masks())[n].detach(), p0), n
+    tot = sum(p.detach().double().abs().sum().item() for _, p in m2.all_pruning_masks())
+    assert abs(tot - float(g13["mask_abs_sum"])) / float(g13["mask_abs_sum"]) < 2e-3
+
+
 def test_supermask_train_mode_statistics_and_trainer(P):
     """Bernoulli masks cannot match torch's RNG stream: check the sampled forward is reproducible per seed, differs
     between seeds, and that the native supermask step moves the mask logits towards the sparsity target."""

@@ -1,7 +1,7 @@
 """The reference's own pruning test (tests/test_prune.py: TestPrune._test_model) replayed on the HIP ORT-prune model
 with the native trainer instead of its toy Embedding/LSTM/Linear model: for every mask type — initial sparsity 0,
-one-shot pruning hits the target within 0.05, a short training run ends at the target (0.35 for the supermask, 0.05
-for the magnitude / SNIP / lottery masks), the frozen scope keeps the active sparsity above the overall one, weights
+one-shot pruning hits the target within 0.05, a short training run ends at the target within 0.05 for the magnitude / SNIP /
+lottery masks and — for the supermask — where the reference's own run of this recipe on this model ends (0.482 +- 0.05), the frozen scope keeps the active sparsity above the overall one, weights
 are only zeroed by `prune_weights()`."""
 import pytest
 import torch
@@ -59,9 +59,16 @@ def test_prune_flow_like_reference_test(P, mask_type):
         if mask_type in prune.MAG_ANNEAL:
             model.update_masks_gradual(sparsity_target=SPARSITY_TARGET, current_step=i, start_step=10,
                                        prune_steps=max(1, ITERS // 4), prune_frequency=3)
-    # supermask: the reference allows 0.3 on its toy model; here the first Adam step at lr 10 sends every logit from 5 to -5
-    # or 15, where sigma' ~ 0, and the run sits at ~0.49 (measured: scratch/supermask_dbg.py) -> 0.35
-    assert abs(sparsity(True) - SPARSITY_TARGET) < (0.35 if mask_type == prune.REGULAR else 0.05), "final sparsity"
+    # Supermask: the reference's test allows 0.3 on its 60-parameter toy model.  On THIS model the reference itself (same
+    # recipe: Adam lr 10 on the active masks, weight 120, 60 iterations, frozen generator) ends at an active sparsity of
+    # 0.482 — the first lr-10 Adam step sends every logit from 5 to about -5 or 15, where sigma' ~ 0, and nothing moves
+    # afterwards (scratch/supermask_ref_flow.py runs the reference; printed trace: 0.485, 0.4625, 0.482, ... 0.4819).  The
+    # HIP path must land where the reference lands, not merely inside a wide band around the target.
+    REF_FINAL = 0.482
+    if mask_type == prune.REGULAR:
+        assert abs(sparsity(True) - REF_FINAL) < 0.05, ("final sparsity vs the reference's own run", sparsity(True))
+    else:
+        assert abs(sparsity(True) - SPARSITY_TARGET) < 0.05, "final sparsity"
     assert sparsity(True) > sparsity(False), "active sparsity is higher: the generator is not pruned"
     assert float(model.all_weight_sparsities[0]) == 0, "weights are not pruned yet"
     model.prune_weights()
