@@ -178,8 +178,8 @@ def selftest(rank, world, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: > 1 s of timed region at 13 ms per step)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="xe", choices=("xe", "sparse_xe", "scst", "decode", "sparse_decode"))
     ap.add_argument("--overlap-allreduce", default="auto", choices=("auto", "on", "off"),
                     help="all-reduce the decoder half of the gradients while the encoder half of the backward runs "
@@ -334,7 +334,12 @@ def main():
             if decode:
                 algo = B * 25.7e6 + config.max_seq_length * (nnz_bytes if sparse else 110.9e6)
             else:
-                algo = by.value + 3 * nnz_bytes
+                # forward + data-gradient products of one step: X (M x K) and Y (M x N) once each in bf16, 4 bytes per non-zero;
+                # the dense weight-gradient products read their two operands once and add into fp32 (M rows: 9 216 / 21 760)
+                Me, Md = B * S, B * spi * (config.max_seq_length - 1)
+                prods = ([(Me, 512, 2048, 1), (Me, 1536, 512, 6), (Me, 512, 512, 6), (Me, 2048, 512, 6), (Me, 512, 2048, 6), (Me, 6144, 512, 1),
+                          (Md, 1536, 512, 6), (Md, 512, 512, 18), (Md, 2048, 512, 6), (Md, 512, 2048, 6), (Md, 10112, 512, 1)])
+                algo = sum(c * (2 * (2 * M * K + 2 * M * N) + (2 * M * K + 2 * M * N + 4 * N * K)) for M, N, K, c in prods) + 3 * nnz_bytes
             gbs = algo / (ms_per_step * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "whole step (all launches): the path is bandwidth-bound as a whole",
                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
