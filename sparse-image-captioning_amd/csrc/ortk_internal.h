@@ -66,6 +66,34 @@ int sample_init(const SampleState& st, int32_t bos, hipStream_t s);
 int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false);
 int sample_finalize(const SampleState& st, hipStream_t s);
 
+// One decode position of the whole decoder stack in one launch (ortk_decstack.hip; mixed precision, d_model 512, 8 heads,
+// d_ff a multiple of 512, bf16 caches).
+constexpr int STACK_MAXL = 8;
+struct StackLayer {
+    const float *n0a, *n0b, *bqkv, *bo, *n1a, *n1b, *cqb, *cob, *n2a, *n2b, *b1, *b2;
+    __bf16 *ck, *cv;               // self-attention caches, (cache rows, 512)
+    const __bf16 *xk, *xv;         // this layer's K / V columns of the projected memory, row pitch ldx
+};
+struct StackArgs {
+    StackLayer layer[STACK_MAXL];
+    const uint4* wpk;              // stack_pack() image of the decoder weights
+    float* x_io;                   // (rows, 512) embedded tokens of this position; also where a workgroup parks its residual rows
+    __bf16* y_out;                 // (rows, 512) final LayerNorm output: the generator's operand
+    const float *fa, *fb;          // final LayerNorm
+    const float* att_masks;        // (images, S)
+    const int32_t* kvidx;          // (rows, t + 1) beam ancestry (cache rows) or NULL: row g owns cache rows g T .. g T + t
+    int64_t ldx;
+    int32_t rows, per_img, S, T, t, L, NC;
+    float eps;
+    int32_t nblocks;               // compute workgroups (set by stack_step); workgroups beyond are L2 prefetchers
+    int32_t* progress;             // [16] zeroed at the start of a decode: units begun by the pace-maker of each XCD
+    int32_t debug;                 // measurement only (ORTK_STACK_DEBUG): 1 skip self-attention, 2 skip cross-attention, 4 skip the FFN, 8 no L2 prefetchers
+};
+struct StackPack { int64_t off[STACK_MAXL][6]; int32_t L, NC; };   // element offsets of wqkv, wo, cqw, cow, w1, w2 per layer
+size_t stack_packed_bytes(int L, int NC);
+int stack_pack(const void* w16, void* wpk, const StackPack& t, hipStream_t s);
+int stack_step(const StackArgs& a, hipStream_t s);
+
 int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
 int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 // kvidx[g*1 + 0] = g*row_mult*tmax  (index table for the first decoder pass)

@@ -997,17 +997,31 @@ struct DecodeWS {
                                                                // decode attention kernels take them (kv16), fp32 otherwise
     int64_t* it; int32_t *unfinished, *last_step;
     int32_t *bseq[2], *kvidx[2], *done_seq, *done_len, *done_cnt; float *blp[2], *cum, *done_lp; double* done_p;
+    void* wpk = nullptr;               // decoder weights in the stack kernel's streaming order (stack path only)
+    int32_t* progress = nullptr;       // pace-maker counters of the stack kernel's L2 prefetchers
     size_t bytes;
 };
-static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w) {
+
+// The one-launch-per-position decoder stack (ortk_decstack.hip) serves the reference's configuration and the ACORT widths
+// with d_model 512: mixed precision, 8 heads of 64, d_ff a multiple of 512, no projection sharing inside the decoder's
+// attention modules.  Everything else — and every call that brings a sparse plan — runs the unfused executor below.
+// ORTK_DEC_STACK=0 switches it off (A/B measurements).
+static bool stack_ok(const ortk_config& c) {
+    const char* e = getenv("ORTK_DEC_STACK");          // read per call: the parity tests run both executors in one process
+    const bool env = !(e && atoi(e) == 0);
+    return env && c.precision == 1 && c.d_model == 512 && c.n_heads == 8 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 &&
+           c.share_att_dec == 0 && c.n_layers <= STACK_MAXL && c.seq_len <= 64;     // (seq_len: one lane per cached key)
+}
+static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
     // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
     w.kvdt = (c.precision && H == 8 && d == 512 && S > 8 && S <= 48 && T <= 32 && K <= 16) ? ORTK_BF16 : ORTK_F32;
-    const size_t kves = ortk_esize(w.kvdt);
     // more than 48 regions (ragged 10-100 bottom-up features): the cross-attention of a step runs in the bf16-operand block
     // kernel on bf16 projected memory and a bf16 query; the self-attention caches stay as the row kernel wants them
     w.xq16 = (c.precision && w.kvdt == ORTK_F32 && S > 48 && attn16_shape_ok(K, S, (int)(d / H))) ? 1 : 0;
     w.ckvdt = w.xq16 ? ORTK_BF16 : w.kvdt;
+    if (stack) { w.kvdt = w.ckvdt = ORTK_BF16; w.xq16 = 0; }      // the stack kernel reads bf16 caches at every S
+    const size_t kves = ortk_esize(w.kvdt);
     const int64_t Me = (int64_t)B * S, rows = (int64_t)B * K;
     w.ldv = ortk_align(c.vocab, 128);
     w.adt = c.precision ? ORTK_BF16 : ORTK_F32;
@@ -1027,6 +1041,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
+    if (stack) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
     if (beam) {
         for (int i = 0; i < 2; ++i) { w.bseq[i] = b.take<int32_t>(rows * T); w.blp[i] = b.take<float>(rows * T); w.kvidx[i] = b.take<int32_t>(rows * (T + 1)); }
         w.cum = b.take<float>(rows);
@@ -1061,7 +1076,7 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
     if (check_cfg(cfg) || !o || B < 1 || S < 1) return 0;
     const int K = decode_K(o);
     if (K < 1) return 0;
-    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w);
+    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack_ok(*cfg) && !o->sparse);
     return w.bytes;
 }
 
@@ -1121,6 +1136,32 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
     return 0;
 }
 
+// The same position through the one-launch decoder stack: embed, stack kernel, generator.
+static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w, const void* wpk, int32_t* progress, int64_t rows, int per_img, int S, int T,
+                              int t, const int32_t* kvidx) {
+    const ortk_config* cfg = c.cfg;
+    const float* P = c.P;
+    ortk_stream stream = (ortk_stream)c.s;
+    const int d = cfg->d_model;
+    TRY(ortk_embed_fwd(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, 1, t, d, cfg->pad_id, 0.f, 0, stream));
+    StackArgs a; std::memset(&a, 0, sizeof(a));
+    for (int l = 0; l < cfg->n_layers; ++l) {
+        const DecOff& e = o.dec[l];
+        StackLayer& y = a.layer[l];
+        y.n0a = P + e.n0a; y.n0b = P + e.n0b; y.bqkv = P + e.bqkv; y.bo = P + e.bo; y.n1a = P + e.n1a; y.n1b = P + e.n1b;
+        y.cqb = P + e.cqb; y.cob = P + e.cob; y.n2a = P + e.n2a; y.n2b = P + e.n2b; y.b1 = P + e.b1; y.b2 = P + e.b2;
+        y.ck = reinterpret_cast<__bf16*>(w.cache_k[l]); y.cv = reinterpret_cast<__bf16*>(w.cache_v[l]);
+        y.xk = reinterpret_cast<const __bf16*>(w.ckv) + o.ckv_slot[l] * o.cw;
+        y.xv = y.xk + o.cv;
+    }
+    a.wpk = reinterpret_cast<const uint4*>(wpk); a.progress = progress; a.x_io = w.xa; a.y_out = reinterpret_cast<__bf16*>(w.y);
+    a.fa = P + o.dec_na; a.fb = P + o.dec_nb; a.att_masks = w.att_masks; a.kvidx = kvidx; a.ldx = o.ckv_slots * o.cw;
+    a.rows = (int)rows; a.per_img = per_img; a.S = S; a.T = T; a.t = t; a.L = cfg->n_layers; a.NC = cfg->d_ff / 512; a.eps = 1e-6f;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORTK_STACK_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
+    TRY(stack_step(a, c.s));
+    return fwd_gemm(c, w.y, ORTK_BF16, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, (int)w.ldv, d);
+}
+
 extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const float* att_feats, const float* boxes,
                            const float* att_masks, int32_t B, int32_t S, const ortk_decode_opts* op, void* ws, size_t ws_bytes,
                            int64_t* seq_out, float* logprob_out, float* score_out, ortk_stream stream) {
@@ -1133,10 +1174,21 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (beam && (K > 8 || K > cfg->vocab)) return ORTK_EINVAL;
     if (op->temperature <= 0.f) return ORTK_EINVAL;
     Offsets o; build_layout(*cfg, o, nullptr);
-    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w);
+    const bool stack = stack_ok(*cfg) && !op->sparse;
+    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     hipStream_t s = ortk_s(stream);
     TRY(make_w16(cfg, o, params, w.w16, stream));
+    if (stack) {
+        StackPack tp; tp.L = cfg->n_layers; tp.NC = cfg->d_ff / 512;
+        for (int l = 0; l < cfg->n_layers; ++l) {
+            const DecOff& e = o.dec[l];
+            const int64_t offs[6] = {e.wqkv, e.wo, e.cqw, e.cow, e.w1, e.w2};
+            for (int i = 0; i < 6; ++i) tp.off[l][i] = offs[i];
+        }
+        TRY(stack_pack(w.w16, w.wpk, tp, s));
+        TRY(fill_i32(w.progress, 16, 0, s));
+    }
     Ctx c{cfg, s, cfg->precision, 0, false, params, w.w16, w.adt};
     if (op->sparse) {
         TRY(ortk_sparse_build(op->sparse, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
@@ -1182,7 +1234,8 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         StepBufs sb{w.it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, w.ckv, att_masks};
         sb.kvdt = w.kvdt; sb.ckvdt = w.ckvdt; sb.xq16 = w.xq16;
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
-        TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
+        if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, w.progress, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
+        else TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.
         const float scale = (beam && t > 0) ? 1.f / op->temperature : 1.f;

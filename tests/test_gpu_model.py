@@ -931,6 +931,69 @@ def test_bf16_decode_logprob_bound(P, full_state):
         assert (s16[:, 0] == s32[:, 0]).all(-1).float().mean().item() >= 0.6
 
 
+def _decode_both_executors(m, b, opt):
+    """(stack kernel, unfused executor) results of the same mixed-precision decode; ORTK_DEC_STACK is read per call."""
+    import os
+    out = []
+    for flag in ("1", "0"):
+        os.environ["ORTK_DEC_STACK"] = flag
+        try:
+            with torch.no_grad():
+                seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt=dict(opt), mode="sample")
+            out.append((seq.clone(), lp.clone()))
+        finally:
+            os.environ.pop("ORTK_DEC_STACK", None)
+    return out
+
+
+@pytest.mark.parametrize("n_reg,n_img", [(36, 70), (100, 37)])
+def test_decoder_stack_kernel_vs_fp32_and_unfused_executor(P, full_state, n_reg, n_img):
+    """The one-launch-per-position decoder stack (ortk_decstack.hip), ragged region counts (12-36 / 33-100 per image), 70 / 37
+    images (partial last row blocks, images straddling blocks):
+      * against the fp32 parity path: every token its greedy decode emits has, teacher-forced in fp32 on the same tokens, a
+        log-prob within 0.02 of the one the stack reported (mean within 0.004) — measured 0.0046 / 0.0013 at every S;
+      * against the unfused mixed-precision executor (36 regions; beyond 64 regions that executor's bf16-probability
+        attention is itself 0.03 off on average, scratch/decstack_s100.py): tokens agree up to near-ties, the log-probs of
+        agreeing tokens to bf16 noise — greedy, beam 5, beam 3 with the repeat constraint, and sampling (no ancestry table:
+        every row owns its cache rows; same Gumbel draws in both executors)."""
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
+    m32 = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=0)
+    b = _cuda(H.torch_batch(C.make_inputs(seed=41, n_img=n_img, n_reg=n_reg, feat=2048, vocab=10001, spi=1, ragged=True)))
+    (s1, l1), (s0, l0) = _decode_both_executors(m, b, {"beam_size": 1})
+    with torch.no_grad():
+        rows = s1[:, 0]
+        tf_in = torch.cat([rows.new_full((rows.size(0), 1), 2), rows], 1)
+        ref = m32(att_feats=b["att_feats"], boxes=b["boxes"], seqs=tf_in, att_masks=b["att_masks"]).gather(2, rows.unsqueeze(2)).squeeze(2)
+    err = (l1[:, 0] - ref)[rows != 0].abs()
+    assert err.max().item() <= 0.02 and err.mean().item() <= 0.004, (err.max().item(), err.mean().item())
+    if n_reg > 64:
+        return
+    for opt, min_tok in (({"beam_size": 1}, 0.95), ({"beam_size": 5}, 0.85), ({"beam_size": 3, "decoding_constraint": 1}, 0.85)):
+        (s1, l1), (s0, l0) = _decode_both_executors(m, b, opt)
+        same = s1 == s0
+        assert same.float().mean().item() >= min_tok, (opt, same.float().mean().item())
+        d = (l1 - l0)[same].abs()
+        assert d.max().item() < 0.25 and d.mean().item() < 0.01, (opt, d.max().item(), d.mean().item())
+    (s1, l1), (s0, l0) = _decode_both_executors(m, b, {"num_random_sample": 3, "beam_size": 0, "seed": 7})
+    assert (s1[..., 0] == s0[..., 0]).float().mean().item() >= 0.9
+    same = s1 == s0
+    assert (l1 - l0)[same].abs().mean().item() < 0.01
+
+
+def test_decoder_stack_kernel_shared_layers_and_long_captions(P):
+    """ACORT-style configuration on the stack path: decoder layers shared in pairs, 26-token captions (more cached keys than
+    one self-attention batch), d_ff 1024 (two hidden chunks) — against the unfused executor."""
+    cfg = dict(C.FULL_CFG, max_seq_length=26, dim_feedforward=1024, share_layer_decoder=(0, 0, 1, 1, 2, 2))
+    from sparse_image_captioning_amd.utils.config import Config
+    torch.manual_seed(3)
+    m = P.get_model("relation_transformer")(Config(**cfg), precision=1).cuda().eval()
+    b = _cuda(H.torch_batch(C.make_inputs(seed=43, n_img=33, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    (s1, l1), (s0, l0) = _decode_both_executors(m, b, {"beam_size": 5})
+    same = s1 == s0
+    assert same.float().mean().item() >= 0.85
+    assert (l1 - l0)[same].abs().mean().item() < 0.01
+
+
 @pytest.mark.parametrize("precision", [0, 1])
 def test_sparse_decode_full_size_95pct(P, full_state, precision):
     """BASELINE configs[4] shape: 95 %-sparse ORT, beam 5, decoded through the sparse kernels.  fp32 mode: token-exact against
