@@ -310,6 +310,19 @@ def main():
             per_key[k] = (n.value, ms.value, fl.value)
         by = C.c_double()
         lib.ortk_prof_collect_bytes(key, C.byref(by))
+        stack = None        # decode: the one-launch-per-position decoder stack (key 16), same HIP-event hook
+        if decode:
+            sn, sms, sfl, sby = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            lib.ortk_prof_collect(16, C.byref(sn), C.byref(sms), C.byref(sfl))
+            lib.ortk_prof_collect_bytes(16, C.byref(sby))
+            if sn.value:
+                gbs_k = sby.value / (sms.value * 1e-3) / 1e9
+                stack = {"kernel": "decoder_stack_kernel (ortk_decstack.hip): all decoder layers of one position, rows stationary, "
+                                   "weights streamed",
+                         "launches_per_step": sn.value, "avg_launch_us": round(sms.value * 1e3 / sn.value, 1),
+                         "algorithmic_bytes_per_launch": round(sby.value / sn.value), "achieved": round(gbs_k, 1),
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4),
+                         "mfma_tflops": round(sfl.value / (sms.value * 1e-3) / 1e12, 1), "ms_per_step": round(sms.value, 3)}
         lib.ortk_prof_enable(0)
         n0, ms0, fl0 = per_key[key]
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
@@ -345,6 +358,8 @@ def main():
                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                         "algorithmic_bytes_per_step": round(algo), "traffic": None,
                         "dense_gemm_launches_of_the_step": gemm}
+            if stack is not None:
+                roofline["dominant_kernel"] = stack
         else:
             roofline = dict(gemm, bound="mfma")
             roofline = {k: roofline[k] for k in ["bound"] + [k for k in gemm]}

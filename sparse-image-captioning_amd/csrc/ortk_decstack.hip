@@ -42,10 +42,14 @@ constexpr int XNR = 5;             // rows of one image served per cross-attenti
 #define XKB_ 4
 #endif
 #ifndef SKB_
-#define SKB_ 4
+#define SKB_ 2
 #endif
 constexpr int XKB = XKB_;             // keys per cross-attention batch
 constexpr int SKB = SKB_;            // keys per self-attention batch
+#ifndef SROWS_
+#define SROWS_ 2
+#endif
+constexpr int SROWS = SROWS_;        // rows a wave serves side by side in the self-attention (1, 2 or 4)
 constexpr int FRAG = 64;           // uint4 per fragment (1 KB)
 constexpr int KSTEP = 4 * FRAG;    // uint4 per k-step of one wave (4 column tiles)
 constexpr int STACK_AHEAD = 3;     // units (512 KB each) the L2 prefetcher may run in front of the pace-maker
@@ -361,58 +365,65 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         // ---- self-attention of rows 4 wave .. 4 wave + 3 over their cache rows + this position; o -> A0
         STACK_FRESH_LANE();
         if (!(a.debug & 1)) {
-            // lane j of idx_*: physical cache row of key j (of the row being served / of the next row)
-            auto row_idx = [&](int i) {
-                const int g = min(r0 + 4 * wave + i, a.rows - 1);
-                return a.kvidx ? a.kvidx[(int64_t)g * Lk + min(lane, a.t)] : g * a.T + min(lane, a.t);
-            };
-            int idx_cur = row_idx(0), idx_nxt = row_idx(1);
+            // The wave's SROWS rows run in lock-step, each with its own K / V registers: SROWS x SKB row loads of K and as
+            // many of V are in flight, K of the next batch requested as soon as the scores have consumed this one's, V as
+            // soon as p . V has.  (Row after row, one batch at a time, the phase was a chain of exposed round trips: 18 us.)
             const uint4* ck = reinterpret_cast<const uint4*>(P.ck) + lane;
             const uint4* cv = reinterpret_cast<const uint4*>(P.cv) + lane;
             const int nb = (a.t + SKB - 1) / SKB;
-            // K and V of a batch travel separately: K of the next batch is requested as soon as the scores have consumed this
-            // one's, V of the next as soon as p . V has — 16 row loads are in flight at every moment of the phase
-            uint4 kq[SKB], vq[SKB];
-            auto issue_k = [&](int rows_idx, int b) {
-#pragma unroll
-                for (int u = 0; u < SKB; ++u) kq[u] = ck[(int64_t)__builtin_amdgcn_readlane(rows_idx, min(b * SKB + u, a.t - 1)) * (SD / 8)];
-            };
-            auto issue_v = [&](int rows_idx, int b) {
-#pragma unroll
-                for (int u = 0; u < SKB; ++u) vq[u] = cv[(int64_t)__builtin_amdgcn_readlane(rows_idx, min(b * SKB + u, a.t - 1)) * (SD / 8)];
-            };
-            if (nb > 0) { issue_k(idx_cur, 0); issue_v(idx_cur, 0); }
 #pragma unroll 1
-            for (int i = 0; i < 4; ++i) {
-                const int row = 4 * wave + i;
-                AttState<1> st;
-                st.init(A1, row, 1, lane);
+            for (int i0 = 0; i0 < 4; i0 += SROWS) {
+                int idx[SROWS];          // lane j: physical cache row of key j of row r
+                AttState<1> st[SROWS];
+                uint4 kq[SROWS][SKB], vq[SROWS][SKB];
+#pragma unroll
+                for (int r = 0; r < SROWS; ++r) {
+                    const int g = min(r0 + 4 * wave + i0 + r, a.rows - 1);
+                    idx[r] = a.kvidx ? a.kvidx[(int64_t)g * Lk + min(lane, a.t)] : g * a.T + min(lane, a.t);
+                }
+                auto issue_k = [&](int b) {
+#pragma unroll
+                    for (int r = 0; r < SROWS; ++r)
+#pragma unroll
+                        for (int u = 0; u < SKB; ++u) kq[r][u] = ck[(int64_t)__builtin_amdgcn_readlane(idx[r], min(b * SKB + u, a.t - 1)) * (SD / 8)];
+                };
+                auto issue_v = [&](int b) {
+#pragma unroll
+                    for (int r = 0; r < SROWS; ++r)
+#pragma unroll
+                        for (int u = 0; u < SKB; ++u) vq[r][u] = cv[(int64_t)__builtin_amdgcn_readlane(idx[r], min(b * SKB + u, a.t - 1)) * (SD / 8)];
+                };
+                if (nb > 0) { issue_k(0); issue_v(0); }
+#pragma unroll
+                for (int r = 0; r < SROWS; ++r) st[r].init(A1, 4 * wave + i0 + r, 1, lane);
                 for (int b = 0; b < nb; ++b) {
-                    float kind[SKB], p[1][SKB];
+                    float kind[SKB], p[SROWS][1][SKB];
 #pragma unroll
                     for (int u = 0; u < SKB; ++u) kind[u] = b * SKB + u < a.t ? 0.f : -INFINITY;
-                    st.scores<SKB>(kq, kind, p);
-                    if (b + 1 < nb) issue_k(idx_cur, b + 1);
-                    else if (i + 1 < 4) issue_k(idx_nxt, 0);
-                    st.pv<SKB>(vq, p);
-                    if (b + 1 < nb) issue_v(idx_cur, b + 1);
-                    else if (i + 1 < 4) issue_v(idx_nxt, 0);
+#pragma unroll
+                    for (int r = 0; r < SROWS; ++r) st[r].scores<SKB>(kq[r], kind, p[r]);
+                    if (b + 1 < nb) issue_k(b + 1);
+#pragma unroll
+                    for (int r = 0; r < SROWS; ++r) st[r].pv<SKB>(vq[r], p[r]);
+                    if (b + 1 < nb) issue_v(b + 1);
                 }
-                // this position: K / V from the LDS images, appended to the cache
-                const uint4 kself[1] = {*reinterpret_cast<const uint4*>(KN + img_off(row, lane))};
-                const uint4 vself[1] = {*reinterpret_cast<const uint4*>(VN + img_off(row, lane))};
-                const float kindself[1] = {0.f};
-                float pself[1][1];
-                st.scores<1>(kself, kindself, pself);
-                st.pv<1>(vself, pself);
-                if (r0 + row < a.rows) {
-                    const int64_t slot = (int64_t)__builtin_amdgcn_readlane(idx_cur, a.t) * (SD / 8);
-                    reinterpret_cast<uint4*>(P.ck)[slot + lane] = kself[0];
-                    reinterpret_cast<uint4*>(P.cv)[slot + lane] = vself[0];
+#pragma unroll
+                for (int r = 0; r < SROWS; ++r) {
+                    // this position: K / V from the LDS images, appended to the cache
+                    const int row = 4 * wave + i0 + r;
+                    const uint4 kself[1] = {*reinterpret_cast<const uint4*>(KN + img_off(row, lane))};
+                    const uint4 vself[1] = {*reinterpret_cast<const uint4*>(VN + img_off(row, lane))};
+                    const float kindself[1] = {0.f};
+                    float pself[1][1];
+                    st[r].scores<1>(kself, kindself, pself);
+                    st[r].pv<1>(vself, pself);
+                    if (r0 + row < a.rows) {
+                        const int64_t slot = (int64_t)__builtin_amdgcn_readlane(idx[r], a.t) * (SD / 8);
+                        reinterpret_cast<uint4*>(P.ck)[slot + lane] = kself[0];
+                        reinterpret_cast<uint4*>(P.cv)[slot + lane] = vself[0];
+                    }
+                    st[r].finish(A0, row, 1, lane);
                 }
-                st.finish(A0, row, 1, lane);
-                idx_cur = idx_nxt;
-                if (i + 2 < 4) idx_nxt = row_idx(i + 2);
             }
         }
         __syncthreads();
@@ -568,7 +579,17 @@ int stack_step(const StackArgs& a, hipStream_t s) {
     StackArgs b = a;
     b.nblocks = (int)ortk_cdiv(a.rows, SRB);
     const bool pf = b.nblocks >= 8 && a.progress != nullptr && !(a.debug & 8);
+    // algorithmic bytes of the launch: the weights once, every image's projected memory (K and V) once per layer, every row's
+    // cached keys and values once per layer plus the appended position, the residual rows in and the normalised rows out
+    ProfMark pm;
+    if (ortk_prof_active()) {
+        const double U = 6 + 2 * a.NC, imgs = (double)ortk_cdiv(a.rows, a.per_img);
+        const double bytes = a.L * (U * SD * SD * 2.0 + imgs * a.S * 2.0 * SD * 2 + (double)a.rows * (a.t + 1) * 2.0 * SD * 2) +
+                             (double)a.rows * SD * (4 + 2);
+        (void)prof_begin(PROF_KEY_DECSTACK, 2.0 * a.rows * a.L * U * SD * SD, bytes, s, pm);
+    } else pm.live = false;
     hipLaunchKernelGGL(decoder_stack_kernel, dim3((unsigned)(b.nblocks + (pf ? 8 : 0))), dim3(512), lds, s, b);
+    prof_end(pm, s);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

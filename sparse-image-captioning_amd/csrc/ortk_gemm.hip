@@ -19,7 +19,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <vector>
-#include "ortk_common.h"
+#include "ortk_internal.h"
 
 namespace {
 
@@ -968,7 +968,25 @@ std::mutex g_prof_mu;          // decode chunks may be driven by several host th
 std::vector<ProfRec>* g_prof = nullptr;
 }  // namespace
 
-namespace ortk { bool ortk_prof_active() { return g_prof_on; } }
+namespace ortk {
+bool ortk_prof_active() { return g_prof_on; }
+// the same hook for launches that are not ortk_gemm (key >= 16): begin records the first event, end the second
+bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m) {
+    m.live = false;
+    if (!g_prof_on) return false;
+    if (hipEventCreate(&m.a) != hipSuccess || hipEventCreate(&m.b) != hipSuccess) return false;
+    m.key = key; m.flops = flops; m.bytes = bytes; m.live = true;
+    (void)hipEventRecord(m.a, s);
+    return true;
+}
+void prof_end(const ProfMark& m, hipStream_t s) {
+    if (!m.live) return;
+    (void)hipEventRecord(m.b, s);
+    ProfRec rec{m.a, m.b, m.key, m.flops, m.bytes};
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof->push_back(rec);
+}
+}  // namespace ortk
 
 extern "C" int ortk_prof_enable(int32_t on) {
     if (!g_prof) g_prof = new std::vector<ProfRec>();

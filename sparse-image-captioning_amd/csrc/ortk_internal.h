@@ -6,6 +6,11 @@ namespace ortk {
 
 // true while bench.py's per-launch GEMM timing is on (the executor then keeps every GEMM on the caller's stream)
 bool ortk_prof_active();
+// the same measurement hook around a launch that is not an ortk_gemm; ortk_prof_collect(key) then reports it
+constexpr int PROF_KEY_DECSTACK = 16;
+struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; };
+bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m);
+void prof_end(const ProfMark& m, hipStream_t s);
 
 // copy the new token's K and V (columns d..3d of the packed QKV row) into the self-attention cache
 int kv_append(const float* qkv, void* cache_k, void* cache_v, int32_t kv_dtype, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax,
