@@ -12,7 +12,7 @@ m16 = pkg.get_model("relation_transformer")(Config(**C.FULL_CFG), precision=1); 
 m32 = pkg.get_model("relation_transformer")(Config(**C.FULL_CFG), precision=0); m32.load_state_dict(st, strict=False); m32 = m32.cuda().eval()
 for n_reg, ragged in ((36, True), (64, True), (65, False), (100, False), (100, True)):
     b = {k: v.cuda() for k, v in H.torch_batch(C.make_inputs(seed=41, n_img=37, n_reg=n_reg, feat=2048, vocab=10001, spi=1, ragged=ragged)).items()}
-    for flag in ("1", "0"):
+    for flag in ("2", "0"):
         os.environ["ORTK_DEC_STACK"] = flag
         with torch.no_grad():
             seq, lp = m16(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 1}, mode="sample")

@@ -1006,12 +1006,18 @@ struct DecodeWS {
 // with d_model 512: mixed precision, 8 heads of 64, d_ff a multiple of 512, no projection sharing inside the decoder's
 // attention modules.  Everything else — and every call that brings a sparse plan — runs the unfused executor below.
 // ORTK_DEC_STACK=0 switches it off (A/B measurements).
-static bool stack_ok(const ortk_config& c) {
+static bool stack_ok(const ortk_config& c, int64_t rows) {
     const char* e = getenv("ORTK_DEC_STACK");          // read per call: the parity tests run both executors in one process
-    const bool env = !(e && atoi(e) == 0);
-    return env && c.precision == 1 && c.d_model == 512 && c.n_heads == 8 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 &&
+    const int mode = e ? atoi(e) : 1;                  // 0 off, 1 by size (default), 2 whenever the configuration is served
+    // Every workgroup of the stack kernel streams ALL decoder weights (42 MB per position at ~85 GB/s per CU: >= 0.5 ms per
+    // position however few rows there are), the unfused GEMMs read each weight once per launch: measured crossover at 320
+    // images x 5 beams (16.1 vs 16.0 ms; 512 images 17.0 vs 21.3, 50 images 14.1 vs 11.1, the SCST rollout of 256 x 6 rows
+    // 29.9 vs 28.3 ms per step).
+    if (mode == 0 || (mode == 1 && rows < 1600)) return false;
+    return c.precision == 1 && c.d_model == 512 && c.n_heads == 8 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 &&
            c.share_att_dec == 0 && c.n_layers <= STACK_MAXL && c.seq_len <= 64;     // (seq_len: one lane per cached key)
 }
+
 static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
     // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
@@ -1076,7 +1082,7 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
     if (check_cfg(cfg) || !o || B < 1 || S < 1) return 0;
     const int K = decode_K(o);
     if (K < 1) return 0;
-    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack_ok(*cfg) && !o->sparse);
+    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack_ok(*cfg, (int64_t)B * K) && !o->sparse);
     return w.bytes;
 }
 
@@ -1174,7 +1180,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (beam && (K > 8 || K > cfg->vocab)) return ORTK_EINVAL;
     if (op->temperature <= 0.f) return ORTK_EINVAL;
     Offsets o; build_layout(*cfg, o, nullptr);
-    const bool stack = stack_ok(*cfg) && !op->sparse;
+    const bool stack = stack_ok(*cfg, (int64_t)B * K) && !op->sparse;
     DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     hipStream_t s = ortk_s(stream);

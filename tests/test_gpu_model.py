@@ -932,10 +932,11 @@ def test_bf16_decode_logprob_bound(P, full_state):
 
 
 def _decode_both_executors(m, b, opt):
-    """(stack kernel, unfused executor) results of the same mixed-precision decode; ORTK_DEC_STACK is read per call."""
+    """(stack kernel, unfused executor) results of the same mixed-precision decode; ORTK_DEC_STACK is read per call
+    (2 = the stack kernel at any size: by default it only takes decodes of 1 600 rows and more)."""
     import os
     out = []
-    for flag in ("1", "0"):
+    for flag in ("2", "0"):
         os.environ["ORTK_DEC_STACK"] = flag
         try:
             with torch.no_grad():
@@ -978,6 +979,25 @@ def test_decoder_stack_kernel_vs_fp32_and_unfused_executor(P, full_state, n_reg,
     assert (s1[..., 0] == s0[..., 0]).float().mean().item() >= 0.9
     same = s1 == s0
     assert (l1 - l0)[same].abs().mean().item() < 0.01
+
+
+def test_decode_executor_is_chosen_by_size(P, full_state):
+    """Default dispatch (ORTK_DEC_STACK unset): decodes of fewer than 1 600 rows run the unfused executor, larger ones the stack
+    kernel — checked through bit-identical outputs against the forced modes."""
+    import os
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
+    for n_img, forced in ((40, "0"), (330, "2")):
+        b = _cuda(H.torch_batch(C.make_inputs(seed=47, n_img=n_img, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+        kw = dict(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 5}, mode="sample")
+        with torch.no_grad():
+            os.environ.pop("ORTK_DEC_STACK", None)
+            seq_d, lp_d = m(**kw)
+            os.environ["ORTK_DEC_STACK"] = forced
+            try:
+                seq_f, lp_f = m(**kw)
+            finally:
+                os.environ.pop("ORTK_DEC_STACK", None)
+        assert torch.equal(seq_d, seq_f) and torch.equal(lp_d, lp_f), (n_img, forced)
 
 
 def test_decoder_stack_kernel_shared_layers_and_long_captions(P):
