@@ -18,8 +18,9 @@
 //   * self-attention: the wave that owns a row reads its cache rows (beam ancestry table or fixed stride) as 1-KB rows,
 //     lane = 8 features, online soft-max over batches of 4 keys; this position's K / V come from LDS and are appended to
 //     the cache on the way.  Cross-attention: the rows of ONE image share every K / V load (up to 5 rows per pass).  Register
-//     budget rules both: with 8 waves per CU a wave has 256 VGPRs, the residual rows are parked in global memory for the two
-//     phases, and any batch size that makes the compiler spill costs more than the extra loads in flight buy (measured).
+//     budget rules both: with 8 waves per CU a wave has 256 VGPRs, 32 of them hold the residual rows throughout, and any batch
+//     size that makes the compiler spill costs more than the extra loads in flight buy (measured; parking the residual rows
+//     in global memory during the two phases to free their registers cost 0.5 ms per decode and bought nothing).
 //
 //   * 8 extra workgroups (one per XCD) run ahead of the compute workgroups and touch the weight stream into that XCD's L2,
 //     paced by a counter the first compute workgroup of the XCD publishes.
@@ -199,27 +200,6 @@ __device__ __forceinline__ void store_img_plain(char* img, const f32x4 (&y)[2][4
         }
 }
 
-// The residual rows leave the registers for the two attention phases (they need them for K / V rows in flight): parked in
-// the workgroup's own rows of the fp32 input buffer, fetched back while the following output projection streams.
-__device__ __forceinline__ void park_x(float* xg, const f32x4 (&x)[2][4], int r0, int rows, int wave, int lane) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int g = r0 + 16 * mt + (lane & 15);
-        if (g < rows) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(xg + (int64_t)g * SD + 64 * wave + 16 * nt + 4 * (lane >> 4)) = x[mt][nt];
-        }
-    }
-}
-__device__ __forceinline__ void fetch_x(const float* xg, f32x4 (&x)[2][4], int r0, int rows, int wave, int lane) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int g = min(r0 + 16 * mt + (lane & 15), rows - 1);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) x[mt][nt] = *reinterpret_cast<const f32x4*>(xg + (int64_t)g * SD + 64 * wave + 16 * nt + 4 * (lane >> 4));
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ attention
 // Online soft-max state of NR query rows that see the same keys; lane = features 8 lane .. 8 lane + 7 (head lane / 8).
 template <int NR>
@@ -354,7 +334,6 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         STACK_FRESH_LANE();
         layer_norm(x, P.n0a, P.n0b, a.eps, red1, red2, wave, lane, y);
         store_img_plain(A0, y, wave, lane);
-        park_x(a.x_io, x, r0, a.rows, wave, lane);
         __syncthreads();
         // ---- packed QKV: three units -> q (A1), k (KN), v (VN)
         STACK_FRESH_LANE();
@@ -430,7 +409,6 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         // ---- output projection + residual, LayerNorm 1 -> A0
         STACK_FRESH_LANE();
         ring_start(ring, wp, lane);
-        fetch_x(a.x_io, x, r0, a.rows, wave, lane);
         load_cols(P.bo, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<true>(acc, A0, wp, ring, lane);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -438,7 +416,6 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
             for (int nt = 0; nt < 4; ++nt) x[mt][nt] += acc[mt][nt] + bias[nt];
         layer_norm(x, P.n1a, P.n1b, a.eps, red1, red2, wave, lane, y);       // (its barriers: every wave is done reading A0)
         store_img_plain(A0, y, wave, lane);
-        park_x(a.x_io, x, r0, a.rows, wave, lane);
         __syncthreads();
         // ---- cross-attention query -> A1
         STACK_FRESH_LANE();
@@ -493,7 +470,6 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         // ---- output projection + residual, LayerNorm 2 -> A0
         STACK_FRESH_LANE();
         ring_start(ring, wp, lane);
-        fetch_x(a.x_io, x, r0, a.rows, wave, lane);
         load_cols(P.cob, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<true>(acc, A0, wp, ring, lane);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)

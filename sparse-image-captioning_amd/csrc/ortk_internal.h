@@ -82,7 +82,7 @@ struct StackLayer {
 struct StackArgs {
     StackLayer layer[STACK_MAXL];
     const uint4* wpk;              // stack_pack() image of the decoder weights
-    float* x_io;                   // (rows, 512) embedded tokens of this position; also where a workgroup parks its residual rows
+    const float* x_io;             // (rows, 512) embedded tokens of this position
     __bf16* y_out;                 // (rows, 512) final LayerNorm output: the generator's operand
     const float *fa, *fb;          // final LayerNorm
     const float* att_masks;        // (images, S)
