@@ -16,7 +16,7 @@
 //     1-KB MFMA fragments over all units of all layers (QKV 3 units, O, CQ, CO, then W1 / W2 interleaved per 512 hidden
 //     units), read through a 4-k-step register ring that keeps running across unit boundaries and LayerNorms;
 //   * self-attention: the wave that owns a row reads its cache rows (beam ancestry table or fixed stride) as 1-KB rows,
-//     lane = 8 features, online soft-max over batches of 4 keys; this position's K / V come from LDS and are appended to
+//     lane = 8 features, two rows side by side, online soft-max over small key batches; this position's K / V come from LDS and are appended to
 //     the cache on the way.  Cross-attention: the rows of ONE image share every K / V load (up to 5 rows per pass).  Register
 //     budget rules both: with 8 waves per CU a wave has 256 VGPRs, 32 of them hold the residual rows throughout, and any batch
 //     size that makes the compiler spill costs more than the extra loads in flight buy (measured; parking the residual rows
@@ -39,18 +39,20 @@ constexpr int SRB = 32;            // rows per workgroup
 constexpr int SPD = 4;             // k-steps of weight fragments in flight per wave
 constexpr int SIMG = SRB * SD * 2; // bytes of one bf16 A image
 constexpr int XNR = 5;             // rows of one image served per cross-attention pass
+// Attention batch sizes (-D overrides are for the sweeps of scratch/variant_sweep.sh): measured best, all within 0.2 ms of
+// each other as long as the kernel does not spill; 8-key batches spill and cost 2 ms per decode.
 #ifndef XKB_
 #define XKB_ 4
 #endif
 #ifndef SKB_
 #define SKB_ 2
 #endif
-constexpr int XKB = XKB_;             // keys per cross-attention batch
-constexpr int SKB = SKB_;            // keys per self-attention batch
 #ifndef SROWS_
 #define SROWS_ 2
 #endif
-constexpr int SROWS = SROWS_;        // rows a wave serves side by side in the self-attention (1, 2 or 4)
+constexpr int XKB = XKB_;          // keys per cross-attention batch
+constexpr int SKB = SKB_;          // keys per self-attention batch
+constexpr int SROWS = SROWS_;      // rows a wave serves side by side in the self-attention (1, 2 or 4)
 constexpr int FRAG = 64;           // uint4 per fragment (1 KB)
 constexpr int KSTEP = 4 * FRAG;    // uint4 per k-step of one wave (4 column tiles)
 constexpr int STACK_AHEAD = 3;     // units (512 KB each) the L2 prefetcher may run in front of the pace-maker
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         if (!(a.debug & 1)) {
             // The wave's SROWS rows run in lock-step, each with its own K / V registers: SROWS x SKB row loads of K and as
             // many of V are in flight, K of the next batch requested as soon as the scores have consumed this one's, V as
-            // soon as p . V has.  (Row after row, one batch at a time, the phase was a chain of exposed round trips: 18 us.)
+            // soon as p . V has.  The phase is bound by the bytes a wave can keep in flight (registers), not by its arithmetic.
             const uint4* ck = reinterpret_cast<const uint4*>(P.ck) + lane;
             const uint4* cv = reinterpret_cast<const uint4*>(P.cv) + lane;
             const int nb = (a.t + SKB - 1) / SKB;
