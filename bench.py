@@ -108,15 +108,21 @@ def pmc_traffic(workload, precision, B):
     2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction for 16-B/lane streaming reads), launch-weighted over the kernel's
     instances.  Returns (bytes | None, note): None for workloads / sizes without a committed PMC profile, and — loudly —
     when the committed CSVs do not contain the kernels this build launches (a stale profile is not a measurement)."""
-    if workload != "xe" or precision != "bf16" or B != 256:
-        return None, "no PMC pass committed for this workload / size"
     import csv
     here = os.path.dirname(os.path.abspath(__file__))
-    want = ("gemm_bf16_glds_kernel<false, false", "gemm_bf16_dma256_kernel<false, false", "gemm_bf16_dma64_kernel")
+    if workload == "decode" and precision == "bf16" and B == 1024:
+        want = ("decoder_stack_kernel",)
+        must = "decoder_stack_kernel"
+        files = [f"{PMC_TAG}_decode_stack_pmc_fetch_size.csv", f"{PMC_TAG}_decode_stack_pmc_write_size.csv"]
+    elif workload == "xe" and precision == "bf16" and B == 256:
+        want = ("gemm_bf16_glds_kernel<false, false", "gemm_bf16_dma256_kernel<false, false", "gemm_bf16_dma64_kernel")
+        must = "gemm_bf16_dma256_kernel<false, false"
+        files = [f"{PMC_TAG}_xe_b256_pmc_fetch_size.csv", f"{PMC_TAG}_xe_b256_pmc_write_size.csv"]
+    else:
+        return None, "no PMC pass committed for this workload / size"
     tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     n = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
     seen = set()
-    files = [f"{PMC_TAG}_xe_b256_pmc_fetch_size.csv", f"{PMC_TAG}_xe_b256_pmc_write_size.csv"]
     try:
         for cname, fname in zip(("FETCH_SIZE", "WRITE_SIZE"), files):
             for r in csv.DictReader(open(os.path.join(here, "profiles", fname))):
@@ -126,10 +132,10 @@ def pmc_traffic(workload, precision, B):
                     tot[cname] += float(r["total"]); n[cname] += int(r["launches"])
     except (OSError, KeyError, ValueError) as e:
         return None, f"profiles/{files[0]} / {files[1]} unreadable ({type(e).__name__}): no traffic figure"
-    if not n["FETCH_SIZE"] or not n["WRITE_SIZE"] or "gemm_bf16_dma256_kernel<false, false" not in seen:
-        return None, f"STALE: profiles/{PMC_TAG}_xe_b256_pmc_*.csv do not contain the forward-layout GEMM kernels of this build"
+    if not n["FETCH_SIZE"] or not n["WRITE_SIZE"] or must not in seen:
+        return None, f"STALE: profiles/{files[0]} / {files[1]} do not contain the dominant kernel of this build ({must})"
     kb = 2.0 * tot["FETCH_SIZE"] / n["FETCH_SIZE"] + tot["WRITE_SIZE"] / n["WRITE_SIZE"]
-    return round(kb * 1024), (f"HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from profiles/{PMC_TAG}_xe_b256_pmc_*.csv "
+    return round(kb * 1024), (f"HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from profiles/{files[0]} / {files[1]} "
                               "(separate rocprofv3 --pmc passes of this command), launch-weighted over the same kernels")
 
 
@@ -323,6 +329,7 @@ def main():
                          "algorithmic_bytes_per_launch": round(sby.value / sn.value), "achieved": round(gbs_k, 1),
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4),
                          "mfma_tflops": round(sfl.value / (sms.value * 1e-3) / 1e12, 1), "ms_per_step": round(sms.value, 3)}
+                stack["traffic"], stack["traffic_note"] = pmc_traffic(args.workload, args.precision, B)
         lib.ortk_prof_enable(0)
         n0, ms0, fl0 = per_key[key]
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
