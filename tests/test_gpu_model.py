@@ -981,6 +981,41 @@ def test_decoder_stack_kernel_vs_fp32_and_unfused_executor(P, full_state, n_reg,
     assert (l1 - l0)[same].abs().mean().item() < 0.01
 
 
+def test_decode_at_bench_size_properties(P, full_state):
+    """BASELINE configs[4]'s decode at its FULL size (1 024 images, beam 5, 36 regions, mixed precision: the decoder stack
+    kernel with its 160 workgroups and the L2 prefetchers), through size-independent properties:
+      * deterministic: two runs give identical tokens, log-probs and scores;
+      * every image is decoded on its own: a permutation of the images permutes the outputs, bit for bit (rows sit in other
+        32-row blocks, other workgroups, other XCDs);
+      * the structure of a beam result: beams of an image in descending score order, tokens and log-probs zero after the
+        first EOS, score = sum of the token log-probs (no length penalty);
+      * a 64-image slice of the batch decodes to the same tokens on its own through the UNFUSED executor up to near-ties
+        (the small batch is below the stack kernel's size threshold)."""
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
+    B = 1024
+    b = _cuda(H.torch_batch(C.make_inputs(seed=61, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    kw = lambda d: dict(att_feats=d["att_feats"], boxes=d["boxes"], att_masks=d["att_masks"], opt={"beam_size": 5}, mode="sample")
+    with torch.no_grad():
+        s1, l1 = m(**kw(b)); sc1 = m._last_decode[2].clone()
+        s2, l2 = m(**kw(b)); sc2 = m._last_decode[2].clone()
+        assert torch.equal(s1, s2) and torch.equal(l1, l2) and torch.equal(sc1, sc2)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+        bp = {k: v[perm] for k, v in b.items() if k in ("att_feats", "boxes", "att_masks")}
+        s3, l3 = m(**kw(bp)); sc3 = m._last_decode[2].clone()
+        assert torch.equal(s3, s1[perm]) and torch.equal(l3, l1[perm]) and torch.equal(sc3, sc1[perm])
+        assert (sc1[:, :-1] >= sc1[:, 1:]).all()
+        eos = (s1 == 3)
+        after = (eos.cumsum(-1) - eos.long()) > 0                      # strictly after the first EOS
+        assert (s1[after] == 0).all() and (l1[after] == 0).all()
+        assert (s1[~after] != 0).all()
+        assert (l1.sum(-1) - sc1).abs().max().item() < 1e-3
+        sub = {k: v[:64] for k, v in b.items() if k in ("att_feats", "boxes", "att_masks")}
+        s4, l4 = m(**kw(sub))
+        same = s4 == s1[:64]
+        assert same.float().mean().item() >= 0.85
+        assert (l4 - l1[:64])[same].abs().mean().item() < 0.01
+
+
 def test_decode_executor_is_chosen_by_size(P, full_state):
     """Default dispatch (ORTK_DEC_STACK unset): decodes of fewer than 1 600 rows run the unfused executor, larger ones the stack
     kernel — checked through bit-identical outputs against the forced modes."""
