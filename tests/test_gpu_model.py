@@ -981,6 +981,103 @@ def test_decoder_stack_kernel_vs_fp32_and_unfused_executor(P, full_state, n_reg,
     assert (l1 - l0)[same].abs().mean().item() < 0.01
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_scst_step_at_bench_size_properties(P, full_state, precision):
+    """BASELINE configs[3] at its FULL size (256 images, greedy baseline + 5 multinomial rollouts = 1 536 decode rows, then the
+    teacher-forced update over 1 280 sampled captions), through size-independent properties: the rollout is a function of
+    the seed (same seed -> same tokens, another seed -> other tokens; the greedy row does not depend on the seed); the
+    loss and the gradient are LINEAR in the reward (RewardCriterion: -sum logp * mask * reward / sum mask) — checked with two
+    reward vectors and their sum on the same rollout."""
+    from sparse_image_captioning_amd.training import NativeTrainer
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=precision)
+    B, ns = 256, 5
+    b = _cuda(H.torch_batch(C.make_inputs(seed=71, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000)
+    flat0 = m._flat.clone()
+    g = torch.Generator().manual_seed(5)
+    r1, r2 = torch.randn(B * ns, generator=g), torch.randn(B * ns, generator=g)
+
+    def step(reward, counter):
+        with torch.no_grad():
+            m._flat.copy_(flat0)
+        tr.m.zero_(); tr.v.zero_(); tr.step_count = 0
+        m._seed_counter = counter
+        m.eval()                                           # no dropout: the update is a deterministic function of the rollout
+        loss, _, seq, greedy = tr.scst_step(b, lambda s_, g_: reward, num_samples=ns, train=False)
+        return loss.item(), tr.grads.clone(), seq.clone(), greedy.clone()
+
+    l1, g1_, s1, gr1 = step(r1, 40)
+    l1b, g1b, s1b, gr1b = step(r1, 40)
+    assert torch.equal(s1, s1b) and torch.equal(gr1, gr1b)
+    assert s1.shape == (B, ns, m.seq_length) and gr1.shape == (B, 1, m.seq_length)
+    l2, g2_, s2, _ = step(r2, 40)
+    assert torch.equal(s2, s1)
+    l3, g3_, s3, gr3 = step(r1 + r2, 40)
+    assert torch.equal(s3, s1)
+    tol = 1e-5 if precision == 0 else 2e-3
+    assert abs(l3 - (l1 + l2)) <= tol * (abs(l1) + abs(l2) + 1e-6), (l1, l2, l3)
+    gs = (g1_ + g2_).abs().max().item()
+    assert (g3_ - (g1_ + g2_)).abs().max().item() <= (1e-5 if precision == 0 else 2e-2) * gs
+    _, _, s4, gr4 = step(r1, 41)
+    assert not torch.equal(s4, s1) and torch.equal(gr4, gr1)
+
+
+def test_supermask_step_at_bench_size_properties(P, full_state):
+    """BASELINE configs[2] at its FULL size (256 images x 5 captions, supermask model, mixed precision) through
+    size-independent properties:
+      * every mask open (logits +6: round(sigmoid) = 1 everywhere) -> the eval-mode step has the loss of the DENSE class on
+        the same weights (a mask of ones is the identity), and its weight gradients match;
+      * 95 % of the logits at -6: the step through the sparse kernels (forward and data gradients as sparse products over
+        images rebuilt on the device in the call) agrees with the step through the masked dense GEMMs — loss within 2e-3,
+        gradient arenas (weights and mask logits) within 3 % in L2 — and the dense-kernel step is deterministic."""
+    from sparse_image_captioning_amd.training import NativeTrainer
+    B = 256
+    b = _cuda(H.torch_batch(C.make_inputs(seed=81, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=5, ragged=True)))
+    dense = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
+    td = NativeTrainer(dense, noamopt_factor=1.0, noamopt_warmup=20000)
+    dense.eval()
+    ld = td.xe_step(b, train=False).item()
+    gd = td.grads.clone()
+
+    def prune_model(logit_fn):
+        m = _model(P, "relation_transformer_prune", C.FULL_CFG, full_state, precision=1, prune_type="supermask")
+        with torch.no_grad():
+            for _, msk in m.all_pruning_masks():
+                msk.copy_(logit_fn(msk))
+        m.eval()
+        return m
+
+    mo = prune_model(lambda t: torch.full_like(t, 6.0))
+    to = NativeTrainer(mo, noamopt_factor=1.0, noamopt_warmup=20000)
+    lo = to.xe_step(b, train=False).item()
+    assert abs(lo - ld) < 1e-5 * abs(ld), (lo, ld)
+    n = min(to.grads.numel(), gd.numel())
+    assert (to.grads[:n] - gd[:n]).abs().max().item() <= 1e-5 * gd.abs().max().item()
+
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    logits = lambda t: torch.where(torch.rand(t.shape, device=t.device, generator=gen) < 0.05, torch.full_like(t, 6.0), torch.full_like(t, -6.0))
+    ms = prune_model(logits)
+    ts = NativeTrainer(ms, noamopt_factor=1.0, noamopt_warmup=20000)
+    flat0, mask0 = ms._flat.clone(), ms._mask_flat.clone()
+
+    def step():
+        with torch.no_grad():
+            ms._flat.copy_(flat0); ms._mask_flat.copy_(mask0)
+        ts.m.zero_(); ts.v.zero_(); ts.step_count = 0
+        loss = ts.xe_step(b, train=False).item()
+        return loss, ts.grads.clone(), ts.dm.clone()
+
+    l_d1, g_d1, dm_d1 = step()
+    l_d2, g_d2, _ = step()
+    assert abs(l_d1 - l_d2) < 2e-5 * abs(l_d1)
+    ms.enable_sparse_kernels(0.9, train=True)
+    l_s, g_s, dm_s = step()
+    ms.check_sparse_overflow()
+    assert abs(l_s - l_d1) < 2e-3, (l_s, l_d1)
+    rel = lambda a, c: ((a - c).norm() / c.norm().clamp_min(1e-12)).item()
+    assert rel(g_s, g_d1) < 0.03 and rel(dm_s, dm_d1) < 0.03, (rel(g_s, g_d1), rel(dm_s, dm_d1))
+
+
 def test_decode_at_bench_size_properties(P, full_state):
     """BASELINE configs[4]'s decode at its FULL size (1 024 images, beam 5, 36 regions, mixed precision: the decoder stack
     kernel with its 160 workgroups and the L2 prefetchers), through size-independent properties:
