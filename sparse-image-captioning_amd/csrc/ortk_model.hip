@@ -509,11 +509,9 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     // att_embed: relu(Linear) on valid regions, zeros elsewhere, dropout (relation_transformer.py:331-333,349-350)
     // (the plain `transformer` embeds every row, padded regions included: transformer.py:627-629)
     const bool plain = cfg.no_box != 0;
-    TRY(fwd_gemm(c, feats, ORTK_F32, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
-                 nullptr, 0, plain ? nullptr : masks));
     const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS];
     for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; }
-    // the geometry bias only depends on the boxes and WG: beside att_embed / the first LayerNorm and QKV projection
+    // the geometry bias only depends on the boxes and WG: queued first, beside att_embed / the first LayerNorm and QKV projection
     hipEvent_t box_done = nullptr;
     if (plain) {
         // no geometry bias
@@ -524,6 +522,8 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     } else {
         TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s));
     }
+    TRY(fwd_gemm(c, feats, ORTK_F32, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
+                 nullptr, 0, plain ? nullptr : masks));
     const float* x = x0;
     const AttMode am = att_mode(cfg.share_att_enc);
     for (int l = 0; l < L; ++l) {
@@ -1207,7 +1207,12 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     // place (x is dead once xm = x + attn(...) exists, so the FFN sublayer writes its output back over x).
     EncPtrs ep[MAXLAYERS];
     for (int l = 0; l < L; ++l) ep[l] = w.enc;
+    // the side stream carries the geometry bias of the encoder (0.4 ms at 1 024 images, VALU-bound) beside att_embed and the
+    // first projection; nothing else of a decode runs there
+    c.side = (c.adt == ORTK_BF16 && !ortk_prof_active()) ? side_for(c.s) : nullptr;
+    c.use_side = c.side != nullptr;
     TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
+    c.use_side = false;
     TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
 
     const int64_t rows_full = (int64_t)B * K;
