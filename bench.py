@@ -194,6 +194,8 @@ def main():
                     help="sparse_decode / sparse_xe: sparse products (ortk_spmm_ell, sorted-ELL images rebuilt on the device every "
                          "call) instead of MFMA GEMMs on zero-filled weights; sparse_xe: forward and data gradients (the weight "
                          "gradients stay dense: the straight-through mask gradient needs them at every position)")
+    ap.add_argument("--decode-streams", type=int, default=0,
+                    help="decode workloads: decode the batch as this many chunks of images on as many streams (0 = one call)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 256; decode 1024)")
     ap.add_argument("--max-seq-length", type=int, default=18, help="caption length incl. BOS/EOS (18 = BASELINE; the ACORT commands use 26)")
     ap.add_argument("--regions", type=int, default=36, help="regions per image (36 = BASELINE; real bottom-up features have 10-100)")
@@ -257,6 +259,8 @@ def main():
     if decode:
         model.eval()
         opt = {"beam_size": 5}
+        if args.decode_streams > 1:
+            opt["decode_streams"] = args.decode_streams
 
         def step():
             model(att_feats=batch["att_feats"], boxes=batch["boxes"], att_masks=batch["att_masks"], opt=opt, mode="sample")

@@ -469,7 +469,8 @@ class RelationTransformerModel(CaptionModelBase):
         # Images are independent: `opt["decode_streams"] = n` decodes the batch as n chunks on n streams, each driven by its
         # own host thread (ctypes releases the GIL) — same tokens as one call (the Gumbel hash takes the global row).
         # MEASURED on the 1 024-image beam-5 decode: 33.8 ms with 1 stream, 33.9 with 2, 51 with 3 (the HIP runtime
-        # serialises the launching threads), so the default stays 1; the option remains for hosts that want to pipeline.
+        # serialises the launching threads); with the decoder stack kernel (round 2) 20.6 ms with 1 stream, 20.8 with 2, 28.1 with
+        # 3 (`bench.py --workload decode --decode-streams n`) — so the default stays 1; the option remains for hosts that want to pipeline.
         n = int(opt.get("decode_streams", 0)) or 1
         n = max(1, min(n, B))
 
