@@ -100,21 +100,23 @@ def cpu_baseline(workload, cfg_dict, seconds=12.0):
                       f"oracle/ort_oracle.py on torch CPU fp32, {cores} threads"}
 
 
-PMC_TAG = "r02"      # profiles/<tag>_xe_b256_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
+PMC_TAG = "r03"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
 
 
-def pmc_traffic(workload, precision, B):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command (profiles/README.md):
-    2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction for 16-B/lane streaming reads), launch-weighted over the kernel's
-    instances.  Returns (bytes | None, note): None for workloads / sizes without a committed PMC profile, and — loudly —
-    when the committed CSVs do not contain the kernels this build launches (a stale profile is not a measurement)."""
+def pmc_traffic(kernel, workload, precision, B):
+    """HBM bytes per launch of ONE kernel family (`kernel`: "stack" = the decoder stack kernel, "gemm" = the forward-layout
+    GEMMs) from the committed PMC passes of THIS command (profiles/README.md): 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction
+    for 16-B/lane streaming reads), launch-weighted over the kernel's instances.  Returns (bytes | None, note): None for
+    kernels / workloads / sizes without a committed PMC profile, and — loudly — when the committed CSVs do not contain the
+    kernels this build launches (a stale profile is not a measurement)."""
     import csv
     here = os.path.dirname(os.path.abspath(__file__))
-    if workload == "decode" and precision == "bf16" and B == 1024:
-        want = ("decoder_stack_kernel",)
-        must = "decoder_stack_kernel"
-        files = [f"{PMC_TAG}_decode_stack_pmc_fetch_size.csv", f"{PMC_TAG}_decode_stack_pmc_write_size.csv"]
-    elif workload == "xe" and precision == "bf16" and B == 256:
+    if kernel == "stack" and workload in ("decode", "sparse_decode") and precision == "bf16" and B == 1024:
+        want = ("decoder_stack_kernel<true" if workload == "sparse_decode" else "decoder_stack_kernel<false",)
+        must = want[0]
+        tag = "sparse_decode_stack" if workload == "sparse_decode" else "decode_stack"
+        files = [f"{PMC_TAG}_{tag}_pmc_fetch_size.csv", f"{PMC_TAG}_{tag}_pmc_write_size.csv"]
+    elif kernel == "gemm" and workload == "xe" and precision == "bf16" and B == 256:
         want = ("gemm_bf16_glds_kernel<false, false", "gemm_bf16_dma256_kernel<false, false", "gemm_bf16_dma64_kernel")
         must = "gemm_bf16_dma256_kernel<false, false"
         files = [f"{PMC_TAG}_xe_b256_pmc_fetch_size.csv", f"{PMC_TAG}_xe_b256_pmc_write_size.csv"]
@@ -181,6 +183,205 @@ def selftest(rank, world, args):
         dist.destroy_process_group()
 
 
+WORKLOAD_NAMES = {
+    "xe": "ORT dense, batch 256 images x 5 captions, teacher-forcing XE fwd+bwd+Adam (BASELINE configs[1])",
+    "sparse_xe": "ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; masked dense GEMM = the reference's flow)",
+    "sparse_xe_kernels": ("ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; forward and data "
+                          "gradients as sparse products, weight gradients dense)"),
+    "scst": "ORT dense SCST: greedy + 5 multinomial rollouts + teacher-forced update (BASELINE configs[3])",
+    "decode": "ORT dense, cached-KV beam-5 decode, 1024 images",
+    "sparse_decode": ("ORT 95% sparse, cached-KV beam-5 decode, 1024 images (BASELINE configs[4]; decoder stack kernel on the "
+                      "sparse weight stream)"),
+    "sparse_decode_dense_kernels": ("ORT 95% sparse, cached-KV beam-5 decode, 1024 images (BASELINE configs[4]; dense kernels on "
+                                    "zero-filled weights = the reference's flow)"),
+}
+
+
+def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
+    """Build the model and the synthetic batch of one workload, time `steps` steps after `warmup` (barrier + synchronize on both
+    sides, MAX over ranks) and measure the roofline of its dominant kernel with HIP events in extra, untimed steps.
+    `variant`: "" | "kernels" (sparse_xe: sparse products) | "dense_kernels" (sparse_decode: zero-filled dense weights)."""
+    from sparse_image_captioning_amd.utils.config import ort_config
+    from sparse_image_captioning_amd.training import NativeTrainer
+    L = pkg._lib
+    decode = workload in ("decode", "sparse_decode")
+    sparse = workload.startswith("sparse")
+    use_csr = workload == "sparse_xe" and variant == "kernels"
+    sstream = workload == "sparse_decode" and variant != "dense_kernels"
+    B = args.batch or (1024 if decode else 256)
+    spi, S = 5, args.regions
+    # ORT pruning / SCST commands use drop_prob_src 0.1 (resources/commands_pruning.sh:240,265); dense XE default 0.5
+    config = ort_config(drop_prob_src=0.5, prune_type="supermask", max_seq_length=args.max_seq_length)
+    torch.manual_seed(8888)     # identical weights (and dropout / mask streams) on every rank
+    name = "relation_transformer_prune" if workload == "sparse_xe" else "relation_transformer"
+    model = pkg.get_model(name)(config, precision=args.precision)
+    if sparse:
+        with torch.no_grad():
+            if workload == "sparse_xe":    # mask logits of a converged supermask run: |m| = 6, 5 % positive -> the
+                # Bernoulli(sigmoid(m)) samples of the training step keep 0.05*0.9975 + 0.95*0.0025 = 5.2 % of the weights
+                for _, m in model.all_pruning_masks():
+                    m.copy_(torch.where(torch.rand_like(m) < 0.05, torch.full_like(m, 6.0), torch.full_like(m, -6.0)))
+            else:                                # decode: dense class on densified 95 %-pruned weights (eval_model.py:64-88)
+                for n_, p in model.named_parameters():
+                    if p.dim() >= 2:
+                        p.mul_((torch.rand_like(p) < 0.05).float())
+    model = model.to(dev)
+    if use_csr:                              # sparse products (ortk_spmm_ell) for the >= 90 %-sparse weight blocks
+        model.enable_sparse_kernels(0.9, train=True)
+    if sstream:
+        model.enable_sparse_stream(True)     # the stack kernel pulls the non-zeros of the decoder weights
+    batch = synth_batch(B, S, config.att_feat_size, config.vocab_size, spi, config.max_seq_length, 1000 + rank, dev)
+
+    if decode:
+        model.eval()
+        opt = {"beam_size": 5}
+        if args.decode_streams > 1:
+            opt["decode_streams"] = args.decode_streams
+
+        def step():
+            model(att_feats=batch["att_feats"], boxes=batch["boxes"], att_masks=batch["att_masks"], opt=opt, mode="sample")
+        units_per_step = B
+    elif workload == "scst":
+        model.train()
+        tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000)
+        rw = torch.randn(B * 5, device=dev)
+
+        def step():
+            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy")
+        units_per_step = B * 5
+    else:
+        model.train()
+        tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000,
+                           sparsity_target=0.95 if workload == "sparse_xe" else None, max_train_step=100000,
+                           overlap_allreduce={"auto": None, "on": True, "off": False}[args.overlap_allreduce])
+
+        def step():
+            tr.xe_step(batch)
+        units_per_step = B * spi
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+    ms_per_step = elapsed / steps * 1e3
+    value = world * units_per_step / (elapsed / steps)
+
+    # ---- roofline of the dominant kernel, measured live with HIP events around every launch of extra (untimed) steps on the
+    # launch stream: once in the TIMED schedule (ortk_prof_enable(2): side stream on, the figure `achieved` reports) and once
+    # with every launch on one stream (enable(1): the kernel in isolation).  EVERY rank runs those steps (they contain the
+    # data-parallel collectives); only rank 0 records and reports.
+    lib = L.lib()
+    key = (4 if args.precision == "bf16" else 0)
+    collected = {}
+    for level in (2, 1):
+        if rank == 0:
+            lib.ortk_prof_enable(level)
+        step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            rec = {}
+            for k in (key, key + 1, key + 3, 16):
+                lib.ortk_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl))
+                lib.ortk_prof_collect_bytes(k, C.byref(by))
+                rec[k] = (n.value, ms.value, fl.value, by.value)
+            collected[level] = rec
+            lib.ortk_prof_enable(0)
+    if rank != 0:
+        return None
+    per_key, iso = collected[2], collected[1]
+    stack = None        # decode: the one-launch-per-position decoder stack (key 16), same HIP-event hook
+    if decode and per_key[16][0]:
+        sn, sms, sfl, sby = per_key[16]
+        gbs_k = sby / (sms * 1e-3) / 1e9
+        stack = {"kernel": ("decoder_stack_kernel<sparse> (ortk_decstack.hip): all decoder layers of one position, rows stationary, the "
+                            "NON-ZEROS of the weights streamed as scatter entries and expanded through LDS" if sstream else
+                            "decoder_stack_kernel (ortk_decstack.hip): all decoder layers of one position, rows stationary, weights streamed"),
+                 "launches_per_step": sn, "avg_launch_us": round(sms * 1e3 / sn, 1),
+                 "algorithmic_bytes_per_launch": round(sby / sn), "achieved": round(gbs_k, 1),
+                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4),
+                 "mfma_tflops": round(sfl / (sms * 1e-3) / 1e12, 1), "ms_per_step": round(sms, 3)}
+        stack["traffic"], stack["traffic_note"] = pmc_traffic("stack", workload, args.precision, B)
+    n0, ms0, fl0, by0 = per_key[key]
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+    ach_iso = iso[key][2] / (iso[key][1] * 1e-3) / 1e12 if iso[key][1] > 0 else 0.0
+    tot_ms = sum(per_key[k][1] for k in (key, key + 1, key + 3))
+    tot_fl = sum(per_key[k][2] for k in (key, key + 1, key + 3))
+    traffic, traffic_note = pmc_traffic("gemm", workload, args.precision, B)
+    gemm = {"kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> / gemm_bf16_dma64_kernel (k-contiguous operands: forward X*W^T, and dY*W on transposed bf16 weight copies; LDS-DMA pipeline)" if args.precision == "bf16"
+                       else "gemm_f32_kernel<false,false> (forward X*W^T)"),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "schedule": "timed schedule (weight-gradient GEMMs on the side stream beside these launches)",
+            "isolated": {"achieved": round(ach_iso, 2), "frac": round(ach_iso / peak, 4),
+                         "avg_launch_us": round(iso[key][1] * 1e3 / max(iso[key][0], 1), 2),
+                         "schedule": "every launch on one stream"},
+            "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
+            "algorithmic_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3),
+            "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
+                                 "ms_per_step": round(tot_ms, 3)},
+            "traffic": traffic, "algorithmic_bytes_per_launch": round(by0 / max(n0, 1)), "traffic_note": traffic_note}
+    if decode or use_csr:
+        # SURVEY section 8(d): the 95 %-sparse step and the cached decode are HBM-bound.  Algorithmic bytes: decode =
+        # 25.7 MB per image (self-KV reads 10.5 + cross-KV 8.0 + logits 7.2) + the weights once per step (18 steps:
+        # 110.9 MB dense bf16, or 4 bytes per non-zero); sparse XE step = activations of the dense step (the bytes
+        # ortk_prof_collect_bytes sums over the GEMM launches of one step) with 4 bytes per non-zero for the weights.
+        nnz_bytes = 2.77e6 * 4
+        if decode:
+            algo = B * 25.7e6 + config.max_seq_length * (nnz_bytes if sparse else 110.9e6)
+        else:
+            # forward + data-gradient products of one step: X (M x K) and Y (M x N) once each in bf16, 4 bytes per non-zero;
+            # the dense weight-gradient products read their two operands once and add into fp32 (M rows: 9 216 / 21 760)
+            Me, Md = B * S, B * spi * (config.max_seq_length - 1)
+            prods = ([(Me, 512, 2048, 1), (Me, 1536, 512, 6), (Me, 512, 512, 6), (Me, 2048, 512, 6), (Me, 512, 2048, 6), (Me, 6144, 512, 1),
+                      (Md, 1536, 512, 6), (Md, 512, 512, 18), (Md, 2048, 512, 6), (Md, 512, 2048, 6), (Md, 10112, 512, 1)])
+            algo = sum(c * (2 * (2 * M * K + 2 * M * N) + (2 * M * K + 2 * M * N + 4 * N * K)) for M, N, K, c in prods) + 3 * nnz_bytes
+        gbs = algo / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "whole step (all launches): the path is bandwidth-bound as a whole",
+                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "algorithmic_bytes_per_step": round(algo), "traffic": None,
+                    "dense_gemm_launches_of_the_step": gemm}
+        if stack is not None:
+            roofline["dominant_kernel"] = stack
+    else:
+        roofline = dict(gemm, bound="mfma")
+        roofline = {k: roofline[k] for k in ["bound"] + [k for k in gemm]}
+    if not decode:
+        # dense-equivalent work of the step (SURVEY 8d: 6.354 GFLOP forward per image, x3).  For sparse_xe this is the work
+        # the masked DENSE GEMMs execute (and the weight gradients always do); the sparse products touch 5 % of it.
+        step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3
+        if workload != "scst":
+            roofline["whole_step"] = {"dense_equivalent_tflop": round(step_tflop, 3),
+                                      "achieved_tflops": round(step_tflop / (ms_per_step * 1e-3), 2),
+                                      "frac_of_peak": round(step_tflop / (ms_per_step * 1e-3) / peak, 4)}
+    wname = workload + ("_" + variant if variant else "")
+    out = {"metric": "captions/sec", "value": round(value, 1), "unit": "captions/sec", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+           "config": {"workload": WORKLOAD_NAMES[wname], "images_per_gpu": B, "regions": S, "captions_per_image": spi,
+                      "parallelism": f"dp{world}" if world > 1 else "single",
+                      "storage": ("fp32 master weights / residual stream / logits; MFMA-operand tensors stored bf16; fp32 accumulate"
+                                  if args.precision == "bf16" else "fp32"),
+                      "sparse_kernels": (os.environ.get("ORTK_SPARSE_FORMAT", "ell16") + " (ortk_spmm)" if use_csr else
+                                         "decoder stack kernel, sparse weight stream (ORTK_DEC_SPARSE_STREAM)" if sstream else None)},
+           "roofline": roofline}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,9 +392,11 @@ def main():
                     help="all-reduce the decoder half of the gradients while the encoder half of the backward runs "
                          "(auto: on when more than one rank)")
     ap.add_argument("--csr-kernels", "--sparse-kernels", dest="csr_kernels", action="store_true",
-                    help="sparse_decode / sparse_xe: sparse products (ortk_spmm_ell, sorted-ELL images rebuilt on the device every "
-                         "call) instead of MFMA GEMMs on zero-filled weights; sparse_xe: forward and data gradients (the weight "
-                         "gradients stay dense: the straight-through mask gradient needs them at every position)")
+                    help="sparse_xe: sparse products (ortk_spmm, sorted-ELL images rebuilt on the device every call) for the forward "
+                         "and the data gradients instead of MFMA GEMMs on zero-filled weights (the weight gradients stay dense: the "
+                         "straight-through mask gradient needs them at every position)")
+    ap.add_argument("--dense-kernels", action="store_true",
+                    help="sparse_decode: the reference's flow — dense kernels on zero-filled weights — instead of the sparse weight stream")
     ap.add_argument("--decode-streams", type=int, default=0,
                     help="decode workloads: decode the batch as this many chunks of images on as many streams (0 = one call)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 256; decode 1024)")
@@ -201,6 +404,8 @@ def main():
     ap.add_argument("--regions", type=int, default=36, help="regions per image (36 = BASELINE; real bottom-up features have 10-100)")
     ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="default run on one GPU: do not add the `workloads` object (BASELINE configs[2], [3], [4] timed in this process)")
     ap.add_argument("--selftest", action="store_true",
                     help="launcher check without a GPU: the ranks form a gloo group, all-reduce their rank ids and rank 0 "
                          "prints one JSON line (tests/test_dist_cpu.py)")
@@ -226,177 +431,22 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     import sparse_image_captioning_amd as pkg
-    from sparse_image_captioning_amd.utils.config import ort_config
-    from sparse_image_captioning_amd.training import NativeTrainer
-    L = pkg._lib
-    L.require_gpu()
+    pkg._lib.require_gpu()
 
-    decode = args.workload in ("decode", "sparse_decode")
-    sparse = args.workload.startswith("sparse")
-    B = args.batch or (1024 if decode else 256)
-    spi, S = 5, args.regions
-    # ORT pruning / SCST commands use drop_prob_src 0.1 (resources/commands_pruning.sh:240,265); dense XE default 0.5
-    config = ort_config(drop_prob_src=0.5, prune_type="supermask", max_seq_length=args.max_seq_length)
-    torch.manual_seed(8888)     # identical weights (and dropout / mask streams) on every rank
-    name = "relation_transformer_prune" if args.workload == "sparse_xe" else "relation_transformer"
-    model = pkg.get_model(name)(config, precision=args.precision)
-    if sparse:
-        with torch.no_grad():
-            if args.workload == "sparse_xe":    # mask logits of a converged supermask run: |m| = 6, 5 % positive -> the
-                # Bernoulli(sigmoid(m)) samples of the training step keep 0.05*0.9975 + 0.95*0.0025 = 5.2 % of the weights
-                for _, m in model.all_pruning_masks():
-                    m.copy_(torch.where(torch.rand_like(m) < 0.05, torch.full_like(m, 6.0), torch.full_like(m, -6.0)))
-            else:                                # decode: dense class on densified 95 %-pruned weights (eval_model.py:64-88)
-                for n_, p in model.named_parameters():
-                    if p.dim() >= 2:
-                        p.mul_((torch.rand_like(p) < 0.05).float())
-    model = model.to(dev)
-    use_csr = sparse and args.csr_kernels
-    if use_csr:                              # sparse products (ortk_spmm_ell) for the >= 90 %-sparse weight blocks
-        model.enable_sparse_kernels(0.9, train=args.workload == "sparse_xe")
-    batch = synth_batch(B, S, config.att_feat_size, config.vocab_size, spi, config.max_seq_length, 1000 + rank, dev)
-
-    if decode:
-        model.eval()
-        opt = {"beam_size": 5}
-        if args.decode_streams > 1:
-            opt["decode_streams"] = args.decode_streams
-
-        def step():
-            model(att_feats=batch["att_feats"], boxes=batch["boxes"], att_masks=batch["att_masks"], opt=opt, mode="sample")
-        units_per_step = B
-    elif args.workload == "scst":
-        model.train()
-        tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000)
-        rw = torch.randn(B * 5, device=dev)
-
-        def step():
-            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy")
-        units_per_step = B * 5
-    else:
-        model.train()
-        tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000,
-                           sparsity_target=0.95 if args.workload == "sparse_xe" else None, max_train_step=100000,
-                           overlap_allreduce={"auto": None, "on": True, "off": False}[args.overlap_allreduce])
-
-        def step():
-            tr.xe_step(batch)
-        units_per_step = B * spi
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = elapsed.item()
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * units_per_step / (elapsed / args.steps)
-
-    out = None
-    # ---- roofline of the dominant kernel: the forward-layout MFMA GEMM (X W^T), measured live with HIP events around
-    # every launch of one extra (untimed) step, on the launch stream.  EVERY rank runs that step (it contains the
-    # data-parallel collectives); only rank 0 records and reports.
-    lib = L.lib()
+    variant = "kernels" if (args.workload == "sparse_xe" and args.csr_kernels) else (
+        "dense_kernels" if (args.workload == "sparse_decode" and args.dense_kernels) else "")
+    out = run_workload(args, args.workload, variant, args.steps, args.warmup, rank, world, dev, pkg)
     if rank == 0:
-        lib.ortk_prof_enable(1)
-    step()
-    torch.cuda.synchronize()
-    if rank == 0:
-        key = (4 if args.precision == "bf16" else 0)
-        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-        per_key = {}
-        for k in (key, key + 1, key + 3):
-            lib.ortk_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl))
-            per_key[k] = (n.value, ms.value, fl.value)
-        by = C.c_double()
-        lib.ortk_prof_collect_bytes(key, C.byref(by))
-        stack = None        # decode: the one-launch-per-position decoder stack (key 16), same HIP-event hook
-        if decode:
-            sn, sms, sfl, sby = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-            lib.ortk_prof_collect(16, C.byref(sn), C.byref(sms), C.byref(sfl))
-            lib.ortk_prof_collect_bytes(16, C.byref(sby))
-            if sn.value:
-                gbs_k = sby.value / (sms.value * 1e-3) / 1e9
-                stack = {"kernel": "decoder_stack_kernel (ortk_decstack.hip): all decoder layers of one position, rows stationary, "
-                                   "weights streamed",
-                         "launches_per_step": sn.value, "avg_launch_us": round(sms.value * 1e3 / sn.value, 1),
-                         "algorithmic_bytes_per_launch": round(sby.value / sn.value), "achieved": round(gbs_k, 1),
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4),
-                         "mfma_tflops": round(sfl.value / (sms.value * 1e-3) / 1e12, 1), "ms_per_step": round(sms.value, 3)}
-                stack["traffic"], stack["traffic_note"] = pmc_traffic(args.workload, args.precision, B)
-        lib.ortk_prof_enable(0)
-        n0, ms0, fl0 = per_key[key]
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
-        tot_ms = sum(v[1] for v in per_key.values())
-        tot_fl = sum(v[2] for v in per_key.values())
-        traffic, traffic_note = pmc_traffic(args.workload, args.precision, B)
-        gemm = {"kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> / gemm_bf16_dma64_kernel (k-contiguous operands: forward X*W^T, and dY*W on transposed bf16 weight copies; LDS-DMA pipeline)" if args.precision == "bf16"
-                           else "gemm_f32_kernel<false,false> (forward X*W^T)"),
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
-                "algorithmic_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3),
-                "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
-                                     "ms_per_step": round(tot_ms, 3)},
-                "traffic": traffic, "algorithmic_bytes_per_launch": round(by.value / max(n0, 1)), "traffic_note": traffic_note}
-        if decode or use_csr:
-            # the 95 %-sparse step and the cached decode are HBM-bound.  Algorithmic bytes: decode =
-            # 25.7 MB per image (self-KV reads 10.5 + cross-KV 8.0 + logits 7.2) + the weights once per step (18 steps:
-            # 110.9 MB dense bf16, or 4 bytes per non-zero); sparse XE step = activations of the dense step (the bytes
-            # ortk_prof_collect_bytes sums over the GEMM launches of one step) with 4 bytes per non-zero for the weights.
-            nnz_bytes = 2.77e6 * 4
-            if decode:
-                algo = B * 25.7e6 + config.max_seq_length * (nnz_bytes if sparse else 110.9e6)
-            else:
-                # forward + data-gradient products of one step: X (M x K) and Y (M x N) once each in bf16, 4 bytes per non-zero;
-                # the dense weight-gradient products read their two operands once and add into fp32 (M rows: 9 216 / 21 760)
-                Me, Md = B * S, B * spi * (config.max_seq_length - 1)
-                prods = ([(Me, 512, 2048, 1), (Me, 1536, 512, 6), (Me, 512, 512, 6), (Me, 2048, 512, 6), (Me, 512, 2048, 6), (Me, 6144, 512, 1),
-                          (Md, 1536, 512, 6), (Md, 512, 512, 18), (Md, 2048, 512, 6), (Md, 512, 2048, 6), (Md, 10112, 512, 1)])
-                algo = sum(c * (2 * (2 * M * K + 2 * M * N) + (2 * M * K + 2 * M * N + 4 * N * K)) for M, N, K, c in prods) + 3 * nnz_bytes
-            gbs = algo / (ms_per_step * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "whole step (all launches): the path is bandwidth-bound as a whole",
-                        "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                        "algorithmic_bytes_per_step": round(algo), "traffic": None,
-                        "dense_gemm_launches_of_the_step": gemm}
-            if stack is not None:
-                roofline["dominant_kernel"] = stack
-        else:
-            roofline = dict(gemm, bound="mfma")
-            roofline = {k: roofline[k] for k in ["bound"] + [k for k in gemm]}
-        if not decode:
-            # dense-equivalent work of the step (6.354 GFLOP forward per image, x3).  For sparse_xe this is the work
-            # the masked DENSE GEMMs execute (and the weight gradients always do); the sparse products touch 5 % of it.
-            step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3
-            roofline["whole_step"] = {"dense_equivalent_tflop": round(step_tflop, 3),
-                                      "achieved_tflops": round(step_tflop / (ms_per_step * 1e-3), 2),
-                                      "frac_of_peak": round(step_tflop / (ms_per_step * 1e-3) / peak, 4)}
-        cfgname = {"xe": "ORT dense, batch 256 images x 5 captions, teacher-forcing XE fwd+bwd+Adam (BASELINE configs[1])",
-                   "sparse_xe": ("ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; forward and data "
-                                 "gradients as sparse products, weight gradients dense)" if use_csr else
-                                 "ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; masked dense GEMM)"),
-                   "scst": "ORT dense SCST: greedy + 5 multinomial rollouts + teacher-forced update (BASELINE configs[3])",
-                   "decode": "ORT dense, cached-KV beam-5 decode, 1024 images",
-                   "sparse_decode": "ORT 95% sparse, cached-KV beam-5 decode, 1024 images (BASELINE configs[4])"}[args.workload]
-        out = {"metric": "captions/sec", "value": round(value, 1), "unit": "captions/sec", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-               "config": {"workload": cfgname, "images_per_gpu": B, "regions": S, "captions_per_image": spi,
-                          "parallelism": f"dp{world}" if world > 1 else "single",
-                          "storage": ("fp32 master weights / residual stream / logits; MFMA-operand tensors stored bf16; fp32 accumulate"
-                                      if args.precision == "bf16" else "fp32"),
-                          "sparse_kernels": os.environ.get("ORTK_SPARSE_FORMAT", "ell16") + " (ortk_spmm)" if use_csr else None},
-               "roofline": roofline, "parity": PARITY}
+        out["parity"] = PARITY
+        # The other BASELINE configs, timed in this same process with the same contract (fewer steps: the whole default run
+        # stays within a couple of minutes).  One GPU only: the driver's scaling runs measure the headline.
+        if args.workload == "xe" and world == 1 and not args.no_extra_workloads and not args.batch:
+            extra = {}
+            for wl, var, st, wu in (("sparse_xe", "", 30, 5), ("sparse_xe", "kernels", 20, 3), ("scst", "", 20, 3),
+                                    ("decode", "", 12, 3), ("sparse_decode", "", 12, 3), ("sparse_decode", "dense_kernels", 12, 3)):
+                r = run_workload(args, wl, var, st, wu, rank, world, dev, pkg)
+                extra[wl + ("_" + var if var else "")] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline")}
+            out["workloads"] = extra
         if not args.no_cpu_baseline and world == 1:
             from sparse_image_captioning_amd.utils.config import ORT_DEFAULTS
             out["cpu_baseline"] = cpu_baseline(args.workload, dict(ORT_DEFAULTS))

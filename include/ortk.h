@@ -204,6 +204,10 @@ typedef struct ortk_spmm_args {
 } ortk_spmm_args;
 int ortk_spmm(const ortk_sparse_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream);
 
+#define ORTK_DEC_UNFUSED 1
+#define ORTK_DEC_STACK 2
+#define ORTK_DEC_SPARSE_STREAM 4
+#define ORTK_DEC_STACK_RB20 8
 typedef struct ortk_decode_opts {
     int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
     int32_t num_random_sample;
@@ -216,7 +220,17 @@ typedef struct ortk_decode_opts {
      * ortk_linear_block).  ortk_decode rebuilds it from the weights of this call and runs every projection that has a
      * block in it as a sparse product (ortk_spmm) instead of a dense GEMM. */
     const struct ortk_sparse_plan* sparse;
-    int32_t reserved0;
+    /* Executor choice (bit flags, 0 = automatic): by default a decode of >= 1 600 rows (images x beams) in mixed precision runs
+     * the one-launch-per-position decoder stack kernel on the dense weight stream, smaller ones the unfused executor.
+     *   ORTK_DEC_UNFUSED        never the stack kernel;
+     *   ORTK_DEC_STACK          the stack kernel whenever the configuration is served, whatever the row count;
+     *   ORTK_DEC_SPARSE_STREAM  the decoder weights of this call are mostly zeros (a pruned checkpoint evaluated as dense
+     *                           linears on zero-filled weights, scripts/eval_model.py:64-88): the stack kernel streams their
+     *                           NON-ZEROS (rebuilt on the device from the weights of the call, no host sync; correct at any
+     *                           density, faster than the dense stream above ~80 % zeros); implies ORTK_DEC_STACK;
+     *   ORTK_DEC_STACK_RB20     dense stream with 20-row workgroups (measurement);
+     *   bits 8-11               measurement only: skip self-attention (1) / cross-attention (2) / the FFN (4), no L2 prefetchers (8). */
+    int32_t exec_flags;
     /* multinomial only: also decode ONE greedy row per image in the same pass (the SCST baseline of
      * utils/training.py:220-237): K = num_random_sample + 1, row 0 of each image is the arg-max decode, rows 1.. are
      * the samples — token for token what two separate calls return, at half the launches. */
@@ -277,7 +291,9 @@ typedef struct ortk_gemm_args {
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its
- * launch stream, summed per kernel instance key = precision*4 + transA*2 + transB.  collect() synchronises. */
+ * launch stream, summed per kernel instance key = precision*4 + transA*2 + transB.  collect() synchronises.
+ * on = 1: the executor also keeps every launch on the caller's stream (kernels timed one at a time); on = 2: the schedule of
+ * the timed region as it is (weight-gradient GEMMs on the executor's side stream beside the launches being timed). */
 int ortk_prof_enable(int32_t on);
 int ortk_prof_collect(int32_t key, int64_t* launches, double* total_ms, double* total_flops);
 /* algorithmic bytes of the same launches: operands once (A: M x K, B: N x K), the output once, residual / gate rows once */

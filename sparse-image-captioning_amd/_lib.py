@@ -60,10 +60,13 @@ class SpmmArgs(C.Structure):
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
 
 
+DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20 = 1, 2, 4, 8      # ortk_decode_opts.exec_flags
+
+
 class DecodeOpts(C.Structure):
     _fields_ = [("beam_size", C.c_int32), ("num_random_sample", C.c_int32), ("temperature", C.c_float),
                 ("decoding_constraint", C.c_int32), ("length_penalty", C.c_int32), ("length_alpha", C.c_double),
-                ("seed", C.c_uint64), ("sparse", C.POINTER(EllPlanStruct)), ("reserved0", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64)]
+                ("seed", C.c_uint64), ("sparse", C.POINTER(EllPlanStruct)), ("exec_flags", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64)]
 
 
 class GemmArgs(C.Structure):

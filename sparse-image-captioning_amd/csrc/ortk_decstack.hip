@@ -28,6 +28,7 @@
 // What bounds it: 14 units x 512 KB of weights per layer pass through every CU's vector-memory path — 3.4 us per unit at the
 // nominal 64 B/clk, ~6 us measured (85 GB/s per CU); 160 workgroups for 1 024 images x 5 beams.  DESIGN.md section 4.
 #include "ortk_internal.h"
+#include <mutex>
 
 namespace ortk {
 namespace {
@@ -35,9 +36,10 @@ namespace {
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 constexpr int SD = 512;            // d_model
-constexpr int SRB = 32;            // rows per workgroup
 constexpr int SPD = 4;             // k-steps of weight fragments in flight per wave
-constexpr int SIMG = SRB * SD * 2; // bytes of one bf16 A image
+// sparse stream: per wave a 4-KB dense fragment buffer (4 column tiles x 64 lanes x 16 B: one k-step) + 256 B of pad slots
+constexpr int SDBUF = 4096 + 256;
+constexpr int SCAP = 128;          // scatter entries per step (64 lanes x 2)
 constexpr int XNR = 5;             // rows of one image served per cross-attention pass
 // Attention batch sizes (-D overrides are for the sweeps of scratch/variant_sweep.sh): measured best, all within 0.2 ms of
 // each other as long as the kernel does not spill; 8-key batches spill and cost 2 ms per decode.
@@ -122,6 +124,97 @@ __device__ __forceinline__ void unit_gemm(f32x4 (&acc)[2][4], const char* A, con
     wp += 16 * KSTEP;
 }
 
+
+// ------------------------------------------------------------------------------------------------ sparse weight stream
+// The same unit product when the decoder weights are mostly zeros (the reference evaluates pruned checkpoints as dense
+// linears on zero-filled weights, scripts/eval_model.py:64-88).  The dense stream is bound by the bytes a CU can pull
+// through its vector-memory path (512 KB per unit per workgroup, ~85 GB/s); here a wave pulls only the NON-ZEROS of its 64
+// weight rows — (position, value) scatter entries, 4 bytes each — expands one k-step (4 column tiles x 64 lanes x 8 weights =
+// 4 KB) at a time into a private LDS buffer with two ds_write_b16 per lane, reads the four dense MFMA fragments back with
+// ds_read_b128 and multiplies on the matrix cores as before (same accumulation order: bit-identical to the dense stream
+// unless a k-step overflows its step, below).  The buffer is kept all-zero between steps by writing zeros to the same
+// positions once the fragments are in registers (two more ds_write_b16), so nothing is ever cleared wholesale.  LDS
+// operations of one wave execute in order: [clear step i] [scatter step i+1] [read step i+1] are queued back to back behind
+// [read step i] with no waits, and the MFMAs of step i run while they complete.
+//
+// Entry: bits 0-15 the bf16 weight, 16-27 its halfword index in the 4-KB fragment buffer ((tile * 64 + lane) * 8 + j; pad
+// entries point at private slots 2048 + 2 lane + j behind it), 28-31 the k-step (32 input columns) of the whole step.  A
+// step = 64 lanes x 2 entries; a k-step with more than 128 non-zeros in the wave's 64 rows (0.5 % of them at 95 % zeros:
+// 102 +- 10) takes further steps with the same k — so the stream is correct at ANY density — and the steps of a unit are
+// padded to a multiple of four (the depth of the register ring that prefetches them).  Inside a step the builder deals the
+// entries to the four 32-lane groups of the two store instructions so that no group has more than two entries on one of the
+// 32 LDS banks where that is possible (a 2-way store conflict is free: the store's data transfer takes as long).
+//
+// What bounds it (counters: profiles/r03_sparse_decode_stack_pmc_*): a wave issues at most one
+// instruction per 4 cycles, the 8 MFMAs of a k-step take 128, and the LDS serves 8 waves: four 2-byte scatter / clear stores,
+// four fragment reads and two operand reads per wave and k-step are ~45 LDS cycles x 8 waves against 256 of MFMA time.  Four
+// other expansions were built and measured this round, all token-identical, all SLOWER than this one (1 024-image beam-5
+// decode; dense stream 20.7 ms): bitmap + compacted 8-byte pieces fetched (a) by one buffer load per piece with out-of-range
+// offsets for the zero lanes: 27.7 ms (~18 cycles of texture-addresser time per sparse wave-instruction), (b) through an LDS
+// ring filled by LDS-DMA: 24.3 ms, (c) through a 16-deep register ring + one LDS staging slot, masks by s_load: 29.2 ms,
+// (d) the same with the masks travelling in the step's own registers (v_readlane): 26.6 ms — the v_mbcnt / select / address
+// arithmetic is ~6 vector + 4 scalar instructions per piece, 150 per k-step, 600 cycles of issue time per wave.
+struct SRing { uint2 e[SPD]; };
+typedef const int __attribute__((address_space(4)))* cint_ptr;       // constant address space: uniform loads become s_load
+
+__device__ __forceinline__ void sring_start(SRing& r, const uint2* sp, int lane) {
+#pragma unroll
+    for (int s = 0; s < SPD; ++s) r.e[s] = sp[s * 64 + lane];
+}
+__device__ __forceinline__ void s_scatter(char* D, const uint2 e) {
+    *reinterpret_cast<unsigned short*>(D + ((e.x >> 15) & 0x1FFE)) = (unsigned short)e.x;
+    *reinterpret_cast<unsigned short*>(D + ((e.y >> 15) & 0x1FFE)) = (unsigned short)e.y;
+}
+__device__ __forceinline__ void s_clear(char* D, const uint2 e) {
+    *reinterpret_cast<unsigned short*>(D + ((e.x >> 15) & 0x1FFE)) = 0;
+    *reinterpret_cast<unsigned short*>(D + ((e.y >> 15) & 0x1FFE)) = 0;
+}
+__device__ __forceinline__ void s_frags(const char* D, uint4 (&f)[4], int lane) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f[nt] = *reinterpret_cast<const uint4*>(D + nt * 1024 + lane * 16);
+}
+__device__ __forceinline__ int s_kstep(const uint2 e) { return __builtin_amdgcn_readfirstlane((int)(e.x >> 28)); }
+
+// NEXT: the first step of the unit that follows in the stream is expanded and read into F[0] on the way out (false: the
+// buffer is left clean and F dead — an attention phase needs the registers — and the next unit calls s_unit_cold first).
+__device__ __forceinline__ void s_unit_cold(char* D, const SRing& E, uint4 (&F)[2][4], int lane) {
+    s_scatter(D, E.e[0]);
+    s_frags(D, F[0], lane);
+}
+template <bool NEXT>
+__device__ __forceinline__ void unit_sparse(f32x4 (&acc)[2][4], const char* A, char* D, const uint2*& sp, int nst, SRing& E, uint4 (&F)[2][4], int lane) {
+    const int m = lane & 15, kg = lane >> 4;
+    bf16x8 a[2][2];
+    {
+        const int ks = s_kstep(E.e[0]);
+        a[0][0] = *reinterpret_cast<const bf16x8*>(A + img_off(m, 4 * ks + kg));
+        a[0][1] = *reinterpret_cast<const bf16x8*>(A + img_off(16 + m, 4 * ks + kg));
+    }
+#pragma unroll 1
+    for (int g = 0; g < nst; g += SPD) {
+#pragma unroll
+        for (int s = 0; s < SPD; ++s) {
+            const int p = s & 1, sn = (s + 1) & (SPD - 1);
+            const bool more = s < SPD - 1 || g + SPD < nst;        // another step of THIS unit follows
+            s_clear(D, E.e[s]);
+            if (NEXT || more) { s_scatter(D, E.e[sn]); s_frags(D, F[p ^ 1], lane); }
+            if (more) {
+                const int ks = s_kstep(E.e[sn]);
+                a[p ^ 1][0] = *reinterpret_cast<const bf16x8*>(A + img_off(m, 4 * ks + kg));
+                a[p ^ 1][1] = *reinterpret_cast<const bf16x8*>(A + img_off(16 + m, 4 * ks + kg));
+            }
+            E.e[s] = sp[(g + s + SPD) * 64 + lane];                // (past the unit: the next unit's steps; past the stream: zeroed slack)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, F[p][nt]);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[p][0], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[p][1], acc[1][nt], 0, 0, 0);
+            }
+        }
+    }
+    sp += (int64_t)nst * 64;
+}
+
 __device__ __forceinline__ void zero(f32x4 (&a)[2][4]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -134,12 +227,14 @@ __device__ __forceinline__ void load_cols(const float* p, int wave, int lane, f3
     for (int nt = 0; nt < 4; ++nt) v[nt] = *reinterpret_cast<const f32x4*>(p + 64 * wave + 16 * nt + 4 * (lane >> 4));
 }
 // (acc + bias [relu]) as bf16 into an A image
+template <int RB>
 __device__ __forceinline__ void store_img(char* img, const f32x4 (&acc)[2][4], const f32x4 (&bias)[4], bool relu, int wave, int lane) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int row = 16 * mt + (lane & 15), col = 64 * wave + 16 * nt + 4 * (lane >> 4);
+            if (RB < 32 && row >= RB) continue;          // rows past the block: no image row (their accumulators are don't-cares)
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[mt][nt][r] + bias[nt][r]; if (relu) v[r] = fmaxf(v[r], 0.f); }
@@ -149,6 +244,7 @@ __device__ __forceinline__ void store_img(char* img, const f32x4 (&acc)[2][4], c
 
 // LayerNorm of the register-resident rows (transformer.py:338-341: a (x - mean) / (std_unbiased + eps) + b), two exchanges
 // of per-wave partial sums through LDS.  The caller puts a barrier between the result and its consumers.
+template <bool RAW>
 __device__ __forceinline__ void layer_norm(const f32x4 (&x)[2][4], const float* ga, const float* be, float eps, float* red1, float* red2,
                                            int wave, int lane, f32x4 (&y)[2][4]) {
     f32x4 a4[4], b4[4];
@@ -166,7 +262,7 @@ __device__ __forceinline__ void layer_norm(const f32x4 (&x)[2][4], const float* 
         s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
         if (lane < 16) red1[(16 * mt + m) * 8 + wave] = s;
     }
-    __syncthreads();
+    if constexpr (RAW) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const f32x4 p0 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * 8), p1 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * 8 + 4);
@@ -179,7 +275,7 @@ __device__ __forceinline__ void layer_norm(const f32x4 (&x)[2][4], const float* 
         q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
         if (lane < 16) red2[(16 * mt + m) * 8 + wave] = q;
     }
-    __syncthreads();
+    if constexpr (RAW) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const f32x4 p0 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * 8), p1 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * 8 + 4);
@@ -191,12 +287,14 @@ __device__ __forceinline__ void layer_norm(const f32x4 (&x)[2][4], const float* 
             for (int r = 0; r < 4; ++r) y[mt][nt][r] = a4[nt][r] * (x[mt][nt][r] - mean[mt]) * rinv[mt] + b4[nt][r];
     }
 }
+template <int RB>
 __device__ __forceinline__ void store_img_plain(char* img, const f32x4 (&y)[2][4], int wave, int lane) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int row = 16 * mt + (lane & 15), col = 64 * wave + 16 * nt + 4 * (lane >> 4);
+            if (RB < 32 && row >= RB) continue;
             *reinterpret_cast<uint2*>(img + img_off(row, col >> 3) + ((col >> 2) & 1) * 8) =
                 make_uint2(pack2(y[mt][nt][0], y[mt][nt][1]), pack2(y[mt][nt][2], y[mt][nt][3]));
         }
@@ -275,18 +373,25 @@ struct AttState {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ the kernel
+// SPARSE: the weights arrive as the scatter-entry stream above instead of packed dense fragments.  RB: rows per workgroup
+// (32: 160 workgroups for 1 024 images x 5 beams; 20: 256 workgroups, one per CU, four images of five beams each — what the
+// sparse stream uses: its cost per workgroup no longer depends on L2 bandwidth shared with the others, so more, smaller
+// workgroups only shorten the attention phases).  Rows RB .. 31 of the two MFMA row tiles do not exist: their operand reads
+// land in whatever follows the image in LDS, their accumulators are never stored.
+template <bool SPARSE, int RB>
 __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IMG = RB * SD * 2;  // bytes of one bf16 A image
     char* A0 = smem;                  // LayerNorm output / attention output: the A operand of the next projection
-    char* A1 = smem + SIMG;           // query image; FFN hidden chunk (even)
-    char* KN = smem + 2 * SIMG;       // this position's K; FFN hidden chunk (odd)
-    char* VN = smem + 3 * SIMG;       // this position's V
-    float* red1 = reinterpret_cast<float*>(smem + 4 * SIMG);
-    float* red2 = red1 + SRB * 8;
+    char* A1 = smem + IMG;            // query image; FFN hidden chunk (even)
+    char* KN = smem + 2 * IMG;        // this position's K; FFN hidden chunk (odd)
+    char* VN = smem + 3 * IMG;        // this position's V
+    float* red1 = reinterpret_cast<float*>(smem + 4 * IMG);
+    float* red2 = red1 + 32 * 8;
     const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = lane0;
     const int U = 6 + 2 * a.NC;
-    if ((int)blockIdx.x >= a.nblocks) {
+    if (!SPARSE && (int)blockIdx.x >= a.nblocks) {
         // L2 prefetcher of one XCD (workgroups are dealt to the 8 XCDs round-robin, so nblocks + j runs on XCD (nblocks + j) % 8
         // and workgroup k < 8 — the pace-maker that publishes its progress — on XCD k).  The compute workgroups of an XCD walk
         // the same weight stream in step; without this every one of their fragment loads is an L2 MISS that all of them wait
@@ -307,13 +412,13 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         if (sink == 0x9E3779B1u) a.progress[8] = 1;                          // (keeps the loads)
         return;
     }
-    const bool pace = blockIdx.x < 8 && tid == 0;
+    const bool pace = !SPARSE && a.progress != nullptr && blockIdx.x < 8 && tid == 0;
     int unit_no = a.t * a.L * U;
 // a fresh, opaque copy of the lane id per phase: without it the compiler hoists every lane-derived address of every phase
     // out of the layer loop and keeps ~60 of them alive (spilled) through the whole kernel
 #define STACK_FRESH_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
 #define STACK_UNIT_BEGIN() do { ++unit_no; if (pace) __hip_atomic_store(a.progress + blockIdx.x, unit_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
-    const int r0 = blockIdx.x * SRB;
+    const int r0 = blockIdx.x * RB;
     const int m = lane & 15, q4 = lane >> 4;
     const int Lk = a.t + 1;
 
@@ -325,25 +430,54 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) x[mt][nt] = *reinterpret_cast<const f32x4*>(a.x_io + (int64_t)g * SD + 64 * wave + 16 * nt + 4 * q4);
     }
+    // dense stream state
     const uint4* wp = a.wpk + (int64_t)wave * a.L * U * 16 * KSTEP;
     Ring ring;
-    ring_start(ring, wp, lane);
+    // sparse stream state
+    const uint2* sp = nullptr;
+    cint_ptr nstp = nullptr;
+    char* D = smem + 4 * IMG + 2 * 32 * 8 * 4 + wave * SDBUF;      // this wave's fragment buffer
+    SRing E;
+    uint4 F[2][4];
+    if constexpr (SPARSE) {
+        auto uni64 = [](uint64_t v) { return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        nstp = (cint_ptr)(uintptr_t)uni64((uint64_t)(uintptr_t)(a.snst + wave * a.L * U));
+        sp = a.sstream + (int64_t)a.sstart[wave] * 64;
+        sring_start(E, sp, lane);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(D + i * 1024 + lane * 16) = z4;
+        if (lane < 16) *reinterpret_cast<uint4*>(D + 4096 + lane * 16) = z4;
+        s_unit_cold(D, E, F, lane);
+    } else {
+        ring_start(ring, wp, lane);
+    }
+    // one [32 x 512] x [512 x 512] unit: NEXT = the stream keeps running into the unit that follows
+#define STACK_UNIT(ACC, AIMG, NEXT)                                                                    \
+    do {                                                                                               \
+        STACK_UNIT_BEGIN();                                                                            \
+        if constexpr (SPARSE) { const int nst_ = *nstp++; unit_sparse<NEXT>(ACC, AIMG, D, sp, nst_, E, F, lane); } \
+        else unit_gemm<NEXT>(ACC, AIMG, wp, ring, lane);                                               \
+    } while (0)
+#define STACK_RESTART()                                                                                \
+    do { if constexpr (SPARSE) s_unit_cold(D, E, F, lane); else ring_start(ring, wp, lane); } while (0)
 
+#define STACK_SYNC() __syncthreads()
     for (int l = 0; l < a.L; ++l) {
         const StackLayer& P = a.layer[l];
         f32x4 acc[2][4], y[2][4], bias[4];
         // ---- LayerNorm 0 -> A0
         STACK_FRESH_LANE();
-        layer_norm(x, P.n0a, P.n0b, a.eps, red1, red2, wave, lane, y);
-        store_img_plain(A0, y, wave, lane);
-        __syncthreads();
+        layer_norm<false>(x, P.n0a, P.n0b, a.eps, red1, red2, wave, lane, y);
+        store_img_plain<RB>(A0, y, wave, lane);
+        STACK_SYNC();
         // ---- packed QKV: three units -> q (A1), k (KN), v (VN)
         STACK_FRESH_LANE();
-        load_cols(P.bqkv, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<true>(acc, A0, wp, ring, lane); store_img(A1, acc, bias, false, wave, lane);
-        load_cols(P.bqkv + SD, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<true>(acc, A0, wp, ring, lane); store_img(KN, acc, bias, false, wave, lane);
-        load_cols(P.bqkv + 2 * SD, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<false>(acc, A0, wp, ring, lane); store_img(VN, acc, bias, false, wave, lane);
-        __syncthreads();
-        // ---- self-attention of rows 4 wave .. 4 wave + 3 over their cache rows + this position; o -> A0
+        load_cols(P.bqkv, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, true); store_img<RB>(A1, acc, bias, false, wave, lane);
+        load_cols(P.bqkv + SD, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, true); store_img<RB>(KN, acc, bias, false, wave, lane);
+        load_cols(P.bqkv + 2 * SD, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, false); store_img<RB>(VN, acc, bias, false, wave, lane);
+        STACK_SYNC();
+        // ---- self-attention: wave w serves rows w, w + 8, w + 16, .. of the block over their cache rows + this position; o -> A0
         STACK_FRESH_LANE();
         if (!(a.debug & 1)) {
             // The wave's SROWS rows run in lock-step, each with its own K / V registers: SROWS x SKB row loads of K and as
@@ -352,14 +486,19 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
             const uint4* ck = reinterpret_cast<const uint4*>(P.ck) + lane;
             const uint4* cv = reinterpret_cast<const uint4*>(P.cv) + lane;
             const int nb = (a.t + SKB - 1) / SKB;
+            constexpr int NI = (RB + 7) / 8;          // rows per wave
 #pragma unroll 1
-            for (int i0 = 0; i0 < 4; i0 += SROWS) {
+            for (int i0 = 0; i0 < NI; i0 += SROWS) {
+                if (wave + 8 * i0 >= RB || r0 + wave + 8 * i0 >= a.rows) break;        // (wave-uniform) no row of this pass exists
                 int idx[SROWS];          // lane j: physical cache row of key j of row r
+                int rowi[SROWS];         // row inside the block (clamped: a missing second row repeats the first)
                 AttState<1> st[SROWS];
                 uint4 kq[SROWS][SKB], vq[SROWS][SKB];
 #pragma unroll
                 for (int r = 0; r < SROWS; ++r) {
-                    const int g = min(r0 + 4 * wave + i0 + r, a.rows - 1);
+                    const int row = wave + 8 * (i0 + r);
+                    rowi[r] = (row < RB && r0 + row < a.rows) ? row : wave + 8 * i0;
+                    const int g = r0 + rowi[r];
                     idx[r] = a.kvidx ? a.kvidx[(int64_t)g * Lk + min(lane, a.t)] : g * a.T + min(lane, a.t);
                 }
                 auto issue_k = [&](int b) {
@@ -376,7 +515,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
                 };
                 if (nb > 0) { issue_k(0); issue_v(0); }
 #pragma unroll
-                for (int r = 0; r < SROWS; ++r) st[r].init(A1, 4 * wave + i0 + r, 1, lane);
+                for (int r = 0; r < SROWS; ++r) st[r].init(A1, rowi[r], 1, lane);
                 for (int b = 0; b < nb; ++b) {
                     float kind[SKB], p[SROWS][1][SKB];
 #pragma unroll
@@ -391,42 +530,42 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
 #pragma unroll
                 for (int r = 0; r < SROWS; ++r) {
                     // this position: K / V from the LDS images, appended to the cache
-                    const int row = 4 * wave + i0 + r;
+                    const int row = rowi[r];
                     const uint4 kself[1] = {*reinterpret_cast<const uint4*>(KN + img_off(row, lane))};
                     const uint4 vself[1] = {*reinterpret_cast<const uint4*>(VN + img_off(row, lane))};
                     const float kindself[1] = {0.f};
                     float pself[1][1];
                     st[r].scores<1>(kself, kindself, pself);
                     st[r].pv<1>(vself, pself);
-                    if (r0 + row < a.rows) {
+                    if (row == wave + 8 * (i0 + r)) {      // (a repeated row writes nothing)
                         const int64_t slot = (int64_t)__builtin_amdgcn_readlane(idx[r], a.t) * (SD / 8);
                         reinterpret_cast<uint4*>(P.ck)[slot + lane] = kself[0];
                         reinterpret_cast<uint4*>(P.cv)[slot + lane] = vself[0];
+                        st[r].finish(A0, row, 1, lane);
                     }
-                    st[r].finish(A0, row, 1, lane);
                 }
             }
         }
-        __syncthreads();
+        STACK_SYNC();
         // ---- output projection + residual, LayerNorm 1 -> A0
         STACK_FRESH_LANE();
-        ring_start(ring, wp, lane);
-        load_cols(P.bo, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<true>(acc, A0, wp, ring, lane);
+        STACK_RESTART();
+        load_cols(P.bo, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, true);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) x[mt][nt] += acc[mt][nt] + bias[nt];
-        layer_norm(x, P.n1a, P.n1b, a.eps, red1, red2, wave, lane, y);       // (its barriers: every wave is done reading A0)
-        store_img_plain(A0, y, wave, lane);
-        __syncthreads();
+        layer_norm<false>(x, P.n1a, P.n1b, a.eps, red1, red2, wave, lane, y);       // (its barriers: every wave is done reading A0)
+        store_img_plain<RB>(A0, y, wave, lane);
+        STACK_SYNC();
         // ---- cross-attention query -> A1
         STACK_FRESH_LANE();
-        load_cols(P.cqb, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<false>(acc, A0, wp, ring, lane); store_img(A1, acc, bias, false, wave, lane);
-        __syncthreads();
+        load_cols(P.cqb, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, false); store_img<RB>(A1, acc, bias, false, wave, lane);
+        STACK_SYNC();
         // ---- cross-attention: chunks of up to XNR rows of one image, dealt round-robin to the waves; o -> A0
         STACK_FRESH_LANE();
         if (!(a.debug & 2)) {
-            const int last = min(r0 + SRB, a.rows) - 1;
+            const int last = min(r0 + RB, a.rows) - 1;
             const int img0 = r0 / a.per_img, img1 = last / a.per_img;
             int chunk = 0;
             for (int im = img0; im <= img1; ++im) {
@@ -468,27 +607,27 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
                 }
             }
         }
-        __syncthreads();
+        STACK_SYNC();
         // ---- output projection + residual, LayerNorm 2 -> A0
         STACK_FRESH_LANE();
-        ring_start(ring, wp, lane);
-        load_cols(P.cob, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<true>(acc, A0, wp, ring, lane);
+        STACK_RESTART();
+        load_cols(P.cob, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, true);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) x[mt][nt] += acc[mt][nt] + bias[nt];
-        layer_norm(x, P.n2a, P.n2b, a.eps, red1, red2, wave, lane, y);
-        store_img_plain(A0, y, wave, lane);
-        __syncthreads();
+        layer_norm<false>(x, P.n2a, P.n2b, a.eps, red1, red2, wave, lane, y);
+        store_img_plain<RB>(A0, y, wave, lane);
+        STACK_SYNC();
         STACK_FRESH_LANE();
         // ---- FFN, 512 hidden units at a time: h_c = relu(y W1_c^T + b1_c) -> LDS, acc2 += h_c W2[:, c]^T
         f32x4 acc2[2][4];
         zero(acc2);
         for (int c = 0; c < ((a.debug & 4) ? 0 : a.NC); ++c) {
             char* Hc = (c & 1) ? KN : A1;
-            load_cols(P.b1 + c * SD, wave, lane, bias); zero(acc); STACK_UNIT_BEGIN(); unit_gemm<true>(acc, A0, wp, ring, lane); store_img(Hc, acc, bias, true, wave, lane);
-            __syncthreads();
-            STACK_UNIT_BEGIN(); unit_gemm<true>(acc2, Hc, wp, ring, lane);
+            load_cols(P.b1 + c * SD, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, true); store_img<RB>(Hc, acc, bias, true, wave, lane);
+            STACK_SYNC();
+            STACK_UNIT(acc2, Hc, true);
         }
         load_cols(P.b2, wave, lane, bias);
 #pragma unroll
@@ -499,17 +638,20 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
     // ---- final LayerNorm -> bf16 rows for the generator
     STACK_FRESH_LANE();
     f32x4 y[2][4];
-    layer_norm(x, a.fa, a.fb, a.eps, red1, red2, wave, lane, y);
+    layer_norm<false>(x, a.fa, a.fb, a.eps, red1, red2, wave, lane, y);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int g = r0 + 16 * mt + (lane & 15);
-        if (g < a.rows) {
+        const int row = 16 * mt + (lane & 15), g = r0 + row;
+        if (g < a.rows && row < RB) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 *reinterpret_cast<uint2*>(a.y_out + (int64_t)g * SD + 64 * wave + 16 * nt + 4 * (lane >> 4)) =
                     make_uint2(pack2(y[mt][nt][0], y[mt][nt][1]), pack2(y[mt][nt][2], y[mt][nt][3]));
         }
     }
+#undef STACK_SYNC
+#undef STACK_UNIT
+#undef STACK_RESTART
 }
 
 // wpk[((((w L + l) U + u) 16 + ks) 4 + nt) 64 + lane] = the 8 bf16 W_u[64 w + 16 nt + (lane & 15)][32 ks + 8 (lane >> 4) ..]
@@ -546,28 +688,235 @@ int stack_pack(const void* w16, void* wpk, const StackPack& t, hipStream_t s) {
     return 0;
 }
 
-int stack_step(const StackArgs& a, hipStream_t s) {
-    static const size_t lds = (size_t)4 * SIMG + 2 * SRB * 8 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+// ------------------------------------------------------------------------------------------------ sparse stream builder
+namespace {
+constexpr int SSLACK = SPD + 4;        // all-zero steps behind every wave's stream (the ring's look-ahead: entry 0 = weight 0 at position 0)
+// the 32 weights lane `lane` of wave w feeds to the MFMAs of k-step ks of unit u (4 column tiles x 8), as in stack_pack_kernel
+__device__ __forceinline__ void sstack_load(const __bf16* w16, const StackPack& t, int w, int l, int u, int ks, int lane, uint4 (&f)[4]) {
+    int64_t base; int ld;
+    if (u < 3)       { base = t.off[l][0] + (int64_t)u * SD * SD; ld = SD; }
+    else if (u < 6)  { base = t.off[l][u - 2]; ld = SD; }
+    else {
+        const int c = (u - 6) >> 1;
+        if (((u - 6) & 1) == 0) { base = t.off[l][4] + (int64_t)c * SD * SD; ld = SD; }
+        else                    { base = t.off[l][5] + (int64_t)c * SD; ld = t.NC * SD; }
     }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        f[nt] = *reinterpret_cast<const uint4*>(w16 + base + (int64_t)(64 * w + 16 * nt + (lane & 15)) * ld + 32 * ks + 8 * (lane >> 4));
+}
+// bit (8 nt + j) = weight j of tile nt is non-zero (+0 and -0 are both zeros: a masked weight is w * 0)
+__device__ __forceinline__ unsigned int sstack_mask(const uint4 (&f)[4]) {
+    unsigned int mk = 0;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const unsigned int d[4] = {f[nt].x, f[nt].y, f[nt].z, f[nt].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (d[i] & 0x00007FFFu) mk |= 1u << (8 * nt + 2 * i);
+            if (d[i] & 0x7FFF0000u) mk |= 1u << (8 * nt + 2 * i + 1);
+        }
+    }
+    return mk;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int steps_of(int cnt) { return max(1, (cnt + SCAP - 1) / SCAP); }
+}  // namespace
+
+// cnt[(w LU + lu) 16 + ks] = non-zeros among the 64 x 32 weights of wave w, unit lu, k-step ks
+__global__ __launch_bounds__(256) void sstack_count_kernel(const __bf16* __restrict__ w16, int32_t* __restrict__ cnt, StackPack t) {
+    const int U = 6 + 2 * t.NC, LU = t.L * U;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= 8 * LU * 16) return;
+    const int ks = item & 15, lu = (item >> 4) % LU, w = (item >> 4) / LU;
+    uint4 f[4];
+    sstack_load(w16, t, w, lu / U, lu % U, ks, lane, f);
+    const int c = wave_sum(__popc(sstack_mask(f)));
+    if (lane == 0) cnt[item] = c;
+}
+// thread w: the step layout of wave w's stream.  cnt[item] -> first step of the k-step (relative to the wave's stream);
+// nst[w LU + lu] = steps of the unit (a multiple of SPD); start[w] = first step of the wave in the buffer;
+// stats = {steps in all, non-zeros}
+__global__ void sstack_scan_kernel(int32_t* __restrict__ cnt, int32_t* __restrict__ nst, int64_t* __restrict__ start, int64_t* __restrict__ stats, int LU) {
+    __shared__ int64_t tot[8], nzs[8];
+    const int w = threadIdx.x;
+    if (w < 8) {
+        int64_t run = 0, z = 0;
+        for (int lu = 0; lu < LU; ++lu) {
+            int st = 0;
+            for (int ks = 0; ks < 16; ++ks) {
+                const int i = (w * LU + lu) * 16 + ks, c = cnt[i];
+                z += c;
+                cnt[i] = (int)(run + st);
+                st += steps_of(c);
+            }
+            st = (st + SPD - 1) / SPD * SPD;
+            nst[w * LU + lu] = st;
+            run += st;
+        }
+        tot[w] = run; nzs[w] = z;
+    }
+    __syncthreads();
+    if (w == 0) {
+        int64_t run = 0, z = 0;
+        for (int i = 0; i < 8; ++i) { start[i] = run; run += tot[i] + SSLACK; z += nzs[i]; }
+        stats[0] = run; stats[1] = z;
+    }
+}
+// One wave per (w, lu, ks): its entries, dealt to the four 32-lane store groups of a step (group g = entries [32 g, 32 g + 32)
+// of the step: lanes 0-31 / 32-63 of the .x store, then of the .y store) so that a group gets at most two entries per LDS bank
+// where possible.  The wave of a unit's last k-step also writes the unit's all-pad steps.
+__global__ __launch_bounds__(256) void sstack_fill_kernel(const __bf16* __restrict__ w16, const int32_t* __restrict__ first, const int32_t* __restrict__ nst,
+                                                         const int64_t* __restrict__ start, uint2* __restrict__ stream, StackPack t) {
+    __shared__ unsigned int ent[4][2048];            // the k-step's entries in (lane, bit) order
+    __shared__ unsigned int slot[4][SCAP];           // one step being dealt
+    const int U = 6 + 2 * t.NC, LU = t.L * U;
+    const int wv = threadIdx.x >> 6, item = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    if (item >= 8 * LU * 16) return;
+    const int ks = item & 15, lu = (item >> 4) % LU, w = (item >> 4) / LU;
+    uint4 f[4];
+    sstack_load(w16, t, w, lu / U, lu % U, ks, lane, f);
+    unsigned int mk = sstack_mask(f);
+    const int mine = __popc(mk);
+    int pre = mine;                                    // inclusive scan over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }
+    const int total = __shfl(pre, 63, 64);
+    int e = pre - mine;
+    const unsigned short* h = reinterpret_cast<const unsigned short*>(f);
+    while (mk) {
+        const int b = __ffs(mk) - 1;
+        mk &= mk - 1;
+        const int nt = b >> 3, j = b & 7;
+        ent[wv][e++] = (unsigned int)h[8 * nt + j] | ((unsigned int)((nt * 64 + lane) * 8 + j) << 16) | ((unsigned int)ks << 28);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are done (one wave owns ent[wv])
+    __builtin_amdgcn_wave_barrier();
+    unsigned int* out = reinterpret_cast<unsigned int*>(stream + (start[w] + first[item]) * 64);     // entry r of step s: out[(s 64 + (r & 63)) 2 + (r >> 6)]
+    const int ns = steps_of(total);
+    for (int st = 0; st < ns; ++st) {
+        const int n = min(SCAP, total - st * SCAP);    // entries of this step
+        // pad entries first (private slots behind the buffer: bank = lane, at most one per bank and group)
+        for (int r = lane; r < SCAP; r += 64) slot[wv][r] = ((unsigned int)(2048 + 2 * (r & 63) + (r >> 6)) << 16) | ((unsigned int)ks << 28);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            // greedy deal: every entry goes to the group with the fewest entries on its bank so far (then the emptiest);
+            // a group holds 32.  bank of an entry = dword index of its halfword mod 32.
+            unsigned char load[4][32];
+            int fill[4] = {0, 0, 0, 0};
+            for (int g = 0; g < 4; ++g) for (int b = 0; b < 32; ++b) load[g][b] = 0;
+            for (int i = 0; i < n; ++i) {
+                const unsigned int v = ent[wv][st * SCAP + i];
+                const int bank = (v >> 17) & 31;
+                int best = -1, bl = 1 << 30;
+                for (int g = 0; g < 4; ++g) {
+                    if (fill[g] >= 32) continue;
+                    const int score = load[g][bank] * 64 + fill[g];
+                    if (score < bl) { bl = score; best = g; }
+                }
+                slot[wv][best * 32 + fill[best]] = v;
+                ++fill[best]; ++load[best][bank];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // slot r of the deal = lane (r & 31) + 32 ((r >> 5) & 1) of store (r >> 6)
+        for (int r = lane; r < SCAP; r += 64) out[((int64_t)st * 64 + (r & 63)) * 2 + (r >> 6)] = slot[wv][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (ks == 15) {
+        const int64_t ustart = start[w] + first[item - 15], uend = ustart + nst[w * LU + lu];
+        uint2* us = stream + (start[w] + first[item] + ns) * 64;
+        for (int64_t st = start[w] + first[item] + ns; st < uend; ++st, us += 64)
+            us[lane] = make_uint2((unsigned int)(2048 + 2 * lane) << 16, (unsigned int)(2048 + 2 * lane + 1) << 16);
+        // behind the wave's last unit: the ring's look-ahead (entry 0 = weight 0 at position 0)
+        if (lu == LU - 1)
+            for (int i = 0; i < SSLACK; ++i, us += 64) us[lane] = make_uint2(0u, 0u);
+    }
+}
+
+// Worst case (no zero at all): 16 steps per k-step, 256 per unit — 8 bytes per lane and step.
+static size_t sstack_cap_steps(int L, int NC) { return 8 * ((size_t)L * (6 + 2 * NC) * 256 + SSLACK); }
+size_t sstack_bytes(int L, int NC, SStackBufs* carve, void* base) {
+    const size_t LU = (size_t)L * (6 + 2 * NC);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = base ? (char*)base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    SStackBufs b;
+    b.stream_bytes = sstack_cap_steps(L, NC) * 64 * sizeof(uint2);
+    b.stream = (uint2*)take(b.stream_bytes);
+    b.cnt = (int32_t*)take(8 * LU * 16 * 4);
+    b.nst = (int32_t*)take(8 * LU * 4);
+    b.start = (int64_t*)take(8 * 8);
+    b.stats = (int64_t*)take(2 * 8);
+    if (carve) *carve = b;
+    return off;
+}
+
+int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStream_t s) {
+    const int LU = t.L * (6 + 2 * t.NC);
+    const __bf16* w = reinterpret_cast<const __bf16*>(w16);
+    const unsigned items = (unsigned)ortk_cdiv(8 * LU * 16, 4);
+    hipLaunchKernelGGL(sstack_count_kernel, dim3(items), dim3(256), 0, s, w, b.cnt, t);
+    ORTK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sstack_scan_kernel, dim3(1), dim3(64), 0, s, b.cnt, b.nst, b.start, b.stats, LU);
+    ORTK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sstack_fill_kernel, dim3(items), dim3(256), 0, s, w, b.cnt, b.nst, b.start, b.stream, t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool SPARSE, int RB>
+static int stack_launch(const StackArgs& b, bool pf, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * RB * SD * 2 + 2 * 32 * 8 * sizeof(float) + (SPARSE ? 8 * SDBUF : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    // (per device: the attribute belongs to the function on ONE device; a process that drives several GPUs sets it on each)
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ORTK_EINVAL;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_stack_kernel<SPARSE, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((decoder_stack_kernel<SPARSE, RB>), dim3((unsigned)(b.nblocks + (pf ? 8 : 0))), dim3(512), lds, s, b);
+    return 0;
+}
+
+int stack_step(const StackArgs& a, hipStream_t s) {
     if (a.rows < 1 || a.S < 1 || a.S > 128 || a.t < 0 || a.t >= 64 || a.per_img < 1 || a.L < 1 || a.L > STACK_MAXL || a.NC < 1) return ORTK_EINVAL;
+    const bool sparse = a.sstream != nullptr;
+    const int rb = (sparse || a.rb == 20) ? 20 : 32;        // (the sparse stream's fragment buffers leave LDS for 20-row images)
     StackArgs b = a;
-    b.nblocks = (int)ortk_cdiv(a.rows, SRB);
-    const bool pf = b.nblocks >= 8 && a.progress != nullptr && !(a.debug & 8);
-    // algorithmic bytes of the launch: the weights once, every image's projected memory (K and V) once per layer, every row's
-    // cached keys and values once per layer plus the appended position, the residual rows in and the normalised rows out
+    b.nblocks = (int)ortk_cdiv(a.rows, rb);
+    const bool pf = !sparse && b.nblocks >= 8 && b.nblocks + 8 <= 256 && a.progress != nullptr && !(a.debug & 8);
+    if (!pf) b.progress = nullptr;
+    // algorithmic bytes of the launch: the weights once (sparse stream: 4 bytes per non-zero), every image's projected
+    // memory (K and V) once per layer, every row's cached keys and values once per layer plus the appended position, the
+    // residual rows in and the normalised rows out
     ProfMark pm;
     if (ortk_prof_active()) {
         const double U = 6 + 2 * a.NC, imgs = (double)ortk_cdiv(a.rows, a.per_img);
-        const double bytes = a.L * (U * SD * SD * 2.0 + imgs * a.S * 2.0 * SD * 2 + (double)a.rows * (a.t + 1) * 2.0 * SD * 2) +
+        const double wbytes = U * SD * SD * (sparse ? 0.05 * 4.0 : 2.0);       // (sparse: priced at the 95 % of BASELINE configs[4])
+        const double bytes = a.L * (wbytes + imgs * a.S * 2.0 * SD * 2 + (double)a.rows * (a.t + 1) * 2.0 * SD * 2) +
                              (double)a.rows * SD * (4 + 2);
         (void)prof_begin(PROF_KEY_DECSTACK, 2.0 * a.rows * a.L * U * SD * SD, bytes, s, pm);
     } else pm.live = false;
-    hipLaunchKernelGGL(decoder_stack_kernel, dim3((unsigned)(b.nblocks + (pf ? 8 : 0))), dim3(512), lds, s, b);
+    int rc;
+    if (sparse) rc = stack_launch<true, 20>(b, pf, s);
+    else if (rb == 20) rc = stack_launch<false, 20>(b, pf, s);
+    else rc = stack_launch<false, 32>(b, pf, s);
     prof_end(pm, s);
+    if (rc) return rc;
     ORTK_CHECK_LAUNCH();
     return 0;
 }

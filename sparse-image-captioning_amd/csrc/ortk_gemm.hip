@@ -964,12 +964,14 @@ template <bool TA, bool TB> gemm16_fn pick16(int adt, int bdt, bool fast) {
 namespace {
 struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; };
 bool g_prof_on = false;
+bool g_prof_serial = false;    // level 1: the executor keeps every launch on the caller's stream (kernels timed in isolation)
 std::mutex g_prof_mu;          // decode chunks may be driven by several host threads
 std::vector<ProfRec>* g_prof = nullptr;
 }  // namespace
 
 namespace ortk {
 bool ortk_prof_active() { return g_prof_on; }
+bool ortk_prof_serial() { return g_prof_serial; }
 // the same hook for launches that are not ortk_gemm (key >= 16): begin records the first event, end the second
 bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m) {
     m.live = false;
@@ -993,6 +995,7 @@ extern "C" int ortk_prof_enable(int32_t on) {
     for (auto& r : *g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof->clear();
     g_prof_on = on != 0;
+    g_prof_serial = on == 1;
     return 0;
 }
 // key = precision*4 + transA*2 + transB.  Waits for the recorded events (host sync: measurement only).

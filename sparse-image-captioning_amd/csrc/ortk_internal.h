@@ -6,6 +6,9 @@ namespace ortk {
 
 // true while bench.py's per-launch GEMM timing is on (the executor then keeps every GEMM on the caller's stream)
 bool ortk_prof_active();
+// ortk_prof_enable(1): additionally, the executor keeps everything on ONE stream (each kernel timed alone); (2): the timed
+// schedule as it is (side stream on: the events of a launch then include what runs beside it)
+bool ortk_prof_serial();
 // the same measurement hook around a launch that is not an ortk_gemm; ortk_prof_collect(key) then reports it
 constexpr int PROF_KEY_DECSTACK = 16;
 struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; };
@@ -81,7 +84,10 @@ struct StackLayer {
 };
 struct StackArgs {
     StackLayer layer[STACK_MAXL];
-    const uint4* wpk;              // stack_pack() image of the decoder weights
+    const uint4* wpk;              // stack_pack() image of the decoder weights (dense stream)
+    const uint2* sstream;          // sparse stream (sstack_pack): per wave, steps of 64 lanes x 2 scatter entries
+    const int32_t* snst;           //   [8][L * U] steps of every (wave, unit) (multiples of 4)
+    const int64_t* sstart;         //   [8] first step of every wave's stream
     const float* x_io;             // (rows, 512) embedded tokens of this position
     __bf16* y_out;                 // (rows, 512) final LayerNorm output: the generator's operand
     const float *fa, *fb;          // final LayerNorm
@@ -92,12 +98,18 @@ struct StackArgs {
     float eps;
     int32_t nblocks;               // compute workgroups (set by stack_step); workgroups beyond are L2 prefetchers
     int32_t* progress;             // [16] zeroed at the start of a decode: units begun by the pace-maker of each XCD
-    int32_t debug;                 // measurement only (ORTK_STACK_DEBUG): 1 skip self-attention, 2 skip cross-attention, 4 skip the FFN, 8 no L2 prefetchers
+    int32_t debug;                 // measurement only: 1 skip self-attention, 2 skip cross-attention, 4 skip the FFN, 8 no L2 prefetchers
+    int32_t rb;                    // rows per workgroup: 32 (default) or 20 (256 workgroups for 1 024 images x 5 beams)
 };
 struct StackPack { int64_t off[STACK_MAXL][6]; int32_t L, NC; };   // element offsets of wqkv, wo, cqw, cow, w1, w2 per layer
 size_t stack_packed_bytes(int L, int NC);
 int stack_pack(const void* w16, void* wpk, const StackPack& t, hipStream_t s);
 int stack_step(const StackArgs& a, hipStream_t s);
+// Sparse stream (mostly-zero decoder weights): the non-zeros of every 2 048-weight MFMA fragment group as (position, value) scatter
+// entries, built on the device from the bf16 weights of the call (three launches, no host sync).
+struct SStackBufs { uint2* stream; int32_t *cnt, *nst; int64_t *start, *stats; size_t stream_bytes; };     // stats: {steps, non-zeros}   // stats: {steps, pieces}
+size_t sstack_bytes(int L, int NC, SStackBufs* carve, void* base);          // worst-case (fully dense weights) capacity
+int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStream_t s);
 
 int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
 int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);

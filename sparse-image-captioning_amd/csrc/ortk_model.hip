@@ -640,13 +640,12 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
         TRY(ortk_sparse_build(cfg->sparse_fwd, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
         c.ell_f = cfg->sparse_fwd;
     }
-    if (cfg->sparse_bwd && cfg->precision) TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, stream));
     const float* P = params;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const int64_t Me = w.Me, Md = w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
-    c.side = (c.adt == ORTK_BF16 && !ortk_prof_active()) ? side_for(c.s) : nullptr;
+    c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
     const AttMode am = att_mode(cfg->share_att_dec);
     const int64_t cw = o.cw, cv = o.cv;
@@ -756,8 +755,14 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     // (train, seed) must match the forward's; the bf16 weight copy made by the forward is still in the workspace
     Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
     c.W16T = w.w16t;
-    if (cfg->precision) c.ell_b = cfg->sparse_bwd;      // built by the forward of this step from the transposed bf16 copies
-    c.side = (c.adt == ORTK_BF16 && !ortk_prof_active()) ? side_for(c.s) : nullptr;
+    if (cfg->precision && cfg->sparse_bwd) {
+        // Rebuilt HERE from this workspace's transposed bf16 weights (the mask sample of THIS graph's forward): the plan's
+        // buffers are shared by every workspace of the model, so another forward (a second autograd graph, another seed) may
+        // have rebuilt them since.  Phase 2 of a split backward reuses phase 1's build.
+        if (phase != 2) TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, stream));
+        c.ell_b = cfg->sparse_bwd;
+    }
+    c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
     float* G = grads;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = w.adt;
@@ -997,8 +1002,9 @@ struct DecodeWS {
                                                                // decode attention kernels take them (kv16), fp32 otherwise
     int64_t* it; int32_t *unfinished, *last_step;
     int32_t *bseq[2], *kvidx[2], *done_seq, *done_len, *done_cnt; float *blp[2], *cum, *done_lp; double* done_p;
-    void* wpk = nullptr;               // decoder weights in the stack kernel's streaming order (stack path only)
+    void* wpk = nullptr;               // decoder weights in the stack kernel's streaming order (stack path, dense stream)
     int32_t* progress = nullptr;       // pace-maker counters of the stack kernel's L2 prefetchers
+    SStackBufs ss{};                   // the sparse stream and its tables (stack path, sparse stream)
     size_t bytes;
 };
 
@@ -1006,19 +1012,19 @@ struct DecodeWS {
 // with d_model 512: mixed precision, 8 heads of 64, d_ff a multiple of 512, no projection sharing inside the decoder's
 // attention modules.  Everything else — and every call that brings a sparse plan — runs the unfused executor below.
 // ORTK_DEC_STACK=0 switches it off (A/B measurements).
-static bool stack_ok(const ortk_config& c, int64_t rows) {
-    const char* e = getenv("ORTK_DEC_STACK");          // read per call: the parity tests run both executors in one process
-    const int mode = e ? atoi(e) : 1;                  // 0 off, 1 by size (default), 2 whenever the configuration is served
+static bool stack_ok(const ortk_config& c, int64_t rows, int32_t flags) {
     // Every workgroup of the stack kernel streams ALL decoder weights (42 MB per position at ~85 GB/s per CU: >= 0.5 ms per
     // position however few rows there are), the unfused GEMMs read each weight once per launch: measured crossover at 320
     // images x 5 beams (16.1 vs 16.0 ms; 512 images 17.0 vs 21.3, 50 images 14.1 vs 11.1, the SCST rollout of 256 x 6 rows
-    // 29.9 vs 28.3 ms per step).
-    if (mode == 0 || (mode == 1 && rows < 1600)) return false;
+    // 29.9 vs 28.3 ms per step).  The SPARSE stream (ORTK_DEC_SPARSE_STREAM) is ~9x shorter and has no such floor.
+    // ortk_decode_opts.exec_flags overrides the size rule (parity tests and A/B measurements run both executors).
+    if (flags & ORTK_DEC_UNFUSED) return false;
+    if (!(flags & (ORTK_DEC_STACK | ORTK_DEC_SPARSE_STREAM)) && rows < 1600) return false;
     return c.precision == 1 && c.d_model == 512 && c.n_heads == 8 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 &&
            c.share_att_dec == 0 && c.n_layers <= STACK_MAXL && c.seq_len <= 64;     // (seq_len: one lane per cached key)
 }
 
-static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false) {
+static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false, bool sstream = false) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
     // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
     w.kvdt = (c.precision && H == 8 && d == 512 && S > 8 && S <= 48 && T <= 32 && K <= 16) ? ORTK_BF16 : ORTK_F32;
@@ -1047,7 +1053,12 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
-    if (stack) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
+    if (stack && !sstream) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
+    if (stack && sstream) {
+        const size_t nb = sstack_bytes((int)L, (int)(ff / 512), nullptr, nullptr);
+        void* p = b.take_bytes(nb);
+        sstack_bytes((int)L, (int)(ff / 512), &w.ss, p);
+    }
     if (beam) {
         for (int i = 0; i < 2; ++i) { w.bseq[i] = b.take<int32_t>(rows * T); w.blp[i] = b.take<float>(rows * T); w.kvidx[i] = b.take<int32_t>(rows * (T + 1)); }
         w.cum = b.take<float>(rows);
@@ -1082,7 +1093,8 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
     if (check_cfg(cfg) || !o || B < 1 || S < 1) return 0;
     const int K = decode_K(o);
     if (K < 1) return 0;
-    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack_ok(*cfg, (int64_t)B * K) && !o->sparse);
+    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack_ok(*cfg, (int64_t)B * K, o->exec_flags) && !o->sparse,
+                             (o->exec_flags & ORTK_DEC_SPARSE_STREAM) != 0);
     return w.bytes;
 }
 
@@ -1143,8 +1155,8 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
 }
 
 // The same position through the one-launch decoder stack: embed, stack kernel, generator.
-static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w, const void* wpk, int32_t* progress, int64_t rows, int per_img, int S, int T,
-                              int t, const int32_t* kvidx) {
+static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w, const void* wpk, const SStackBufs* ss, int32_t* progress, int32_t flags,
+                              int64_t rows, int per_img, int S, int T, int t, const int32_t* kvidx) {
     const ortk_config* cfg = c.cfg;
     const float* P = c.P;
     ortk_stream stream = (ortk_stream)c.s;
@@ -1161,9 +1173,11 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
         y.xv = y.xk + o.cv;
     }
     a.wpk = reinterpret_cast<const uint4*>(wpk); a.progress = progress; a.x_io = w.xa; a.y_out = reinterpret_cast<__bf16*>(w.y);
+    if (ss) { a.sstream = ss->stream; a.snst = ss->nst; a.sstart = ss->start; }
+    a.rb = (flags & ORTK_DEC_STACK_RB20) ? 20 : 32;
     a.fa = P + o.dec_na; a.fb = P + o.dec_nb; a.att_masks = w.att_masks; a.kvidx = kvidx; a.ldx = o.ckv_slots * o.cw;
     a.rows = (int)rows; a.per_img = per_img; a.S = S; a.T = T; a.t = t; a.L = cfg->n_layers; a.NC = cfg->d_ff / 512; a.eps = 1e-6f;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORTK_STACK_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
+    a.debug = (flags >> 8) & 0xF;        // ORTK_DEC_DEBUG_*: phase-skipping measurement switches
     TRY(stack_step(a, c.s));
     return fwd_gemm(c, w.y, ORTK_BF16, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, (int)w.ldv, d);
 }
@@ -1180,8 +1194,9 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (beam && (K > 8 || K > cfg->vocab)) return ORTK_EINVAL;
     if (op->temperature <= 0.f) return ORTK_EINVAL;
     Offsets o; build_layout(*cfg, o, nullptr);
-    const bool stack = stack_ok(*cfg, (int64_t)B * K) && !op->sparse;
-    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack);
+    const bool stack = stack_ok(*cfg, (int64_t)B * K, op->exec_flags) && !op->sparse;
+    const bool sstream = stack && (op->exec_flags & ORTK_DEC_SPARSE_STREAM);
+    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack, sstream);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     hipStream_t s = ortk_s(stream);
     TRY(make_w16(cfg, o, params, w.w16, stream));
@@ -1192,8 +1207,11 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
             const int64_t offs[6] = {e.wqkv, e.wo, e.cqw, e.cow, e.w1, e.w2};
             for (int i = 0; i < 6; ++i) tp.off[l][i] = offs[i];
         }
-        TRY(stack_pack(w.w16, w.wpk, tp, s));
-        TRY(fill_i32(w.progress, 16, 0, s));
+        if (sstream) TRY(sstack_pack(w.w16, w.ss, tp, s));
+        else {
+            TRY(stack_pack(w.w16, w.wpk, tp, s));
+            TRY(fill_i32(w.progress, 16, 0, s));
+        }
     }
     Ctx c{cfg, s, cfg->precision, 0, false, params, w.w16, w.adt};
     if (op->sparse) {
@@ -1209,7 +1227,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     for (int l = 0; l < L; ++l) ep[l] = w.enc;
     // the side stream carries the geometry bias of the encoder (0.4 ms at 1 024 images, VALU-bound) beside att_embed and the
     // first projection; nothing else of a decode runs there
-    c.side = (c.adt == ORTK_BF16 && !ortk_prof_active()) ? side_for(c.s) : nullptr;
+    c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
     TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
     c.use_side = false;
@@ -1245,7 +1263,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         StepBufs sb{w.it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, w.ckv, att_masks};
         sb.kvdt = w.kvdt; sb.ckvdt = w.ckvdt; sb.xq16 = w.xq16;
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
-        if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, w.progress, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
+        if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         else TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.

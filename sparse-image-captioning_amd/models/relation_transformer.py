@@ -8,6 +8,7 @@
   participate in torch autograd, ``model(..., mode="sample", opt=...)`` -> ``(seq, seq_logprobs)``.
 """
 import ctypes as C
+import os
 import math
 import weakref
 
@@ -275,7 +276,9 @@ class RelationTransformerModel(CaptionModelBase):
         from ..utils.model_utils import densify_state_dict
         sd = {k: (v.float() if isinstance(v, torch.Tensor) and v.is_floating_point() and v.dtype != torch.float32 else v)
               for k, v in densify_state_dict(state_dict).items()}
-        return super().load_state_dict(sd, strict=strict, **kw)
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._plans = None          # sparse plans: block selection and capacities were taken from the OLD weights
+        return out
 
     # ------------------------------------------------------------------ helpers
     def _eff_params_ptr(self, train, seed):
@@ -303,6 +306,21 @@ class RelationTransformerModel(CaptionModelBase):
         if min_sparsity is not None and self._flat.is_cuda:
             self._sparse_plans()
 
+    def enable_sparse_stream(self, on=True):
+        """Decode pruned weights through the decoder stack kernel's SPARSE weight stream (``ORTK_DEC_SPARSE_STREAM``,
+        ``include/ortk.h``): the kernel pulls only the non-zeros of the decoder weights (rebuilt on the device inside every
+        ``ortk_decode`` from that call's weights) instead of the zero-filled dense matrices the reference multiplies by
+        (scripts/eval_model.py:64-88).  Correct at any density; pays above ~80 % zeros.  ``on="auto"`` measures the
+        decoder's zero fraction once (host sync) and switches the stream on when it is >= 0.8."""
+        if on == "auto":
+            self._eff_params_ptr(False, 0)          # (the `_prune` variant materialises s*W)
+            eff = self._eff_params_tensor()
+            dec = [e for e in self._entries if ".decoder.layers." in e["name"] and len(e["shape"]) >= 2]
+            nz = sum(int(torch.count_nonzero(eff[e["offset"]:e["offset"] + e["numel"]])) for e in dec)
+            on = nz <= 0.2 * sum(e["numel"] for e in dec)
+        self._sparse_stream = bool(on)
+        return self._sparse_stream
+
     def _sparse_plans(self):
         """(forward plan, backward plan) or (None, None); created on first use after enable / a device move."""
         if getattr(self, "_sparse_min", None) is None:
@@ -312,7 +330,8 @@ class RelationTransformerModel(CaptionModelBase):
             L.require_gpu()
             self._eff_params_ptr(False, 0)
             eff = self._eff_params_tensor()
-            pf, pb = make_plans(self._ccfg, eff, self._sparse_min, self.precision, backward=self._sparse_train)
+            pf, pb = make_plans(self._ccfg, eff, self._sparse_min, self.precision, backward=self._sparse_train,
+                                density_of=self._train_density if self._sparse_train else None)
             if pf is not None:       # validate the capacities against the weights they were planned from
                 pf.build(eff[:self._n_train].bfloat16() if self.precision else eff)
                 pf.check_overflow()
@@ -321,6 +340,10 @@ class RelationTransformerModel(CaptionModelBase):
                 self._ccfg.sparse_fwd = C.cast(pf.ref(), C.c_void_p) if pf is not None else None
                 self._ccfg.sparse_bwd = C.cast(pb.ref(), C.c_void_p) if pb is not None else None
         return self._plans
+
+    def _train_density(self, offset, N, K):
+        """Expected density of a weight block under the TRAINING-mode mask sample (dense class: no masks, 0)."""
+        return 0.0
 
     def check_sparse_overflow(self):
         """Host sync: raises if a sparse image built since the last check had to drop entries."""
@@ -462,9 +485,20 @@ class RelationTransformerModel(CaptionModelBase):
         lp = torch.empty(B, K, self.seq_length, device=dev)
         score = torch.empty(B, K, device=dev)
         pptr = self._eff_params_ptr(False, 0)
+        # executor choice (ortk_decode_opts.exec_flags): opt["executor"] = "auto" | "unfused" | "stack" | "sparse_stream";
+        # ORTK_DEC_STACK=0 / 2 in the environment (read here, on the host side, per call) = "unfused" / "stack"
+        ex = opt.get("executor", {"0": "unfused", "2": "stack"}.get(os.environ.get("ORTK_DEC_STACK", ""), "auto"))
+        if ex == "auto" and getattr(self, "_sparse_stream", False):
+            ex = "sparse_stream"
+        o.exec_flags = {"auto": 0, "unfused": L.DEC_UNFUSED, "stack": L.DEC_STACK, "sparse_stream": L.DEC_SPARSE_STREAM,
+                        "stack_rb20": L.DEC_STACK | L.DEC_STACK_RB20,
+                        "sparse_stream_rb20": L.DEC_SPARSE_STREAM | L.DEC_STACK_RB20}[ex] | (int(opt.get("stack_debug", 0)) & 0xF) << 8
+        fresh_plan = getattr(self, "_plans", None) is None
         plan = self._sparse_plans()[0]
-        if plan is not None:
+        if plan is not None and not ex.startswith("sparse_stream"):
             o.sparse = plan.ref()
+        else:
+            plan = None
         beam = o.beam_size > 1 and o.num_random_sample <= 0
         # Images are independent: `opt["decode_streams"] = n` decodes the batch as n chunks on n streams, each driven by its
         # own host thread (ctypes releases the GIL) — same tokens as one call (the Gumbel hash takes the global row).
@@ -473,6 +507,8 @@ class RelationTransformerModel(CaptionModelBase):
         # 3 (`bench.py --workload decode --decode-streams n`) — so the default stays 1; the option remains for hosts that want to pipeline.
         n = int(opt.get("decode_streams", 0)) or 1
         n = max(1, min(n, B))
+        if plan is not None and n > 1:
+            n = 1       # every chunk's ortk_decode rebuilds the plan's shared buffers on its own stream: not concurrently
 
         def run(i, b0, b1, stream_ptr, out):
             oi = L.DecodeOpts.from_buffer_copy(o)
@@ -510,6 +546,8 @@ class RelationTransformerModel(CaptionModelBase):
             if r == -1 and n > 1:
                 raise L.OrtkError("unsupported decode options")
             L.check(r, "ortk_decode")
+        if plan is not None and fresh_plan:
+            plan.check_overflow()      # (host sync, first decode on a new plan: the images were built from THIS call's weights)
         return seq, lp, score
 
     def _sample(self, att_feats, boxes, att_masks=None, opt=None, **kwargs):

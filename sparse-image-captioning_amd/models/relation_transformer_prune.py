@@ -107,6 +107,16 @@ class RelationTransformerModel(PruningMixin, _Dense):
     def _eff_params_tensor(self):
         return self._weff
 
+    def _train_density(self, offset, N, K):
+        """Supermask training samples Bernoulli(sigmoid(m)) (pruning/sampler.py:10-17): the expected density of a block is
+        the mean of sigmoid(m), which is ABOVE the eval-mode round(sigmoid(m)) density the block selection sees; +15 % and
+        four standard deviations of the sample on top (host sync, once per plan)."""
+        if not self._supermask:
+            return 0.0
+        p = torch.sigmoid(self._mask_flat[offset: offset + N * K].float())
+        mean = float(p.mean())
+        return min(1.0, 1.15 * mean + 4.0 * (mean / max(N * K, 1)) ** 0.5)
+
     @staticmethod
     def _mask_seed(seed):
         return (int(seed) * 2654435761 + 0x5BD1E995) & 0xFFFFFFFF

@@ -108,9 +108,12 @@ class SparsePlan:
         L.check(L.lib().ortk_spmm(self.ref(), block, C.byref(args), L.stream_ptr()), "ortk_spmm")
 
     def check_overflow(self):
-        """Host sync: raises if the last build dropped entries (ELL: a block denser than the capacity it was planned with;
-        the GU16 format is worst-case sized and cannot overflow)."""
-        if int(self.overflow.item()):
+        """Host sync: raises if a build SINCE THE LAST CHECK dropped entries (ELL: a block denser than the capacity it was
+        planned with; the GU16 format is worst-case sized and cannot overflow).  The device flag is sticky across builds and
+        cleared here."""
+        hit = int(self.overflow.item())
+        self.overflow.zero_()
+        if hit:
             raise L.OrtkError("sparse plan overflow: a weight block has more non-zeros than the capacity reserved at "
                               "enable_sparse_kernels(); call it again with a lower min_sparsity")
 
@@ -147,7 +150,7 @@ def default_format(precision):
     return {"ell16": L.SP_ELL16, "gu16": L.SP_GU16}[os.environ.get("ORTK_SPARSE_FORMAT", "ell16").lower()]
 
 
-def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None):
+def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None, density_of=None):
     """(forward plan, backward plan | None) for the blocks of ``eff`` that are sparse enough.
 
     Forward: the (N, K) weight blocks at their arena offsets.  Backward (mixed precision only): the same blocks transposed
@@ -158,11 +161,16 @@ def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None):
     if not sel:
         return None, None
     fmt = default_format(precision) if fmt is None else fmt
-    dens = 1.0 - min_sparsity
+    dens0 = 1.0 - min_sparsity
+    # capacity density per block: the planned bound, or — training with Bernoulli(sigmoid(m)) samples, whose density is the
+    # MEAN of sigmoid(m), above the eval-mode round(sigmoid(m)) the selection saw — what `density_of(offset, N, K)` expects
+    for b in sel:
+        b["dens"] = max(dens0, density_of(b["offset"], b["N"], b["K"])) if density_of is not None else dens0
     first = linear_blocks(ccfg)[0][0]
     gu = fmt == L.SP_GU16
-    ok = (lambda N, K: K <= GKC or N <= 512) if gu else (lambda N, K: K <= KMAX)
-    fwd = [dict(offset=b["offset"], N=b["N"], K=b["K"], ld=b["K"], capacity=capacity_for(b["N"], b["K"], dens), sparsity=b["sparsity"])
+    # (blocks the formats do not take — more than 16 384 outputs: the ELL planner's per-range tables — stay dense)
+    ok = (lambda N, K: K <= GKC or N <= 512) if gu else (lambda N, K: K <= KMAX and N <= 16384)
+    fwd = [dict(offset=b["offset"], N=b["N"], K=b["K"], ld=b["K"], capacity=capacity_for(b["N"], b["K"], b["dens"]), sparsity=b["sparsity"])
            for b in sel if ok(b["N"], b["K"])]
     plan_f = SparsePlan(fwd, fmt, eff.device) if fwd else None
     plan_b = None
@@ -175,9 +183,11 @@ def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None):
                 if ok(b["K"], b["N"]):
                     bwd.append(dict(offset=b["offset"], N=b["K"], K=b["N"], ld=b["N"], sparsity=b["sparsity"]))
                 continue
+            if b["K"] > 16384:
+                continue
             for k0 in range(0, b["N"], KMAX):            # inputs of the transposed block = outputs of the weight
                 kw = min(KMAX, b["N"] - k0)
-                bwd.append(dict(offset=b["offset"] + k0, N=b["K"], K=kw, ld=b["N"], capacity=capacity_for(b["K"], kw, dens),
+                bwd.append(dict(offset=b["offset"] + k0, N=b["K"], K=kw, ld=b["N"], capacity=capacity_for(b["K"], kw, b["dens"]),
                                 sparsity=b["sparsity"]))
         plan_b = SparsePlan(bwd, fmt if gu else L.SP_ELL16, eff.device) if bwd else None
     return plan_f, plan_b

@@ -73,6 +73,10 @@ class NativeTrainer:
         self.overlap = (self.world > 1 if overlap_allreduce is None else bool(overlap_allreduce)) and not self.masked
         self._dec_off = int(L.lib().ortk_arena_decoder_offset(C.byref(model._ccfg)))
         self._pending = None
+        # sparse training plans (enable_sparse_kernels(train=True)): the images are rebuilt from every step's mask sample; a
+        # block denser than its reserved capacity would silently lose weights, so the sticky device flag is read (host sync)
+        # after the first step and then every `overflow_check_every` steps, and a hit raises
+        self.overflow_check_every = 50
 
     # ------------------------------------------------------------------ pieces
     def _batch(self, data, tok_weight):
@@ -174,6 +178,8 @@ class NativeTrainer:
         batch = self._batch(data, tok_weight)
         seed = self._fwd_bwd(batch, self.norm_dev, train)
         loss = self.loss_dev.clone()
+        if getattr(m, "_sparse_train", False) and (self.step_count == 1 or self.step_count % self.overflow_check_every == 0):
+            m.check_sparse_overflow()
         parallel.reduce_scalar_sum(loss)            # every rank's partial is already divided by the GLOBAL normaliser
         lr = self.rate()
         if self.masked:
