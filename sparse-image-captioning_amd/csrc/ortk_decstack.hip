@@ -154,12 +154,16 @@ __device__ __forceinline__ void unit_gemm(f32x4 (&acc)[2][4], const char* A, con
 // ring filled by LDS-DMA: 24.3 ms, (c) through a 16-deep register ring + one LDS staging slot, masks by s_load: 29.2 ms,
 // (d) the same with the masks travelling in the step's own registers (v_readlane): 26.6 ms — the v_mbcnt / select / address
 // arithmetic is ~6 vector + 4 scalar instructions per piece, 150 per k-step, 600 cycles of issue time per wave.
-struct SRing { uint2 e[SPD]; };
+#ifndef SSPD_
+#define SSPD_ 4
+#endif
+constexpr int SSPD = SSPD_;      // steps of entries in flight per wave (2 VGPRs each)
+struct SRing { uint2 e[SSPD]; };
 typedef const int __attribute__((address_space(4)))* cint_ptr;       // constant address space: uniform loads become s_load
 
 __device__ __forceinline__ void sring_start(SRing& r, const uint2* sp, int lane) {
 #pragma unroll
-    for (int s = 0; s < SPD; ++s) r.e[s] = sp[s * 64 + lane];
+    for (int s = 0; s < SSPD; ++s) r.e[s] = sp[s * 64 + lane];
 }
 __device__ __forceinline__ void s_scatter(char* D, const uint2 e) {
     *reinterpret_cast<unsigned short*>(D + ((e.x >> 15) & 0x1FFE)) = (unsigned short)e.x;
@@ -191,11 +195,11 @@ __device__ __forceinline__ void unit_sparse(f32x4 (&acc)[2][4], const char* A, c
         a[0][1] = *reinterpret_cast<const bf16x8*>(A + img_off(16 + m, 4 * ks + kg));
     }
 #pragma unroll 1
-    for (int g = 0; g < nst; g += SPD) {
+    for (int g = 0; g < nst; g += SSPD) {
 #pragma unroll
-        for (int s = 0; s < SPD; ++s) {
-            const int p = s & 1, sn = (s + 1) & (SPD - 1);
-            const bool more = s < SPD - 1 || g + SPD < nst;        // another step of THIS unit follows
+        for (int s = 0; s < SSPD; ++s) {
+            const int p = s & 1, sn = (s + 1) & (SSPD - 1);
+            const bool more = s < SSPD - 1 || g + SSPD < nst;        // another step of THIS unit follows
             s_clear(D, E.e[s]);
             if (NEXT || more) { s_scatter(D, E.e[sn]); s_frags(D, F[p ^ 1], lane); }
             if (more) {
@@ -203,7 +207,7 @@ __device__ __forceinline__ void unit_sparse(f32x4 (&acc)[2][4], const char* A, c
                 a[p ^ 1][0] = *reinterpret_cast<const bf16x8*>(A + img_off(m, 4 * ks + kg));
                 a[p ^ 1][1] = *reinterpret_cast<const bf16x8*>(A + img_off(16 + m, 4 * ks + kg));
             }
-            E.e[s] = sp[(g + s + SPD) * 64 + lane];                // (past the unit: the next unit's steps; past the stream: zeroed slack)
+            E.e[s] = sp[(g + s + SSPD) * 64 + lane];                // (past the unit: the next unit's steps; past the stream: zeroed slack)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const bf16x8 b = __builtin_bit_cast(bf16x8, F[p][nt]);
@@ -247,6 +251,7 @@ __device__ __forceinline__ void store_img(char* img, const f32x4 (&acc)[2][4], c
 template <bool RAW>
 __device__ __forceinline__ void layer_norm(const f32x4 (&x)[2][4], const float* ga, const float* be, float eps, float* red1, float* red2,
                                            int wave, int lane, f32x4 (&y)[2][4]) {
+#pragma clang fp contract(off)
     f32x4 a4[4], b4[4];
     load_cols(ga, wave, lane, a4);
     load_cols(be, wave, lane, b4);
@@ -271,7 +276,7 @@ __device__ __forceinline__ void layer_norm(const f32x4 (&x)[2][4], const float* 
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = x[mt][nt][r] - mean[mt]; q += d * d; }
+            for (int r = 0; r < 4; ++r) { const float d = x[mt][nt][r] - mean[mt]; q = __builtin_fmaf(d, d, q); }
         q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
         if (lane < 16) red2[(16 * mt + m) * 8 + wave] = q;
     }
@@ -284,7 +289,7 @@ __device__ __forceinline__ void layer_norm(const f32x4 (&x)[2][4], const float* 
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[mt][nt][r] = a4[nt][r] * (x[mt][nt][r] - mean[mt]) * rinv[mt] + b4[nt][r];
+            for (int r = 0; r < 4; ++r) y[mt][nt][r] = __builtin_fmaf(a4[nt][r] * (x[mt][nt][r] - mean[mt]), rinv[mt], b4[nt][r]);
     }
 }
 template <int RB>
@@ -319,8 +324,13 @@ struct AttState {
     // kind[u] = 0 (a key), -1e9 (masked: REPLACES the score, like the reference's masked_fill) or -inf (past the last key).
     // Leaves the un-normalised probabilities in p.  pv() then adds p . V; the two halves are separate so that the K registers
     // can be refilled with the next batch while V of this one is still in flight.
+    // (fp contract off + explicit fmaf in scores / pv / layer_norm: every row must get the SAME arithmetic whichever unrolled
+    // instance — row of a chunk, row of a pair, tile position — serves it.  Left to -ffp-contract=fast, hipcc fuses some
+    // instances and not others, and a decode stops being bit-for-bit equivariant under a permutation of the images:
+    // tests/test_gpu_model.py::test_decode_at_bench_size_properties)
     template <int KB>
     __device__ __forceinline__ void scores(const uint4 (&kk)[KB], const float (&kind)[KB], float (&p)[NR][KB]) {
+#pragma clang fp contract(off)
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             float bm = -INFINITY;
@@ -340,7 +350,7 @@ struct AttState {
             float s = 0.f;
 #pragma unroll
             for (int u = 0; u < KB; ++u) { p[i][u] = __expf(p[i][u] - mn); s += p[i][u]; }
-            l[i] = l[i] * corr + s;
+            l[i] = __builtin_fmaf(l[i], corr, s);
             m[i] = mn;
 #pragma unroll
             for (int d = 0; d < 8; ++d) o[i][d] *= corr;
@@ -348,16 +358,18 @@ struct AttState {
     }
     template <int KB>
     __device__ __forceinline__ void pv(const uint4 (&vv)[KB], const float (&p)[NR][KB]) {
+#pragma clang fp contract(off)
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
             const float v[8] = {lo_f(vv[u].x), hi_f(vv[u].x), lo_f(vv[u].y), hi_f(vv[u].y), lo_f(vv[u].z), hi_f(vv[u].z), lo_f(vv[u].w), hi_f(vv[u].w)};
 #pragma unroll
             for (int i = 0; i < NR; ++i)
 #pragma unroll
-                for (int d = 0; d < 8; ++d) o[i][d] += p[i][u] * v[d];
+                for (int d = 0; d < 8; ++d) o[i][d] = __builtin_fmaf(p[i][u], v[d], o[i][d]);
         }
     }
     __device__ __forceinline__ void finish(char* O, int row0, int nr, int lane) {
+#pragma clang fp contract(off)
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if (i < nr) {
@@ -489,15 +501,16 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
             constexpr int NI = (RB + 7) / 8;          // rows per wave
 #pragma unroll 1
             for (int i0 = 0; i0 < NI; i0 += SROWS) {
-                if (wave + 8 * i0 >= RB || r0 + wave + 8 * i0 >= a.rows) break;        // (wave-uniform) no row of this pass exists
+                auto rowof = [&](int i) { return RB == 32 ? 4 * wave + i : wave + 8 * i; };     // i-th row of this wave
+                if (rowof(i0) >= RB || r0 + rowof(i0) >= a.rows) break;        // (wave-uniform) no row of this pass exists
                 int idx[SROWS];          // lane j: physical cache row of key j of row r
                 int rowi[SROWS];         // row inside the block (clamped: a missing second row repeats the first)
                 AttState<1> st[SROWS];
                 uint4 kq[SROWS][SKB], vq[SROWS][SKB];
 #pragma unroll
                 for (int r = 0; r < SROWS; ++r) {
-                    const int row = wave + 8 * (i0 + r);
-                    rowi[r] = (row < RB && r0 + row < a.rows) ? row : wave + 8 * i0;
+                    const int row = rowof(i0 + r);
+                    rowi[r] = (row < RB && r0 + row < a.rows) ? row : rowof(i0);
                     const int g = r0 + rowi[r];
                     idx[r] = a.kvidx ? a.kvidx[(int64_t)g * Lk + min(lane, a.t)] : g * a.T + min(lane, a.t);
                 }
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
                     float pself[1][1];
                     st[r].scores<1>(kself, kindself, pself);
                     st[r].pv<1>(vself, pself);
-                    if (row == wave + 8 * (i0 + r)) {      // (a repeated row writes nothing)
+                    if (row == rowof(i0 + r)) {      // (a repeated row writes nothing)
                         const int64_t slot = (int64_t)__builtin_amdgcn_readlane(idx[r], a.t) * (SD / 8);
                         reinterpret_cast<uint4*>(P.ck)[slot + lane] = kself[0];
                         reinterpret_cast<uint4*>(P.cv)[slot + lane] = vself[0];
@@ -690,7 +703,7 @@ int stack_pack(const void* w16, void* wpk, const StackPack& t, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ sparse stream builder
 namespace {
-constexpr int SSLACK = SPD + 4;        // all-zero steps behind every wave's stream (the ring's look-ahead: entry 0 = weight 0 at position 0)
+constexpr int SSLACK = SSPD + 4;        // all-zero steps behind every wave's stream (the ring's look-ahead: entry 0 = weight 0 at position 0)
 // the 32 weights lane `lane` of wave w feeds to the MFMAs of k-step ks of unit u (4 column tiles x 8), as in stack_pack_kernel
 __device__ __forceinline__ void sstack_load(const __bf16* w16, const StackPack& t, int w, int l, int u, int ks, int lane, uint4 (&f)[4]) {
     int64_t base; int ld;
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(256) void sstack_count_kernel(const __bf16* __restr
     if (lane == 0) cnt[item] = c;
 }
 // thread w: the step layout of wave w's stream.  cnt[item] -> first step of the k-step (relative to the wave's stream);
-// nst[w LU + lu] = steps of the unit (a multiple of SPD); start[w] = first step of the wave in the buffer;
+// nst[w LU + lu] = steps of the unit (a multiple of SSPD); start[w] = first step of the wave in the buffer;
 // stats = {steps in all, non-zeros}
 __global__ void sstack_scan_kernel(int32_t* __restrict__ cnt, int32_t* __restrict__ nst, int64_t* __restrict__ start, int64_t* __restrict__ stats, int LU) {
     __shared__ int64_t tot[8], nzs[8];
@@ -754,7 +767,7 @@ __global__ void sstack_scan_kernel(int32_t* __restrict__ cnt, int32_t* __restric
                 cnt[i] = (int)(run + st);
                 st += steps_of(c);
             }
-            st = (st + SPD - 1) / SPD * SPD;
+            st = (st + SSPD - 1) / SSPD * SSPD;
             nst[w * LU + lu] = st;
             run += st;
         }

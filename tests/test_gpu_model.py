@@ -1185,3 +1185,86 @@ def test_sparse_decode_full_size_95pct(P, full_state, precision):
         assert (seq_d[:, 0] == seq_s[:, 0]).all(-1).float().mean().item() >= 0.8      # the best beam of an image
         same = (seq_d == seq_s).all(-1)
         assert (lp_d[same] - lp_s[same]).abs().max().item() < 3e-2
+
+
+def _pruned_dense_model(P, full_state, keep, seed=11):
+    """The reference's eval flow for pruned checkpoints (scripts/eval_model.py:64-88): the DENSE class on zero-filled weights;
+    every >= 2-D tensor keeps a random `keep` fraction of its entries."""
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.dim() >= 2 and keep < 1.0:
+                p.mul_((torch.rand(p.shape, generator=g) < keep).to(p.device, p.dtype))
+    return m
+
+
+def _decode_ex(m, b, opt, ex):
+    with torch.no_grad():
+        seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt=dict(opt, executor=ex), mode="sample")
+    return seq.clone(), lp.clone()
+
+
+@pytest.mark.parametrize("keep", [0.05, 0.5, 1.0])
+def test_sparse_weight_stream_vs_dense_stream(P, full_state, keep):
+    """The decoder stack kernel on its SPARSE weight stream (ortk_decode_opts.exec_flags = ORTK_DEC_SPARSE_STREAM: scatter entries
+    expanded through LDS, csrc/ortk_decstack.hip) against the same kernel on the dense stream, same zero-filled weights, 70
+    ragged images (partial last row blocks of 20 / 32 rows, images straddling blocks): the multiply-adds are the same bf16 MFMAs
+    in the same order except where a k-step overflows its 128-entry step (keep = 0.05: 0.5 % of them; keep = 0.5 and the
+    fully dense model run 8 / 16 steps per k-step — the stream is correct at ANY density), so tokens agree up to near-ties and
+    log-probs to fp32 summation noise.  Greedy, beam 5, beam 3 with the repeat constraint, sampling."""
+    m = _pruned_dense_model(P, full_state, keep)
+    b = _cuda(H.torch_batch(C.make_inputs(seed=43, n_img=70, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    for opt, min_tok in (({"beam_size": 1}, 0.99), ({"beam_size": 5}, 0.97), ({"beam_size": 3, "decoding_constraint": 1}, 0.97),
+                         ({"num_random_sample": 3, "beam_size": 0, "seed": 7}, 0.97)):
+        sd, ld = _decode_ex(m, b, opt, "stack")
+        ss, ls = _decode_ex(m, b, opt, "sparse_stream")
+        same = (sd == ss).all(-1)            # whole hypotheses (a near-tie that flips re-ranks the beams of its image)
+        assert same.float().mean().item() >= min_tok - 0.04, (keep, opt, same.float().mean().item())
+        assert (sd == ss).float().mean().item() >= min_tok - 0.02, (keep, opt)
+        assert (ld - ls)[same].abs().max().item() < 2e-3, (keep, opt, (ld - ls)[same].abs().max().item())
+
+
+def test_sparse_weight_stream_vs_fp32_teacher_forcing(P, full_state):
+    """The sparse stream against the fp32 PARITY path (which is golden-pinned to the reference): every token its greedy decode
+    emits on 95 %-pruned weights has, teacher-forced in fp32 on the same tokens and weights, a log-prob within 0.02 of the one
+    the stream reported (mean within 0.004) — the bar of the dense stream's test above."""
+    m = _pruned_dense_model(P, full_state, 0.05)
+    m32 = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=0)
+    with torch.no_grad():
+        m32._flat.copy_(m._flat)
+    b = _cuda(H.torch_batch(C.make_inputs(seed=41, n_img=70, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    s1, l1 = _decode_ex(m, b, {"beam_size": 1}, "sparse_stream")
+    with torch.no_grad():
+        rows = s1[:, 0]
+        tf_in = torch.cat([rows.new_full((rows.size(0), 1), 2), rows], 1)
+        ref = m32(att_feats=b["att_feats"], boxes=b["boxes"], seqs=tf_in, att_masks=b["att_masks"]).gather(2, rows.unsqueeze(2)).squeeze(2)
+    err = (l1[:, 0] - ref)[rows != 0].abs()
+    assert err.max().item() <= 0.02 and err.mean().item() <= 0.004, (err.max().item(), err.mean().item())
+
+
+def test_sparse_decode_at_bench_size_properties(P, full_state):
+    """BASELINE configs[4] at its FULL size on the sparse weight stream (1 024 images, beam 5, 95 %-pruned weights, 256 workgroups
+    of 20 rows): deterministic; bit-for-bit equivariant under a permutation of the images; beams in descending score order,
+    score = sum of the token log-probs; the best beam of (nearly) every image equal to the dense stream's; and
+    `enable_sparse_stream("auto")` picks the stream for these weights (and not for the unpruned model)."""
+    m = _pruned_dense_model(P, full_state, 0.05)
+    assert m.enable_sparse_stream("auto") is True
+    B = 1024
+    b = _cuda(H.torch_batch(C.make_inputs(seed=61, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    kw = lambda d: dict(att_feats=d["att_feats"], boxes=d["boxes"], att_masks=d["att_masks"], opt={"beam_size": 5}, mode="sample")
+    with torch.no_grad():
+        s1, l1 = m(**kw(b)); sc1 = m._last_decode[2].clone()
+        s2, l2 = m(**kw(b)); sc2 = m._last_decode[2].clone()
+        assert torch.equal(s1, s2) and torch.equal(l1, l2) and torch.equal(sc1, sc2)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+        bp = {k: v[perm] for k, v in b.items() if k in ("att_feats", "boxes", "att_masks")}
+        s3, l3 = m(**kw(bp)); sc3 = m._last_decode[2].clone()
+        assert torch.equal(s3, s1[perm]) and torch.equal(l3, l1[perm]) and torch.equal(sc3, sc1[perm])
+        assert (sc1[:, :-1] >= sc1[:, 1:]).all()
+        assert (sc1 - l1.sum(-1)).abs().max().item() < 1e-3
+        m.enable_sparse_stream(False)
+        sd, ld = _decode_ex(m, b, {"beam_size": 5}, "stack")
+        assert (sd[:, 0] == s1[:, 0]).all(-1).float().mean().item() >= 0.99
+    dense = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
+    assert dense.enable_sparse_stream("auto") is False
