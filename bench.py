@@ -53,7 +53,8 @@ def synth_batch(B, S, F, V, spi, seq_len, seed, device):
         seqs[r, 1 + L] = 3
         masks[r, :L + 2] = 1
     t = lambda a: torch.from_numpy(a).to(device)
-    return dict(att_feats=t(att), boxes=t(boxes), att_masks=torch.ones(B, S, device=device), seqs=t(seqs), masks=t(masks))
+    return dict(att_feats=t(att), boxes=t(boxes), att_masks=torch.ones(B, S, device=device), seqs=t(seqs), masks=t(masks),
+                att_max_len=S)      # (what the collate function reports: no read-back of the mask per step)
 
 
 def cpu_baseline(workload, cfg_dict, seconds=12.0):
@@ -239,7 +240,8 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
             opt["decode_streams"] = args.decode_streams
 
         def step():
-            model(att_feats=batch["att_feats"], boxes=batch["boxes"], att_masks=batch["att_masks"], opt=opt, mode="sample")
+            model(att_feats=batch["att_feats"], boxes=batch["boxes"], att_masks=batch["att_masks"], opt=opt, mode="sample",
+                  att_max_len=batch["att_max_len"])
         units_per_step = B
     elif workload == "scst":
         model.train()

@@ -162,6 +162,9 @@ class _RegionBatcher:
             arrays = [self._fetch(os.path.join(folder, f"{i}.npy"), loader) for i in image_ids]
             if with_mask:
                 out[key], out["att_masks"] = pad_rows(arrays, want_mask=True)
+                # (not in the reference's dict) the longest region list: lets the model clip the padded regions
+                # (relation_transformer.py:398-405) without reading the mask back from the device
+                out["att_max_len"] = max(int(a.shape[0]) for a in arrays)
             else:
                 out[key] = pad_rows(arrays)
         token_rows = []

@@ -364,18 +364,23 @@ class RelationTransformerModel(CaptionModelBase):
         return ws
 
     @staticmethod
-    def clip_att(att_feats, att_masks, boxes):
-        """relation_transformer.py:398-405 (boxes are cut to the same length; collate pads all three alike)."""
+    def clip_att(att_feats, att_masks, boxes, max_len=None):
+        """relation_transformer.py:398-405 (boxes are cut to the same length; collate pads all three alike).  The longest
+        region list of the batch is a device-to-host read of the mask (in the reference too: `.max()`), i.e. a stream
+        synchronisation per call; a caller that knows it — the collate function builds the mask from the list lengths and
+        returns it as ``att_max_len`` — passes it as `max_len` and nothing is read back."""
         if att_masks is not None:
-            max_len = int(att_masks.long().sum(1).max())
-            att_feats, att_masks = att_feats[:, :max_len], att_masks[:, :max_len]
-            boxes = boxes[:, :max_len]
+            if max_len is None:
+                max_len = int(att_masks.long().sum(1).max())
+            if max_len < att_masks.size(1):
+                att_feats, att_masks = att_feats[:, :max_len], att_masks[:, :max_len]
+                boxes = boxes[:, :max_len] if boxes is not None else boxes
         return att_feats, att_masks, boxes
 
-    def _prepare(self, att_feats, boxes, att_masks):
+    def _prepare(self, att_feats, boxes, att_masks, att_max_len=None):
         L.require_gpu()
         assert att_feats.is_cuda and boxes.is_cuda, "inputs must live on the MI355X (no CPU path)"
-        att_feats, att_masks, boxes = self.clip_att(att_feats, att_masks, boxes)
+        att_feats, att_masks, boxes = self.clip_att(att_feats, att_masks, boxes, att_max_len)
         if att_masks is None:
             att_masks = att_feats.new_ones(att_feats.shape[:2])
         assert att_feats.size(-1) == self.att_feat_size and boxes.size(-1) == 4
@@ -438,7 +443,7 @@ class RelationTransformerModel(CaptionModelBase):
 
     def _forward(self, att_feats, boxes, seqs, att_masks=None, **kwargs):
         """``_forward`` (relation_transformer.py:368-372): log-probs (R, T, V), T = seqs.size(1) - 1."""
-        att_feats, boxes, att_masks = self._prepare(att_feats, boxes, att_masks)
+        att_feats, boxes, att_masks = self._prepare(att_feats, boxes, att_masks, kwargs.get("att_max_len"))
         batch = self._make_batch(att_feats, boxes, att_masks, seqs)
         train = bool(self.training)
         seed = self._next_seed() if train else 0
@@ -512,7 +517,7 @@ class RelationTransformerModel(CaptionModelBase):
 
         def run(i, b0, b1, stream_ptr, out):
             oi = L.DecodeOpts.from_buffer_copy(o)
-            oi.sample_row_offset = b0 * K
+            oi.sample_row_offset = int(opt.get("sample_row_offset", 0)) + b0 * K
             nb = lib.ortk_decode_workspace_bytes(C.byref(self._ccfg), b1 - b0, S, C.byref(oi))
             if nb == 0:
                 out[i] = -1
@@ -559,7 +564,7 @@ class RelationTransformerModel(CaptionModelBase):
         (SURVEY.md §9.3), far cheaper backward than the reference's 18-step incremental graph.
         """
         opt = {} if opt is None else opt
-        feats, bxs, masks = self._prepare(att_feats, boxes, att_masks)
+        feats, bxs, masks = self._prepare(att_feats, boxes, att_masks, kwargs.get("att_max_len"))
         seq, lp, score = self._decode(feats, bxs, masks, opt)
         self._last_decode = (seq, lp, score, int(opt.get("beam_size", 1)))
         self.done_beams = None
@@ -601,14 +606,18 @@ class RelationTransformerModel(CaptionModelBase):
         in a module counter reset by ``reset_cache``).  This is the API-compatible path: every call re-packs the caches;
         ``mode="sample"`` runs the whole loop on the device."""
         lib = L.lib()
-        if any(self._ccfg.share_dec[l] for l in range(self.num_layers)):
-            raise NotImplementedError("get_logprobs_state with share_layer_decoder: use mode='sample'")
-        if self._ccfg.share_att_dec:
-            raise NotImplementedError("get_logprobs_state with share_att_decoder: use mode='sample'")
         rows, S, d = memory.shape
         Lr, H = self.num_layers, self.num_heads
         dk, T = d // H, self.seq_length
         dev = self._flat.device
+        # layout of the projected memory (ortk_project_memory): one cw-wide slice per DISTINCT decoder layer (ACORT layer
+        # sharing, ortk_config.share_dec), cw = d when the module shares its key / value projection ("kv": K = V) else [K | V]
+        share = [int(self._ccfg.share_dec[l]) for l in range(Lr)]
+        distinct = [l for l in range(Lr) if share[l] == 0]
+        slot = [distinct.index(l if share[l] == 0 else share[l] - 1) for l in range(Lr)]
+        U = len(distinct)
+        kv_shared = int(self._ccfg.share_att_dec) == 1
+        cw, vo = (d, 0) if kv_shared else (2 * d, d)
         it = it.to(dev).long().contiguous()
         masks = mask.reshape(rows, S).to(dev).float().contiguous()
         pptr = self._eff_params_ptr(False, 0)
@@ -618,7 +627,7 @@ class RelationTransformerModel(CaptionModelBase):
         self_v = torch.zeros(Lr, rows, T, d, device=dev)
         if state is None:
             t = 0
-            ckv = torch.empty(rows * S, Lr * 2 * d, device=dev)
+            ckv = torch.empty(rows * S, U * cw, device=dev)
             mem = memory.to(dev).float().contiguous()
             L.check(lib.ortk_project_memory(C.byref(self._ccfg), pptr, L.ptr(mem), rows * S, L.ptr(ws), ws.numel(),
                                             L.ptr(ckv), L.stream_ptr()), "ortk_project_memory")
@@ -628,22 +637,24 @@ class RelationTransformerModel(CaptionModelBase):
             t = caches[0].size(2)
             assert t < T, "cache is full"
             unhead = lambda c: c.permute(1, 2, 0, 3).reshape(rows, c.size(2), d)      # (h, rows, len, dk) -> (rows, len, d)
-            ckv = torch.empty(rows, S, Lr, 2, d, device=dev)
+            ckv = torch.empty(rows, S, U, cw, device=dev)
             for l in range(Lr):
                 self_k[l, :, :t] = unhead(caches[4 * l])
                 self_v[l, :, :t] = unhead(caches[4 * l + 1])
-                ckv[:, :, l, 0] = unhead(caches[4 * l + 2])
-                ckv[:, :, l, 1] = unhead(caches[4 * l + 3])
-            ckv = ckv.view(rows * S, Lr * 2 * d)
+                ckv[:, :, slot[l], 0:d] = unhead(caches[4 * l + 2])
+                if not kv_shared:
+                    ckv[:, :, slot[l], d:2 * d] = unhead(caches[4 * l + 3])
+            ckv = ckv.view(rows * S, U * cw)
         logp = torch.empty(rows, self.vocab_size, device=dev)
         L.check(lib.ortk_decode_step(C.byref(self._ccfg), pptr, L.ptr(it), t, rows, rows, S, L.ptr(ckv), L.ptr(masks),
                                      L.ptr(self_k), L.ptr(self_v), T, L.ptr(ws), ws.numel(), L.ptr(logp), self.vocab_size,
                                      L.stream_ptr()), "ortk_decode_step")
         head = lambda x: x.reshape(rows, -1, H, dk).permute(2, 0, 1, 3).contiguous()  # (rows, len, d) -> (h, rows, len, dk)
-        ckv5 = ckv.view(rows, S, Lr, 2, d)
+        ckv4 = ckv.view(rows, S, U, cw)
         new_state = [it.view(1, rows, 1)]
         for l in range(Lr):
-            new_state += [head(self_k[l, :, :t + 1]), head(self_v[l, :, :t + 1]), head(ckv5[:, :, l, 0]), head(ckv5[:, :, l, 1])]
+            new_state += [head(self_k[l, :, :t + 1]), head(self_v[l, :, :t + 1]), head(ckv4[:, :, slot[l], 0:d]),
+                          head(ckv4[:, :, slot[l], vo:vo + d])]
         return logp, new_state
 
     @torch.no_grad()

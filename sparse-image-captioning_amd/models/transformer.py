@@ -22,13 +22,13 @@ class TransformerModel(RelationTransformerModel):
     COLLATE_FN = UpDownCollate     # no boxes in the batch dict (data/collate.py:77-188)
     NO_BOX = True
 
-    def _prepare(self, att_feats, boxes, att_masks):
+    def _prepare(self, att_feats, boxes, att_masks, att_max_len=None):
         # the executor never reads the boxes of this model; a (B, S, 4) placeholder keeps the shared batch plumbing
         boxes = att_feats.new_zeros(att_feats.shape[0], att_feats.shape[1], 4)
-        return super()._prepare(att_feats, boxes, att_masks)
+        return super()._prepare(att_feats, boxes, att_masks, att_max_len)
 
     def _forward(self, att_feats, att_masks=None, seqs=None, boxes=None, **kwargs):
-        return super()._forward(att_feats, None, seqs, att_masks)
+        return super()._forward(att_feats, None, seqs, att_masks, **kwargs)
 
     def _sample(self, att_feats, att_masks=None, opt=None, boxes=None, **kwargs):
         return super()._sample(att_feats, None, att_masks, opt)

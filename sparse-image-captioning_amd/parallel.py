@@ -39,10 +39,33 @@ def shard_batch(data, r=None, n=None):
     return out
 
 
+def _staged(t):
+    """gloo (the CPU backend; also what two ranks that SHARE one GPU have to use: RCCL refuses two ranks on one device) cannot
+    be relied on for device tensors on this build: exchange such a tensor through the host."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+class _StagedWork:
+    """all-reduce of a device tensor through a host copy: the copy out waits for the work queued on the current stream (what
+    the RCCL collective does on its own stream), ``wait()`` copies the sum back."""
+
+    def __init__(self, t):
+        self.t = t
+        self.h = t.detach().cpu()
+        self.work = dist.all_reduce(self.h, op=dist.ReduceOp.SUM, async_op=True)
+
+    def wait(self):
+        self.work.wait()
+        self.t.copy_(self.h)
+
+
 def reduce_scalar_sum(t):
     """In-place SUM over ranks of a (1,) tensor (the loss normaliser)."""
     if world() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if _staged(t):
+            _StagedWork(t).wait()
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -52,6 +75,8 @@ def allreduce_async(t):
     backend the collective first waits for the work already queued on the current stream, then runs on its own stream."""
     if not (dist.is_available() and dist.is_initialized()):
         return None
+    if _staged(t):
+        return _StagedWork(t)
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 
@@ -60,5 +85,8 @@ def allreduce_arena(*arenas):
     if world() > 1:
         for a in arenas:
             if a is not None:
-                dist.all_reduce(a, op=dist.ReduceOp.SUM)
+                if _staged(a):
+                    _StagedWork(a).wait()
+                else:
+                    dist.all_reduce(a, op=dist.ReduceOp.SUM)
     return arenas

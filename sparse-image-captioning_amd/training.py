@@ -81,7 +81,7 @@ class NativeTrainer:
     # ------------------------------------------------------------------ pieces
     def _batch(self, data, tok_weight):
         m = self.model
-        feats, boxes, masks = m._prepare(data["att_feats"], data.get("boxes"), data.get("att_masks"))
+        feats, boxes, masks = m._prepare(data["att_feats"], data.get("boxes"), data.get("att_masks"), data.get("att_max_len"))
         return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight)
 
     def _fwd_bwd(self, batch, norm, train=True):
@@ -145,7 +145,11 @@ class NativeTrainer:
             # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
             # token for token what the two calls of utils/training.py:220-237 return, at half the launches
             seq, _ = m(att_feats=data["att_feats"], boxes=data.get("boxes"), att_masks=data.get("att_masks"), mode="sample",
-                       opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy"})
+                       att_max_len=data.get("att_max_len"),
+                       opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
+                            # the draws are keyed by the GLOBAL row of the batch: N ranks on their shards sample what one
+                            # process samples on the whole batch
+                            "sample_row_offset": parallel.rank() * data["att_feats"].size(0) * (num_samples + (baseline == "greedy"))})
         if baseline == "greedy":
             greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
         m.train(was_training)

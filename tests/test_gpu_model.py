@@ -90,6 +90,28 @@ def test_decode_options_vs_reference_golden(P, g1):
         m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"num_random_sample": 2, "beam_size": 2}, mode="sample")
 
 
+def _greedy_via_step_api(m, b):
+    """Greedy decode driven from the host through get_logprobs_state (the reference's own loop, transformer.py:531-561):
+    tokens (rows, L) with zeros after the first EOS, and the log-prob of every emitted token."""
+    mem = m.encode(b["att_feats"], b["boxes"], b["att_masks"])
+    amask = b["att_masks"][:, None, :mem.size(1)]
+    rows, T = mem.size(0), m.seq_length
+    it = torch.full((rows,), C.BOS, dtype=torch.long, device="cuda")
+    seq = torch.zeros(rows, T, dtype=torch.long, device="cuda")
+    lps = torch.zeros(rows, T, device="cuda")
+    unfinished = torch.ones(rows, dtype=torch.bool, device="cuda")
+    state = None
+    for t in range(T):
+        lp, state = m.get_logprobs_state(it, mem, amask, state)
+        best, it = lp.max(-1)
+        seq[:, t] = it * unfinished
+        lps[:, t] = best
+        unfinished = unfinished & (it != m.eos_idx)
+        if not bool(unfinished.any()):
+            break
+    return seq, lps
+
+
 def test_get_logprobs_state_step_api_vs_reference_golden(P, g1):
     """The per-step host API (relation_transformer.py:374-387): log-probs of two steps and the state layout equal the
     reference's; a beam-style re-ordering of the returned state (caption_model.py:106-110) equals the oracle's."""
@@ -242,6 +264,14 @@ def test_share_layer_vs_reference_golden(P, golden):
     seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 3}, mode="sample")
     np.testing.assert_array_equal(seq.cpu().numpy(), oseq.numpy())
     close(lp, olp.numpy(), 2e-4)
+    # the per-step host API with layer sharing in the decoder (one projected-memory slice per DISTINCT layer): a host-driven
+    # greedy loop = the on-device greedy decode = the oracle's
+    with torch.no_grad():
+        gseq, glp = O.sample_greedy_or_multinomial(Po, ocfg, bc["att_feats"], bc["boxes"], bc["att_masks"])
+    sq, lq = _greedy_via_step_api(m, b)
+    np.testing.assert_array_equal(sq.cpu().numpy(), gseq[:, 0].numpy())
+    valid = gseq[:, 0].numpy() != 0
+    np.testing.assert_allclose(lq.cpu().numpy()[valid], glp[:, 0].numpy()[valid], rtol=2e-4, atol=2e-4)
     # ... and against the reference itself with encoder sharing only
     cfgb = dict(C.TINY_CFG, num_layers=3, share_layer_encoder=(0, 1, 0))
     nb = [str(n) for n in g8["enc_only/param_names"]]
@@ -292,9 +322,13 @@ def test_share_att_vs_reference_golden(P, golden, tag, enc, dec):
         seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": bs}, mode="sample")
         np.testing.assert_array_equal(seq.cpu().numpy(), g9[f"{tag}/decode_b{bs}/seq"])
         close(lp, g9[f"{tag}/decode_b{bs}/logprobs"], 2e-4)
-    with pytest.raises(NotImplementedError):
-        m.get_logprobs_state(b["seqs"][:, 0], torch.zeros(b["seqs"].size(0), 12, cfgd["d_model"], device="cuda"),
-                             torch.ones(b["seqs"].size(0), 12, device="cuda"), None)
+    # the per-step host API with projection sharing in the decoder (packed memory projection of width d per layer for "kv"):
+    # a host-driven greedy loop gives the reference's greedy tokens and log-probs
+    sq, lq = _greedy_via_step_api(m, b)
+    ref_seq = g9[f"{tag}/decode_b1/seq"][:, 0]
+    np.testing.assert_array_equal(sq.cpu().numpy(), ref_seq)
+    valid = ref_seq != 0
+    np.testing.assert_allclose(lq.cpu().numpy()[valid], g9[f"{tag}/decode_b1/logprobs"][:, 0][valid], rtol=2e-4, atol=2e-4)
     from sparse_image_captioning_amd.training import NativeTrainer
     tr = NativeTrainer(m, noamopt_warmup=10)
     l0 = float(tr.xe_step(b, train=False))
