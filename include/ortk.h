@@ -89,6 +89,15 @@ int ortk_arena_entry(const ortk_config* cfg, int32_t index, char* name_buf, int6
 /* ------------------------------------------------------------------------------------------------
  * Whole-path entry points (the native executor).
  * ---------------------------------------------------------------------------------------------- */
+/* The 32-bit dropout key of one site of a training-mode ortk_forward(seed): stack 0 = the region embedding's dropout
+ * (relation_transformer.py:331-333; element index row*d + col over the (B*S, d) output), 1 = the PositionalEncoding's
+ * (transformer.py:398-401; (R*T, d)), 2 / 3 = encoder / decoder layer `layer` with k = 0 self-attention probabilities
+ * ((group, head, query, key) flattened as the kernel's P tensor), 1 self-attention sublayer output, [decoder: 2 cross-attention
+ * probabilities ((image, head, caption*T + t, region)), 3 cross-attention sublayer output, 4 FFN hidden, 5 FFN sublayer output;
+ * encoder: 2 FFN hidden, 3 FFN sublayer output].  Element i of that site keeps iff ortk_dropout_apply(ones, .., n, p, key)[i]
+ * != 0 — the hook the train-mode parity test uses to replay the SAME masks through the oracle. */
+uint32_t ortk_dropout_site_seed(uint64_t seed, int32_t stack, int32_t layer, int32_t k);
+
 typedef struct ortk_batch {
     const float*   att_feats;   /* (B, S, feat)   zero padded                       collate.py:119-169 */
     const float*   boxes;       /* (B, S, 4)      relative x0,y0,x1,y1                                  */

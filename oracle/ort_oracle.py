@@ -125,14 +125,22 @@ def project_qkv(P, prefix: str, share_att, xq: Tensor, xkv: Tensor, h: int, need
     return q, k, v, out
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], bias: Optional[Tensor] = None) -> Tensor:
-    """transformer.py:285-295 / relation_transformer.py:258-293 (mask fill BEFORE the additive log-bias)."""
+def _drop(drop, site: str, x: Tensor) -> Tensor:
+    """Training-mode dropout at a named site.  `drop` is None (eval: identity) or a callable (site, x) -> x * keep / (1 - p)
+    with an explicit keep mask: torch's RNG stream cannot be matched, so train-mode parity INJECTS the masks (the HIP path's
+    counter hash, read back through ortk_dropout_apply in tests/test_gpu_model.py::test_train_mode_dropout_vs_oracle)."""
+    return x if drop is None else drop(site, x)
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], bias: Optional[Tensor] = None, drop=None, site: str = "") -> Tensor:
+    """transformer.py:285-295 / relation_transformer.py:258-293 (mask fill BEFORE the additive log-bias; dropout on the
+    probabilities, transformer.py:293-294)."""
     scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(q.size(-1))
     if mask is not None:
         scores = scores.masked_fill(mask == 0, NEG)
     if bias is not None:
         scores = bias + scores
-    p = torch.softmax(scores, dim=-1)
+    p = _drop(drop, site, torch.softmax(scores, dim=-1))
     return torch.matmul(p, v)
 
 
@@ -141,31 +149,35 @@ def _merge(x: Tensor) -> Tensor:
     return x.transpose(1, 2).reshape(n, l, h * dk)
 
 
-def att_embed(P, att_feats: Tensor, att_masks: Tensor) -> Tensor:
-    """relu(Linear(att_feats)) on valid regions, exact zeros on padded ones (model_utils.py:149-168)."""
-    y = torch.relu(_linear(P, "att_embed.0", att_feats))
+def att_embed(P, att_feats: Tensor, att_masks: Tensor, drop=None) -> Tensor:
+    """Dropout(relu(Linear(att_feats))) on valid regions (relation_transformer.py:331-333), exact zeros on padded ones
+    (model_utils.py:149-168)."""
+    y = _drop(drop, "src", torch.relu(_linear(P, "att_embed.0", att_feats)))
     return y * (att_masks != 0).to(y.dtype)[..., None]
 
 
-def encode(P, cfg, att_feats: Tensor, boxes: Tensor, att_masks: Tensor) -> Tensor:
-    """relation_transformer.py:341-365 (feature prep) + :92-113,148-191 (encoder). Returns memory (B,S,d)."""
+def encode(P, cfg, att_feats: Tensor, boxes: Tensor, att_masks: Tensor, drop=None) -> Tensor:
+    """relation_transformer.py:341-365 (feature prep) + :92-113,148-191 (encoder). Returns memory (B,S,d).
+    Dropout sites (drop != None): SublayerConnection x + dropout(sublayer(norm(x))) (transformer.py:356-358), the FFN's
+    w_2(dropout(relu(w_1 x))) (transformer.py:324-325), the attention probabilities."""
     h = cfg.num_heads
     plain = getattr(cfg, "plain", False)
     if plain:   # transformer.py:627-629: Linear + ReLU (+ Dropout) on every row; boxes unused
-        x = torch.relu(_linear(P, "att_embed.0", att_feats))
+        x = _drop(drop, "src", torch.relu(_linear(P, "att_embed.0", att_feats)))
         emb = None
     else:
-        x = att_embed(P, att_feats, att_masks)
+        x = att_embed(P, att_feats, att_masks, drop)
         emb = box_relational_embedding(boxes, not cfg.no_box_trigonometric_embedding)
     kmask = (att_masks != 0)[:, None, None, :]  # (B,1,1,S)
     for l in range(cfg.num_layers):
         pre = f"model.encoder.layers.{l}."
         y = layer_norm(x, P[pre + "sublayer.0.norm.a_2"], P[pre + "sublayer.0.norm.b_2"])
         q, k, v, out = project_qkv(P, pre + "self_attn.", getattr(cfg, "share_att_encoder", None), y, y, h)
-        o = attention(q, k, v, kmask, None if plain else box_logbias(P, l, emb, h))
-        x = x + _linear(P, out, _merge(o))
+        o = attention(q, k, v, kmask, None if plain else box_logbias(P, l, emb, h), drop, f"enc{l}.att")
+        x = x + _drop(drop, f"enc{l}.sub0", _linear(P, out, _merge(o)))
         y = layer_norm(x, P[pre + "sublayer.1.norm.a_2"], P[pre + "sublayer.1.norm.b_2"])
-        x = x + _linear(P, pre + "feed_forward.w_2", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
+        hid = _drop(drop, f"enc{l}.ffn", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
+        x = x + _drop(drop, f"enc{l}.sub1", _linear(P, pre + "feed_forward.w_2", hid))
     return layer_norm(x, P["model.encoder.norm.a_2"], P["model.encoder.norm.b_2"])
 
 
@@ -196,11 +208,12 @@ def embed_tokens(P, cfg, tok: Tensor, pos0: int = 0) -> Tensor:
     return e + pe[pos0:pos0 + tok.size(1)]
 
 
-def decode_tf(P, cfg, memory: Tensor, att_masks: Tensor, seq_in: Tensor) -> Tensor:
-    """Teacher-forced decoder (transformer.py:187-210); memory/att_masks already repeated per caption row."""
+def decode_tf(P, cfg, memory: Tensor, att_masks: Tensor, seq_in: Tensor, drop=None) -> Tensor:
+    """Teacher-forced decoder (transformer.py:187-210); memory/att_masks already repeated per caption row.  Dropout sites as
+    in `encode`, plus the PositionalEncoding's (transformer.py:398-401)."""
     h = cfg.num_heads
     T = seq_in.size(1)
-    x = embed_tokens(P, cfg, seq_in)
+    x = _drop(drop, "emb", embed_tokens(P, cfg, seq_in))
     causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
     self_mask = ((seq_in != cfg.pad_token_id)[:, None, :] & causal[None])[:, None]  # (R,1,T,T)
     src_mask = (att_masks != 0)[:, None, None, :]
@@ -209,12 +222,13 @@ def decode_tf(P, cfg, memory: Tensor, att_masks: Tensor, seq_in: Tensor) -> Tens
         pre = f"model.decoder.layers.{l}."
         y = layer_norm(x, P[pre + "sublayer.0.norm.a_2"], P[pre + "sublayer.0.norm.b_2"])
         q, k, v, out = project_qkv(P, pre + "self_attn.", sa, y, y, h)
-        x = x + _linear(P, out, _merge(attention(q, k, v, self_mask)))
+        x = x + _drop(drop, f"dec{l}.sub0", _linear(P, out, _merge(attention(q, k, v, self_mask, None, drop, f"dec{l}.self"))))
         y = layer_norm(x, P[pre + "sublayer.1.norm.a_2"], P[pre + "sublayer.1.norm.b_2"])
         q, k, v, out = project_qkv(P, pre + "src_attn.", sa, y, memory, h)
-        x = x + _linear(P, out, _merge(attention(q, k, v, src_mask)))
+        x = x + _drop(drop, f"dec{l}.sub1", _linear(P, out, _merge(attention(q, k, v, src_mask, None, drop, f"dec{l}.cross"))))
         y = layer_norm(x, P[pre + "sublayer.2.norm.a_2"], P[pre + "sublayer.2.norm.b_2"])
-        x = x + _linear(P, pre + "feed_forward.w_2", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
+        hid = _drop(drop, f"dec{l}.ffn", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
+        x = x + _drop(drop, f"dec{l}.sub2", _linear(P, pre + "feed_forward.w_2", hid))
     return layer_norm(x, P["model.decoder.norm.a_2"], P["model.decoder.norm.b_2"])
 
 
@@ -223,16 +237,16 @@ def generator(P, x: Tensor) -> Tensor:
     return F.log_softmax(_linear(P, "model.generator.proj", x), dim=-1)
 
 
-def forward_logp(P, cfg, att_feats, boxes, seqs, att_masks) -> Tensor:
-    """``_forward`` (relation_transformer.py:368-372): (R, T, V) log-probs, T = seqs.size(1)-1."""
-    mem = encode(P, cfg, att_feats, boxes, att_masks)
+def forward_logp(P, cfg, att_feats, boxes, seqs, att_masks, drop=None) -> Tensor:
+    """``_forward`` (relation_transformer.py:368-372): (R, T, V) log-probs, T = seqs.size(1)-1.  `drop`: see `_drop`."""
+    mem = encode(P, cfg, att_feats, boxes, att_masks, drop)
     R, B = seqs.size(0), att_feats.size(0)
     if R != B:
         assert R % B == 0
         spi = R // B
         mem = mem.repeat_interleave(spi, 0)
         att_masks = att_masks.repeat_interleave(spi, 0)
-    return generator(P, decode_tf(P, cfg, mem, att_masks, seqs[:, :-1]))
+    return generator(P, decode_tf(P, cfg, mem, att_masks, seqs[:, :-1], drop))
 
 
 def xe_loss(logp: Tensor, target: Tensor, mask: Tensor) -> Tensor:

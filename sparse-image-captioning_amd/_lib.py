@@ -138,6 +138,7 @@ SIGNATURES = {
     "ortk_colsum": (_I32, [_P, _I32, _I64, _P, _I64, _I32, _P]),
     "ortk_gate_apply": (_I32, [_P, _P, _P, _I32, _I64, _F, _P]),
     "ortk_dropout_apply": (_I32, [_P, _P, _I32, _I64, _F, _U32, _P]),
+    "ortk_dropout_site_seed": (_U32, [_U64, _I32, _I32, _I32]),
     "ortk_cast_bf16": (_I32, [_P, _P, _I64, _P]),
     "ortk_fill": (_I32, [_P, _I64, _F, _P]),
     "ortk_sum": (_I32, [_P, _I64, _P, _P]),

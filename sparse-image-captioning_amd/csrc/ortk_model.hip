@@ -495,6 +495,13 @@ static const float* dim_mat() {
 enum Op : uint32_t { OP_SRC = 1, OP_EMB = 2, OP_ENC = 16, OP_DEC = 16 + 16 * MAXLAYERS };
 static inline uint32_t eop(int l, int k) { return OP_ENC + 16 * l + k; }
 static inline uint32_t dop(int l, int k) { return OP_DEC + 16 * l + k; }
+}  // namespace ortk
+extern "C" uint32_t ortk_dropout_site_seed(uint64_t seed, int32_t stack, int32_t layer, int32_t k) {
+    using namespace ortk;
+    const uint32_t op = stack == 0 ? (uint32_t)OP_SRC : stack == 1 ? (uint32_t)OP_EMB : stack == 2 ? eop(layer, k) : dop(layer, k);
+    return ortk_subseed(seed, op);
+}
+namespace ortk {
 
 struct EncPtrs { void* y1; void* qkv; float* P; void* o; float* xm; void* y2; void* h; float* xout; float *st1, *st2; };
 

@@ -1302,3 +1302,70 @@ def test_sparse_decode_at_bench_size_properties(P, full_state):
         assert (sd[:, 0] == s1[:, 0]).all(-1).float().mean().item() >= 0.99
     dense = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
     assert dense.enable_sparse_stream("auto") is False
+
+
+def test_train_mode_dropout_vs_oracle(P, g1):
+    """The TRAINING-mode forward / backward (dropout on, transformer.py:293-294,324-325,356-358,398-401 and
+    relation_transformer.py:331-333) against the oracle with the SAME keep masks: the HIP path draws them from its counter
+    hash, `ortk_dropout_site_seed` + `ortk_dropout_apply` read every site's mask back, and `oracle.forward_logp(drop=...)`
+    applies them at the reference's dropout positions.  XE loss within 1e-4, every parameter gradient within 2e-4 * scale —
+    the bars of the eval-mode golden tests — on the G1 model and batch (ragged region masks, 2 layers)."""
+    import ctypes as Ct
+    from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
+    lib = P._lib.lib()
+    m = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state())
+    m.train()
+    b = _cuda(H.g1_batch())
+    cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
+    B, S = b["att_feats"].shape[:2]
+    Sc = int(b["att_masks"].sum(1).max())                   # clip_att
+    R, T = b["seqs"].size(0), b["seqs"].size(1) - 1
+    spi, Hh, d, ff, Lr = R // B, cfg.num_heads, cfg.d_model, C.TINY_CFG["dim_feedforward"], cfg.num_layers
+    p_src, p = float(C.TINY_CFG["drop_prob_src"]), 0.1
+    m._seed_counter = 77
+    seed = m._next_seed()
+    m._seed_counter = 77                                      # the forward below draws the same seed
+
+    def keep(stack, layer, k, n, prob):
+        key = lib.ortk_dropout_site_seed(Ct.c_uint64(seed), stack, layer, k)
+        ones, out = torch.ones(n, device="cuda"), torch.empty(n, device="cuda")
+        P._lib.check(lib.ortk_dropout_apply(P._lib.ptr(ones), P._lib.ptr(out), 0, n, prob, key, P._lib.stream_ptr()), "ortk_dropout_apply")
+        return out.cpu()                                      # keep / (1 - p) per element
+
+    masks = {"src": keep(0, 0, 0, B * Sc * d, p_src).view(B, Sc, d), "emb": keep(1, 0, 0, R * T * d, p).view(R, T, d)}
+    for l in range(Lr):
+        masks[f"enc{l}.att"] = keep(2, l, 0, B * Hh * Sc * Sc, p).view(B, Hh, Sc, Sc)
+        masks[f"enc{l}.sub0"] = keep(2, l, 1, B * Sc * d, p).view(B, Sc, d)
+        masks[f"enc{l}.ffn"] = keep(2, l, 2, B * Sc * ff, p).view(B, Sc, ff)
+        masks[f"enc{l}.sub1"] = keep(2, l, 3, B * Sc * d, p).view(B, Sc, d)
+        masks[f"dec{l}.self"] = keep(3, l, 0, R * Hh * T * T, p).view(R, Hh, T, T)
+        masks[f"dec{l}.sub0"] = keep(3, l, 1, R * T * d, p).view(R, T, d)
+        # the kernel's cross-attention groups the spi captions of an image: (image, head, caption * T + t, region)
+        masks[f"dec{l}.cross"] = keep(3, l, 2, B * Hh * spi * T * Sc, p).view(B, Hh, spi, T, Sc).permute(0, 2, 1, 3, 4).reshape(R, Hh, T, Sc)
+        masks[f"dec{l}.sub1"] = keep(3, l, 3, R * T * d, p).view(R, T, d)
+        masks[f"dec{l}.ffn"] = keep(3, l, 4, R * T * ff, p).view(R, T, ff)
+        masks[f"dec{l}.sub2"] = keep(3, l, 5, R * T * d, p).view(R, T, d)
+    rate = 1.0 - float((masks["dec0.ffn"] != 0).float().mean())
+    assert abs(rate - p) < 0.02, rate
+
+    def drop(site, x):
+        mk = masks[site]
+        assert mk.shape == x.shape, (site, mk.shape, x.shape)
+        return x * mk
+
+    Pm = H.g1_state(requires_grad=True)
+    bc = H.g1_batch()
+    feats, boxes, amask = bc["att_feats"][:, :Sc], bc["boxes"][:, :Sc], bc["att_masks"][:, :Sc]
+    ref_logp = O.forward_logp(Pm, cfg, feats, boxes, bc["seqs"], amask, drop=drop)
+    ref_loss = O.xe_loss(ref_logp, bc["seqs"][:, 1:], bc["masks"][:, 1:])
+    ref_loss.backward()
+    logp = m(att_feats=b["att_feats"], boxes=b["boxes"], seqs=b["seqs"], att_masks=b["att_masks"])
+    loss = LanguageModelCriterion()(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    assert abs(loss.item() - ref_loss.item()) < 1e-4, (loss.item(), ref_loss.item())
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), ref_logp.detach().numpy(), rtol=1e-4, atol=1e-4)
+    loss.backward()
+    eval_loss = float(g1["xe_loss"])
+    assert abs(loss.item() - eval_loss) > 1e-3              # (the masks did something)
+    for n, prm in m.named_parameters():
+        ref = Pm[n].grad.numpy()
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(ref).max())), err_msg=n)
