@@ -53,8 +53,11 @@ def synth_batch(B, S, F, V, spi, seq_len, seed, device):
         seqs[r, 1 + L] = 3
         masks[r, :L + 2] = 1
     t = lambda a: torch.from_numpy(a).to(device)
+    # att_max_len / cap_len: what the collate function reports from the host-side lists (longest region list; decoder positions
+    # of every caption that carry a target = BOS + tokens) — no read-back of the masks per step
+    cap_len = torch.from_numpy(np.minimum(lens, seq_len - 2).astype(np.int64) + 1)
     return dict(att_feats=t(att), boxes=t(boxes), att_masks=torch.ones(B, S, device=device), seqs=t(seqs), masks=t(masks),
-                att_max_len=S)      # (what the collate function reports: no read-back of the mask per step)
+                att_max_len=S, cap_len=cap_len)
 
 
 def cpu_baseline(workload, cfg_dict, seconds=12.0):
@@ -256,6 +259,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
         tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000,
                            sparsity_target=0.95 if workload == "sparse_xe" else None, max_train_step=100000,
                            overlap_allreduce={"auto": None, "on": True, "off": False}[args.overlap_allreduce])
+        tr.valid_positions = not args.padded_positions
 
         def step():
             tr.xe_step(batch)
@@ -405,6 +409,9 @@ def main():
     ap.add_argument("--max-seq-length", type=int, default=18, help="caption length incl. BOS/EOS (18 = BASELINE; the ACORT commands use 26)")
     ap.add_argument("--regions", type=int, default=36, help="regions per image (36 = BASELINE; real bottom-up features have 10-100)")
     ap.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
+    ap.add_argument("--padded-positions", action="store_true",
+                    help="teacher forcing over all 17 positions of every caption as the reference does (default: the decoder runs on "
+                         "the valid positions only; same loss and gradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="default run on one GPU: do not add the `workloads` object (BASELINE configs[2], [3], [4] timed in this process)")

@@ -106,9 +106,22 @@ typedef struct ortk_batch {
     int64_t        seq_stride;  /*                 columns 1..T the targets (T = teacher-forced steps)  */
     const float*   tok_weight;  /* (R, T) per-target weight: XE -> masks[:,1:]; SCST -> mask*reward     */
     int32_t B, S, R, T;         /* R = B * captions-per-image                                           */
+    /* Optional (all three or none; mixed precision, fused criterion only — ortk_forward with logp_out != NULL refuses them):
+     * VALID-POSITION layout of the decoder rows.  The reference runs its decoder over all T positions of every caption and
+     * masks the padded ones out of the loss (transformer.py:187-210, utils/losses.py:36-43); a padded position never feeds a
+     * valid one (causal self-attention), so the decoder here runs on the valid PREFIX of every caption only: caption r owns
+     * rows [cap_off[r], cap_off[r+1]) of a compact row space of Mc rows (cap_off: device, R+1 entries, cap_off[0] = 0,
+     * 1 <= length <= T; the captions of an image stay adjacent), row_pos[i] = r*T + t of compact row i (device, Mc entries).
+     * The caller guarantees tok_weight[r][t] == 0 for every position outside the prefix.  Same loss and gradients as the
+     * padded layout (dropout draws are keyed by the compact row). */
+    const int32_t* cap_off;
+    const int32_t* row_pos;
+    int32_t        Mc;
 } ortk_batch;
 
 size_t ortk_train_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T);
+/* 1 if a batch of this geometry may carry the valid-position layout (cap_off / row_pos / Mc), else 0. */
+int ortk_valid_positions_ok(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T);
 
 /* Teacher-forced forward (RelationTransformerModel._forward, models/relation_transformer.py:368-372).
  * Activations stay in `ws` for a following backward.  If logp_out != NULL the (R,T,ldv) log-probs are
@@ -371,6 +384,11 @@ typedef struct ortk_attn_args {
      * step, which only ever feed these products.  Served by the bf16-operand kernels
      * only (precision = 1, dk = 64 or 32, Lk <= 128, Lq <= 128); anything else returns ORTK_EINVAL. */
     int32_t qkv_dtype;
+    /* Ragged query groups (bf16-operand kernels only: precision = 1, qkv_dtype = 1; anything else returns ORTK_EINVAL):
+     * group g's query rows (q, o, d_o, dq) are rows [q_off[g*q_off_stride], q_off[(g+1)*q_off_stride]) instead of
+     * [g*Lq, (g+1)*Lq) — at most Lq of them (Lq stays the row count of the P / bias / dscore blocks).  kv_ragged = 1: the keys
+     * of a group are its own query rows (self-attention: k, v, d_k, dv, kmask indexed like q); 0: keys as without q_off. */
+    const int32_t* q_off; int32_t q_off_stride; int32_t kv_ragged;
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);

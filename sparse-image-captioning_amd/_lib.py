@@ -35,7 +35,8 @@ class Config(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("att_feats", C.c_void_p), ("boxes", C.c_void_p), ("att_masks", C.c_void_p), ("seqs", C.c_void_p),
                 ("seq_stride", C.c_int64), ("tok_weight", C.c_void_p),
-                ("B", C.c_int32), ("S", C.c_int32), ("R", C.c_int32), ("T", C.c_int32)]
+                ("B", C.c_int32), ("S", C.c_int32), ("R", C.c_int32), ("T", C.c_int32),
+                ("cap_off", C.c_void_p), ("row_pos", C.c_void_p), ("Mc", C.c_int32)]
 
 
 SP_ELL32, SP_ELL16, SP_GU16 = 0, 1, 2     # ortk_sparse_plan.format
@@ -92,7 +93,8 @@ class AttnArgs(C.Structure):
                 ("lddo", C.c_int64), ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64),
                 ("o_dtype", C.c_int32), ("dqkv_dtype", C.c_int32), ("kv_dtype", C.c_int32),
                 ("k_new", C.c_void_p), ("v_new", C.c_void_p), ("ld_new", C.c_int64), ("bwd_part", C.c_int32),
-                ("precision", C.c_int32), ("qkv_dtype", C.c_int32)]
+                ("precision", C.c_int32), ("qkv_dtype", C.c_int32),
+                ("q_off", C.c_void_p), ("q_off_stride", C.c_int32), ("kv_ragged", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _U32, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t
@@ -108,6 +110,7 @@ SIGNATURES = {
     "ortk_arena_entry": (_I32, [_CFG, _I32, C.c_char_p, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I32),
                                C.POINTER(_I64), C.POINTER(_I32)]),
     "ortk_train_workspace_bytes": (_SZ, [_CFG, _I32, _I32, _I32, _I32]),
+    "ortk_valid_positions_ok": (_I32, [_CFG, _I32, _I32, _I32, _I32]),
     "ortk_forward": (_I32, [_CFG, _P, C.POINTER(Batch), _P, _SZ, _P, _I64, _I32, _U64, _P]),
     "ortk_loss": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _P]),
     "ortk_loss_external": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _I64, _P]),

@@ -1152,7 +1152,7 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a_in, ortk_stream stream
         }
     }
     if ((attn_impl() == 0 || a->qkv_dtype) && ortk::attn16_ok(a, false)) return ortk::attn16_fwd(a, ortk_s(stream));   // mixed precision
-    if (a->qkv_dtype) return ORTK_EINVAL;          // bf16 Q / K / V are only understood by the bf16-operand kernels
+    if (a->qkv_dtype || a->q_off) return ORTK_EINVAL;   // bf16 Q / K / V and ragged groups are only understood by the bf16-operand kernels
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1232,7 +1232,7 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
     if (a->nkv == 0) return 0;
     if ((attn_impl() == 0 || a->qkv_dtype) && ortk::attn16_ok(a, true))     // mixed precision: one kernel does both parts
         return a->bwd_part == 2 ? 0 : ortk::attn16_bwd(a, ortk_s(stream));
-    if (a->qkv_dtype) return ORTK_EINVAL;
+    if (a->qkv_dtype || a->q_off) return ORTK_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

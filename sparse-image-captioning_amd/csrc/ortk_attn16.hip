@@ -102,17 +102,22 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     const int lr = lane & 15, lq = lane >> 4;
     const bool vec_p = (Lk & 3) == 0;               // P / bias rows start 16-byte aligned
     const int nit = (Lq + 15) >> 4;
+    // ragged groups (ortk_attn_args.q_off): the group's first query row and its row count; with kv_ragged its keys are those rows
+    const int64_t qrow0 = a.q_off ? (int64_t)a.q_off[(int64_t)g * a.q_off_stride] : (int64_t)g * Lq;
+    const int Lqg = a.q_off ? min(Lq, (int)(a.q_off[(int64_t)(g + 1) * a.q_off_stride] - qrow0)) : Lq;
+    const int64_t krow0 = (a.q_off && a.kv_ragged) ? qrow0 : (int64_t)g * Lk;
+    const int Lkg = (a.q_off && a.kv_ragged) ? min(Lk, Lqg) : Lk;
     // The launcher gives every 16-row query tile its own wave (nw = nit).  This wave's Q fragments and bias rows are
     // requested BEFORE the K / V staging and its barrier, so that the workgroup pays one global round trip, not two.
     const int it = wave;
     const int i = it * 16 + lr;                     // this lane's query (operand row and output row)
-    const bool iv = it < nit && i < Lq;
+    const bool iv = it < nit && i < Lqg;
     const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
     bf16x8 qf[DK / 32];
 #pragma unroll
     for (int ks = 0; ks < DK / 32; ++ks) qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     if (iv) {
-        const TQ* qp = aq + ((int64_t)g * Lq + i) * a.ldq + h * DK + 8 * lq;
+        const TQ* qp = aq + (qrow0 + i) * a.ldq + h * DK + 8 * lq;
 #pragma unroll
         for (int ks = 0; ks < DK / 32; ++ks) qf[ks] = ld_frag(qp + 32 * ks);
     }
@@ -126,9 +131,9 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
             else { float* bp = &bias4[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) bp[r] = a.bias[prow + j0 + r]; }
         }
     }
-    stage_rows<DK>(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, 16 * NJT, tid, blockDim.x);
-    stage_rows<DK>(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, KJ, tid, blockDim.x);
-    if (tid < 128) sMask[tid] = (tid < Lk) ? (a.kmask ? a.kmask[(int64_t)g * Lk + tid] : 1.f) : -1.f;   // -1: padded key
+    stage_rows<DK>(sK, ak + krow0 * a.ldk + h * DK, a.ldk, Lkg, 16 * NJT, tid, blockDim.x);
+    stage_rows<DK>(sV, av + krow0 * a.ldv + h * DK, a.ldv, Lkg, KJ, tid, blockDim.x);
+    if (tid < 128) sMask[tid] = (tid < Lkg) ? (a.kmask ? a.kmask[krow0 + tid] : 1.f) : -1.f;   // -1: padded key
     // key columns 16*NJT .. KJ-1 of the P image are never written below: zero the image once
     for (int idx = lane; idx < 16 * (KJ / 4); idx += 64)
         *reinterpret_cast<bf16x4*>(sP + (idx / (KJ / 4)) * PJ + (idx % (KJ / 4)) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KJ / 32; ++ks) o = mma(frag_tr<PD>(sV, 32 * ks, 16 * dt, lane), pf[ks], o);
-            if (iv) st_elem4(a.o, ((int64_t)g * Lq + i) * a.ldo + h * DK + 16 * dt + 4 * lq, a.o_dtype, make_float4(o[0], o[1], o[2], o[3]));
+            if (iv) st_elem4(a.o, (qrow0 + i) * a.ldo + h * DK + 16 * dt + 4 * lq, a.o_dtype, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
@@ -229,10 +234,16 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
     const int lr = lane & 15, lq = lane >> 4;
     const bool vec_p = (Lk & 3) == 0;
     const int nit = (Lq + 15) >> 4;
+    // ragged groups: see the forward kernel.  Query rows past the group's count are staged as ZERO rows of Q and dO (they are
+    // another group's rows): they add nothing to dK / dV
+    const int64_t qrow0 = a.q_off ? (int64_t)a.q_off[(int64_t)g * a.q_off_stride] : (int64_t)g * Lq;
+    const int Lqg = a.q_off ? min(Lq, (int)(a.q_off[(int64_t)(g + 1) * a.q_off_stride] - qrow0)) : Lq;
+    const int64_t krow0 = (a.q_off && a.kv_ragged) ? qrow0 : (int64_t)g * Lk;
+    const int Lkg = (a.q_off && a.kv_ragged) ? min(Lk, Lqg) : Lk;
     // one 16-row query tile per wave (nw = nit); its saved probabilities are requested before the staging barrier
     const int it = wave;
     const int i0 = it * 16, i = i0 + lr;
-    const bool iv = it < nit && i < Lq;
+    const bool iv = it < nit && i < Lqg;
     const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
     float4 praw[NJT];
 #pragma unroll
@@ -244,10 +255,10 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             else { float* q = &praw[jt].x; for (int r = 0; r < 4; ++r) if (j0 + r < Lk) q[r] = a.p[prow + j0 + r]; }
         }
     }
-    stage_rows<DK>(sK, ak + (int64_t)g * Lk * a.ldk + h * DK, a.ldk, Lk, KJ, tid, blockDim.x);
-    stage_rows<DK>(sV, av + (int64_t)g * Lk * a.ldv + h * DK, a.ldv, Lk, 16 * NJT, tid, blockDim.x);
-    stage_rows<DK>(sQ, aq + (int64_t)g * Lq * a.ldq + h * DK, a.ldq, Lq, Lqp, tid, blockDim.x);
-    stage_rows<DK>(sG, reinterpret_cast<const TQ*>(a.d_o) + (int64_t)g * Lq * a.lddo + h * DK, a.lddo, Lq, Lqp, tid, blockDim.x);
+    stage_rows<DK>(sK, ak + krow0 * a.ldk + h * DK, a.ldk, Lkg, KJ, tid, blockDim.x);
+    stage_rows<DK>(sV, av + krow0 * a.ldv + h * DK, a.ldv, Lkg, 16 * NJT, tid, blockDim.x);
+    stage_rows<DK>(sQ, aq + qrow0 * a.ldq + h * DK, a.ldq, Lqg, Lqp, tid, blockDim.x);
+    stage_rows<DK>(sG, reinterpret_cast<const TQ*>(a.d_o) + qrow0 * a.lddo + h * DK, a.lddo, Lqg, Lqp, tid, blockDim.x);
     // dS / P images: the key columns 16*NJT .. 63 and the query rows past the last wave tile are never written below
     for (int idx = tid; idx < 2 * Lqp * (KJ / 4); idx += blockDim.x)
         *reinterpret_cast<bf16x4*>(sS + (idx / (KJ / 4)) * PJ + (idx % (KJ / 4)) * 4) = cvt4(make_float4(0.f, 0.f, 0.f, 0.f));   // sD follows sS
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KJ / 32; ++ks) acc = mma(frag_tr<PD>(sK, 32 * ks, 16 * dt, lane), sf[ks], acc);
-            if (iv) st_elem4(a.dq, ((int64_t)g * Lq + i) * a.lddq + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, make_float4(acc[0], acc[1], acc[2], acc[3]));
+            if (iv) st_elem4(a.dq, (qrow0 + i) * a.lddq + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, make_float4(acc[0], acc[1], acc[2], acc[3]));
         }
     }
     __syncthreads();
@@ -317,8 +328,8 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < Lqp; k0 += 32) acc = mma(frag_tr<PD>(sB, k0, 16 * dt, lane), frag_tr<PJ>(sA, k0, 16 * jt, lane), acc);
         const int j = 16 * jt + lr;
-        if (j < Lk) {
-            const int64_t row = (int64_t)g * Lk + j;
+        if (j < Lkg) {
+            const int64_t row = krow0 + j;
             const float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
             if (which == 0) st_elem4(a.d_k, row * a.lddk + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, v);
             else            st_elem4(a.dv, row * a.lddv + h * DK + 16 * dt + 4 * lq, a.dqkv_dtype, v);
@@ -345,6 +356,7 @@ bool attn16_ok(const ortk_attn_args* a, bool bwd) {
     // (short query blocks over at most 48 keys stay with the register-only kernels; past 48 keys those do not apply)
     if (a->precision != 1 || !attn16_shape_ok(a->Lq, a->Lk, a->dk) || (a->qkv_dtype == 0 && a->Lq < min_lq && a->Lk <= 48)) return false;
     if (a->kv_index || a->kv_group_stride > 0 || a->kv_dtype != 0 || a->k_new || a->v_new) return false;
+    if (a->q_off && (a->qkv_dtype != 1 || a->q_off_stride < 1)) return false;
     if ((a->ldq | a->ldk | a->ldv) % (a->qkv_dtype ? 8 : 4) || !al16(a->q) || !al16(a->k) || !al16(a->v)) return false;
     if (!bwd) {
         const int64_t eo = a->o_dtype == ORTK_BF16 ? 2 : 4;

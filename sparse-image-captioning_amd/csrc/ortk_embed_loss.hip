@@ -10,10 +10,12 @@ namespace {
 __global__ __launch_bounds__(128) void embed_fwd_kernel(const int64_t* __restrict__ seq, int64_t seq_stride,
                                                         const float* __restrict__ lut, const float* __restrict__ pe,
                                                         float* __restrict__ out, float* __restrict__ keymask, int T, int t0,
-                                                        int d, int pad_id, float scale, float drop_p, uint32_t seed) {
-    const int64_t row = blockIdx.x;           // r*T + t
-    const int64_t r = row / T;
-    const int t = (int)(row - r * T);
+                                                        int d, int pad_id, float scale, float drop_p, uint32_t seed,
+                                                        const int32_t* __restrict__ row_pos) {
+    const int64_t row = blockIdx.x;           // output row; r*T + t, or row_pos[row] in the valid-position layout
+    const int64_t prow = row_pos ? (int64_t)row_pos[row] : row;
+    const int64_t r = prow / T;
+    const int t = (int)(prow - r * T);
     const int64_t tok = seq[r * seq_stride + t];
     if (keymask && threadIdx.x == 0) keymask[row] = tok != pad_id ? 1.f : 0.f;
     const float* e = lut + tok * d;
@@ -28,10 +30,12 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const int64_t* __restric
 
 __global__ __launch_bounds__(128) void embed_bwd_kernel(const int64_t* __restrict__ seq, int64_t seq_stride,
                                                         const float* __restrict__ dout, float* __restrict__ dlut, int T,
-                                                        int d, float scale, float drop_p, uint32_t seed) {
+                                                        int d, float scale, float drop_p, uint32_t seed,
+                                                        const int32_t* __restrict__ row_pos) {
     const int64_t row = blockIdx.x;
-    const int64_t r = row / T;
-    const int t = (int)(row - r * T);
+    const int64_t prow = row_pos ? (int64_t)row_pos[row] : row;
+    const int64_t r = prow / T;
+    const int t = (int)(prow - r * T);
     const int64_t tok = seq[r * seq_stride + t];
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     for (int c = threadIdx.x; c < d; c += 128) {
@@ -80,12 +84,13 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x,
 __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                    int64_t target_stride, int T, const float* __restrict__ weight,
                                                    const float* __restrict__ norm_dev, float* __restrict__ loss_dev, int V,
-                                                   int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl) {
+                                                   int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl, const int32_t* __restrict__ row_pos) {
     __shared__ float sh[4];
     const int64_t r = blockIdx.x;
     const float* row = logits + r * ld;
-    const int64_t tgt = targets[(r / T) * target_stride + (r % T)];
-    const float w = weight[r] / norm_dev[0];
+    const int64_t pr = row_pos ? (int64_t)row_pos[r] : r;
+    const int64_t tgt = targets[(pr / T) * target_stride + (pr % T)];
+    const float w = weight[pr] / norm_dev[0];
     float mx = -INFINITY;
     for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, row[c]);
     mx = block_max(mx, sh);
@@ -109,7 +114,7 @@ template <int NPT>
 __global__ __launch_bounds__(256) void xent_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                        int64_t target_stride, int T, const float* __restrict__ weight,
                                                        const float* __restrict__ norm_dev, float* __restrict__ loss_dev, int V,
-                                                       int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl) {
+                                                       int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl, const int32_t* __restrict__ row_pos) {
     __shared__ float sh[4];
     const int64_t r = blockIdx.x;
     const float* row = logits + r * ld;
@@ -117,8 +122,9 @@ __global__ __launch_bounds__(256) void xent_reg_kernel(const float* __restrict__
     float z[NPT];
 #pragma unroll
     for (int u = 0; u < NPT; ++u) { const int c = tid + 256 * u; z[u] = c < V ? row[c] : 0.f; }
-    const int64_t tgt = targets[(r / T) * target_stride + (r % T)];
-    const float w = weight[r] / norm_dev[0];
+    const int64_t pr = row_pos ? (int64_t)row_pos[r] : r;      // (caption, position) of this row: targets / weights stay (R, T)
+    const int64_t tgt = targets[(pr / T) * target_stride + (pr % T)];
+    const float w = weight[pr] / norm_dev[0];
     float mx = -INFINITY;
 #pragma unroll
     for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) mx = fmaxf(mx, z[u]);
@@ -261,27 +267,40 @@ inline unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>(ortk_cdi
 
 }  // namespace
 
+// (nrows output rows; row_pos == NULL: nrows = R * T rows in (caption, position) order)
+namespace ortk {
+int embed_fwd_rows(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out, float* keymask, int64_t nrows,
+                   const int32_t* row_pos, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p, uint32_t seed, hipStream_t s) {
+    if (!seq || !lut || !pe || !out || nrows < 0 || T < 1 || d < 1) return ORTK_EINVAL;
+    if (nrows == 0) return 0;
+    const float scale = (float)sqrt((double)d);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)nrows), dim3(128), 0, s, seq, seq_stride, lut, pe, out, keymask, T, t0, d, pad_id,
+                       scale, drop_p, seed, row_pos);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int embed_bwd_rows(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut, int64_t nrows, const int32_t* row_pos, int32_t T,
+                   int32_t d, float drop_p, uint32_t seed, hipStream_t s) {
+    if (!seq || !dout || !dlut || nrows < 0 || T < 1 || d < 1) return ORTK_EINVAL;
+    if (nrows == 0) return 0;
+    const float scale = (float)sqrt((double)d);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)nrows), dim3(128), 0, s, seq, seq_stride, dout, dlut, T, d, scale, drop_p, seed, row_pos);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace ortk
+
 extern "C" int ortk_embed_fwd(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out,
                               float* keymask, int64_t R, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p,
                               uint32_t seed, ortk_stream stream) {
-    if (!seq || !lut || !pe || !out || R < 0 || T < 1 || d < 1) return ORTK_EINVAL;
-    if (R == 0) return 0;
-    const float scale = (float)sqrt((double)d);
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)(R * T)), dim3(128), 0, ortk_s(stream), seq, seq_stride, lut, pe, out,
-                       keymask, T, t0, d, pad_id, scale, drop_p, seed);
-    ORTK_CHECK_LAUNCH();
-    return 0;
+    if (R < 0) return ORTK_EINVAL;
+    return ortk::embed_fwd_rows(seq, seq_stride, lut, pe, out, keymask, R * T, nullptr, T, t0, d, pad_id, drop_p, seed, ortk_s(stream));
 }
 
 extern "C" int ortk_embed_bwd(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut, int64_t R, int32_t T,
                               int32_t d, float drop_p, uint32_t seed, ortk_stream stream) {
-    if (!seq || !dout || !dlut || R < 0 || T < 1 || d < 1) return ORTK_EINVAL;
-    if (R == 0) return 0;
-    const float scale = (float)sqrt((double)d);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(R * T)), dim3(128), 0, ortk_s(stream), seq, seq_stride, dout, dlut, T, d,
-                       scale, drop_p, seed);
-    ORTK_CHECK_LAUNCH();
-    return 0;
+    if (R < 0) return ORTK_EINVAL;
+    return ortk::embed_bwd_rows(seq, seq_stride, dout, dlut, R * T, nullptr, T, d, drop_p, seed, ortk_s(stream));
 }
 
 extern "C" int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, float scale, ortk_stream stream) {
@@ -292,22 +311,30 @@ extern "C" int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, f
     return 0;
 }
 
-extern "C" int ortk_xent_fwd_bwd(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
-                                 const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, void* dlogits,
-                                 int32_t dl_dtype, int64_t ld_dl, ortk_stream stream) {
+namespace ortk {
+int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight, const float* norm_dev,
+              float* loss_dev, int64_t rows, const int32_t* row_pos, int32_t V, int64_t ld, void* dlogits, int32_t dl_dtype, int64_t ld_dl,
+              hipStream_t s) {
     if (!logits || !targets || !weight || !norm_dev || !loss_dev || !dlogits || rows < 0 || V < 1 || ld < V || ld_dl < V || T < 1)
         return ORTK_EINVAL;
     if (dl_dtype != ORTK_F32 && dl_dtype != ORTK_BF16) return ORTK_EINVAL;
-    if ((const void*)dlogits == (const void*)logits && (dl_dtype != ORTK_F32 || ld_dl != ld)) return ORTK_EINVAL;
     if (rows == 0) return 0;
     if (V <= 256 * 40 && ld_dl <= 256 * 40 && V > 256 * 8)
-        hipLaunchKernelGGL(xent_reg_kernel<40>, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logits, targets, target_stride, T,
-                           weight, norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl);
+        hipLaunchKernelGGL(xent_reg_kernel<40>, dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T,
+                           weight, norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
     else
-        hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, ortk_s(stream), logits, targets, target_stride, T, weight,
-                           norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl);
+        hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T, weight,
+                           norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
     ORTK_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace ortk
+
+extern "C" int ortk_xent_fwd_bwd(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
+                                 const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, void* dlogits,
+                                 int32_t dl_dtype, int64_t ld_dl, ortk_stream stream) {
+    return ortk::xent_rows(logits, targets, target_stride, T, weight, norm_dev, loss_dev, rows, nullptr, V, ld, dlogits, dl_dtype, ld_dl,
+                           ortk_s(stream));
 }
 
 extern "C" int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, void* dlogits, int32_t dl_dtype,

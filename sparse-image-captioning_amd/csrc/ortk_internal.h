@@ -111,6 +111,16 @@ struct SStackBufs { uint2* stream; int32_t *cnt, *nst; int64_t *start, *stats; s
 size_t sstack_bytes(int L, int NC, SStackBufs* carve, void* base);          // worst-case (fully dense weights) capacity
 int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStream_t s);
 
+// embedding / fused criterion over an explicit list of (caption, position) rows (row_pos[i] = r*T + t; NULL = all R*T rows in order):
+// the valid-position decoder layout of ortk_batch.cap_off / row_pos
+int embed_fwd_rows(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out, float* keymask, int64_t nrows,
+                   const int32_t* row_pos, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p, uint32_t seed, hipStream_t s);
+int embed_bwd_rows(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut, int64_t nrows, const int32_t* row_pos, int32_t T,
+                   int32_t d, float drop_p, uint32_t seed, hipStream_t s);
+int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight, const float* norm_dev,
+              float* loss_dev, int64_t rows, const int32_t* row_pos, int32_t V, int64_t ld, void* dlogits, int32_t dl_dtype, int64_t ld_dl,
+              hipStream_t s);
+
 int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
 int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 // kvidx[g*1 + 0] = g*row_mult*tmax  (index table for the first decoder pass)

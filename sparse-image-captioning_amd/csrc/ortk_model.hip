@@ -620,8 +620,21 @@ static int check_batch(const ortk_config* cfg, const ortk_batch* b, bool need_se
         if (!b->seqs || b->R < 1 || b->T < 1 || b->R % b->B || b->seq_stride < b->T + 1) return ORTK_EINVAL;
         if (b->T > 64 || (int64_t)(b->R / b->B) * b->T > 4096) return ORTK_EINVAL;
         if (b->T > cfg->seq_len) return ORTK_EINVAL;
+        if (b->cap_off || b->row_pos || b->Mc) {       // valid-position layout: all three, mixed precision only
+            if (!b->cap_off || !b->row_pos || b->Mc < b->R || (int64_t)b->Mc > (int64_t)b->R * b->T || cfg->precision != 1) return ORTK_EINVAL;
+        }
     }
     return 0;
+}
+// decoder rows of the step: the valid positions only (ortk_batch.cap_off / row_pos / Mc) or all R x T
+static inline bool batch_compact(const ortk_batch* b) { return b->row_pos != nullptr; }
+
+// 1 if a training batch of this geometry may use the valid-position decoder layout (ortk_batch.cap_off / row_pos): mixed
+// precision with every decoder attention on the bf16-operand kernels (dk = 64 or 32, T and captions-per-image * T <= 128)
+extern "C" int ortk_valid_positions_ok(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T) {
+    if (check_cfg(cfg) || B < 1 || S < 1 || R < 1 || T < 1 || R % B) return 0;
+    TrainWS w; carve_train(*cfg, B, S, R, T, nullptr, w);
+    return cfg->precision == 1 && w.qdt_self && w.qdt_cross ? 1 : 0;
 }
 
 extern "C" size_t ortk_train_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T) {
@@ -650,7 +663,9 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     const float* P = params;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
-    const int64_t Me = w.Me, Md = w.Md;
+    const bool compact = batch_compact(bt);
+    if (compact && (logp_out || !w.qdt_self || !w.qdt_cross)) return ORTK_EINVAL;     // fused criterion + bf16-operand attention only
+    const int64_t Me = w.Me, Md = compact ? bt->Mc : w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
     c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
@@ -666,6 +681,7 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
         a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
         a.kmask = w.keymask; a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.causal_period = T;
         a.drop_p = cx.p_drop(); a.drop_seed = cx.sub(dop(l, 0));
+        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = 1; a.kv_ragged = 1; }      // a caption's keys are its own (valid) rows
         TRY(ortk_attention_fwd(&a, (ortk_stream)cx.s));
         TRY(fwd_gemm(cx, b.o1, A, d, e.wo, P + e.bo, b.xm1, ORTK_F32, d, Md, d, d, false, cx.p_drop(), cx.sub(dop(l, 1)), x, d));
         TRY(ln_fwd(cx, b.xm1, e.n1a, e.n1b, b.y2, A, b.st2, Md));
@@ -681,8 +697,8 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc));
     {
         const Ctx cx = c.use_side ? c.on_side() : c;
-        TRY(ortk_embed_fwd(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, R, T, 0, d, cfg->pad_id, c.p_drop(),
-                           c.sub(OP_EMB), (ortk_stream)cx.s));
+        TRY(embed_fwd_rows(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, Md, compact ? bt->row_pos : nullptr, T, 0, d,
+                           cfg->pad_id, c.p_drop(), c.sub(OP_EMB), cx.s));
         if (c.use_side) { TRY(self_part(cx, 0, w.dx0)); TRY(c.side_mark(&prefix_done)); }
     }
     // decoder
@@ -698,6 +714,7 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
         a.ldk = a.ldv = U * cw;
         a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
+        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; }                       // an image's rows: those of its spi captions
         TRY(ortk_attention_fwd(&a, stream));
         TRY(fwd_gemm(c, b.o2, A, d, e.cow, P + e.cob, b.xm2, ORTK_F32, d, Md, d, d, false, c.p_drop(), c.sub(dop(l, 3)), b.xm1, d));
         TRY(ln_fwd(c, b.xm2, e.n2a, e.n2b, b.y3, A, b.st3, Md));
@@ -725,14 +742,16 @@ extern "C" int ortk_loss(const ortk_config* cfg, const ortk_batch* bt, void* ws,
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     TRY(ortk_fill(loss_dev, 1, 0.f, stream));
-    return ortk_xent_fwd_bwd(w.logits, bt->seqs + 1, bt->seq_stride, bt->T, bt->tok_weight, norm_dev, loss_dev, w.Md, cfg->vocab,
-                             w.ldv, w.dlogits, w.adt, w.ldv, stream);
+    const bool compact = batch_compact(bt);
+    return xent_rows(w.logits, bt->seqs + 1, bt->seq_stride, bt->T, bt->tok_weight, norm_dev, loss_dev, compact ? bt->Mc : w.Md,
+                     compact ? bt->row_pos : nullptr, cfg->vocab, w.ldv, w.dlogits, w.adt, w.ldv, ortk_s(stream));
 }
 
 extern "C" int ortk_loss_external(const ortk_config* cfg, const ortk_batch* bt, void* ws, size_t ws_bytes, const float* logp,
                                   const float* dlogp, int64_t ldv, ortk_stream stream) {
     if (int e = check_cfg(cfg)) return e;
     if (int e = check_batch(cfg, bt, true)) return e;
+    if (batch_compact(bt)) return ORTK_EINVAL;      // log-probs (R, T, V) exist in the padded layout only
     if (!ws || !logp || !dlogp || ldv < cfg->vocab) return ORTK_EINVAL;
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
@@ -774,7 +793,9 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     float* G = grads;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
-    const int64_t Me = w.Me, Md = w.Md;
+    const bool compact = batch_compact(bt);
+    if (compact && (!w.qdt_self || !w.qdt_cross)) return ORTK_EINVAL;
+    const int64_t Me = w.Me, Md = compact ? bt->Mc : w.Md;
     const float inv_keep = c.p_drop() > 0.f ? 1.f / (1.f - c.p_drop()) : 1.f;
     // dK|dV slice of every decoder layer in w.gkv: distinct layers first (the order of the packed K|V weight block), the
     // layers that share one of them behind
@@ -831,6 +852,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.d_o = (const float*)dO; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
         a.d_k = off_elems(w.gkv, gslot[l] * cw, A); a.dv = off_elems(w.gkv, gslot[l] * cw + gdv, A);
         a.lddk = a.lddv = ldg;
+        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; }
         TRY(c.before_write(gt_cur));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, gt_cur, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
@@ -847,6 +869,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
         a.d_o = (const float*)dO; a.lddo = d; a.dqkv_dtype = A;
         a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, amd.gk * d, A); a.dv = off_elems(w.gqkv, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = 1; a.kv_ragged = 1; }
         TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(fold(amd, Md));
@@ -858,12 +881,12 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     // the embedding gradient (atomics into the 5 M-element table) only feeds the optimizer: beside the K/V projection GEMMs
     if (c.use_side) {
         TRY(c.fork());
-        TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), (ortk_stream)c.side->s));
+        TRY(embed_bwd_rows(bt->seqs, bt->seq_stride, dx, G + o.lut, Md, compact ? bt->row_pos : nullptr, T, d, c.p_drop(), c.sub(OP_EMB), c.side->s));
         hipEvent_t e_done = nullptr;
         TRY(c.side_mark(&e_done));
         c.reads(dx, e_done);               // dx (w.ga / w.gb) is rewritten by the encoder half
     } else {
-        TRY(ortk_embed_bwd(bt->seqs, bt->seq_stride, dx, G + o.lut, R, T, d, c.p_drop(), c.sub(OP_EMB), stream));
+        TRY(embed_bwd_rows(bt->seqs, bt->seq_stride, dx, G + o.lut, Md, compact ? bt->row_pos : nullptr, T, d, c.p_drop(), c.sub(OP_EMB), ortk_s(stream)));
     }
     // cross-attention K/V projections of all layers, and the gradient of the encoder memory
     // layers that share weights also share the projected K|V: their dK|dV slices add up into the slice of the layer they share

@@ -173,6 +173,9 @@ class _RegionBatcher:
                 ids = self.tokenizer.encode(text, add_bos_eos=True, max_seq_length=cfg.max_seq_length)
                 token_rows.append(np.asarray(ids, dtype=np.int64))
         out["seqs"], out["masks"] = pad_seqs(token_rows, 0)
+        # (not in the reference's dict) decoder positions of every caption row that carry a target — BOS and the tokens, each
+        # predicting its successor: len(ids) - 1 — for the valid-position decoder of NativeTrainer (ortk_batch.cap_off)
+        out["cap_len"] = torch.tensor([max(1, len(r) - 1) for r in token_rows], dtype=torch.int64)
         out["gts"], out["image_paths"], out["image_ids"] = all_gts, image_paths, image_ids
         return out
 

@@ -386,7 +386,46 @@ class RelationTransformerModel(CaptionModelBase):
         assert att_feats.size(-1) == self.att_feat_size and boxes.size(-1) == 4
         return L.f32c(att_feats), L.f32c(boxes), L.f32c(att_masks)
 
-    def _make_batch(self, att_feats, boxes, att_masks, seqs=None, tok_weight=None):
+    def _valid_rows(self, cap_len, R, T, dev):
+        """Device tables of the valid-position decoder layout (``ortk_batch.cap_off / row_pos``) from the HOST-side caption
+        lengths: ``cap_len[r]`` = decoder positions of caption r that carry a target (1 + index of its last non-zero target
+        weight: ``len(tokens) + 1`` for BOS, tokens, EOS).  Everything is computed on the host (the collate function knows
+        the lengths): no device read-back, two small asynchronous uploads."""
+        n = torch.as_tensor(cap_len, dtype=torch.int64, device="cpu").clamp(1, T).clone()
+        assert n.numel() == R, "cap_len needs one entry per caption row"
+        # Row counts that are not a multiple of the GEMM tiles (256 rows) send the weight-gradient products (their reduction
+        # runs over the rows) to the bounds-checked kernels: top the count up with padded positions of captions that have
+        # some — computed like the reference computes them, weight zero — until it is a multiple of 256.
+        extra = int((-int(n.sum())) % 256)
+        if extra:
+            room = (T - n).clamp(min=0)
+            take = torch.minimum(room, (extra - (torch.cumsum(room, 0) - room)).clamp(min=0))
+            if int(take.sum()) < extra:
+                return None          # (nearly no padding in this batch: nothing to gain)
+            n += take
+        off = torch.zeros(R + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(n, 0)
+        Mc = int(off[-1])
+        rows = torch.repeat_interleave(torch.arange(R, dtype=torch.int64) * T - off[:-1], n) + torch.arange(Mc, dtype=torch.int64)
+        # (pinned staging: an upload from pageable memory makes the host wait for the stream — a full synchronisation per step)
+        up = lambda t: t.to(torch.int32).pin_memory().to(dev, non_blocking=True)
+        return up(off), up(rows), Mc
+
+    def valid_position_tables(self, data):
+        """The device tables of the valid-position decoder layout for a batch dict that carries ``cap_len`` (see
+        :meth:`_valid_rows`), built ONCE per batch and remembered in the dict (``data["_valid_rows"]``): call it where the
+        batch is moved to the GPU (NativeTrainer does on first use).  None when the layout does not apply."""
+        if "cap_len" not in data or data["cap_len"] is None:
+            return None
+        if "_valid_rows" not in data:
+            seqs = data["seqs"]
+            R, T = seqs.size(0), seqs.size(1) - 1
+            B, S = data["att_feats"].shape[:2]
+            ok = L.lib().ortk_valid_positions_ok(C.byref(self._ccfg), B, S, R, T)
+            data["_valid_rows"] = self._valid_rows(data["cap_len"], R, T, seqs.device) if ok else None
+        return data["_valid_rows"]
+
+    def _make_batch(self, att_feats, boxes, att_masks, seqs=None, tok_weight=None, valid_rows=None):
         b = L.Batch()
         keep = [att_feats, boxes, att_masks]
         b.att_feats, b.boxes, b.att_masks = att_feats.data_ptr(), boxes.data_ptr(), att_masks.data_ptr()
@@ -403,6 +442,12 @@ class RelationTransformerModel(CaptionModelBase):
                 assert tok_weight.shape == (b.R, b.T)
                 b.tok_weight = tok_weight.data_ptr()
                 keep.append(tok_weight)
+            if valid_rows is not None:
+                # valid-position decoder (mixed precision, fused criterion): skip the padded caption positions
+                off, rows, Mc = valid_rows
+                assert off.numel() == b.R + 1
+                b.cap_off, b.row_pos, b.Mc = off.data_ptr(), rows.data_ptr(), Mc
+                keep += [off, rows]
         b._keep = keep
         return b
 

@@ -28,9 +28,11 @@ def shard_batch(data, r=None, n=None):
     out = {}
     spi = data["seqs"].size(0) // B if "seqs" in data and data["seqs"] is not None else 0
     for k, v in data.items():
+        if k.startswith("_"):
+            continue                 # per-batch caches (the valid-position tables): rebuilt for the shard
         if not torch.is_tensor(v):
             out[k] = v[r * per:(r + 1) * per] if isinstance(v, (list, tuple)) and len(v) == B else v
-        elif k in ("seqs", "masks"):
+        elif k in ("seqs", "masks", "cap_len"):          # one row per caption
             out[k] = v[r * per * spi:(r + 1) * per * spi]
         elif v.size(0) == B:
             out[k] = v[r * per:(r + 1) * per]

@@ -71,6 +71,7 @@ class NativeTrainer:
         # (RCCL, on the collective's own stream) while the encoder half still runs.  Dense models only: the masked variants
         # post-process the whole gradient arena (ortk_mask_bwd) before the exchange.  Default: on whenever world > 1.
         self.overlap = (self.world > 1 if overlap_allreduce is None else bool(overlap_allreduce)) and not self.masked
+        self.valid_positions = True        # use data["cap_len"] when the batch has it (mixed precision)
         self._dec_off = int(L.lib().ortk_arena_decoder_offset(C.byref(model._ccfg)))
         self._pending = None
         # sparse training plans (enable_sparse_kernels(train=True)): the images are rebuilt from every step's mask sample; a
@@ -82,7 +83,9 @@ class NativeTrainer:
     def _batch(self, data, tok_weight):
         m = self.model
         feats, boxes, masks = m._prepare(data["att_feats"], data.get("boxes"), data.get("att_masks"), data.get("att_max_len"))
-        return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight)
+        # `cap_len` (host-side list / CPU tensor, one entry per caption row: decoder positions that carry a target) switches the
+        # decoder to the valid positions only (ortk_batch.cap_off / row_pos); the collate function provides it
+        return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight, m.valid_position_tables(data) if self.valid_positions else None)
 
     def _fwd_bwd(self, batch, norm, train=True):
         """forward + fused criterion + backward into self.grads; returns the device loss scalar."""
@@ -157,6 +160,7 @@ class NativeTrainer:
         rows = seq.view(-1, seq.size(-1))
         mask = (rows != m.pad_idx).float()
         tf = dict(data)
+        tf.pop("cap_len", None); tf.pop("_valid_rows", None)      # (the lengths of the SAMPLED captions live on the device: padded layout)
         tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
         loss = self._step(tf, mask * reward[:, None], mask, train)
         return loss, reward, seq, greedy

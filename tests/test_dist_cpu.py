@@ -70,10 +70,12 @@ def test_two_rank_data_parallel_equals_full_batch(tmp_path):
 def test_shard_batch_single_process():
     from sparse_image_captioning_amd import parallel
     data = dict(att_feats=torch.zeros(6, 3, 4), boxes=torch.zeros(6, 3, 4), att_masks=torch.ones(6, 3),
-                seqs=torch.arange(6 * 5 * 18).view(30, 18), masks=torch.ones(30, 18), image_ids=list(range(6)))
+                seqs=torch.arange(6 * 5 * 18).view(30, 18), masks=torch.ones(30, 18), image_ids=list(range(6)),
+                cap_len=torch.arange(30), att_max_len=3, _valid_rows=("cached", "tables"))
     s = parallel.shard_batch(data, 2, 3)
     assert s["att_feats"].shape[0] == 2 and s["image_ids"] == [4, 5]
     assert torch.equal(s["seqs"], data["seqs"][20:30])
+    assert torch.equal(s["cap_len"], torch.arange(20, 30)) and s["att_max_len"] == 3 and "_valid_rows" not in s
     with pytest.raises(AssertionError):
         parallel.shard_batch(data, 0, 4)
 
