@@ -76,7 +76,11 @@ __device__ __forceinline__ float blk_sum(float v, float* sh) {
 // FUSED: `logp` holds raw generator logits; the row's log-soft-max (of logits * scale) is taken here — max, sum and
 // candidate scan are three strided passes over the row (the 2nd and 3rd hit L2), with 8 independent loads in flight
 // per thread.  Saves the separate log-soft-max launch (read + write of rows x V fp32 per step).
-template <bool FUSED, int NPT>
+// FASTEXP (mixed precision only): v_exp_f32 (__expf, ~1 ulp) for the soft-max sum instead of libm's expf — the step is bound by
+// the ~20 vector instructions per element of the exact function, not by its one read of the logits (111 -> 60 us per step of
+// the 1 024-image beam-5 decode); the fp32 parity mode keeps the exact function (token-exact goldens).
+template <bool FAST> __device__ __forceinline__ float exp_sel(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FUSED, int NPT, bool FASTEXP = false>
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logp, int t, float scale) {
     __shared__ float sv[256 * MAXB];
     __shared__ float sh_red[4];
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
             const float mx = blk_max(m, sh_red);
             float sum = 0.f;
 #pragma unroll
-            for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) sum += expf(z[u] * scale - mx);
+            for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) sum += exp_sel<FASTEXP>(z[u] * scale - mx);
             sum = blk_sum(sum, sh_red);
             const float lse = logf(sum);
             if (tid == 0) { row_mx[q] = mx; row_lse[q] = lse; }
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256) void sample_step_kernel(SampleState st, const 
 // Same step on RAW generator logits: the row stays in registers (one read), its log-soft-max statistics are taken with the
 // reductions of log_softmax_kernel (bit-identical log-probabilities), then the arg-max / Gumbel-max runs on
 // logp = (logit - max) - lse.  Saves the separate log-soft-max pass (read + write of rows x V fp32 per step).
-template <int NPT>
+template <int NPT, bool FASTEXP = false>
 __global__ __launch_bounds__(256) void sample_step_fused_kernel(SampleState st, const float* __restrict__ logits, int t) {
     __shared__ float sh_red[4];
     __shared__ float red_v[4], red_l[4];
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void sample_step_fused_kernel(SampleState st, 
     const float mx = blk_max(m, sh_red);
     float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < NPT; ++u) if (tid + 256 * u < st.V) sum += expf(z[u] - mx);
+    for (int u = 0; u < NPT; ++u) if (tid + 256 * u < st.V) sum += exp_sel<FASTEXP>(z[u] - mx);
     sum = blk_sum(sum, sh_red);
     const float lse = logf(sum);
     float mv = -INFINITY, ml = 0.f; int mi = 0x7FFFFFFF;
@@ -512,10 +516,11 @@ int kvidx_init(int32_t* kvidx, int64_t rows, int32_t row_mult, int32_t tmax, hip
     ORTK_CHECK_LAUNCH();
     return 0;
 }
-int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused, float scale) {
+int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused, float scale, bool fast_exp) {
     if (st.b < 1 || st.b > MAXB) return ORTK_EINVAL;
     if (st.B == 0) return 0;
-    if (fused && st.V <= 256 * 40) hipLaunchKernelGGL((beam_step_kernel<true, 40>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
+    if (fused && st.V <= 256 * 40 && fast_exp) hipLaunchKernelGGL((beam_step_kernel<true, 40, true>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
+    else if (fused && st.V <= 256 * 40) hipLaunchKernelGGL((beam_step_kernel<true, 40>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
     else if (fused) hipLaunchKernelGGL((beam_step_kernel<true, 0>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
     else            hipLaunchKernelGGL((beam_step_kernel<false, 0>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, 1.f);
     ORTK_CHECK_LAUNCH();
@@ -533,11 +538,12 @@ int sample_init(const SampleState& st, int32_t bos, hipStream_t s) {
     ORTK_CHECK_LAUNCH();
     return 0;
 }
-int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused) {
+int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused, bool fast_exp) {
     if (st.rows == 0) return 0;
     if (fused) {       // `logp` holds raw logits (V <= 10 240: the caller checks sample_step_can_fuse)
         if (st.V > 256 * 40) return ORTK_EINVAL;
-        hipLaunchKernelGGL(sample_step_fused_kernel<40>, dim3((unsigned)st.rows), dim3(256), 0, s, st, logp, t);
+        if (fast_exp) hipLaunchKernelGGL((sample_step_fused_kernel<40, true>), dim3((unsigned)st.rows), dim3(256), 0, s, st, logp, t);
+        else hipLaunchKernelGGL(sample_step_fused_kernel<40>, dim3((unsigned)st.rows), dim3(256), 0, s, st, logp, t);
         ORTK_CHECK_LAUNCH();
         return 0;
     }

@@ -52,7 +52,7 @@ struct BeamState {
     int32_t tmax;             // cache time capacity
 };
 // fused = true: `logp` holds raw logits and the log-soft-max of (logits * scale) is taken inside the step
-int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false, float scale = 1.f);
+int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false, float scale = 1.f, bool fast_exp = false);
 int beam_finalize(const BeamState& st, int64_t* seq_out, float* lp_out, float* score_out, hipStream_t s);
 
 struct SampleState {
@@ -71,7 +71,7 @@ struct SampleState {
 };
 int sample_init(const SampleState& st, int32_t bos, hipStream_t s);
 // fused = true: `logp` holds raw logits (V <= 10 240) and the log-soft-max is taken inside the step
-int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false);
+int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false, bool fast_exp = false);
 int sample_finalize(const SampleState& st, hipStream_t s);
 
 // One decode position of the whole decoder stack in one launch (ortk_decstack.hip; mixed precision, d_model 512, 8 heads,

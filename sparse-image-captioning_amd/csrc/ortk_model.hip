@@ -1298,8 +1298,9 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.
         const float scale = (beam && t > 0) ? 1.f / op->temperature : 1.f;
-        if (beam) TRY(beam_step(bs, w.logits, t, s, true, scale));     // log-soft-max fused into the candidate scan
-        else if (V <= 256 * 40) TRY(sample_step(ss, w.logits, t, s, true));     // log-soft-max fused (scale is 1 on this branch)
+        const bool fast_exp = cfg->precision == 1;                     // (the fp32 parity mode keeps libm's expf)
+        if (beam) TRY(beam_step(bs, w.logits, t, s, true, scale, fast_exp));     // log-soft-max fused into the candidate scan
+        else if (V <= 256 * 40) TRY(sample_step(ss, w.logits, t, s, true, fast_exp));     // log-soft-max fused (scale is 1 on this branch)
         else {
             TRY(ortk_log_softmax(w.logits, rows, V, w.ldv, scale, stream));
             TRY(sample_step(ss, w.logits, t, s));

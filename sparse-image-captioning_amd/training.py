@@ -137,32 +137,51 @@ class NativeTrainer:
         tok_w = data["masks"][:, 1:].contiguous().float()
         return self._step(data, tok_w, tok_w, train)
 
-    def scst_step(self, data, reward_fn, num_samples=5, baseline="greedy", train=True):
-        """SCST step (utils/training.py:202-255): greedy baseline + `num_samples` multinomial rollouts (no graph,
-        cached attention), rewards from ``reward_fn(sample_seq (N,ns,L), greedy_seq (N,1,L) | None) -> (N*ns,)``,
-        then ONE teacher-forced pass over [BOS, sample] with per-token weight mask*reward (RewardCriterion)."""
+    def scst_step(self, data, reward_fn, num_samples=5, baseline="greedy", train=True, sample="random", update_dropout=False):
+        """SCST step (utils/training.py:202-255): greedy baseline + `num_samples` rollouts (no graph, cached attention), rewards
+        from ``reward_fn(sample_seq (N,ns,L), greedy_seq (N,1,L) | None) -> (N*ns,)``, then ONE teacher-forced pass over
+        [BOS, sample] with per-token weight mask*reward (RewardCriterion).
+
+        ``sample``: "random" = multinomial rollouts (``scst_sample == "random"``, utils/training.py:232-237) or "beam_search" = the
+        `num_samples` beams of a beam search (utils/training.py:226-231).
+
+        Which policy is differentiated.  The reference draws its rollouts in TRAIN mode — dropout on in every one of the 18
+        incremental passes — and back-propagates through those very passes, so the log-probs it differentiates are those of
+        the (dropout-perturbed) policy that sampled.  Here the rollout runs on the decode executor WITHOUT dropout (its fast
+        kernels have none) and the log-probs are recomputed by one teacher-forced pass; that pass therefore runs without dropout
+        too (``update_dropout=False``): sampling policy = differentiated policy = the eval-mode model, exactly (teacher-forced
+        and incremental log-probs agree to 3e-6).  ``update_dropout=True`` recomputes under a fresh dropout pattern
+        (rounds 1-2: a regulariser, but then the differentiated policy is not the one that sampled)."""
         m = self.model
         was_training = m.training
         greedy = None
+        B = data["att_feats"].size(0)
+        kw = dict(att_feats=data["att_feats"], boxes=data.get("boxes"), att_masks=data.get("att_masks"), mode="sample",
+                  att_max_len=data.get("att_max_len"))
         with torch.no_grad():
-            # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
-            # token for token what the two calls of utils/training.py:220-237 return, at half the launches
-            seq, _ = m(att_feats=data["att_feats"], boxes=data.get("boxes"), att_masks=data.get("att_masks"), mode="sample",
-                       att_max_len=data.get("att_max_len"),
-                       opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
-                            # the draws are keyed by the GLOBAL row of the batch: N ranks on their shards sample what one
-                            # process samples on the whole batch
-                            "sample_row_offset": parallel.rank() * data["att_feats"].size(0) * (num_samples + (baseline == "greedy"))})
-        if baseline == "greedy":
-            greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
+            if sample == "beam_search":
+                assert num_samples > 1, "beam search needs more than one beam"
+                if baseline == "greedy":
+                    greedy, _ = m(**kw, opt={"beam_size": 1})
+                seq, _ = m(**kw, opt={"beam_size": num_samples})
+            else:
+                assert sample == "random", sample
+                # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
+                # token for token what the two calls of utils/training.py:220-237 return, at half the launches
+                seq, _ = m(**kw, opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
+                                      # the draws are keyed by the GLOBAL row of the batch: N ranks on their shards sample what
+                                      # one process samples on the whole batch
+                                      "sample_row_offset": parallel.rank() * B * (num_samples + (baseline == "greedy"))})
+                if baseline == "greedy":
+                    greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
         m.train(was_training)
         reward = reward_fn(seq, greedy).to(self.dev).float().reshape(-1)
-        rows = seq.view(-1, seq.size(-1))
+        rows = seq.reshape(-1, seq.size(-1))
         mask = (rows != m.pad_idx).float()
         tf = dict(data)
         tf.pop("cap_len", None); tf.pop("_valid_rows", None)      # (the lengths of the SAMPLED captions live on the device: padded layout)
         tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
-        loss = self._step(tf, mask * reward[:, None], mask, train)
+        loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout)
         return loss, reward, seq, greedy
 
     @staticmethod

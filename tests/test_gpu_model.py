@@ -1427,3 +1427,30 @@ def test_valid_position_decoder_equals_padded_layout(P, g1, full_state, size):
     lt, _ = grads(True, train=True)
     lpt, _ = grads(False, train=True)
     assert abs(lt - lpt) < 0.05 * abs(lpt), (lt, lpt)
+
+
+def test_scst_beam_search_sample_mode_vs_oracle(P, g1):
+    """``scst_sample == "beam_search"`` (utils/training.py:226-231): the `num_samples` beams of a beam search are the samples,
+    the greedy decode the baseline; tokens against the oracle's beam search, loss against its RewardCriterion on the oracle's
+    teacher-forced log-probs of those tokens.  With ``model.train()`` and the default ``update_dropout=False`` the update
+    differentiates the policy that produced the samples (no dropout in either): the loss equals the eval-mode loss."""
+    from sparse_image_captioning_amd.training import NativeTrainer
+    ns = 3
+    m, b = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state()), _cuda(H.g1_batch())
+    cb = H.g1_batch()
+    cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
+    N = cb["att_feats"].size(0)
+    rw = torch.linspace(-1.0, 1.0, N * ns)
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=10)
+    m.train()
+    loss, reward, seq, greedy = tr.scst_step(b, lambda s_, g_: rw, num_samples=ns, baseline="greedy", sample="beam_search")
+    Pm = H.g1_state()
+    with torch.no_grad():
+        oseq, _, _ = O.beam_search(Pm, cfg, cb["att_feats"], cb["boxes"], cb["att_masks"], ns)
+        ogreedy, _ = O.sample_greedy_or_multinomial(Pm, cfg, cb["att_feats"], cb["boxes"], cb["att_masks"])
+        assert torch.equal(seq.cpu(), oseq) and torch.equal(greedy.cpu(), ogreedy)
+        rows = oseq.view(-1, oseq.size(-1))
+        tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
+        logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"])
+        ref_loss = O.reward_loss(logp.gather(2, rows.unsqueeze(2)).squeeze(2), rows, rw)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4, (loss.item(), ref_loss.item())
