@@ -252,7 +252,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
         rw = torch.randn(B * 5, device=dev)
 
         def step():
-            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy")
+            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy", sample_dropout=args.scst_train_sampling)
         units_per_step = B * 5
     else:
         model.train()
@@ -412,6 +412,9 @@ def main():
     ap.add_argument("--padded-positions", action="store_true",
                     help="teacher forcing over all 17 positions of every caption as the reference does (default: the decoder runs on "
                          "the valid positions only; same loss and gradients)")
+    ap.add_argument("--scst-train-sampling", action="store_true",
+                    help="scst: draw the rollouts in TRAIN mode as the reference does (dropout on, generic kernels, separate greedy pass) "
+                         "instead of the default eval-mode rollout + dropout-free update (same policy sampled and differentiated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="default run on one GPU: do not add the `workloads` object (BASELINE configs[2], [3], [4] timed in this process)")

@@ -260,6 +260,13 @@ typedef struct ortk_decode_opts {
     /* multinomial only: index of this call's first output row in the full batch, so that a host that decodes a batch
      * in several chunks (e.g. one per stream) draws the same tokens as one call would (the Gumbel hash is keyed by row) */
     int64_t sample_row_offset;
+    /* multinomial only (num_random_sample > 0, no with_greedy): TRAIN-mode sampling — every dropout of the model is on while
+     * the captions are drawn (the reference samples its SCST rollouts after model.train(), utils/training.py:224-237), keyed
+     * by drop_seed exactly as ortk_forward(train = 1, seed = drop_seed) keys the teacher-forced pass over [BOS, sample]: that
+     * pass then reproduces, token for token, the log-probs of the policy that sampled.  Runs the unfused executor on fp32
+     * caches (the fast decode kernels have no dropout). */
+    int32_t train;
+    uint64_t drop_seed;
 } ortk_decode_opts;
 
 size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, const ortk_decode_opts* o);
@@ -310,6 +317,9 @@ typedef struct ortk_gemm_args {
     int32_t accumulate, splitk, precision;
     int32_t a_dtype, b_dtype, c_dtype, gate_dtype;   /* storage type of A / B / C / gate: 0 = fp32, 1 = bf16 (precision 1 only) */
     float* colsum;   /* optional, transA && precision 1: colsum[m] += sum_k A[k,m] (bias gradient fused into the wgrad GEMM) */
+    /* dropout draw of output element (m, n): index (m * drop_row_stride + drop_row_off) * N + n; 0 / 0 = the plain m * N + n.
+     * A decode step at position t reproduces the draws of the teacher-forced (rows x T positions, N) output with (T, t). */
+    int32_t drop_row_stride, drop_row_off;
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its
@@ -389,6 +399,12 @@ typedef struct ortk_attn_args {
      * [g*Lq, (g+1)*Lq) — at most Lq of them (Lq stays the row count of the P / bias / dscore blocks).  kv_ragged = 1: the keys
      * of a group are its own query rows (self-attention: k, v, d_k, dv, kmask indexed like q); 0: keys as without q_off. */
     const int32_t* q_off; int32_t q_off_stride; int32_t kv_ragged;
+    /* forward only, drop_p > 0: draw the probability dropout of a DECODE step at position drop_tf_t as the teacher-forced pass
+     * over drop_tf_T positions draws it (transformer.py:293-294 in train mode during sampling, utils/training.py:224-237):
+     * query row i of group g at key j uses index ((g*H + h) * (Lq * drop_tf_T) + i * drop_tf_T + drop_tf_t) * drop_tf_lk + j —
+     * self-attention: Lq = 1, drop_tf_lk = drop_tf_T; cross-attention: Lq = samples of the image, drop_tf_lk = regions.
+     * drop_tf_T = 0: the natural index ((g*H + h) * Lq + i) * Lk + j.  Served by the generic kernel only. */
+    int32_t drop_tf_T, drop_tf_t, drop_tf_lk;
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);

@@ -293,12 +293,16 @@ class DecodeState:
                     lst[i] = lst[i][idx]
 
 
-def decode_step(st: DecodeState, it: Tensor) -> Tensor:
-    """One ``get_logprobs_state`` call (relation_transformer.py:374-387): tokens (rows,) -> logp (rows,V)."""
+def decode_step(st: DecodeState, it: Tensor, drop=None) -> Tensor:
+    """One ``get_logprobs_state`` call (relation_transformer.py:374-387): tokens (rows,) -> logp (rows,V).
+    `drop` (see `_drop`; train-mode sampling, utils/training.py:224-237): called as drop(site, x) with the sites of `decode_tf`
+    and the tensors of THIS position ((rows, 1, d), probabilities (rows, h, 1, keys so far)); it reads the position from
+    `st.step - 1`."""
     P, cfg = st.P, st.cfg
     h = cfg.num_heads
     x = embed_tokens(P, cfg, it[:, None], pos0=st.step)
     st.step += 1
+    x = _drop(drop, "emb", x)
     src_mask = (st.att_masks != 0)[:, None, None, :]
     sa = getattr(cfg, "share_att_decoder", None)
     for l in range(cfg.num_layers):
@@ -309,14 +313,15 @@ def decode_step(st: DecodeState, it: Tensor) -> Tensor:
             k = torch.cat((st.self_k[l], k), 2)
             v = torch.cat((st.self_v[l], v), 2)
         st.self_k[l], st.self_v[l] = k, v
-        x = x + _linear(P, out, _merge(attention(q, k, v, None)))
+        x = x + _drop(drop, f"dec{l}.sub0", _linear(P, out, _merge(attention(q, k, v, None, None, drop, f"dec{l}.self"))))
         y = layer_norm(x, P[pre + "sublayer.1.norm.a_2"], P[pre + "sublayer.1.norm.b_2"])
         q, k, v, out = project_qkv(P, pre + "src_attn.", sa, y, st.memory, h, need_kv=st.src_k[l] is None)
         if st.src_k[l] is None:
             st.src_k[l], st.src_v[l] = k, v
-        x = x + _linear(P, out, _merge(attention(q, st.src_k[l], st.src_v[l], src_mask)))
+        x = x + _drop(drop, f"dec{l}.sub1", _linear(P, out, _merge(attention(q, st.src_k[l], st.src_v[l], src_mask, None, drop, f"dec{l}.cross"))))
         y = layer_norm(x, P[pre + "sublayer.2.norm.a_2"], P[pre + "sublayer.2.norm.b_2"])
-        x = x + _linear(P, pre + "feed_forward.w_2", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
+        hid = _drop(drop, f"dec{l}.ffn", torch.relu(_linear(P, pre + "feed_forward.w_1", y)))
+        x = x + _drop(drop, f"dec{l}.sub2", _linear(P, pre + "feed_forward.w_2", hid))
     x = layer_norm(x, P["model.decoder.norm.a_2"], P["model.decoder.norm.b_2"])
     return generator(P, x[:, -1])
 
@@ -336,14 +341,14 @@ def gumbel_from_hash(seed: int, t: int, rows: int, vocab: int) -> Tensor:
 
 
 def sample_greedy_or_multinomial(P, cfg, att_feats, boxes, att_masks, num_random_sample: int = 0,
-                                 temperature: float = 1.0, decoding_constraint: int = 0, seed: int = 0):
+                                 temperature: float = 1.0, decoding_constraint: int = 0, seed: int = 0, drop=None, drop_step=None):
     """``_generate_captions`` greedy / multinomial branches (transformer.py:507-561).
 
     Multinomial draws use Gumbel-max over ``gumbel_from_hash`` (an exact sampler of
     multinomial(exp(logp/temperature))); the reference's torch RNG stream cannot be reproduced.
     """
     L = cfg.max_seq_length
-    mem = encode(P, cfg, att_feats, boxes, att_masks)
+    mem = encode(P, cfg, att_feats, boxes, att_masks, drop)          # (drop: encoder sites; drop_step(t): the decoder sites of position t)
     n = att_feats.size(0)
     if num_random_sample > 0:
         mem = mem.repeat_interleave(num_random_sample, 0)
@@ -355,7 +360,7 @@ def sample_greedy_or_multinomial(P, cfg, att_feats, boxes, att_masks, num_random
     seq_lp = torch.zeros(n, L)
     unfinished = it != cfg.eos_token_id
     for t in range(L):
-        logp = decode_step(st, it)
+        logp = decode_step(st, it, None if drop_step is None else drop_step(t))
         if decoding_constraint and t > 0:
             logp = logp.scatter(1, seq[:, t - 1:t], float("-inf"))
         if num_random_sample > 0:

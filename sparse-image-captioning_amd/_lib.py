@@ -67,7 +67,8 @@ DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20 = 1, 2, 4, 8      # or
 class DecodeOpts(C.Structure):
     _fields_ = [("beam_size", C.c_int32), ("num_random_sample", C.c_int32), ("temperature", C.c_float),
                 ("decoding_constraint", C.c_int32), ("length_penalty", C.c_int32), ("length_alpha", C.c_double),
-                ("seed", C.c_uint64), ("sparse", C.POINTER(EllPlanStruct)), ("exec_flags", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64)]
+                ("seed", C.c_uint64), ("sparse", C.POINTER(EllPlanStruct)), ("exec_flags", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64),
+                ("train", C.c_int32), ("drop_seed", C.c_uint64)]
 
 
 class GemmArgs(C.Structure):
@@ -79,7 +80,7 @@ class GemmArgs(C.Structure):
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
                 ("accumulate", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32),
                 ("a_dtype", C.c_int32), ("b_dtype", C.c_int32), ("c_dtype", C.c_int32), ("gate_dtype", C.c_int32),
-                ("colsum", C.c_void_p)]
+                ("colsum", C.c_void_p), ("drop_row_stride", C.c_int32), ("drop_row_off", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -94,7 +95,8 @@ class AttnArgs(C.Structure):
                 ("o_dtype", C.c_int32), ("dqkv_dtype", C.c_int32), ("kv_dtype", C.c_int32),
                 ("k_new", C.c_void_p), ("v_new", C.c_void_p), ("ld_new", C.c_int64), ("bwd_part", C.c_int32),
                 ("precision", C.c_int32), ("qkv_dtype", C.c_int32),
-                ("q_off", C.c_void_p), ("q_off_stride", C.c_int32), ("kv_ragged", C.c_int32)]
+                ("q_off", C.c_void_p), ("q_off_stride", C.c_int32), ("kv_ragged", C.c_int32),
+                ("drop_tf_T", C.c_int32), ("drop_tf_t", C.c_int32), ("drop_tf_lk", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _U32, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ortk_attn_args a) {
         wave_sync();
         const int qpos = a.causal_period > 0 ? i % a.causal_period : 0;
         const int64_t pbase = (((int64_t)g * a.H + h) * a.Lq + i) * a.Lk;
+        // dropout draws: the natural index, or (decode step in train mode) the teacher-forced pass's (ortk_attn_args.drop_tf_*)
+        const int64_t dbase = a.drop_tf_T > 0 ? (((int64_t)g * a.H + h) * ((int64_t)a.Lq * a.drop_tf_T) + (int64_t)i * a.drop_tf_T + a.drop_tf_t) * a.drop_tf_lk
+                                              : pbase;
         float s[2], mx = -INFINITY;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ortk_attn_args a) {
             if (j < a.Lk) {
                 float p = e[u] / sum;
                 if (a.p) a.p[pbase + j] = p;
-                if (a.drop_p > 0.f) p = ortk_keep(a.drop_seed, (uint64_t)(pbase + j), a.drop_p) ? p * inv_keep : 0.f;
+                if (a.drop_p > 0.f) p = ortk_keep(a.drop_seed, (uint64_t)(dbase + j), a.drop_p) ? p * inv_keep : 0.f;
                 t.p[wave][j] = p;
             }
         }
@@ -1160,6 +1163,17 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a_in, ortk_stream stream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(float) * 4 * (2 * 64 * KP + 128)));
         attr_set = true;
+    }
+    if (a->drop_tf_T > 0) {      // teacher-forced dropout geometry (train-mode decode step): the generic kernel
+        if (a->kv_dtype || a->qkv_dtype || a->Lk > MAXK || a->dk > MAXD) return ORTK_EINVAL;
+        static bool attr_tf = false;
+        if (!attr_tf) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes(MAXK));
+            attr_tf = true;
+        }
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(a->nkv * a->H)), dim3(256), fwd_lds_bytes(a->Lk), ortk_s(stream), *a);
+        ORTK_CHECK_LAUNCH();
+        return 0;
     }
     // Dispatch measured on the path's three shapes (scratch/attn_bench.py, us fwd/bwd): 36x36 MFMA 81/132 vs 82/147,
     // 85x36 MFMA 101/218 vs 170/293, 17x17 (10 240 tiny pairs) MFMA 200/526 vs 138/196 for the per-lane kernels.

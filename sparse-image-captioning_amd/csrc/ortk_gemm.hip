@@ -55,6 +55,7 @@ struct Epi {
     const void* gate; int64_t ldg; int g_dt; float gate_scale;
     int relu; float drop_p; uint32_t drop_seed; int accumulate; bool first_split;
     int M, N;
+    int drop_rs, drop_r0;      // dropout draw of element (m, n): index (m * drop_rs + drop_r0) * N + n   (1, 0: the plain m * N + n)
 };
 
 // 4 consecutive elements of a row vector / matrix row, zero beyond N
@@ -117,7 +118,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
             const float gg[4] = {gat[j].x, gat[j].y, gat[j].z, gat[j].w};
             float v[4];
             bool kp[4] = {true, true, true, true};
-            if (e.drop_p > 0.f) ortk_keep4(e.drop_seed, (uint64_t)m * (uint64_t)e.N + n0, e.drop_p, kp);
+            if (e.drop_p > 0.f) ortk_keep4(e.drop_seed, ((uint64_t)m * (uint64_t)e.drop_rs + (uint64_t)e.drop_r0) * (uint64_t)e.N + n0, e.drop_p, kp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = acc[i][j][r] + bb[r];
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
     }
 
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
     epilogue_tile<false>(e, mb + wm * 64 + lr, nb + wn * 64 + 4 * lk, acc);
 }
 
@@ -450,7 +451,7 @@ __device__ __forceinline__ void epilogue_staged(const Epi& e, float* sC, int mb,
             float x = a4[q] + bb[q];
             if (e.relu) x = fmaxf(x, 0.f);
             x *= rs;
-            if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, (uint64_t)m * (uint64_t)e.N + (n0 + q), e.drop_p) ? x * inv_keep : 0.f;
+            if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, ((uint64_t)m * (uint64_t)e.drop_rs + (uint64_t)e.drop_r0) * (uint64_t)e.N + (n0 + q), e.drop_p) ? x * inv_keep : 0.f;
             if (e.gate) x = gg[q] > 0.f ? x * e.gate_scale : 0.f;
             v[q] = x + rr[q];
         }
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
         }
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
     if (TA && do_cs) __syncthreads();     // the column-sum scratch shares the LDS with the staged C tile
     static_assert(128 * CP * sizeof(float) <= BF16_LDS_BYTES_C, "staged C tile must fit the staging LDS");
     // plain stores are faster straight from the accumulator layout (64-B segments, no LDS round trip: 491 vs 436 TF
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
     }
     if (TA && do_cs && tid < TM) atomicAdd(p.colsum + mb + tid, cs);
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
     if (!BIG && p.accumulate) {
         __syncthreads();      // the staged C tile reuses the ring
         epilogue_staged<true>(e, reinterpret_cast<float*>(smem16), mb, nb, wm, wn, lane, wave,
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
         }
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
     if (mb + 256 <= p.M) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)

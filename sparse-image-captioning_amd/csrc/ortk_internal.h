@@ -114,7 +114,8 @@ int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStr
 // embedding / fused criterion over an explicit list of (caption, position) rows (row_pos[i] = r*T + t; NULL = all R*T rows in order):
 // the valid-position decoder layout of ortk_batch.cap_off / row_pos
 int embed_fwd_rows(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out, float* keymask, int64_t nrows,
-                   const int32_t* row_pos, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p, uint32_t seed, hipStream_t s);
+                   const int32_t* row_pos, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p, uint32_t seed, hipStream_t s,
+                   int32_t drop_rs = 1, int32_t drop_r0 = 0);
 int embed_bwd_rows(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut, int64_t nrows, const int32_t* row_pos, int32_t T,
                    int32_t d, float drop_p, uint32_t seed, hipStream_t s);
 int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight, const float* norm_dev,

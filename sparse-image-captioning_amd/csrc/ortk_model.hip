@@ -302,6 +302,8 @@ struct Ctx {
     const ortk_sparse_plan* ell_f = nullptr;        // optional sparse plan over (N,K) weight blocks: forward-layout products
     const ortk_sparse_plan* ell_b = nullptr;        // ... over their transposed copies: data-gradient products (mixed precision)
     const void* W16T = nullptr;                  // transposed bf16 weight blocks (training workspaces, mixed precision)
+    int drop_rs = 0, drop_r0 = 0;                // decode step in train mode: output row m draws like row m * drop_rs + drop_r0 of the
+                                                 // teacher-forced pass (ortk_gemm_args.drop_row_stride / _off); 0: the natural index
     bool use_side = false;                       // weight-gradient GEMMs (and other independent work) on `side`
     SideStream* side = nullptr;                  // the side stream of this call's (device, caller stream)
     struct Pend { const void* buf; hipEvent_t done; };
@@ -378,6 +380,7 @@ static int fwd_gemm(const Ctx& c, const void* X, int xdt, int64_t ldx, int64_t w
     a.A = X; a.a_dtype = xdt; a.lda = ldx; a.B = c.W(woff); a.b_dtype = c.wdt(); a.ldb = K; a.C = Y; a.c_dtype = ydt; a.ldc = ldy;
     a.M = (int)M; a.N = N; a.K = K;
     a.bias = bias; a.relu = relu; a.drop_p = drop; a.drop_seed = seed; a.resid = resid; a.ldr = ldr; a.rowscale = rowscale;
+    a.drop_row_stride = c.drop_rs; a.drop_row_off = c.drop_r0;
     a.precision = c.prec;
     return ortk_gemm(&a, (ortk_stream)c.s);
 }
@@ -1054,7 +1057,8 @@ static bool stack_ok(const ortk_config& c, int64_t rows, int32_t flags) {
            c.share_att_dec == 0 && c.n_layers <= STACK_MAXL && c.seq_len <= 64;     // (seq_len: one lane per cached key)
 }
 
-static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false, bool sstream = false) {
+static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false, bool sstream = false,
+                         bool train = false) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
     // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
     w.kvdt = (c.precision && H == 8 && d == 512 && S > 8 && S <= 48 && T <= 32 && K <= 16) ? ORTK_BF16 : ORTK_F32;
@@ -1063,6 +1067,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.xq16 = (c.precision && w.kvdt == ORTK_F32 && S > 48 && attn16_shape_ok(K, S, (int)(d / H))) ? 1 : 0;
     w.ckvdt = w.xq16 ? ORTK_BF16 : w.kvdt;
     if (stack) { w.kvdt = w.ckvdt = ORTK_BF16; w.xq16 = 0; }      // the stack kernel reads bf16 caches at every S
+    if (train) { w.kvdt = w.ckvdt = ORTK_F32; w.xq16 = 0; }       // train-mode sampling: the generic attention kernel (fp32 rows)
     const size_t kves = ortk_esize(w.kvdt);
     const int64_t Me = (int64_t)B * S, rows = (int64_t)B * K;
     w.ldv = ortk_align(c.vocab, 128);
@@ -1123,8 +1128,8 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
     if (check_cfg(cfg) || !o || B < 1 || S < 1) return 0;
     const int K = decode_K(o);
     if (K < 1) return 0;
-    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack_ok(*cfg, (int64_t)B * K, o->exec_flags) && !o->sparse,
-                             (o->exec_flags & ORTK_DEC_SPARSE_STREAM) != 0);
+    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w,
+                             stack_ok(*cfg, (int64_t)B * K, o->exec_flags) && !o->sparse && !o->train, (o->exec_flags & ORTK_DEC_SPARSE_STREAM) != 0, o->train != 0);
     return w.bytes;
 }
 
@@ -1148,7 +1153,12 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
     const float* att_masks = w.att_masks;
     const int B = groups, per_img = per_group;
     const AttMode am = att_mode(cfg->share_att_dec);
-        TRY(ortk_embed_fwd(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, 1, t, d, cfg->pad_id, 0.f, 0, stream));
+        // Train-mode sampling (c.train: utils/training.py:224-237 samples after model.train()): every dropout of the step draws
+        // what the teacher-forced pass over [BOS, sample] draws at (row, position t) — same site keys, the element index of the
+        // (rows x T, N) teacher-forced tensors (cd.drop_rs / drop_r0; ortk_attn_args.drop_tf_*).  pd = 0 in eval mode.
+        Ctx cd = c; cd.drop_rs = T; cd.drop_r0 = t;
+        const float pd = c.p_drop();
+        TRY(embed_fwd_rows(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, nullptr, 1, t, d, cfg->pad_id, pd, c.sub(OP_EMB), c.s, T, t));
         float* x = w.xa; float* xn = w.xb;
         for (int l = 0; l < L; ++l) {
             const DecOff& e = o.dec[l];
@@ -1160,8 +1170,9 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             a.kv_dtype = w.kvdt; a.ldk = a.ldv = d; a.o = w.o; a.o_dtype = A; a.ldo = d;
             a.nkv = (int)rows; a.H = H; a.Lq = 1; a.Lk = t + 1; a.dk = dk;
             if (kvidx) a.kv_index = kvidx; else a.kv_group_stride = T;
+            if (pd > 0.f) { a.drop_p = pd; a.drop_seed = c.sub(dop(l, 0)); a.drop_tf_T = T; a.drop_tf_t = t; a.drop_tf_lk = T; }
             TRY(ortk_attention_fwd(&a, stream));
-            TRY(fwd_gemm(c, w.o, A, d, e.wo, P + e.bo, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
+            TRY(fwd_gemm(cd, w.o, A, d, e.wo, P + e.bo, xn, ORTK_F32, d, rows, d, d, false, pd, c.sub(dop(l, 1)), x, d));
             std::swap(x, xn);
             TRY(ln_fwd(c, x, e.n1a, e.n1b, w.y, A, w.st, rows));
             TRY(fwd_gemm(c, w.y, A, d, e.cqw, P + e.cqb, w.q, w.xq16 ? ORTK_BF16 : ORTK_F32, d, rows, d, d));
@@ -1171,12 +1182,13 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             if (w.xq16) a.qkv_dtype = 1; else a.kv_dtype = w.ckvdt;
             a.ldk = a.ldv = o.ckv_slots * o.cw;
             a.o = w.o; a.o_dtype = A; a.ldo = d; a.kmask = att_masks; a.nkv = B; a.H = H; a.Lq = per_img; a.Lk = S; a.dk = dk;
+            if (pd > 0.f) { a.drop_p = pd; a.drop_seed = c.sub(dop(l, 2)); a.drop_tf_T = T; a.drop_tf_t = t; a.drop_tf_lk = S; }
             TRY(ortk_attention_fwd(&a, stream));
-            TRY(fwd_gemm(c, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, 0.f, 0, x, d));
+            TRY(fwd_gemm(cd, w.o, A, d, e.cow, P + e.cob, xn, ORTK_F32, d, rows, d, d, false, pd, c.sub(dop(l, 3)), x, d));
             std::swap(x, xn);
             TRY(ln_fwd(c, x, e.n2a, e.n2b, w.y, A, w.st, rows));
-            TRY(fwd_gemm(c, w.y, A, d, e.w1, P + e.b1, w.h, A, ff, rows, ff, d, true));
-            TRY(fwd_gemm(c, w.h, A, ff, e.w2, P + e.b2, xn, ORTK_F32, d, rows, d, ff, false, 0.f, 0, x, d));
+            TRY(fwd_gemm(cd, w.y, A, d, e.w1, P + e.b1, w.h, A, ff, rows, ff, d, true, pd, c.sub(dop(l, 4))));
+            TRY(fwd_gemm(cd, w.h, A, ff, e.w2, P + e.b2, xn, ORTK_F32, d, rows, d, ff, false, pd, c.sub(dop(l, 5)), x, d));
             std::swap(x, xn);
         }
         TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.y, A, w.st, rows));
@@ -1224,9 +1236,11 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (beam && (K > 8 || K > cfg->vocab)) return ORTK_EINVAL;
     if (op->temperature <= 0.f) return ORTK_EINVAL;
     Offsets o; build_layout(*cfg, o, nullptr);
-    const bool stack = stack_ok(*cfg, (int64_t)B * K, op->exec_flags) && !op->sparse;
+    // train-mode sampling (dropout on while the captions are drawn): multinomial rollouts only, on the unfused executor
+    if (op->train && (op->num_random_sample <= 0 || op->with_greedy || op->sparse)) return ORTK_EINVAL;
+    const bool stack = stack_ok(*cfg, (int64_t)B * K, op->exec_flags) && !op->sparse && !op->train;
     const bool sstream = stack && (op->exec_flags & ORTK_DEC_SPARSE_STREAM);
-    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack, sstream);
+    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack, sstream, op->train != 0);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     hipStream_t s = ortk_s(stream);
     TRY(make_w16(cfg, o, params, w.w16, stream));
@@ -1243,7 +1257,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
             TRY(fill_i32(w.progress, 16, 0, s));
         }
     }
-    Ctx c{cfg, s, cfg->precision, 0, false, params, w.w16, w.adt};
+    Ctx c{cfg, s, cfg->precision, op->train ? op->drop_seed : 0, op->train != 0, params, w.w16, w.adt};
     if (op->sparse) {
         TRY(ortk_sparse_build(op->sparse, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
         c.ell_f = op->sparse;

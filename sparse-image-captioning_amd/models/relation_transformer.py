@@ -522,6 +522,11 @@ class RelationTransformerModel(CaptionModelBase):
                 raise NotImplementedError("diverse beam groups (group_size > 1): the reference's own path raises AttributeError "
                                           "(caption_model.py:50 calls an undefined self.repeat_tensor); nothing to match")
         o.with_greedy = 1 if (o.num_random_sample > 0 and opt.get("with_greedy", False)) else 0
+        # train-mode sampling (ortk_decode_opts.train): dropout on while the captions are drawn, keyed like the teacher-forced
+        # pass of seed opt["drop_seed"]; default: follows model.training only when asked (opt["train_mode"])
+        if opt.get("train_mode", False):
+            assert o.num_random_sample > 0 and not o.with_greedy, "train-mode sampling: multinomial rollouts without the fused greedy row"
+            o.train, o.drop_seed = 1, int(opt["drop_seed"]) & 0xFFFFFFFFFFFFFFFF
         if o.num_random_sample > 0:
             assert o.beam_size < 1, f"Beam size must be < 1, saw {o.beam_size}"      # transformer.py:509
             K = o.num_random_sample + o.with_greedy

@@ -87,10 +87,11 @@ class NativeTrainer:
         # decoder to the valid positions only (ortk_batch.cap_off / row_pos); the collate function provides it
         return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight, m.valid_position_tables(data) if self.valid_positions else None)
 
-    def _fwd_bwd(self, batch, norm, train=True):
-        """forward + fused criterion + backward into self.grads; returns the device loss scalar."""
+    def _fwd_bwd(self, batch, norm, train=True, seed=None):
+        """forward + fused criterion + backward into self.grads; returns the seed the dropout / mask draws used."""
         m, lib = self.model, L.lib()
-        seed = m._next_seed() if train else 0
+        if seed is None:
+            seed = m._next_seed() if train else 0
         m._sparse_plans()          # sparse training plans (enable_sparse_kernels(train=True)) ride on the config
         nbytes = lib.ortk_train_workspace_bytes(C.byref(m._ccfg), batch.B, batch.S, batch.R, batch.T)
         ws = m._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, True)
@@ -137,7 +138,8 @@ class NativeTrainer:
         tok_w = data["masks"][:, 1:].contiguous().float()
         return self._step(data, tok_w, tok_w, train)
 
-    def scst_step(self, data, reward_fn, num_samples=5, baseline="greedy", train=True, sample="random", update_dropout=False):
+    def scst_step(self, data, reward_fn, num_samples=5, baseline="greedy", train=True, sample="random", update_dropout=False,
+                  sample_dropout=False):
         """SCST step (utils/training.py:202-255): greedy baseline + `num_samples` rollouts (no graph, cached attention), rewards
         from ``reward_fn(sample_seq (N,ns,L), greedy_seq (N,1,L) | None) -> (N*ns,)``, then ONE teacher-forced pass over
         [BOS, sample] with per-token weight mask*reward (RewardCriterion).
@@ -151,15 +153,30 @@ class NativeTrainer:
         kernels have none) and the log-probs are recomputed by one teacher-forced pass; that pass therefore runs without dropout
         too (``update_dropout=False``): sampling policy = differentiated policy = the eval-mode model, exactly (teacher-forced
         and incremental log-probs agree to 3e-6).  ``update_dropout=True`` recomputes under a fresh dropout pattern
-        (rounds 1-2: a regulariser, but then the differentiated policy is not the one that sampled)."""
+        (rounds 1-2: a regulariser, but then the differentiated policy is not the one that sampled).
+
+        ``sample_dropout=True`` is the reference's own semantics: the rollouts are drawn in TRAIN mode (``ortk_decode_opts.train``:
+        every dropout on, keyed by one seed) and the teacher-forced pass runs with dropout under the SAME seed, so it reproduces
+        the sampling passes' masks position by position and differentiates exactly the dropout-perturbed policy that sampled
+        (tests/test_gpu_model.py::test_train_mode_sampling_vs_oracle).  Costs a separate greedy pass (the baseline is an
+        eval-mode decode, its encoder memory is not the sampled one's) and the generic attention / GEMM kernels in the rollout:
+        the fast decode kernels have no dropout."""
         m = self.model
         was_training = m.training
         greedy = None
         B = data["att_feats"].size(0)
         kw = dict(att_feats=data["att_feats"], boxes=data.get("boxes"), att_masks=data.get("att_masks"), mode="sample",
                   att_max_len=data.get("att_max_len"))
+        drop_seed = None
         with torch.no_grad():
-            if sample == "beam_search":
+            if sample_dropout and train:
+                assert sample == "random", "train-mode sampling: multinomial rollouts"
+                drop_seed = m._next_seed()
+                if baseline == "greedy":
+                    greedy, _ = m(**kw, opt={"beam_size": 1})
+                seq, _ = m(**kw, opt={"num_random_sample": num_samples, "beam_size": 0, "train_mode": True, "drop_seed": drop_seed,
+                                      "sample_row_offset": parallel.rank() * B * num_samples})
+            elif sample == "beam_search":
                 assert num_samples > 1, "beam search needs more than one beam"
                 if baseline == "greedy":
                     greedy, _ = m(**kw, opt={"beam_size": 1})
@@ -181,7 +198,10 @@ class NativeTrainer:
         tf = dict(data)
         tf.pop("cap_len", None); tf.pop("_valid_rows", None)      # (the lengths of the SAMPLED captions live on the device: padded layout)
         tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
-        loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout)
+        if drop_seed is not None:
+            loss = self._step(tf, mask * reward[:, None], mask, True, seed=drop_seed)
+        else:
+            loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout)
         return loss, reward, seq, greedy
 
     @staticmethod
@@ -196,14 +216,14 @@ class NativeTrainer:
             return torch.from_numpy(sc_sample - sc_baseline).float()
         return fn
 
-    def _step(self, data, tok_weight, norm_mask, train):
+    def _step(self, data, tok_weight, norm_mask, train, seed=None):
         m = self.model
         self.step_count += 1
         self.grads.zero_()
         L.check(L.lib().ortk_sum(L.ptr(norm_mask.contiguous()), norm_mask.numel(), L.ptr(self.norm_dev), L.stream_ptr()), "ortk_sum")
         parallel.reduce_scalar_sum(self.norm_dev)   # LanguageModelCriterion semantics over the GLOBAL batch
         batch = self._batch(data, tok_weight)
-        seed = self._fwd_bwd(batch, self.norm_dev, train)
+        seed = self._fwd_bwd(batch, self.norm_dev, train, seed)
         loss = self.loss_dev.clone()
         if getattr(m, "_sparse_train", False) and (self.step_count == 1 or self.step_count % self.overflow_check_every == 0):
             m.check_sparse_overflow()

@@ -1454,3 +1454,93 @@ def test_scst_beam_search_sample_mode_vs_oracle(P, g1):
         logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"])
         ref_loss = O.reward_loss(logp.gather(2, rows.unsqueeze(2)).squeeze(2), rows, rw)
     assert abs(loss.item() - ref_loss.item()) < 1e-4, (loss.item(), ref_loss.item())
+
+
+def test_train_mode_sampling_vs_oracle(P, g1):
+    """Train-mode sampling (``ortk_decode_opts.train``; the reference draws its SCST rollouts after ``model.train()``,
+    utils/training.py:224-237: every dropout on in each of the 18 incremental passes).  The decode step draws its masks as
+    the teacher-forced pass of the same seed draws them at (row, position), so:
+      * the sampled tokens equal the oracle's incremental sampler under THOSE masks (read back through
+        ortk_dropout_site_seed / ortk_dropout_apply) and the same Gumbel draws, and so do the log-probs of the chosen tokens;
+      * the teacher-forced log-probs of the sampled tokens under the same seed equal the rollout's: the pass
+        NativeTrainer.scst_step(sample_dropout=True) differentiates is the policy that sampled, to 2e-4."""
+    import ctypes as Ct
+    lib = P._lib.lib()
+    m = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state())
+    m.train()
+    b, cb = _cuda(H.g1_batch()), H.g1_batch()
+    cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
+    B = b["att_feats"].size(0)
+    Sc = int(b["att_masks"].sum(1).max())
+    ns, T = 3, cfg.max_seq_length
+    R, Hh, d, ff, Lr = B * ns, cfg.num_heads, cfg.d_model, C.TINY_CFG["dim_feedforward"], cfg.num_layers
+    p_src, p = float(C.TINY_CFG["drop_prob_src"]), 0.1
+    drop_seed, gseed = 0x1234567890AB, 991
+
+    def keep(stack, layer, k, n, prob):
+        key = lib.ortk_dropout_site_seed(Ct.c_uint64(drop_seed), stack, layer, k)
+        ones, out = torch.ones(n, device="cuda"), torch.empty(n, device="cuda")
+        P._lib.check(lib.ortk_dropout_apply(P._lib.ptr(ones), P._lib.ptr(out), 0, n, prob, key, P._lib.stream_ptr()), "ortk_dropout_apply")
+        return out.cpu()
+
+    masks = {"src": keep(0, 0, 0, B * Sc * d, p_src).view(B, Sc, d), "emb": keep(1, 0, 0, R * T * d, p).view(R, T, d)}
+    for l in range(Lr):
+        masks[f"enc{l}.att"] = keep(2, l, 0, B * Hh * Sc * Sc, p).view(B, Hh, Sc, Sc)
+        masks[f"enc{l}.sub0"] = keep(2, l, 1, B * Sc * d, p).view(B, Sc, d)
+        masks[f"enc{l}.ffn"] = keep(2, l, 2, B * Sc * ff, p).view(B, Sc, ff)
+        masks[f"enc{l}.sub1"] = keep(2, l, 3, B * Sc * d, p).view(B, Sc, d)
+        masks[f"dec{l}.self"] = keep(3, l, 0, R * Hh * T * T, p).view(R, Hh, T, T)
+        masks[f"dec{l}.sub0"] = keep(3, l, 1, R * T * d, p).view(R, T, d)
+        masks[f"dec{l}.cross"] = keep(3, l, 2, B * Hh * ns * T * Sc, p).view(B, Hh, ns, T, Sc).permute(0, 2, 1, 3, 4).reshape(R, Hh, T, Sc)
+        masks[f"dec{l}.sub1"] = keep(3, l, 3, R * T * d, p).view(R, T, d)
+        masks[f"dec{l}.ffn"] = keep(3, l, 4, R * T * ff, p).view(R, T, ff)
+        masks[f"dec{l}.sub2"] = keep(3, l, 5, R * T * d, p).view(R, T, d)
+    drop_full = lambda site, x: x * masks[site]
+
+    def drop_step(t):                   # the masks of position t, in the shapes of the incremental pass
+        def f(site, x):
+            mk = masks[site]
+            if mk.dim() == 4:           # attention probabilities (rows, h, 1, keys): self = keys 0..t, cross = all regions
+                return x * mk[:, :, t:t + 1, :x.size(-1)]
+            return x * mk[:, t:t + 1]
+        return f
+
+    Pm = H.g1_state()
+    feats, boxes, amask = cb["att_feats"][:, :Sc], cb["boxes"][:, :Sc], cb["att_masks"][:, :Sc]
+    with torch.no_grad():
+        oseq, olp = O.sample_greedy_or_multinomial(Pm, cfg, feats, boxes, amask, num_random_sample=ns, seed=gseed,
+                                                   drop=drop_full, drop_step=drop_step)
+        seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], mode="sample",
+                    opt={"num_random_sample": ns, "beam_size": 0, "seed": gseed, "train_mode": True, "drop_seed": drop_seed})
+        eseq, _ = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], mode="sample",
+                    opt={"num_random_sample": ns, "beam_size": 0, "seed": gseed})
+    agree = (seq.cpu() == oseq).float().mean().item()
+    assert agree > 0.97, agree                          # (a Gumbel near-tie may flip a token)
+    assert not torch.equal(seq, eseq)                   # dropout changed the policy
+    same = (seq.cpu() == oseq).all(-1) 
+    valid = (oseq != 0) & same[..., None]
+    assert (lp.cpu() - olp)[valid].abs().max().item() < 2e-4
+    # the teacher-forced pass of the same seed reproduces the rollout's log-probs (the pass scst_step differentiates)
+    rows = seq.view(-1, seq.size(-1))
+    tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
+    batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in)
+    logp, _ = m._run_forward(batch, True, drop_seed, want_logp=True, cache_ws=False)
+    tok_lp = logp[..., :m.vocab_size].gather(2, rows.unsqueeze(2)).squeeze(2)
+    v2 = rows != 0
+    assert (tok_lp - lp.view(-1, lp.size(-1)))[v2].abs().max().item() < 2e-4
+    # ... and the trainer's step in that mode: RewardCriterion on exactly those log-probs
+    from sparse_image_captioning_amd.training import NativeTrainer
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=10)
+    rw = torch.linspace(-1.0, 1.0, R)
+    m._seed_counter = 300
+    loss, _, sseq, sgreedy = tr.scst_step(b, lambda s_, g_: rw, num_samples=ns, baseline="greedy", sample_dropout=True)
+    seed_used = (torch.initial_seed() * 1000003 + 301) & 0xFFFFFFFFFFFFFFFF or 1          # the first seed scst_step drew
+    srows = sseq.view(-1, sseq.size(-1))
+    sbatch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), torch.cat([srows.new_full((R, 1), C.BOS), srows], 1))
+    # (the step has updated the weights: recompute on the restored ones)
+    m.load_state_dict(H.g1_state(), strict=False)
+    slogp, _ = m._run_forward(sbatch, True, seed_used, want_logp=True, cache_ws=False)
+    stok = slogp[..., :m.vocab_size].gather(2, srows.unsqueeze(2)).squeeze(2)
+    ref = O.reward_loss(stok.cpu(), srows.cpu(), rw)
+    assert abs(loss.item() - ref.item()) < 1e-4, (loss.item(), ref.item())
+    assert sgreedy.shape == (B, 1, T)
