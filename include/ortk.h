@@ -320,6 +320,16 @@ typedef struct ortk_gemm_args {
     /* dropout draw of output element (m, n): index (m * drop_row_stride + drop_row_off) * N + n; 0 / 0 = the plain m * N + n.
      * A decode step at position t reproduces the draws of the teacher-forced (rows x T positions, N) output with (T, t). */
     int32_t drop_row_stride, drop_row_off;
+    /* Row-wise LayerNorm fused into the epilogue (C fp32 with ldc == N <= 2048; no transA / accumulate / gate / rowscale).
+     *   ln_mode 1: C = v as above, ln_y = LayerNorm(v) (ln_y_dtype), ln_stats[m] = {mean, std}: the projection + residual +
+     *              next sublayer's norm of SublayerConnection (transformer.py:345-358) in one launch.
+     *   ln_mode 2: the product (no bias / residual / relu) is dy, the gradient of the LayerNorm output of input rows ln_x with
+     *              statistics ln_stats: C = dLN/dx (+ ln_dres), ln_da / ln_db +=, and the optional copy ln_y =
+     *              dropout(C; drop_p, drop_seed, index m*N+n) (ortk_layernorm_bwd_drop's dz).
+     * One launch for N = 512 in mixed precision with bf16 operands; any other case runs the separate kernels. */
+    int32_t ln_mode, ln_y_dtype;
+    const float* ln_a; const float* ln_b; void* ln_y; float* ln_stats; float ln_eps;
+    const float* ln_x; const float* ln_dres; float* ln_da; float* ln_db;
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its

@@ -80,7 +80,10 @@ class GemmArgs(C.Structure):
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
                 ("accumulate", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32),
                 ("a_dtype", C.c_int32), ("b_dtype", C.c_int32), ("c_dtype", C.c_int32), ("gate_dtype", C.c_int32),
-                ("colsum", C.c_void_p), ("drop_row_stride", C.c_int32), ("drop_row_off", C.c_int32)]
+                ("colsum", C.c_void_p), ("drop_row_stride", C.c_int32), ("drop_row_off", C.c_int32),
+                ("ln_mode", C.c_int32), ("ln_y_dtype", C.c_int32),
+                ("ln_a", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
+                ("ln_x", C.c_void_p), ("ln_dres", C.c_void_p), ("ln_da", C.c_void_p), ("ln_db", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):

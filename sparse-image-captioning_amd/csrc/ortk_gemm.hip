@@ -843,6 +843,286 @@ constexpr size_t DMA256_LDS_BYTES = (size_t)2 * 2 * 256 * HBK * sizeof(__bf16); 
 
 
 // ------------------------------------------------------------------------------------------------
+// 128 x 512 "row panel" tile (forward operand layout, N = 512 = d_model): the workgroup owns WHOLE rows of the output, so
+// the LayerNorm that follows the projection in the residual stream (forward: x' = x + dropout(proj), y = LN(x')) or that
+// the product is the output gradient of (backward: dy = dY W, dx = dLN/dx(dy) + residual gradient) runs in the epilogue,
+// on the accumulators, instead of as a second kernel that reads the (rows, 512) fp32 matrix back: 30 + 32 launches of an
+// XE step and the 44 + 34 MB round trip of each.  Same pipeline as the 256 x 256 kernel above: two stages of 64 columns
+// (A 16 KB + B 64 KB each: the whole 160 KB of LDS), 8 waves as 2 x 4, each 64 rows x 128 columns = 4 x 8 MFMA tiles; the
+// 10 DMA pieces a wave moves per stage are issued between the MFMA groups.  Row reductions: in-lane over the lane's 32
+// values of a row, two shuffles over the four lane groups, one LDS exchange over the four column waves.
+constexpr int RP_M = 128, RP_N = 512;
+constexpr int RP_IMG_A = RP_M * HBK, RP_IMG_B = RP_N * HBK;
+constexpr size_t RP_LDS_BYTES = (size_t)2 * (RP_IMG_A + RP_IMG_B) * sizeof(__bf16);   // 163 840
+
+// sum over the 16 lanes of a DPP row (the lanes that hold the same columns of 16 different rows); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+#define ORTK_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    ORTK_DPP_ADD(0xB1);     // quad_perm [1,0,3,2]
+    ORTK_DPP_ADD(0x4E);     // quad_perm [2,3,0,1]
+    ORTK_DPP_ADD(0x141);    // row_half_mirror: the other quad of the half row
+    ORTK_DPP_ADD(0x140);    // row_mirror: the other half row
+#undef ORTK_DPP_ADD
+    return v;
+}
+
+template <int MODE>     // 1: LayerNorm forward of the epilogue's result; 2: LayerNorm backward of the product
+__global__ __launch_bounds__(512, 1) void gemm_bf16_row512_kernel(ortk_gemm_args p, int, int, int) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int mb = blockIdx.x * RP_M;
+    const __bf16* Ap = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bp = reinterpret_cast<const __bf16*>(p.B);
+    const int T = p.K / HBK;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one 1-KB piece = 8 rows of 128 bytes of an [m][k] image (chunk' = chunk ^ ((row >> 1) & 7))
+    auto piece = [&](const __bf16* base, int64_t ld, int tile0, int k0, __bf16* img, int inst, int rmax) {
+        const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
+        const __bf16* g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
+    };
+    if (T > 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) piece(Ap, p.lda, mb, 0, smem16, wave * 2 + u, p.M - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) piece(Bp, p.ldb, 0, 0, smem16 + RP_IMG_A, wave * 8 + u, RP_N - 1);
+    }
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool next = t + 1 < T;
+        __bf16* nst = smem16 + (size_t)((t + 1) & 1) * (RP_IMG_A + RP_IMG_B);
+        const int nk0 = (t + 1) * HBK;
+        const __bf16* sA = smem16 + (size_t)(t & 1) * (RP_IMG_A + RP_IMG_B);
+        const __bf16* sB = sA + RP_IMG_A;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = gfrag64<false>(sB, wn * 128 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = gfrag64<false>(sA, wm * 64 + 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (next) {
+                    const int u = ks * 4 + i;                         // 0..7
+                    piece(Bp, p.ldb, 0, nk0, nst + RP_IMG_A, wave * 8 + u, RP_N - 1);
+                    if (u < 2) piece(Ap, p.lda, mb, nk0, nst, wave * 2 + u, p.M - 1);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // the stages become reduction scratch
+    // the epilogue's lane-derived addresses come from an opaque copy of the lane id: otherwise the compiler computes all
+    // ~100 of them before the K loop and spills them (131 registers)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int lr = lane_e & 15, lg = lane_e >> 4;
+    const int tid_e = wave * 64 + lane_e;
+    float* red0 = reinterpret_cast<float*>(smem16);    // [128 rows][4 column waves]
+    float* red1 = red0 + RP_M * 4;
+    float* colr = red1 + RP_M * 4;                     // [2 (da, db)][2 row waves][512]
+    const int row0 = mb + wm * 64 + lr;                // + 16 i
+    const int col0 = wn * 128 + 4 * lg;                // + 16 j (+ r)
+    // sum over the row's 512 columns of one value per (lane, i): lane groups by two shuffles, column waves through LDS
+    auto row_total = [&](float (&s)[4], float* red) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] += __shfl_xor(s[i], 16, 64);
+            s[i] += __shfl_xor(s[i], 32, 64);
+            if (lg == 0) red[(wm * 64 + 16 * i + lr) * 4 + wn] = s[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(red + (wm * 64 + 16 * i + lr) * 4);
+            s[i] = (q[0] + q[1]) + (q[2] + q[3]);
+        }
+    };
+    if (MODE == 1) {
+        const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+        const int drs = p.drop_row_stride > 0 ? p.drop_row_stride : 1;
+        f32x4 bias4[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // (optional operands: an unconditional load from memory that is readable in any case + a select — a uniform branch
+            // around the load makes the compiler wait for every load right after issuing it)
+            const f32x4 t_ = *reinterpret_cast<const f32x4*>((p.bias ? p.bias : p.ln_a) + col0 + 16 * j);
+            bias4[j] = p.bias ? t_ : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        float s[4], q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 16 * i, rowc = min(row, p.M - 1);
+            f32x4 res[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 t_ = *reinterpret_cast<const f32x4*>((p.resid ? p.resid + (int64_t)rowc * p.ldr : reinterpret_cast<const float*>(p.C) + (int64_t)rowc * p.ldc) + col0 + 16 * j);
+                res[j] = p.resid ? t_ : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            float si = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool kp[4] = {true, true, true, true};
+                if (p.drop_p > 0.f)
+                    ortk_keep4(p.drop_seed, ((uint64_t)rowc * (uint64_t)drs + (uint64_t)p.drop_row_off) * (uint64_t)RP_N + (col0 + 16 * j), p.drop_p, kp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r] + bias4[j][r];
+                    if (p.drop_p > 0.f) x = kp[r] ? x * inv_keep : 0.f;
+                    x += res[j][r];
+                    acc[i][j][r] = x;
+                    si += x;
+                }
+                if (row < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)row * p.ldc + col0 + 16 * j) = acc[i][j];
+            }
+            s[i] = si;
+        }
+        row_total(s, red0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] *= (1.f / RP_N);                      // mean
+            float qi = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float t_ = acc[i][j][r] - s[i]; qi += t_ * t_; }
+            q[i] = qi;
+        }
+        row_total(q, red1);
+        float rinv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sd = sqrtf(q[i] / (float)(RP_N - 1));
+            rinv[i] = 1.f / (sd + p.ln_eps);
+            const int row = row0 + 16 * i;
+            if (p.ln_stats && wn == 0 && lg == 0 && row < p.M) { p.ln_stats[(int64_t)row * 2] = s[i]; p.ln_stats[(int64_t)row * 2 + 1] = sd; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.ln_a + col0 + 16 * j);
+            const f32x4 gb = *reinterpret_cast<const f32x4*>(p.ln_b + col0 + 16 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 16 * i;
+                if (row >= p.M) continue;
+                float4 o;
+                o.x = ga[0] * (acc[i][j][0] - s[i]) * rinv[i] + gb[0];
+                o.y = ga[1] * (acc[i][j][1] - s[i]) * rinv[i] + gb[1];
+                o.z = ga[2] * (acc[i][j][2] - s[i]) * rinv[i] + gb[2];
+                o.w = ga[3] * (acc[i][j][3] - s[i]) * rinv[i] + gb[3];
+                st_elem4(p.ln_y, (int64_t)row * RP_N + col0 + 16 * j, p.ln_y_dtype, o);
+            }
+        }
+    } else {
+        // dy = acc.  With xc = x - mean, rr = 1 / (sd + eps), g = dy * a:  dx = rr (g - mean(g)) - rr^2 sum(g xc) xc / (511 sd) + dres;
+        // da += sum_rows dy xc rr, db += sum_rows dy  (ortk_norm.hip: ln_bwd_kernel, the same formulas)
+        float mean[4], sd[4], rr[4], vf[4], sg[4], sgx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rowc = min(row0 + 16 * i, p.M - 1);
+            mean[i] = p.ln_stats[(int64_t)rowc * 2]; sd[i] = p.ln_stats[(int64_t)rowc * 2 + 1];
+            rr[i] = 1.f / (sd[i] + p.ln_eps);
+            vf[i] = row0 + 16 * i < p.M ? 1.f : 0.f;
+        }
+        // four partial row sums per row (one per r): the same shape as the packed column sums, so that the compiler's pairing
+        // of the r's does not leave a scalar chain behind that keeps every product alive (148 spilled registers)
+        f32x4 sg4[4], sgx4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sg4[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; sgx4[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        // pass 1, two column tiles at a time: row sums of g and g xc (g replaces dy in the accumulators), column sums of the
+        // parameter gradients over the lane's 4 rows, then over the 16 rows of the wave's lane row by DPP
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            f32x4 xv[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    xv[i][jj] = *reinterpret_cast<const f32x4*>(p.ln_x + (int64_t)min(row0 + 16 * i, p.M - 1) * RP_N + col0 + 16 * (2 * jp + jj));
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(p.ln_a + col0 + 16 * j);
+                float pa[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // (rows past M only have to stay out of the column sums: vf = 0; their own results are never stored)
+                        const float dyv = acc[i][j][r];
+                        const float t_ = dyv * (xv[i][jj][r] - mean[i]);        // dy xc
+                        pa[r] += t_ * (rr[i] * vf[i]); pb[r] += dyv * vf[i];
+                        const float g = dyv * ga[r];
+                        acc[i][j][r] = g; sg4[i][r] += g; sgx4[i][r] += t_ * ga[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pa[r] = row16_sum(pa[r]); pb[r] = row16_sum(pb[r]); }
+                if (lr == 0) {
+                    *reinterpret_cast<f32x4*>(colr + wm * RP_N + col0 + 16 * j) = (f32x4){pa[0], pa[1], pa[2], pa[3]};
+                    *reinterpret_cast<f32x4*>(colr + 2 * RP_N + wm * RP_N + col0 + 16 * j) = (f32x4){pb[0], pb[1], pb[2], pb[3]};
+                }
+            }
+            // keep the batches apart: hoisting all 32 row loads of the pass to its top costs 131 spilled registers
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sg[i] = (sg4[i][0] + sg4[i][1]) + (sg4[i][2] + sg4[i][3]);
+            sgx[i] = (sgx4[i][0] + sgx4[i][1]) + (sgx4[i][2] + sgx4[i][3]);
+        }
+        row_total(sg, red0);
+        row_total(sgx, red1);          // (its barrier also publishes the column sums)
+        {
+            atomicAdd(p.ln_da + tid_e, colr[tid_e] + colr[RP_N + tid_e]);
+            atomicAdd(p.ln_db + tid_e, colr[2 * RP_N + tid_e] + colr[3 * RP_N + tid_e]);
+        }
+        const float ik = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 16 * i, rowc = min(row, p.M - 1);
+            const float mg = sg[i] * (1.f / RP_N);
+            const float coef = rr[i] * rr[i] * sgx[i] / ((float)(RP_N - 1) * sd[i]);
+            f32x4 xv[8], dr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xv[j] = *reinterpret_cast<const f32x4*>(p.ln_x + (int64_t)rowc * RP_N + col0 + 16 * j);
+                const f32x4 t_ = *reinterpret_cast<const f32x4*>((p.ln_dres ? p.ln_dres : p.ln_x) + (int64_t)rowc * RP_N + col0 + 16 * j);
+                dr[j] = p.ln_dres ? t_ : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (row < p.M)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = rr[i] * (acc[i][j][r] - mg) - coef * (xv[j][r] - mean[i]) + dr[j][r];
+                const int64_t i0 = (int64_t)row * RP_N + col0 + 16 * j;
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + i0) = o;
+                if (p.ln_y) {
+                    bool kp[4] = {true, true, true, true};
+                    if (p.drop_p > 0.f) ortk_keep4(p.drop_seed, (uint64_t)i0, p.drop_p, kp);
+                    st_elem4(p.ln_y, i0, p.ln_y_dtype, make_float4(kp[0] ? o[0] * ik : 0.f, kp[1] ? o[1] * ik : 0.f, kp[2] ? o[2] * ik : 0.f, kp[3] ? o[3] * ik : 0.f));
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 64 x 64 tile, 64-column K-steps, forward layout only, for SHORT grids: the decode-time projections (rows = images x
 // beams, a few thousand at most) give the 128 x 128 kernels 48-640 workgroups, so most CUs idle or the last round is
 // nearly empty, and every workgroup walks its K panel as a chain of fetch round trips.  Four times as many workgroups
@@ -1030,6 +1310,46 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     if (p.accumulate && p.c_dtype) return ORTK_EINVAL;                   // accumulation targets the fp32 gradient arena
     if (p.transA && !p.transB) return ORTK_EINVAL;                       // layout not needed by the path
     if (p.colsum && !(p.precision && p.transA)) return ORTK_EINVAL;      // fused column sums: bf16-MFMA wgrad layout only
+    if (p.ln_mode) {
+        // LayerNorm fused into the epilogue (forward: of the result; backward: the product is the LayerNorm's output gradient)
+        if (p.ln_mode < 1 || p.ln_mode > 2 || p.c_dtype != ORTK_F32 || p.ldc != p.N || p.accumulate || p.transA || p.gate || p.rowscale ||
+            p.N < 2 || p.N > 2048 || !p.ln_a || !p.ln_stats) return ORTK_EINVAL;
+        if (p.ln_mode == 1 && (!p.ln_b || !p.ln_y)) return ORTK_EINVAL;
+        if (p.ln_mode == 2 && (!p.ln_x || !p.ln_da || !p.ln_db || p.bias || p.resid || p.relu)) return ORTK_EINVAL;
+        auto al = [](const void* q, size_t a_) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) % a_) == 0; };
+        const bool fused = p.precision && !p.transB && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.N == RP_N && p.K > 0 &&
+                           p.K % HBK == 0 && !p.relu && al(p.A, 16) && al(p.B, 16) && (p.lda % 8) == 0 && (p.ldb % 8) == 0 && al(p.C, 16) &&
+                           al(p.bias, 16) && al(p.resid, 16) && (p.ldr % 4) == 0 && al(p.ln_a, 16) && al(p.ln_b, 16) && al(p.ln_y, 16) &&
+                           al(p.ln_x, 16) && al(p.ln_dres, 16);
+        if (!fused) {
+            // any other shape / precision: the same result from the separate kernels
+            ortk_gemm_args q = p; q.ln_mode = 0;
+            if (p.ln_mode == 2) q.drop_p = 0.f;
+            if (int e = ortk_gemm(&q, stream)) return e;
+            float* Cf = reinterpret_cast<float*>(p.C);
+            if (p.ln_mode == 1) return ortk_layernorm_fwd(Cf, p.ln_a, p.ln_b, p.ln_y, p.ln_y_dtype, p.ln_stats, p.M, p.N, p.ln_eps, stream);
+            return ortk_layernorm_bwd_drop(Cf, p.ln_x, p.ln_a, p.ln_stats, p.ln_dres, Cf, p.ln_da, p.ln_db, p.M, p.N, p.ln_eps,
+                                           p.ln_y, p.ln_y_dtype, p.drop_p, p.drop_seed, stream);
+        }
+        gemm16_fn g = p.ln_mode == 1 ? gemm_bf16_row512_kernel<1> : gemm_bf16_row512_kernel<2>;
+        static bool rp_attr[2] = {false, false};
+        if (!rp_attr[p.ln_mode - 1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RP_LDS_BYTES);
+            rp_attr[p.ln_mode - 1] = true;
+        }
+        hipStream_t s = ortk_s(stream);
+        ProfRec rec{};
+        if (g_prof_on) {
+            if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return ORTK_EINVAL;
+            rec.key = 4; rec.flops = 2.0 * p.M * p.N * p.K;
+            rec.bytes = (double)p.M * p.K * 2 + (double)p.N * p.K * 2 + (double)p.M * p.N * (4 + 4 + 2 + (p.ln_mode == 2 ? 8 : 0));
+            (void)hipEventRecord(rec.a, s);
+        }
+        hipLaunchKernelGGL(g, dim3((unsigned)ortk_cdiv(p.M, RP_M)), dim3(512), RP_LDS_BYTES, s, p, 0, 0, 0);
+        if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
+        ORTK_CHECK_LAUNCH();
+        return 0;
+    }
     const int tilesM = (int)ortk_cdiv(p.M, BM), tilesN = (int)ortk_cdiv(p.N, BN);
     const int bk = p.precision ? BK16 : 16;
     int splitk = p.accumulate ? (p.splitk > 0 ? p.splitk : 1) : 1;
@@ -1084,11 +1404,13 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         // Measured with bias + residual epilogues (scratch/gemm_t64.py, us, 128^2/256^2 kernels -> 64^2): 1536x512x512 16.4 -> 7.9,
         // 1536x512x2048 33.3 -> 15.6, 5120x512x512 16.8 -> 10.5, 5120x512x2048 35.9 -> 23.4, 5120x2048x512 31.4 -> 29.1,
         // 9216x512x512 23.3 -> 17.6; past ~640 big tiles or with the generator's N = 10240 the small tiles lose (5120x10240x512
-        // 163 -> 178, 21760x1536x512 87 -> 106).
+        // 163 -> 178, 21760x1536x512 87 -> 106).  Decode-sized row counts only (M <= 6 144): inside the training step, beside
+        // the side stream's weight gradients, the 9 216- and 16 640-row projections are faster on the big tiles (XE step
+        // 12.67 ms with them on the 64 x 64 tiles, 12.51 without).
         static int t64 = -2;    // ORTK_GEMM_T64: use them while the 128 x 128 grid has at most this many workgroups (-1 = never)
         if (t64 == -2) { const char* ev = getenv("ORTK_GEMM_T64"); t64 = ev ? atoi(ev) : 640; }
         if (fast4 && impl != 1 && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.K % HBK == 0 &&
-            p.drop_p == 0.f && !p.gate && !p.rowscale && (int64_t)tilesM * tilesN <= t64 && p.N <= 2048) {
+            p.drop_p == 0.f && !p.gate && !p.rowscale && (int64_t)tilesM * tilesN <= t64 && p.N <= 2048 && p.M <= 6144) {
             const int tm = (int)ortk_cdiv(p.M, 64), tn = p.N / 64;
             const bool one = (int64_t)tm * tn <= 256 + 64;          // one workgroup per CU: the whole K = 512 panel in flight
             gemm16_fn g = one ? gemm_bf16_dma64_kernel<8> : gemm_bf16_dma64_kernel<3>;    // else three per CU
@@ -1111,7 +1433,10 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             // last round (170 blocks: 29.6 vs 33.7 us; 510: 58 vs 72 us) and loses on short grids (72 blocks: 26 vs 17 us;
             // 288 blocks = 1.1 rounds: 50 vs 44 us)
             const int64_t rounds = (big_blocks + 255) / 256;
-            const bool fills = big_blocks * 10 >= rounds * 256 * 6;
+            // In the training step the threshold is 50 %: the 130-tile launches of the valid-position decoder (16 640 x 512) leave
+            // the other half of the chip to the weight-gradient GEMM of the side stream (XE step 12.47 -> 12.10 ms; 40 % and
+            // 30 % measure the same)
+            const bool fills = big_blocks * 10 >= rounds * 256 * 5;
             const bool big = !p.accumulate && (p.M % 256 == 0 || fast4) && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
             // 8-deep ring for grids of at most one workgroup per CU (decode-time projections): measured SLOWER in the
             // 1024-image decode (36.9 vs 35.8 ms) -> experiment only (ORTK_GEMM_IMPL=5)

@@ -510,8 +510,25 @@ struct EncPtrs { void* y1; void* qkv; float* P; void* o; float* xm; void* y2; vo
 
 // encoder stack; `bufs[l]` may alias between layers when nothing has to be kept for a backward pass.
 // `mem` receives the final LayerNorm in dtype `mem_dt`.
+// the geometry bias of all encoder layers (depends on the boxes and the fp32 WG weights only), on the side stream when there is one
+static int queue_box_bias(const Ctx& c, const Offsets& o, const float* boxes, float* logbias, int B, int S, hipEvent_t* done) {
+    const ortk_config& cfg = *c.cfg;
+    const int L = cfg.n_layers, H = cfg.n_heads;
+    const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS];
+    for (int l = 0; l < L; ++l) { wg[l] = c.P + o.enc[l].wg; bg[l] = c.P + o.enc[l].bg; }
+    *done = nullptr;
+    if (c.use_side) {
+        TRY(c.fork());
+        TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.side->s));
+        return c.side_mark(done);
+    }
+    return ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s);
+}
+
+// `box_queued`: the caller has already queued the geometry bias (queue_box_bias; *box_queued = its completion event or NULL)
 static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, const float* boxes, const float* masks, int B, int S,
-                           float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem, int qdt = ORTK_F32) {
+                           float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem, int qdt = ORTK_F32,
+                           const hipEvent_t* box_queued = nullptr) {
     const ortk_config& cfg = *c.cfg;
     const float* P = c.P;
     const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H, A = c.adt;
@@ -519,18 +536,14 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     // att_embed: relu(Linear) on valid regions, zeros elsewhere, dropout (relation_transformer.py:331-333,349-350)
     // (the plain `transformer` embeds every row, padded regions included: transformer.py:627-629)
     const bool plain = cfg.no_box != 0;
-    const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS];
-    for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; }
     // the geometry bias only depends on the boxes and WG: queued first, beside att_embed / the first LayerNorm and QKV projection
     hipEvent_t box_done = nullptr;
     if (plain) {
         // no geometry bias
-    } else if (c.use_side) {
-        TRY(c.fork());
-        TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.side->s));
-        TRY(c.side_mark(&box_done));
+    } else if (box_queued) {
+        box_done = *box_queued;
     } else {
-        TRY(ortk_box_logbias_fwd(boxes, wg, bg, cfg.box_trig ? dim_mat() : nullptr, logbias, L, B, S, H, (ortk_stream)c.s));
+        TRY(queue_box_bias(c, o, boxes, logbias, B, S, &box_done));
     }
     TRY(fwd_gemm(c, feats, ORTK_F32, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
                  nullptr, 0, plain ? nullptr : masks));
@@ -655,9 +668,23 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     if (logp_out && (ldv_out < cfg->vocab)) return ORTK_EINVAL;
-    TRY(make_w16(cfg, o, params, w.w16, stream));
-    TRY(make_w16t(cfg, o, params, w.w16t, stream));      // read by the backward that follows this forward
     Ctx c{cfg, ortk_s(stream), cfg->precision, seed, train != 0, params, w.w16, w.adt};
+    c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
+    c.use_side = c.side != nullptr;
+    // The geometry bias reads the fp32 parameters: with the side stream it starts BEFORE the bf16 weight copies are made
+    // (0.14 ms of casts it used to wait behind; the encoder's first attention then waited for it), and the transposed copy,
+    // which only the backward reads, is made on the side stream behind it.
+    hipEvent_t box_done = nullptr;
+    const bool box_early = c.use_side && !cfg->no_box;
+    if (box_early) TRY(queue_box_bias(c, o, bt->boxes, w.logbias, bt->B, bt->S, &box_done));
+    TRY(make_w16(cfg, o, params, w.w16, stream));
+    if (c.use_side) {
+        if (!box_early) TRY(c.fork());      // (the previous backward on the caller's stream still reads the old copy)
+        TRY(make_w16t(cfg, o, params, w.w16t, (ortk_stream)c.side->s));     // done before the decoder prefix the forward waits for
+        TRY(c.side_mark(nullptr));
+    } else {
+        TRY(make_w16t(cfg, o, params, w.w16t, stream));      // read by the backward that follows this forward
+    }
     // sparse plans are rebuilt from THIS call's effective weights (a new mask sample per step): no stale images
     if (cfg->sparse_fwd) {
         TRY(ortk_sparse_build(cfg->sparse_fwd, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
@@ -670,8 +697,6 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     if (compact && (logp_out || !w.qdt_self || !w.qdt_cross)) return ORTK_EINVAL;     // fused criterion + bf16-operand attention only
     const int64_t Me = w.Me, Md = compact ? bt->Mc : w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
-    c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
-    c.use_side = c.side != nullptr;
     const AttMode am = att_mode(cfg->share_att_dec);
     const int64_t cw = o.cw, cv = o.cv;
     // Self-attention sublayer (and the cross-attention query projection) of decoder layer l, on context `cx`'s stream.
@@ -697,7 +722,8 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     if (c.use_side) {
         TRY(c.fork());                     // the side stream sees the bf16 weight copy
     }
-    TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc));
+    TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc,
+                        box_early ? &box_done : nullptr));
     {
         const Ctx cx = c.use_side ? c.on_side() : c;
         TRY(embed_fwd_rows(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, Md, compact ? bt->row_pos : nullptr, T, 0, d,
@@ -904,6 +930,24 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     }
     if (phase == 1) return 0;
     // ---- encoder half (reads the memory gradient left in w.gy)
+    // Gradient of the geometry-bias weights of layers [l0, l0 + n): only feeds the optimizer.  With the side stream the
+    // layers 1 .. L-1 go as soon as layer 1's attention backward has written their score gradients — one 0.36 ms VALU
+    // kernel for all layers at the very end of the step had the att_embed weight gradient as its only company (the
+    // embedding's sin / cos are then evaluated twice: 2 x 0.08 ms of side-stream time against 0.25 ms of exposed tail).
+    const bool box_split = c.use_side && !cfg->no_box && L > 2;
+    auto box_grad = [&](int l0, int n) -> int {
+        const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS]; float* dwg[MAXLAYERS]; float* dbg[MAXLAYERS];
+        for (int l = 0; l < n; ++l) {
+            wg[l] = params + o.enc[l0 + l].wg; bg[l] = params + o.enc[l0 + l].bg; dwg[l] = G + o.enc[l0 + l].wg; dbg[l] = G + o.enc[l0 + l].bg;
+        }
+        const float* ds = w.dscore + (int64_t)l0 * B * H * S * S;
+        if (c.use_side) {
+            TRY(c.fork());
+            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, ds, dwg, dbg, n, B, S, H, (ortk_stream)c.side->s));
+            return c.side_mark(nullptr);
+        }
+        return ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, ds, dwg, dbg, n, B, S, H, stream);
+    };
     dx = w.ga; dx2 = w.gb;
     TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me, gt_new(), eop(L - 1, 3)));
     for (int l = L - 1; l >= 0; --l) {
@@ -929,25 +973,14 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.dscore = cfg->no_box ? nullptr : w.dscore + (int64_t)l * B * H * S * S;
         TRY(c.before_write(w.gqkv));
         TRY(ortk_attention_bwd(&a, stream));
+        if (l == 1 && box_split) TRY(box_grad(1, L - 1));     // layers 1 .. L-1: beside the last two encoder layers
         TRY(fold(ame, Me));
         TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, ame.n * d, d));
         TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, ame.n * d, d));
         TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, gt_new(), l > 0 ? (int)eop(l - 1, 3) : -1));
     }
-    // geometry bias weights
-    if (!cfg->no_box) {
-        const float* P = params;
-        const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS]; float* dwg[MAXLAYERS]; float* dbg[MAXLAYERS];
-        for (int l = 0; l < L; ++l) { wg[l] = P + o.enc[l].wg; bg[l] = P + o.enc[l].bg; dwg[l] = G + o.enc[l].wg; dbg[l] = G + o.enc[l].bg; }
-        // only feeds the optimizer: beside the att_embed gradient
-        if (c.use_side) {
-            TRY(c.fork());
-            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, (ortk_stream)c.side->s));
-            TRY(c.side_mark(nullptr));
-        } else {
-            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, w.dscore, dwg, dbg, L, B, S, H, stream));
-        }
-    }
+    // geometry bias weights: layer 0 (with the side stream; else all layers), beside the att_embed gradient
+    if (!cfg->no_box) TRY(box_grad(0, box_split ? 1 : L));
     // att_embed: x0 = dropout(relu(.) * mask)  ->  d(pre-activation) = dx * [x0 > 0] / (1 - p_src)
     TRY(c.before_write(gt_new()));
     TRY(ortk_gate_apply(dx, w.x0, gt_cur, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));

@@ -781,3 +781,72 @@ def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
         gemm(L, At16, Bt16, M, N, K, 1, 1, 1, a_dtype=1, b_dtype=1, C=Cacc, accumulate=1, splitk=sk, colsum=csum)
         assert (Cacc.cpu().double() - 1 - ref).abs().max().item() < 1e-3 * sc
         torch.testing.assert_close(csum.cpu(), 2 + At16.float().cpu().sum(0), rtol=1e-3, atol=1e-2)
+
+
+def _ln_gemm_inputs(M, K, seed):
+    A = rnd(M, K, seed=seed).bfloat16()
+    W = rnd(512, K, seed=seed + 1, scale=K ** -0.5).bfloat16()
+    return A, W
+
+
+@pytest.mark.parametrize("M,K,p", [(16640, 512, 0.1), (1000, 2048, 0.0), (129, 64, 0.1), (77, 512, 0.0)])
+def test_gemm_with_fused_layernorm_forward(L, M, K, p):
+    """ortk_gemm(ln_mode = 1) — projection + residual + the next sublayer's LayerNorm in one launch (the 128 x 512 row-panel
+    kernel) — against the same call without ln_mode followed by ortk_layernorm_fwd.  The GEMM result is the same MFMA
+    arithmetic in a different accumulation order (1e-5 of the scale); the LayerNorm is fp32 on that result."""
+    A, W = _ln_gemm_inputs(M, K, 20)
+    bias, res, ga, gb = rnd(512, seed=22), rnd(M, 512, seed=23), 1 + 0.1 * rnd(512, seed=24), 0.1 * rnd(512, seed=25)
+    kw = dict(a_dtype=1, b_dtype=1, bias=dev(bias), resid=dev(res), drop_p=p, drop_seed=77)
+    Ad, Wd = dev(A), dev(W)
+    c_ref = gemm(L, Ad, Wd, M, 512, K, 0, 0, 1, **kw)
+    y_ref = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16); st_ref = torch.empty(M, 2, device="cuda")
+    gad, gbd = dev(ga), dev(gb)
+    L.check(L.lib().ortk_layernorm_fwd(L.ptr(c_ref), L.ptr(gad), L.ptr(gbd), L.ptr(y_ref), 1, L.ptr(st_ref), M, 512, 1e-6, L.stream_ptr()), "ln")
+    y = torch.full((M, 512), float("nan"), device="cuda", dtype=torch.bfloat16); st = torch.full((M, 2), float("nan"), device="cuda")
+    c = gemm(L, Ad, Wd, M, 512, K, 0, 0, 1, ln_mode=1, ln_y_dtype=1, ln_a=gad, ln_b=gbd, ln_y=y, ln_stats=st, ln_eps=1e-6, **kw)
+    torch.cuda.synchronize()
+    scale = c_ref.abs().max().item()
+    assert (c - c_ref).abs().max().item() <= 1e-5 * scale
+    assert (c == 0).float().mean().item() == pytest.approx((c_ref == 0).float().mean().item(), abs=1e-6)     # same dropout draws
+    torch.testing.assert_close(st, st_ref, rtol=1e-5, atol=1e-5)
+    assert (y.float() - y_ref.float()).abs().max().item() <= 2 ** -7 * y_ref.float().abs().max().item()      # one bf16 ulp at the top
+
+
+@pytest.mark.parametrize("M,K,p,with_res", [(16640, 512, 0.1, True), (1000, 2048, 0.0, True), (129, 64, 0.1, False), (77, 1536, 0.0, True)])
+def test_gemm_with_fused_layernorm_backward(L, M, K, p, with_res):
+    """ortk_gemm(ln_mode = 2) — data-gradient product + LayerNorm backward + residual-gradient add + the masked bf16 copy —
+    against ortk_gemm followed by ortk_layernorm_bwd_drop."""
+    A, W = _ln_gemm_inputs(M, K, 30)
+    x, ga, gb, dres = rnd(M, 512, seed=32), 1 + 0.1 * rnd(512, seed=33), 0.1 * rnd(512, seed=34), rnd(M, 512, seed=35)
+    xd, gad, gbd, rd = dev(x), dev(ga), dev(gb), dev(dres)
+    y = torch.empty(M, 512, device="cuda"); st = torch.empty(M, 2, device="cuda")
+    L.check(L.lib().ortk_layernorm_fwd(L.ptr(xd), L.ptr(gad), L.ptr(gbd), L.ptr(y), 0, L.ptr(st), M, 512, 1e-6, L.stream_ptr()), "ln")
+    Ad, Wd = dev(A), dev(W)
+    dy = gemm(L, Ad, Wd, M, 512, K, 0, 0, 1, a_dtype=1, b_dtype=1)
+    dx_ref = torch.empty(M, 512, device="cuda"); dz_ref = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+    da_ref = torch.zeros(512, device="cuda"); db_ref = torch.zeros(512, device="cuda")
+    L.check(L.lib().ortk_layernorm_bwd_drop(L.ptr(dy), L.ptr(xd), L.ptr(gad), L.ptr(st), L.ptr(rd) if with_res else None, L.ptr(dx_ref),
+                                            L.ptr(da_ref), L.ptr(db_ref), M, 512, 1e-6, L.ptr(dz_ref), 1, p, 99, L.stream_ptr()), "lnb")
+    dz = torch.full((M, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
+    da = torch.zeros(512, device="cuda"); db = torch.zeros(512, device="cuda")
+    kw = dict(ln_dres=rd) if with_res else {}
+    dx = gemm(L, Ad, Wd, M, 512, K, 0, 0, 1, a_dtype=1, b_dtype=1, ln_mode=2, ln_y_dtype=1, ln_a=gad, ln_y=dz, ln_stats=st, ln_eps=1e-6,
+              ln_x=xd, ln_da=da, ln_db=db, drop_p=p, drop_seed=99, **kw)
+    torch.cuda.synchronize()
+    s = dx_ref.abs().max().item()
+    assert (dx - dx_ref).abs().max().item() <= 2e-5 * s
+    assert (dz.float() - dz_ref.float()).abs().max().item() <= 2 ** -7 * dz_ref.float().abs().max().item()
+    assert ((dz == 0) == (dz_ref == 0)).float().mean().item() > 1 - 1e-5
+    torch.testing.assert_close(da, da_ref, rtol=1e-4, atol=1e-4 * da_ref.abs().max().item())
+    torch.testing.assert_close(db, db_ref, rtol=1e-4, atol=1e-4 * db_ref.abs().max().item())
+
+
+def test_gemm_fused_layernorm_fallback_shapes(L):
+    """Shapes the row-panel kernel does not take (N != 512, fp32 operands) give the same results through the separate kernels."""
+    M, N, K = 50, 96, 80
+    A, W, ga, gb = rnd(M, K, seed=40), rnd(N, K, seed=41), 1 + 0.1 * rnd(N, seed=42), 0.1 * rnd(N, seed=43)
+    y = torch.empty(M, N, device="cuda"); st = torch.empty(M, 2, device="cuda")
+    c = gemm(L, dev(A), dev(W), M, N, K, ln_mode=1, ln_y_dtype=0, ln_a=dev(ga), ln_b=dev(gb), ln_y=y, ln_stats=st, ln_eps=1e-6)
+    ref = A @ W.t()
+    torch.testing.assert_close(c.cpu(), ref, rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(y.cpu(), O.layer_norm(ref, ga, gb), rtol=1e-4, atol=1e-4)
