@@ -455,6 +455,10 @@ int ortk_sum(const float* x, int64_t n, float* out_dev, ortk_stream stream);  /*
  * bc1 = 1-beta1^t, bc2 = 1-beta2^t computed by the host in double precision. */
 int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float clip, float bc1, float bc2, ortk_stream stream);
+/* The same update; the gradient is cleared on the way (`optimizer.zero_grad()` of scripts/train_transformer.py:66 without its
+ * own pass over the arena: the next step's weight-gradient GEMMs accumulate into zeros). */
+int ortk_adam_clip_zero(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float clip, float bc1, float bc2, ortk_stream stream);
 
 /* MaskMixin.get_masked_weight over the whole arena (pruning/masked_layer.py:84-110, pruning/sampler.py):
  *   mode 0: s = round(sigmoid(m))  (supermask, eval)      mode 1: s = bernoulli(sigmoid(m)) (supermask, train)

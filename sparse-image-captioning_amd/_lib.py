@@ -151,6 +151,7 @@ SIGNATURES = {
     "ortk_fill": (_I32, [_P, _I64, _F, _P]),
     "ortk_sum": (_I32, [_P, _I64, _P, _P]),
     "ortk_adam_clip": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "ortk_adam_clip_zero": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P]),
     "ortk_mask_apply": (_I32, [_P, _P, _P, _I64, _I32, _U32, _P]),
     "ortk_mask_bwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _U32, _P, _P]),
     "ortk_mask_count": (_I32, [_P, _I64, _I32, _P, _P]),

@@ -9,7 +9,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// ZERO: the gradient is cleared on the way (the next step accumulates into it: no separate fill pass over the arena)
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, float step_size, float b1, float b2,
                                                         float eps, float clip, float sqrt_bc2) {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -29,6 +31,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (ZERO) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float gc = fminf(fmaxf(g[i], -clip), clip);
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
         const float vi = v[i] * b2 + gc * gc * (1.f - b2);
         m[i] = mi; v[i] = vi;
         p[i] = p[i] - step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+        if (ZERO) g[i] = 0.f;
     }
 }
 
@@ -93,18 +97,28 @@ inline unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>(ortk_cdi
 
 }  // namespace
 
-extern "C" int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                              float eps, float clip, float bc1, float bc2, ortk_stream stream) {
+static int adam_clip_launch(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float clip,
+                            float bc1, float bc2, bool zero, ortk_stream stream) {
     if (!p || !g || !m || !v || n < 0 || bc1 <= 0.f || bc2 <= 0.f) return ORTK_EINVAL;
     if (n == 0) return 0;
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (!(al(p) && al(g) && al(m) && al(v))) return ORTK_EINVAL;
     const float step_size = lr / bc1;
     const float sqrt_bc2 = (float)sqrt((double)bc2);
-    hipLaunchKernelGGL(adam_clip_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ortk_s(stream), p, g, m, v, n, step_size, beta1,
-                       beta2, eps, clip, sqrt_bc2);
+    if (zero) hipLaunchKernelGGL(adam_clip_kernel<true>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ortk_s(stream), p, g, m, v, n, step_size,
+                                 beta1, beta2, eps, clip, sqrt_bc2);
+    else      hipLaunchKernelGGL(adam_clip_kernel<false>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ortk_s(stream), p, g, m, v, n, step_size,
+                                 beta1, beta2, eps, clip, sqrt_bc2);
     ORTK_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int ortk_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float clip, float bc1, float bc2, ortk_stream stream) {
+    return adam_clip_launch(p, const_cast<float*>(g), m, v, n, lr, beta1, beta2, eps, clip, bc1, bc2, false, stream);
+}
+extern "C" int ortk_adam_clip_zero(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                   float eps, float clip, float bc1, float bc2, ortk_stream stream) {
+    return adam_clip_launch(p, g, m, v, n, lr, beta1, beta2, eps, clip, bc1, bc2, true, stream);
 }
 
 extern "C" int ortk_mask_apply(const float* w, const float* m, float* w_eff, int64_t n, int32_t mode, uint32_t seed,

@@ -28,7 +28,7 @@ def noam_rate(step, d_model, factor, warmup):
 class NativeTrainer:
     def __init__(self, model, noamopt_factor=1.0, noamopt_warmup=20000, grad_clip=0.1, betas=(0.9, 0.98), eps=1e-9,
                  prune_supermask_lr=100.0, mask_eps=1e-2, sparsity_target=None, sparsity_weight=None, max_train_step=1,
-                 overlap_allreduce=None):
+                 overlap_allreduce=None, keep_grads=False):
         L.require_gpu()
         self.model = model
         self.dev = model._flat.device
@@ -74,6 +74,15 @@ class NativeTrainer:
         self.valid_positions = True        # use data["cap_len"] when the batch has it (mixed precision)
         self._dec_off = int(L.lib().ortk_arena_decoder_offset(C.byref(model._ccfg)))
         self._pending = None
+        # One process, dense model: the decoder half of the arena (64 % of the parameters) takes its Adam update on a second
+        # stream as soon as the decoder half of the backward has finished, beside the encoder half (clip_grad_value_ is
+        # element-wise, so the split is exact); the gradient arena is cleared by the update itself (ortk_adam_clip_zero).
+        self.early_adam = self.world == 1 and not self.masked and self._dec_off % 4 == 0 and 0 < self._dec_off < self.grads.numel()
+        self._opt_stream = None
+        self._grads_clean = False
+        # keep_grads: `self.grads` still holds the step's gradient after the step (tests, diagnostics); default: the update
+        # clears it on the way and the next step skips its zero-fill
+        self.keep_grads = bool(keep_grads)
         # sparse training plans (enable_sparse_kernels(train=True)): the images are rebuilt from every step's mask sample; a
         # block denser than its reserved capacity would silently lose weights, so the sticky device flag is read (host sync)
         # after the first step and then every `overflow_check_every` steps, and a hit raises
@@ -87,8 +96,9 @@ class NativeTrainer:
         # decoder to the valid positions only (ortk_batch.cap_off / row_pos); the collate function provides it
         return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight, m.valid_position_tables(data) if self.valid_positions else None)
 
-    def _fwd_bwd(self, batch, norm, train=True, seed=None):
-        """forward + fused criterion + backward into self.grads; returns the seed the dropout / mask draws used."""
+    def _fwd_bwd(self, batch, norm, train=True, seed=None, after_decoder_half=None):
+        """forward + fused criterion + backward into self.grads; returns the seed the dropout / mask draws used.
+        `after_decoder_half()`: called between the two backward phases (every gradient at offsets >= _dec_off is final)."""
         m, lib = self.model, L.lib()
         if seed is None:
             seed = m._next_seed() if train else 0
@@ -100,12 +110,14 @@ class NativeTrainer:
                                  L.stream_ptr()), "ortk_forward")
         L.check(lib.ortk_loss(C.byref(m._ccfg), C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(norm), L.ptr(self.loss_dev),
                               L.stream_ptr()), "ortk_loss")
-        if self.overlap:
+        if self.overlap or after_decoder_half is not None:
             for phase in (1, 2):
                 L.check(lib.ortk_backward_phase(C.byref(m._ccfg), pptr, L.ptr(self.grads), C.byref(batch), L.ptr(ws), ws.numel(),
                                                 int(train), seed, phase, L.stream_ptr()), "ortk_backward_phase")
-                if phase == 1:      # the collective waits for the work queued so far, then runs beside phase 2
+                if phase == 1 and self.overlap:      # the collective waits for the work queued so far, then runs beside phase 2
                     self._pending = parallel.allreduce_async(self.grads[self._dec_off:])
+                if phase == 1 and after_decoder_half is not None:
+                    after_decoder_half()
         else:
             L.check(lib.ortk_backward(C.byref(m._ccfg), pptr, L.ptr(self.grads), C.byref(batch), L.ptr(ws), ws.numel(), int(train),
                                       seed, L.stream_ptr()), "ortk_backward")
@@ -122,11 +134,12 @@ class NativeTrainer:
             return
         parallel.allreduce_arena(self.grads, self.dm if (self.masked and self.train_masks) else None)
 
-    def _adam(self, p, g, m, v, lr, eps):
+    def _adam(self, p, g, m, v, lr, eps, zero=False):
         t = self.step_count
         b1, b2 = self.betas
-        L.check(L.lib().ortk_adam_clip(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, self.clip,
-                                       1.0 - b1 ** t, 1.0 - b2 ** t, L.stream_ptr()), "ortk_adam_clip")
+        fn = L.lib().ortk_adam_clip_zero if zero else L.lib().ortk_adam_clip
+        L.check(fn(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, self.clip,
+                   1.0 - b1 ** t, 1.0 - b2 ** t, L.stream_ptr()), "ortk_adam_clip")
 
     def rate(self):
         return noam_rate(max(self.step_count, 1), self.model.d_model, self.factor, self.warmup)
@@ -219,16 +232,34 @@ class NativeTrainer:
     def _step(self, data, tok_weight, norm_mask, train, seed=None):
         m = self.model
         self.step_count += 1
-        self.grads.zero_()
+        if not self._grads_clean:
+            self.grads.zero_()
+        self._grads_clean = False
         L.check(L.lib().ortk_sum(L.ptr(norm_mask.contiguous()), norm_mask.numel(), L.ptr(self.norm_dev), L.stream_ptr()), "ortk_sum")
         parallel.reduce_scalar_sum(self.norm_dev)   # LanguageModelCriterion semantics over the GLOBAL batch
         batch = self._batch(data, tok_weight)
-        seed = self._fwd_bwd(batch, self.norm_dev, train, seed)
+        lr = self.rate()
+        early = None
+        if self.early_adam:
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream()
+            d0 = self._dec_off
+
+            def early():
+                cur = torch.cuda.current_stream()
+                self._opt_stream.wait_stream(cur)
+                with torch.cuda.stream(self._opt_stream):
+                    self._adam(m._flat[d0:m._n_train], self.grads[d0:], self.m[d0:], self.v[d0:], lr, self.eps, zero=not self.keep_grads)
+        seed = self._fwd_bwd(batch, self.norm_dev, train, seed, after_decoder_half=early)
         loss = self.loss_dev.clone()
         if getattr(m, "_sparse_train", False) and (self.step_count == 1 or self.step_count % self.overflow_check_every == 0):
             m.check_sparse_overflow()
         parallel.reduce_scalar_sum(loss)            # every rank's partial is already divided by the GLOBAL normaliser
-        lr = self.rate()
+        if early is not None:
+            self._adam(m._flat[:d0], self.grads[:d0], self.m[:d0], self.v[:d0], lr, self.eps, zero=not self.keep_grads)
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._grads_clean = not self.keep_grads
+            return loss
         if self.masked:
             coef = None
             if self.train_masks:
@@ -252,7 +283,8 @@ class NativeTrainer:
             if self.train_masks and self.mask_active is not None:
                 self.dm.mul_(self.mask_active)
         self._allreduce()
-        self._adam(m._flat[:m._n_train], self.grads, self.m, self.v, lr, self.eps)
+        self._adam(m._flat[:m._n_train], self.grads, self.m, self.v, lr, self.eps, zero=not self.keep_grads)
+        self._grads_clean = not self.keep_grads
         if self.masked and self.train_masks:
             # second param group of train_n_prune_transformer.py:67-82: lr = prune_supermask_lr (not Noam), eps 1e-2
             self._adam(m._mask_flat, self.dm, self.mm, self.mv, self.mask_lr, self.mask_eps)

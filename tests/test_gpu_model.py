@@ -492,7 +492,7 @@ def test_native_scst_step_vs_oracle(P, g1):
     refs = [[[int(t) for t in rs.randint(4, 60, size=rs.randint(5, 12))] for _ in range(3)] for _ in range(N)]
     scorer = CaptionScorer("corpus", cider_weight=1.0, bleu_weight=[0.0, 0.0, 0.0, 0.5])
     reward_fn = NativeTrainer.scorer_reward_fn(scorer, refs, eos_idx=C.EOS, pad_idx=0)
-    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=10)
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=10, keep_grads=True)
     m._seed_counter = 20
     seed = ((torch.initial_seed() * 1000003 + 21) & 0xFFFFFFFFFFFFFFFF or 1) & 0xFFFFFFFF      # what _decode will draw
     loss, reward, seq, greedy = tr.scst_step(b, reward_fn, num_samples=ns, baseline="greedy", train=False)
@@ -537,7 +537,7 @@ def test_xe_step_at_bench_size_properties(P, full_state, precision):
     m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=precision)
     B = 256
     b = _cuda(H.torch_batch(C.make_inputs(seed=11, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=5, ragged=True)))
-    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000)
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000, keep_grads=True)
     flat0 = m._flat.clone()
 
     def step(data, train, counter):
@@ -854,7 +854,7 @@ def test_mixed_precision_gradients_track_fp32_gradients(P, full_state, inputs):
     grads = {}
     for prec in (0, "bf16"):
         m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=prec)
-        tr = NativeTrainer(m, noamopt_factor=0.0, noamopt_warmup=10)       # lr 0: keep the weights, read the gradients
+        tr = NativeTrainer(m, noamopt_factor=0.0, noamopt_warmup=10, keep_grads=True)       # lr 0: keep the weights, read the gradients
         for _ in range(2):                                                 # twice: the second step reuses every buffer
             tr.xe_step(b, train=False)
         grads[prec] = {n: tr.grads[e["offset"]:e["offset"] + e["numel"]].clone() for n, e in
@@ -1026,7 +1026,7 @@ def test_scst_step_at_bench_size_properties(P, full_state, precision):
     m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=precision)
     B, ns = 256, 5
     b = _cuda(H.torch_batch(C.make_inputs(seed=71, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
-    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000)
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000, keep_grads=True)
     flat0 = m._flat.clone()
     g = torch.Generator().manual_seed(5)
     r1, r2 = torch.randn(B * ns, generator=g), torch.randn(B * ns, generator=g)
@@ -1068,7 +1068,7 @@ def test_supermask_step_at_bench_size_properties(P, full_state):
     B = 256
     b = _cuda(H.torch_batch(C.make_inputs(seed=81, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=5, ragged=True)))
     dense = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
-    td = NativeTrainer(dense, noamopt_factor=1.0, noamopt_warmup=20000)
+    td = NativeTrainer(dense, noamopt_factor=1.0, noamopt_warmup=20000, keep_grads=True)
     dense.eval()
     ld = td.xe_step(b, train=False).item()
     gd = td.grads.clone()
@@ -1082,7 +1082,7 @@ def test_supermask_step_at_bench_size_properties(P, full_state):
         return m
 
     mo = prune_model(lambda t: torch.full_like(t, 6.0))
-    to = NativeTrainer(mo, noamopt_factor=1.0, noamopt_warmup=20000)
+    to = NativeTrainer(mo, noamopt_factor=1.0, noamopt_warmup=20000, keep_grads=True)
     lo = to.xe_step(b, train=False).item()
     assert abs(lo - ld) < 1e-5 * abs(ld), (lo, ld)
     n = min(to.grads.numel(), gd.numel())
@@ -1091,7 +1091,7 @@ def test_supermask_step_at_bench_size_properties(P, full_state):
     gen = torch.Generator(device="cuda").manual_seed(9)
     logits = lambda t: torch.where(torch.rand(t.shape, device=t.device, generator=gen) < 0.05, torch.full_like(t, 6.0), torch.full_like(t, -6.0))
     ms = prune_model(logits)
-    ts = NativeTrainer(ms, noamopt_factor=1.0, noamopt_warmup=20000)
+    ts = NativeTrainer(ms, noamopt_factor=1.0, noamopt_warmup=20000, keep_grads=True)
     flat0, mask0 = ms._flat.clone(), ms._mask_flat.clone()
 
     def step():
@@ -1396,7 +1396,7 @@ def test_valid_position_decoder_equals_padded_layout(P, g1, full_state, size):
         b = _cuda(H.torch_batch(C.make_inputs(seed=81, n_img=256, n_reg=36, feat=2048, vocab=10001, spi=5, ragged=True)))
     b["cap_len"] = _cap_len(b["masks"])
     assert int(b["cap_len"].sum()) < b["seqs"].size(0) * (b["seqs"].size(1) - 1)          # something is skipped
-    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000)
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000, keep_grads=True)
     flat0 = m._flat.clone()
 
     def grads(valid, train=False, counter=5):
