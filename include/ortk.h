@@ -330,6 +330,11 @@ typedef struct ortk_gemm_args {
     int32_t ln_mode, ln_y_dtype;
     const float* ln_a; const float* ln_b; void* ln_y; float* ln_stats; float ln_eps;
     const float* ln_x; const float* ln_dres; float* ln_da; float* ln_db;
+    /* Soft-max partials of the output rows (the generator of a decode step: the beam step then reads 2 floats per 64 logits
+     * instead of the logits): tile_stats[(m * ceil(N / 64) + j) * 2 + {0, 1}] = {max, sum exp(v - max)} over the columns
+     * [64 j, 64 j + 64) below stat_ncols of row m of C (bias included; {-inf, 0} for an empty block).  Mixed precision, bf16
+     * operands, forward layout, plain bias epilogue, N a multiple of 128, K of 64; ORTK_EINVAL otherwise. */
+    float* tile_stats; int32_t stat_ncols;
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its

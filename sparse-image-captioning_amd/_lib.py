@@ -83,7 +83,8 @@ class GemmArgs(C.Structure):
                 ("colsum", C.c_void_p), ("drop_row_stride", C.c_int32), ("drop_row_off", C.c_int32),
                 ("ln_mode", C.c_int32), ("ln_y_dtype", C.c_int32),
                 ("ln_a", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
-                ("ln_x", C.c_void_p), ("ln_dres", C.c_void_p), ("ln_da", C.c_void_p), ("ln_db", C.c_void_p)]
+                ("ln_x", C.c_void_p), ("ln_dres", C.c_void_p), ("ln_da", C.c_void_p), ("ln_db", C.c_void_p),
+                ("tile_stats", C.c_void_p), ("stat_ncols", C.c_int32)]
 
 
 class AttnArgs(C.Structure):

@@ -80,7 +80,11 @@ __device__ __forceinline__ float blk_sum(float v, float* sh) {
 // the ~20 vector instructions per element of the exact function, not by its one read of the logits (111 -> 60 us per step of
 // the 1 024-image beam-5 decode); the fp32 parity mode keeps the exact function (token-exact goldens).
 template <bool FAST> __device__ __forceinline__ float exp_sel(float x) { return FAST ? __expf(x) : expf(x); }
-template <bool FUSED, int NPT, bool FASTEXP = false>
+// STATS (with FUSED, scale = 1): the generator GEMM has left {max, sum exp(. - max)} of every block of 64 logits (st.gstats).
+// The row's log-sum-exp comes from those 2 x 158 floats; the (b + 1)-th largest block maximum is a lower bound of the row's
+// b-th best admissible element (block maxima are elements of distinct blocks, at most one of them is the token the decoding
+// constraint excludes), so only the b + 1 blocks at or above it are read: 1.6 KB of a 40-KB logit row.
+template <bool FUSED, int NPT, bool FASTEXP = false, bool STATS = false>
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logp, int t, float scale) {
     __shared__ float sv[256 * MAXB];
     __shared__ float sh_red[4];
@@ -100,7 +104,77 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
 #pragma unroll
     for (int k = 0; k < MAXB; ++k) { bv[k] = -INFINITY; bi[k] = 0x7FFFFFFF; }
     bool staged = false;     // true once sv / si hold the candidates (fast path); block-uniform
-    if (FUSED && NPT > 0) {
+    if (STATS) {
+        // one WAVE per row (rows q = wave, wave + 4): the 158 block statistics sit 3 per lane, every reduction is a wave
+        // reduction and the b + 1 block reads of a row are issued together — the rows of an image proceed in parallel instead
+        // of as a chain of block-wide barriers and dependent loads
+        __shared__ int cand_cnt2;
+        for (int k = 0; k < MAXB; ++k) { sv[tid * MAXB + k] = -INFINITY; si[tid * MAXB + k] = 0x7FFFFFFF; }
+        if (tid == 0) cand_cnt2 = 0;
+        __syncthreads();
+        const int nblk = st.nblk;                     // <= 256: at most 4 blocks per lane
+        const int want = min(b + 1, nblk);            // blocks to read per row
+        for (int q = wave; q < nq; q += 4) {
+            const int64_t srow = t == 0 ? (int64_t)img : (int64_t)img * b + q;
+            const float* gs = st.gstats + srow * nblk * 2;
+            float m[4], sb_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int blk = lane + 64 * u;
+                const float2 v2 = blk < nblk ? *reinterpret_cast<const float2*>(gs + 2 * blk) : make_float2(-INFINITY, 0.f);
+                m[u] = v2.x; sb_[u] = v2.y;
+            }
+            const float cum = t == 0 ? 0.f : st.cum[(int64_t)img * b + q];
+            const int prev = (st.decoding_constraint && t > 0) ? st.seq[cur][((int64_t)img * b + q) * L + t - 1] : -1;
+            const float mx = wave_max(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum += m[u] > -INFINITY ? sb_[u] * __expf(m[u] - mx) : 0.f;
+            const float lse = logf(wave_sum(sum));
+            if (lane == 0) { row_mx[q] = mx; row_lse[q] = lse; }
+            // the `want` largest block maxima, one wave arg-max round each (ties: the lower block)
+            int selb[MAXB + 1];
+            float tau_raw = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < MAXB + 1; ++r) {
+                selb[r] = -1;
+                if (r < want) {
+                    float bv_ = m[0]; int bb = lane;
+#pragma unroll
+                    for (int u = 1; u < 4; ++u) if (m[u] > bv_) { bv_ = m[u]; bb = lane + 64 * u; }
+#pragma unroll
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                        const float ov = __shfl_xor(bv_, o2, 64); const int ob = __shfl_xor(bb, o2, 64);
+                        if (ov > bv_ || (ov == bv_ && ob < bb)) { bv_ = ov; bb = ob; }
+                    }
+                    selb[r] = bb; tau_raw = bv_;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (bb == lane + 64 * u) m[u] = -INFINITY;      // (never selected twice)
+                }
+            }
+            const float tau = cum + ((tau_raw - mx) - lse);
+            float zv[MAXB + 1];
+#pragma unroll
+            for (int r = 0; r < MAXB + 1; ++r) {
+                const int v = selb[r] * 64 + lane;
+                zv[r] = (selb[r] >= 0 && v < V) ? logp[srow * st.ldv + v] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < MAXB + 1; ++r) {
+                const int v = selb[r] * 64 + lane;
+                if (selb[r] >= 0 && v < V && v != prev) {
+                    const float z = cum + ((zv[r] - mx) - lse);
+                    if (z >= tau) {
+                        const int pos = atomicAdd(&cand_cnt2, 1);
+                        if (pos < 256 * MAXB) { sv[pos] = z; si[pos] = q * V + v; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        staged = cand_cnt2 <= 256 * MAXB;          // (massive ties: the exact per-thread lists below)
+        __syncthreads();
+    } else if (FUSED && NPT > 0) {
         // Register-resident rows: each thread holds its NPT strided elements of a row (ONE memory round trip per row, the
         // next row's loads are issued before the current row is reduced); max and sum-exp run in the element order of
         // log_softmax_kernel.  Candidate selection without per-thread sorted lists (their insertion network ran for almost
@@ -519,7 +593,9 @@ int kvidx_init(int32_t* kvidx, int64_t rows, int32_t row_mult, int32_t tmax, hip
 int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused, float scale, bool fast_exp) {
     if (st.b < 1 || st.b > MAXB) return ORTK_EINVAL;
     if (st.B == 0) return 0;
-    if (fused && st.V <= 256 * 40 && fast_exp) hipLaunchKernelGGL((beam_step_kernel<true, 40, true>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
+    if (fused && fast_exp && st.gstats && scale == 1.f && st.nblk <= 256 && st.nblk * 64 >= st.V)
+        hipLaunchKernelGGL((beam_step_kernel<true, 0, true, true>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
+    else if (fused && st.V <= 256 * 40 && fast_exp) hipLaunchKernelGGL((beam_step_kernel<true, 40, true>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
     else if (fused && st.V <= 256 * 40) hipLaunchKernelGGL((beam_step_kernel<true, 40>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
     else if (fused) hipLaunchKernelGGL((beam_step_kernel<true, 0>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, scale);
     else            hipLaunchKernelGGL((beam_step_kernel<false, 0>), dim3((unsigned)st.B), dim3(256), 0, s, st, logp, t, 1.f);

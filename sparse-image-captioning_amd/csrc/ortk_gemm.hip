@@ -644,8 +644,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_cs = TA && p.colsum != nullptr && nt == 0;
-    float cs = 0.f;
+    // fused bias gradient (wgrad layout): column sums of the k-major A tile = one more output column against a vector of
+    // ones, taken by the wn = 0 waves of the first N-tile's workgroups with MI extra MFMAs per tile
+    const bool do_cs = TA && p.colsum != nullptr && nt == 0 && wn == 0;
+    f32x4 acc_cs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc_cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
 
     auto issue = [&](int t) {
         __bf16* st = smem16 + (size_t)(t & (NS - 1)) * 2 * IMG;
@@ -676,11 +681,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
         for (int j = 0; j < 4; ++j) b[j] = gfrag<TB, TM>(sB, wn * 64 + 16 * j, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[i] = gfrag<TA, TM>(sA, wm * (16 * MI) + 16 * i, lane);
-        if (TA && do_cs && tid < TM) {
-            // fused bias gradient: column tid of the k-major A tile, straight from the LDS image
-            const int ch = tid >> 3, off = tid & 7;
-#pragma unroll 8
-            for (int kr = 0; kr < GBK; ++kr) cs += (float)sA[kr * TM + (((ch ^ swz_km(kr)) << 3) | off)];
+        if (TA && do_cs) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], acc_cs[i], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -688,7 +691,44 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
-    if (TA && do_cs && tid < TM) atomicAdd(p.colsum + mb + tid, cs);
+    if (TA && do_cs && lane < 16) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) atomicAdd(p.colsum + mb + wm * (16 * MI) + 16 * i + lane, acc_cs[i][0]);
+    }
+    if (!BIG && !TA && !TB && p.tile_stats) {
+        // soft-max partials of this wave's 64 rows x 64 columns (bias included, columns past stat_ncols left out): in-lane over
+        // the lane's 16 values of a row, two shuffles over the four lane groups
+        const int lr = lane & 15, lg = lane >> 4;
+        const int c0 = nb + wn * 64 + 4 * lg;
+        const int nblk = p.N >> 6, blk = (nb >> 6) + wn;
+        f32x4 bias4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mb + wm * (16 * MI) + 16 * i + lr;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 16 * j + r < p.stat_ncols) mx = fmaxf(mx, acc[i][j][r] + bias4[j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 16 * j + r < p.stat_ncols) sm += __expf((acc[i][j][r] + bias4[j][r]) - mx);
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            if (lg == 0 && m < p.M) {
+                float* q = p.tile_stats + ((int64_t)m * nblk + blk) * 2;
+                q[0] = mx; q[1] = sm;
+            }
+        }
+    }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
     if (!BIG && p.accumulate) {
@@ -1374,6 +1414,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         (void)hipEventRecord(rec.a, s);
     }
     if (!p.precision) {
+        if (p.tile_stats) return ORTK_EINVAL;
         switch (key) {
             case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
@@ -1394,6 +1435,10 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         // runs the bounds-checked epilogue.  (Without this every batch size that is not a multiple of 128 images fell back to
         // the guarded register-staged kernel: 13.4 ms per XE step at 127 images against 9.0 ms at 128.)
         const bool fast4 = fast_nk && key == 4 && !p.accumulate;
+        const bool want_stats = p.tile_stats != nullptr;      // soft-max partials: the 128 x 128 LDS-DMA kernel's epilogue
+        if (want_stats && !(fast4 && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0 && p.K % HBK == 0 && !p.relu &&
+                            p.drop_p == 0.f && !p.gate && !p.rowscale && !p.resid && p.stat_ncols > 0 && p.stat_ncols <= p.N))
+            return ORTK_EINVAL;
         static int impl = -1;   // experiments: 1 = register-staged kernel only, 2 = 128^2 DMA tiles only, 3 = 256^2 whenever legal
         if (impl < 0) { const char* ev = getenv("ORTK_GEMM_IMPL"); impl = ev ? atoi(ev) : 0; }
         // Measured in the XE step (bench.py, ms/step): register-staged kernel everywhere 17.9; DMA kernels everywhere
@@ -1409,7 +1454,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         // 12.67 ms with them on the 64 x 64 tiles, 12.51 without).
         static int t64 = -2;    // ORTK_GEMM_T64: use them while the 128 x 128 grid has at most this many workgroups (-1 = never)
         if (t64 == -2) { const char* ev = getenv("ORTK_GEMM_T64"); t64 = ev ? atoi(ev) : 640; }
-        if (fast4 && impl != 1 && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.K % HBK == 0 &&
+        if (fast4 && impl != 1 && !want_stats && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.K % HBK == 0 &&
             p.drop_p == 0.f && !p.gate && !p.rowscale && (int64_t)tilesM * tilesN <= t64 && p.N <= 2048 && p.M <= 6144) {
             const int tm = (int)ortk_cdiv(p.M, 64), tn = p.N / 64;
             const bool one = (int64_t)tm * tn <= 256 + 64;          // one workgroup per CU: the whole K = 512 panel in flight
@@ -1425,7 +1470,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             ORTK_CHECK_LAUNCH();
             return 0;
         }
-        if ((fast || fast4) && impl != 1 && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0) {
+        if ((fast || fast4) && (impl != 1 || want_stats) && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0) {
             // 256 x 256 tiles when they still give enough workgroups (and no split-K accumulation, which needs the
             // staged 128 x 128 epilogue); impl 2 = small tiles only, impl 3 = big tiles whenever legal
             const int64_t big_blocks = (int64_t)ortk_cdiv(p.M, 256) * (p.N / 256);
@@ -1437,7 +1482,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             // the other half of the chip to the weight-gradient GEMM of the side stream (XE step 12.47 -> 12.10 ms; 40 % and
             // 30 % measure the same)
             const bool fills = big_blocks * 10 >= rounds * 256 * 5;
-            const bool big = !p.accumulate && (p.M % 256 == 0 || fast4) && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
+            const bool big = !p.accumulate && !want_stats && (p.M % 256 == 0 || fast4) && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
             // 8-deep ring for grids of at most one workgroup per CU (decode-time projections): measured SLOWER in the
             // 1024-image decode (36.9 vs 35.8 ms) -> experiment only (ORTK_GEMM_IMPL=5)
             const bool deep = !big && (int64_t)tilesM * tilesN * splitk <= 256 && impl == 5;

@@ -50,6 +50,8 @@ struct BeamState {
     int32_t decoding_constraint, length_penalty;
     double length_alpha;
     int32_t tmax;             // cache time capacity
+    // optional soft-max partials of the logit rows (ortk_gemm_args.tile_stats): {max, sum exp} per block of 64 columns
+    const float* gstats; int32_t nblk;
 };
 // fused = true: `logp` holds raw logits and the log-soft-max of (logits * scale) is taken inside the step
 int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false, float scale = 1.f, bool fast_exp = false);

@@ -1063,6 +1063,7 @@ struct DecodeWS {
     float *x0, *logbias; void* mem /*A*/; float* st; void* ckv /*ckvdt*/;
     EncPtrs enc;                       // one set of encoder buffers, reused by every layer
     float *xa, *xb; void* y /*A*/; float* qkv; void* o /*A*/; void* q /*ckvdt when xq16*/; void* h /*A*/; float* logits;
+    float* gstats = nullptr;           // soft-max partials of the logit rows (rows, ldv / 64, 2): beam search in mixed precision
     int ckvdt, xq16;                   // projected memory dtype; 1 = cross-attention through the bf16-operand kernels (bf16 query too)
     void *cache_k[MAXLAYERS], *cache_v[MAXLAYERS]; int kvdt;   // K/V caches + projected memory: bf16 in mixed precision when the
                                                                // decode attention kernels take them (kv16), fp32 otherwise
@@ -1119,6 +1120,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = act(rows * d);
     w.qkv = b.take<float>(rows * 3 * d); w.o = act(rows * d); w.q = b.take<float>(rows * d);      // (fp32-sized; holds bf16 when xq16)
     w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
+    if (beam && c.precision) w.gstats = b.take<float>(rows * (w.ldv / 64) * 2);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
     if (stack && !sstream) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
@@ -1176,7 +1178,18 @@ struct StepBufs {
     void* cache_k[MAXLAYERS]; void* cache_v[MAXLAYERS];
     int kvdt;      // element type of cache_k / cache_v
     int ckvdt = ORTK_F32, xq16 = 0;   // element type of ckv; 1 = bf16 cross-attention query + bf16-operand kernel
+    float* gstats = nullptr; int stat_ncols = 0;    // soft-max partials of the logit rows wanted from the generator GEMM
 };
+// generator logits of a decode step (w.y: the final LayerNorm's output); with w.gstats also their soft-max partials
+static int gen_gemm(const Ctx& c, const Offsets& o, const StepBufs& w, int ydt, int64_t rows) {
+    const int d = c.cfg->d_model;
+    if (!w.gstats) return fwd_gemm(c, w.y, ydt, d, o.gen_w, c.P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, (int)w.ldv, d);
+    ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
+    a.A = w.y; a.a_dtype = ydt; a.lda = d; a.B = c.W(o.gen_w); a.b_dtype = c.wdt(); a.ldb = d; a.C = w.logits; a.c_dtype = ORTK_F32; a.ldc = w.ldv;
+    a.M = (int)rows; a.N = (int)w.ldv; a.K = d; a.bias = c.P + o.gen_b; a.precision = c.prec;
+    a.tile_stats = w.gstats; a.stat_ncols = w.stat_ncols;
+    return ortk_gemm(&a, (ortk_stream)c.s);
+}
 static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64_t rows, int groups, int per_group, int /*row_mult*/,
                         int S, int T, int t, const int32_t* kvidx) {
     const ortk_config* cfg = c.cfg;
@@ -1225,7 +1238,7 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
             std::swap(x, xn);
         }
         TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.y, A, w.st, rows));
-        TRY(fwd_gemm(c, w.y, A, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, (int)w.ldv, d));
+        TRY(gen_gemm(c, o, w, A, rows));
     return 0;
 }
 
@@ -1254,7 +1267,7 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
     a.rows = (int)rows; a.per_img = per_img; a.S = S; a.T = T; a.t = t; a.L = cfg->n_layers; a.NC = cfg->d_ff / 512; a.eps = 1e-6f;
     a.debug = (flags >> 8) & 0xF;        // ORTK_DEC_DEBUG_*: phase-skipping measurement switches
     TRY(stack_step(a, c.s));
-    return fwd_gemm(c, w.y, ORTK_BF16, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, rows, (int)w.ldv, d);
+    return gen_gemm(c, o, w, ORTK_BF16, rows);
 }
 
 extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const float* att_feats, const float* boxes,
@@ -1319,6 +1332,11 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         bs.cum = w.cum; bs.it = w.it; bs.done_seq = w.done_seq; bs.done_lp = w.done_lp; bs.done_p = w.done_p;
         bs.done_len = w.done_len; bs.done_cnt = w.done_cnt; bs.decoding_constraint = op->decoding_constraint;
         bs.length_penalty = op->length_penalty; bs.length_alpha = op->length_alpha; bs.tmax = T;
+        // Soft-max partials from the generator GEMM instead of a second pass over the logits (mixed precision, no temperature,
+        // dense generator, d_model a multiple of 64 and full 128-column tiles: what the GEMM's statistics epilogue serves)
+        if (w.gstats && op->temperature == 1.f && !op->sparse && A == ORTK_BF16 && d % 64 == 0 && w.ldv % 128 == 0 && w.ldv / 64 <= 256) {
+            bs.gstats = w.gstats; bs.nblk = (int32_t)(w.ldv / 64);
+        }
         TRY(fill_i32(w.done_cnt, B, 0, s));
         TRY(fill_i64(w.it, B, cfg->bos_id, s));
         TRY(kvidx_init(w.kvidx[0], B, K, T, s));
@@ -1339,6 +1357,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         const int row_mult = first_beam ? K : 1;
         StepBufs sb{w.it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, w.ckv, att_masks};
         sb.kvdt = w.kvdt; sb.ckvdt = w.ckvdt; sb.xq16 = w.xq16;
+        if (beam && bs.gstats) { sb.gstats = w.gstats; sb.stat_ncols = V; }
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
         if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         else TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));

@@ -205,11 +205,20 @@ class NativeTrainer:
                 if baseline == "greedy":
                     greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
         m.train(was_training)
-        reward = reward_fn(seq, greedy).to(self.dev).float().reshape(-1)
+        reward = reward_fn(seq, greedy)
+        host_reward = not reward.is_cuda
+        reward = reward.to(self.dev).float().reshape(-1)
         rows = seq.reshape(-1, seq.size(-1))
         mask = (rows != m.pad_idx).float()
         tf = dict(data)
-        tf.pop("cap_len", None); tf.pop("_valid_rows", None)      # (the lengths of the SAMPLED captions live on the device: padded layout)
+        tf.pop("cap_len", None); tf.pop("_valid_rows", None)      # (those of the ground-truth captions)
+        if host_reward and self.valid_positions:
+            # The lengths of the SAMPLED captions live on the device.  A reward computed on the host (the CIDEr-D scorer of
+            # scst/scorers.py) has already waited for the rollout, so reading them back costs one small copy and the update
+            # pass then runs its decoder on the valid positions only (a sampled caption is tokens, EOS, then pads: its
+            # weights lie in a prefix).  A device-side reward_fn keeps the whole step free of host synchronisation: padded layout.
+            pos = torch.arange(1, mask.size(1) + 1, device=mask.device, dtype=mask.dtype)
+            tf["cap_len"] = (mask * pos).amax(1).clamp_(min=1).to(torch.int64).cpu()       # 1 + index of the last weighted position
         tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
         if drop_seed is not None:
             loss = self._step(tf, mask * reward[:, None], mask, True, seed=drop_seed)

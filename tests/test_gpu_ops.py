@@ -850,3 +850,28 @@ def test_gemm_fused_layernorm_fallback_shapes(L):
     ref = A @ W.t()
     torch.testing.assert_close(c.cpu(), ref, rtol=2e-5, atol=2e-4)
     torch.testing.assert_close(y.cpu(), O.layer_norm(ref, ga, gb), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,V", [(300, 1000), (129, 10000)])
+def test_gemm_tile_softmax_partials(L, M, V):
+    """ortk_gemm_args.tile_stats: {max, sum exp(. - max)} per block of 64 output columns (bias included, columns >= stat_ncols
+    left out) — what the beam step reads instead of the logits.  Against torch on the GEMM's own fp32 output."""
+    N, K = ((V + 127) // 128) * 128, 512
+    A = rnd(M, K, seed=50).bfloat16()
+    W = torch.zeros(N, K); W[:V] = rnd(V, K, seed=51, scale=K ** -0.5) * 3
+    bias = torch.zeros(N); bias[:V] = rnd(V, seed=52)
+    nblk = N // 64
+    stats = torch.full((M, nblk, 2), float("nan"), device="cuda")
+    c = gemm(L, dev(A), dev(W.bfloat16()), M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1, bias=dev(bias), tile_stats=stats, stat_ncols=V)
+    torch.cuda.synchronize()
+    x = c.clone(); x[:, V:] = float("-inf")
+    xb = x.view(M, nblk, 64)
+    mx = xb.amax(2)
+    sm = torch.where(mx.isinf(), torch.zeros_like(mx), torch.exp(xb - mx.clamp(min=-1e30)[..., None]).sum(2))
+    assert torch.equal(stats[..., 0], mx)
+    torch.testing.assert_close(stats[..., 1], sm, rtol=2e-6, atol=1e-6)
+    # the row's log-sum-exp from the partials
+    lse = torch.logsumexp(x[:, :V], 1)
+    m_row = stats[..., 0].amax(1)
+    lse2 = m_row + torch.log((stats[..., 1] * torch.exp(stats[..., 0] - m_row[:, None])).sum(1))
+    torch.testing.assert_close(lse2, lse, rtol=1e-6, atol=2e-6)
