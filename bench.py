@@ -149,10 +149,14 @@ def pmc_traffic(kernel, workload, precision, B):
 PARITY = {
     "fp32": "XE loss within 1e-4 of the reference goldens (observed 2e-6), every gradient within 2e-4*scale, greedy / beam-3 / "
             "beam-5 tokens exact (tests/test_gpu_model.py: *_vs_reference_golden, full size: test_full_size_config1_*)",
-    "bf16": "timed mode: bf16 MFMA operands, fp32 accumulate / soft-max / LayerNorm / residual / optimizer; XE loss within "
-            "2e-2, gradients within 5 % relative L2 of the fp32 path (test_mixed_precision_gradients_track_fp32_gradients), "
-            "teacher-forced log-prob error of the decode <= 0.1 over 64 images (test_bf16_decode_logprob_bound), bench-size "
-            "determinism / permutation / fused-criterion properties (test_xe_step_at_bench_size_properties)",
+    "bf16": "timed mode: bf16 MFMA operands, fp32 accumulate / soft-max / LayerNorm / residual / optimizer.  Checked against the "
+            "library's own fp32 parity mode (HIP-bf16 vs HIP-fp32, not against the oracle directly; the fp32 mode is what the "
+            "oracle pins): XE loss within 2e-2 of the golden, gradients within 5 % relative L2 of the fp32 path "
+            "(test_mixed_precision_gradients_track_fp32_gradients), teacher-forced log-prob error of the decode <= 0.1 over 64 "
+            "images (test_bf16_decode_logprob_bound), valid-position layout == padded layout "
+            "(test_valid_position_decoder_equals_padded_layout), train-mode dropout replayed through the oracle "
+            "(test_train_mode_dropout_vs_oracle, fp32), bench-size determinism / permutation / fused-criterion properties "
+            "(test_xe_step_at_bench_size_properties)",
 }
 
 
@@ -319,7 +323,8 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
                  "algorithmic_bytes_per_launch": round(sby / sn), "achieved": round(gbs_k, 1),
                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4),
                  "mfma_tflops": round(sfl / (sms * 1e-3) / 1e12, 1), "ms_per_step": round(sms, 3)}
-        stack["traffic"], stack["traffic_note"] = pmc_traffic("stack", workload, args.precision, B)
+        # (sparse_decode on the DENSE stream is the decode workload's kernel: its counters are that profile's)
+        stack["traffic"], stack["traffic_note"] = pmc_traffic("stack", workload if sstream else "decode", args.precision, B)
     n0, ms0, fl0, by0 = per_key[key]
     peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
     ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0

@@ -47,8 +47,10 @@ __device__ __forceinline__ void pair_embedding(const float* __restrict__ boxes, 
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float arg = p100 * dm[k];
-                e[(c * 8 + k) % DG] = sinf(arg);
-                e[(32 + c * 8 + k) % DG] = cosf(arg);
+                float sn, cs;
+                sincosf(arg, &sn, &cs);            // one range reduction for both (the same OCML kernels as sinf / cosf)
+                e[(c * 8 + k) % DG] = sn;
+                e[(32 + c * 8 + k) % DG] = cs;
             }
         }
     }
