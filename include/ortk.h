@@ -230,6 +230,7 @@ int ortk_spmm(const ortk_sparse_plan* plan, int32_t block, const ortk_spmm_args*
 #define ORTK_DEC_STACK 2
 #define ORTK_DEC_SPARSE_STREAM 4
 #define ORTK_DEC_STACK_RB20 8
+#define ORTK_DEC_STACK_SPLIT 16
 typedef struct ortk_decode_opts {
     int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
     int32_t num_random_sample;
@@ -251,6 +252,10 @@ typedef struct ortk_decode_opts {
      *                           NON-ZEROS (rebuilt on the device from the weights of the call, no host sync; correct at any
      *                           density, faster than the dense stream above ~80 % zeros); implies ORTK_DEC_STACK;
      *   ORTK_DEC_STACK_RB20     dense stream with 20-row workgroups (measurement);
+     *   ORTK_DEC_STACK_SPLIT    the column-split form of the stack kernel: groups of 2 / 4 / 8 workgroups of one XCD share 64 rows
+     *                           and split every projection's output columns (each streams 1/2 .. 1/8 of the weights; partial
+     *                           results are exchanged through that XCD's L2).  Dense stream; implies ORTK_DEC_STACK; row counts
+     *                           whose groups do not all fit the chip at once (> 8 192 rows) run the plain stack kernel;
      *   bits 8-11               measurement only: skip self-attention (1) / cross-attention (2) / the FFN (4), no L2 prefetchers (8). */
     int32_t exec_flags;
     /* multinomial only: also decode ONE greedy row per image in the same pass (the SCST baseline of

@@ -29,6 +29,7 @@
 // nominal 64 B/clk, ~6 us measured (85 GB/s per CU); 160 workgroups for 1 024 images x 5 beams.  DESIGN.md section 4.
 #include "ortk_internal.h"
 #include <mutex>
+#include <cstdlib>
 
 namespace ortk {
 namespace {
@@ -884,6 +885,545 @@ int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStr
     return 0;
 }
 
+// ================================================================================================ column-split form
+// The kernel above is bound by the bytes ONE compute unit pulls out of L2 (every workgroup streams all 42 MB of decoder weights
+// per position at 79-85 GB/s; a CU gets 95 GB/s at most, profiles/r03_fetch_rate_probe.txt), whatever the number of rows it
+// holds.  Here G workgroups SHARE 64 rows and split every unit's 512 output columns (and the 8 heads) G ways: each streams 1/G
+// of the weights.  What a member needs of the others — the attention output and the FFN hidden chunk as the next unit's A
+// operand (bf16), the out-projections' residual updates (fp32; every member keeps the FULL residual rows in registers, so
+// LayerNorm stays local) — travels through a [64 x 512] tile in global memory: plain stores (the vector L1 is write-through),
+// `s_waitcnt vmcnt(0)`, a relaxed counter in L2, `sc1` loads that bypass the reader's L1.  That is only coherent inside ONE
+// XCD's L2, so the members of a group are the workgroups x + 8 k of one XCD x; with agent-scope fences (L2 write-back +
+// invalidate) an exchange costs 19-23 us, this way 1.8 us (bf16 tile) / 2.8 us (fp32): profiles/r03_xchg_probe.txt.
+// Every member spins on its group's counter, so all workgroups of a launch must be resident: groups x G <= 256.
+namespace {
+constexpr int TR = 64;                     // rows per group
+typedef __attribute__((ext_vector_type(4))) unsigned int tpu4;
+template <int G> struct TP {
+    static constexpr int C = SD / G;                 // columns per slice
+    static constexpr int LR = 64 / G;                // 16-byte chunks (lanes) per slice row
+    static constexpr int NT = G == 2 ? 2 : 1;        // column tiles per wave
+    static constexpr int MT = G == 8 ? 2 : 4;        // row tiles per wave
+    static constexpr int WS = G == 8 ? 4 : 8;        // weight streams per slice (G = 8: waves w and w + 4 share one)
+    static constexpr int KST = NT * FRAG;            // uint4 per k-step of one stream
+    // k-steps of weight fragments in flight per wave.  The stream is bound by latency x steps in flight, not by bytes, so the
+    // narrower streams would want 16 / NT steps (the 64 VGPRs decoder_stack_kernel spends) — measured SLOWER (25.5 vs 23.9 ms per
+    // 1 024-image decode): with the full residual rows in registers (64 VGPRs) the deeper ring spills
+    static constexpr int DEP = SPD;
+    static constexpr int SLICE = TR * C * 2;         // bytes of a bf16 slice image
+    static constexpr int R2 = 3 * SLICE > 65536 ? 3 * SLICE : 65536;
+    static constexpr size_t LDS = 65536 + R2;
+};
+constexpr size_t XTILE = (size_t)TR * SD * 4;        // bytes of one exchange tile (fp32 form)
+
+// slice image [64 rows][LR chunks of 16 B]: chunk' = chunk ^ (row & min(15, LR - 1)) (the accumulator-layout stores of 16 rows
+// of one column tile land on distinct chunks)
+template <int G> __device__ __forceinline__ int sl_off(int row, int chunk) {
+    constexpr int LR = 64 / G;
+    return row * (LR * 16) + ((chunk ^ (row & (LR - 1) & 15)) << 4);
+}
+__device__ __forceinline__ tpu4 load_sc1(const void* p) {
+    tpu4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// the compiler does not know that the registers above are in flight: the wait names them as in-out operands, so that no copy or
+// use of them can be scheduled in front of it
+__device__ __forceinline__ void wait_sc1(tpu4 (&v)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+}
+template <int G> struct RingTP { uint4 f[TP<G>::DEP][TP<G>::NT]; };
+template <int G> __device__ __forceinline__ void ring_tp_start(RingTP<G>& r, const uint4* wp, int lane) {
+#pragma unroll
+    for (int s = 0; s < TP<G>::DEP; ++s)
+#pragma unroll
+        for (int nt = 0; nt < TP<G>::NT; ++nt) r.f[s][nt] = wp[s * TP<G>::KST + nt * FRAG + lane];
+}
+// acc[mt][nt] += A[16 (mt0 + mt) .. +15][:] . W[this wave's column tile nt][:]^T over the 512 inputs of one unit
+template <int G, bool NEXT>
+__device__ __forceinline__ void unit_tp(f32x4 (&acc)[TP<G>::MT][TP<G>::NT], const char* A, const uint4*& wp, RingTP<G>& r, int lane, int mt0) {
+    constexpr int NT = TP<G>::NT, MT = TP<G>::MT, KST = TP<G>::KST, DEP = TP<G>::DEP, NIT = 16 / DEP;
+    const int m = lane & 15, kg = lane >> 4;
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+        for (int s = 0; s < DEP; ++s) {
+            const int ks = it * DEP + s;
+            bf16x8 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(A + img_off(16 * (mt0 + mt) + m, 4 * ks + kg));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, r.f[s][nt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[mt], acc[mt][nt], 0, 0, 0);
+            }
+            if (NEXT || it < NIT - 1) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) r.f[s][nt] = wp[(ks + DEP) * KST + nt * FRAG + lane];
+            }
+        }
+    }
+    wp += 16 * KST;
+}
+}  // namespace
+
+template <int G>
+__global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
+    using T_ = TP<G>;
+    constexpr int C = T_::C, LR = T_::LR, NT = T_::NT, MT = T_::MT, KST = T_::KST;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* A0 = smem;                        // [64 x 512] bf16: LayerNorm output / gathered attention output
+    char* QI = smem + 65536;                // this member's query / key / value slices of the current position
+    char* KI = QI + T_::SLICE;
+    char* VI = KI + T_::SLICE;
+    char* Hh = QI;                          // [64 x 512] bf16 gathered FFN hidden chunk (the slices are dead by then)
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = lane0;
+    const int U = 6 + 2 * a.NC;
+    // exchanges of one launch: per layer o(self), wo, o(cross), co, NC hidden chunks, w2 (a.debug: phases skipped for measurements)
+    const int NX = a.L * (3 + ((a.debug & 1) ? 0 : 1) + ((a.debug & 2) ? 0 : 1) + ((a.debug & 4) ? 0 : a.NC));
+    const int xcd = (int)(blockIdx.x & 7), kk = (int)(blockIdx.x >> 3), c = kk % G, grp = (kk / G) * 8 + xcd;
+    if ((int)blockIdx.x >= a.tp_groups * G) {
+        // L2 prefetcher of one XCD (as in decoder_stack_kernel): the members of an XCD's groups walk the G x WS weight streams in
+        // step, so without it every fragment load is an L2 miss all of them wait for.  One dword per 128-byte line of the
+        // unit's 512 KB, kept STACK_AHEAD units in front of the XCD's pace-maker (its first workgroup).
+        constexpr int NS = G * T_::WS;                     // streams; unit chunk of a stream: 16 k-steps x KST uint4
+        constexpr int LINES = 16 * KST * 16 / 128;         // 128-byte lines of one stream's unit chunk
+        const int base = a.tp_launch * a.L * U;
+        unsigned int sink = 0;
+        int spin = 0;
+        for (int u = 0; u < a.L * U; ++u) {
+            for (; spin < 4096 && __hip_atomic_load(a.progress + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + u + 1 - STACK_AHEAD; ++spin)
+                __builtin_amdgcn_s_sleep(8);
+            spin = spin >= 4096 ? 4096 : 0;
+            for (int sidx = wave; sidx < NS; sidx += 8) {
+                const unsigned int* src = reinterpret_cast<const unsigned int*>(a.tp_wpk + ((int64_t)sidx * a.L * U + u) * 16 * KST);
+                for (int ln = lane; ln < LINES; ln += 64) sink += src[ln * 32];
+            }
+        }
+        if (sink == 0x9E3779B1u) a.progress[8] = 1;        // (keeps the loads)
+        return;
+    }
+    const bool pace = a.progress != nullptr && blockIdx.x < 8 && tid == 0;
+    int unit_no = a.tp_launch * a.L * U;
+    int32_t* flag = a.tp_flag + grp * 32;
+    const int r0 = grp * TR;
+    if (r0 >= a.rows) {                      // no rows in this launch (the first beam pass): keep the group's counter in step
+        if (tid == 0) __hip_atomic_fetch_add(flag, NX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int xn = a.tp_launch * NX;              // exchanges this group has completed
+    char* xb = a.tp_xbuf + (size_t)grp * 2 * XTILE;
+    // publish this member's part of tile (xn & 1) and wait for the others'
+#define TP_XWAIT()                                                                                              \
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+        __syncthreads();                                                                                         \
+        if (tid == 0) {                                                                                          \
+            __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                         \
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (xn + 1) * G) __builtin_amdgcn_s_sleep(1); \
+        }                                                                                                        \
+        __syncthreads();                                                                                         \
+        ++xn;                                                                                                    \
+    } while (0)
+#define TP_FRESH_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
+#define TP_UNIT_BEGIN() do { ++unit_no; if (pace) __hip_atomic_store(a.progress + blockIdx.x, unit_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+    const int Lk = a.t + 1;
+    const int mt0 = G == 8 ? 2 * (wave >> 2) : 0;
+    const int ws = G == 8 ? (wave & 3) : wave;
+    const int tile0 = G == 2 ? 2 * wave : ws;       // column tile (of the slice) of accumulator 0; accumulator nt: tile0 + nt
+
+    // residual rows, row layout: wave w holds rows 8 w .. 8 w + 7, lane l columns 8 l .. 8 l + 7
+    float x[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = min(r0 + 8 * wave + i, a.rows - 1);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(a.x_io + (int64_t)g * SD + 8 * lane);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(a.x_io + (int64_t)g * SD + 8 * lane + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[i][j] = u0[j]; x[i][4 + j] = u1[j]; }
+    }
+    // LayerNorm of the 8 rows of this wave -> bf16 rows of an A image (wave reductions only)
+    // (::wave_sum: the float reduction of ortk_common.h — inside namespace ortk the name finds the builder's int overload first)
+    auto ln_rows = [&](const float* ga, const float* be, char* img) {
+#pragma clang fp contract(off)
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ga + 8 * lane), g1 = *reinterpret_cast<const f32x4*>(ga + 8 * lane + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(be + 8 * lane), b1 = *reinterpret_cast<const f32x4*>(be + 8 * lane + 4);
+        const float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm += x[i][j];
+            const float mean = ::wave_sum(sm) * (1.f / SD);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = x[i][j] - mean; q = __builtin_fmaf(d, d, q); }
+            const float rinv = 1.f / (sqrtf(::wave_sum(q) * (1.f / (SD - 1))) + a.eps);
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = __builtin_fmaf(gv[j] * (x[i][j] - mean), rinv, bv[j]);
+            const uint4 pk = make_uint4(pack2(y[0], y[1]), pack2(y[2], y[3]), pack2(y[4], y[5]), pack2(y[6], y[7]));
+            *reinterpret_cast<uint4*>(img + img_off(8 * wave + i, lane)) = pk;
+        }
+    };
+    // (acc + bias [relu]) of this wave's tiles as bf16 into a slice image
+    auto store_slice = [&](char* img, const f32x4 (&acc)[MT][NT], const float* bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cl = 16 * (tile0 + nt) + 4 * (lane >> 4);              // column inside the slice
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c * C + cl);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = 16 * (mt0 + mt) + (lane & 15);
+                *reinterpret_cast<uint2*>(img + sl_off<G>(row, cl >> 3) + ((cl >> 2) & 1) * 8) =
+                    make_uint2(pack2(acc[mt][nt][0] + b4[0], acc[mt][nt][1] + b4[1]), pack2(acc[mt][nt][2] + b4[2], acc[mt][nt][3] + b4[3]));
+            }
+        }
+    };
+    // (acc + bias) of this wave's tiles into the exchange tile: fp32 (a residual update) or relu + bf16 (an FFN hidden chunk)
+    auto store_tile = [&](char* tile, const f32x4 (&acc)[MT][NT], const float* bias, bool hidden) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = c * C + 16 * (tile0 + nt) + 4 * (lane >> 4);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = 16 * (mt0 + mt) + (lane & 15);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + b4[r];
+                if (hidden) *reinterpret_cast<uint2*>(tile + ((size_t)row * SD + col) * 2) = make_uint2(pack2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), pack2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)));
+                else *reinterpret_cast<f32x4*>(tile + ((size_t)row * SD + col) * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+            }
+        }
+    };
+    // the gathered bf16 tile -> an A image (8 chunks of 16 B per thread)
+    auto gather_img = [&](const char* tile, char* img) {
+        tpu4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = load_sc1(tile + (size_t)(tid + 512 * u) * 16);
+        wait_sc1(v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int q = tid + 512 * u; *reinterpret_cast<tpu4*>(img + img_off(q >> 6, q & 63)) = v[u]; }
+    };
+    // the gathered fp32 tile: x += update
+    auto add_tile = [&](const char* tile) {
+        tpu4 v0[8], v1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v0[i] = load_sc1(tile + ((size_t)(8 * wave + i) * SD + 8 * lane) * 4);
+            v1[i] = load_sc1(tile + ((size_t)(8 * wave + i) * SD + 8 * lane + 4) * 4);
+        }
+        wait_sc1(v0); wait_sc1(v1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[i][j] += __uint_as_float(v0[i][j]); x[i][4 + j] += __uint_as_float(v1[i][j]); }
+    };
+    auto zero_acc = [&](f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    const uint4* wp = a.tp_wpk + (int64_t)(c * T_::WS + ws) * a.L * U * 16 * KST;
+    RingTP<G> ring;
+    ring_tp_start<G>(ring, wp, lane);
+
+    for (int l = 0; l < a.L; ++l) {
+        const StackLayer& P = a.layer[l];
+        f32x4 acc[MT][NT];
+        // ---- LayerNorm 0 -> A0
+        TP_FRESH_LANE();
+        ln_rows(P.n0a, P.n0b, A0);
+        __syncthreads();
+        // ---- packed QKV: this member's columns of q, k, v -> slice images
+        TP_FRESH_LANE();
+        zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0); store_slice(QI, acc, P.bqkv);
+        zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0); store_slice(KI, acc, P.bqkv + SD);
+        zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, false>(acc, A0, wp, ring, lane, mt0); store_slice(VI, acc, P.bqkv + 2 * SD);
+        __syncthreads();
+        // ---- self-attention over this member's heads: G rows side by side in a wave (LR lanes each); o -> the exchange tile
+        TP_FRESH_LANE();
+        if (!(a.debug & 1)) {
+            char* tile = xb + (xn & 1) * XTILE;
+            const int rs = lane / LR, fc = lane % LR;
+            uint4* ck = reinterpret_cast<uint4*>(P.ck);
+            uint4* cv = reinterpret_cast<uint4*>(P.cv);
+#pragma unroll 1
+            for (int p0 = 0; p0 < 8; p0 += G) {
+                const int row = 8 * wave + p0 + rs;
+                const int g = r0 + row, gc = min(g, a.rows - 1);
+                int idx[G];                  // this lane: cache rows of keys fc + LR u of its row
+#pragma unroll
+                for (int u = 0; u < G; ++u) { const int j = min(fc + LR * u, a.t); idx[u] = a.kvidx ? a.kvidx[(int64_t)gc * Lk + j] : gc * a.T + j; }
+                // cache row of (wave-uniform) key J for this lane's row: register J / LR of lane rs LR + J % LR
+#define TP_KEY_ROW(J, OUT)                                                                   \
+                do {                                                                          \
+                    int v_ = idx[0];                                                          \
+                    _Pragma("unroll") for (int u_ = 1; u_ < G; ++u_) v_ = ((J) / LR == u_) ? idx[u_] : v_; \
+                    OUT = __shfl(v_, rs * LR + ((J) % LR), 64);                               \
+                } while (0)
+                AttState<1> st;
+                st.q[0] = *reinterpret_cast<const uint4*>(QI + sl_off<G>(row, fc));
+                st.m[0] = -INFINITY; st.l[0] = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) st.o[0][d] = 0.f;
+                const int nb = (a.t + SKB - 1) / SKB;
+                uint4 kq[SKB], vq[SKB];
+#define TP_ISSUE(B)                                                                           \
+                do {                                                                          \
+                    _Pragma("unroll") for (int u_ = 0; u_ < SKB; ++u_) {                      \
+                        const int j_ = min((B) * SKB + u_, max(a.t - 1, 0));                  \
+                        int kr_; TP_KEY_ROW(j_, kr_);                                         \
+                        const int64_t ko_ = (int64_t)kr_ * (SD / 8) + c * LR + fc;            \
+                        kq[u_] = ck[ko_]; vq[u_] = cv[ko_];                                   \
+                    }                                                                         \
+                } while (0)
+                if (nb > 0) TP_ISSUE(0);
+                for (int b = 0; b < nb; ++b) {
+                    float kind[SKB], pr[1][SKB];
+#pragma unroll
+                    for (int u = 0; u < SKB; ++u) kind[u] = b * SKB + u < a.t ? 0.f : -INFINITY;
+                    uint4 kc[SKB], vc[SKB];
+#pragma unroll
+                    for (int u = 0; u < SKB; ++u) { kc[u] = kq[u]; vc[u] = vq[u]; }
+                    if (b + 1 < nb) TP_ISSUE(b + 1);
+                    st.scores<SKB>(kc, kind, pr);
+                    st.pv<SKB>(vc, pr);
+                }
+                const uint4 kself[1] = {*reinterpret_cast<const uint4*>(KI + sl_off<G>(row, fc))};
+                const uint4 vself[1] = {*reinterpret_cast<const uint4*>(VI + sl_off<G>(row, fc))};
+                const float kindself[1] = {0.f};
+                float pself[1][1];
+                st.scores<1>(kself, kindself, pself);
+                st.pv<1>(vself, pself);
+                int srow_; TP_KEY_ROW(a.t, srow_);
+                const int64_t slot = (int64_t)srow_ * (SD / 8) + c * LR + fc;
+                if (g < a.rows) { ck[slot] = kself[0]; cv[slot] = vself[0]; }
+                {
+#pragma clang fp contract(off)
+                    const float inv = 1.f / st.l[0];
+                    reinterpret_cast<uint4*>(tile)[row * 64 + c * LR + fc] =
+                        make_uint4(pack2(st.o[0][0] * inv, st.o[0][1] * inv), pack2(st.o[0][2] * inv, st.o[0][3] * inv),
+                                   pack2(st.o[0][4] * inv, st.o[0][5] * inv), pack2(st.o[0][6] * inv, st.o[0][7] * inv));
+                }
+            }
+            TP_XWAIT();
+            gather_img(tile, A0);
+        }
+        __syncthreads();
+        // ---- output projection: residual update through the exchange, LayerNorm 1 -> A0
+        TP_FRESH_LANE();
+        {
+            char* tile = xb + (xn & 1) * XTILE;
+            ring_tp_start<G>(ring, wp, lane);
+            zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
+            store_tile(tile, acc, P.bo, false);
+            TP_XWAIT();
+            add_tile(tile);
+        }
+        ln_rows(P.n1a, P.n1b, A0);         // (every wave is past its reads of A0: the exchange's barriers)
+        __syncthreads();
+        // ---- cross-attention query -> QI
+        TP_FRESH_LANE();
+        zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, false>(acc, A0, wp, ring, lane, mt0); store_slice(QI, acc, P.cqb);
+        __syncthreads();
+        // ---- cross-attention: chunks of up to XNR rows of one image share their key / value loads; one chunk per LR-lane group
+        TP_FRESH_LANE();
+        if (!(a.debug & 2)) {
+            char* tile = xb + (xn & 1) * XTILE;
+            const int rs = lane / LR, fc = lane % LR;
+            const int last = min(r0 + TR, a.rows) - 1;
+            const int img0 = r0 / a.per_img, img1 = last / a.per_img;
+            int nch = 0;
+            for (int im = img0; im <= img1; ++im) {
+                const int lo = max(im * a.per_img, r0), hi = min((im + 1) * a.per_img - 1, last);
+                nch += (hi - lo) / XNR + 1;
+            }
+            for (int pass = 0; pass * 8 * G < nch; ++pass) {
+                const int mine = pass * 8 * G + wave * G + rs;
+                int c0 = r0, nr = 0, imm = img0, k = 0;
+                for (int im = img0; im <= img1; ++im) {
+                    const int lo = max(im * a.per_img, r0), hi = min((im + 1) * a.per_img - 1, last);
+                    for (int cc = lo; cc <= hi; cc += XNR, ++k)
+                        if (k == mine) { c0 = cc; nr = min(XNR, hi - cc + 1); imm = im; }
+                }
+                AttState<XNR> st;
+#pragma unroll
+                for (int i = 0; i < XNR; ++i) {
+                    st.q[i] = *reinterpret_cast<const uint4*>(QI + sl_off<G>(c0 - r0 + (i < nr ? i : 0), fc));
+                    st.m[i] = -INFINITY; st.l[i] = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) st.o[i][d] = 0.f;
+                }
+                const int64_t pitch = a.ldx / 8;
+                const uint4* xk = reinterpret_cast<const uint4*>(P.xk) + (int64_t)imm * a.S * pitch + c * LR + fc;
+                const uint4* xv = reinterpret_cast<const uint4*>(P.xv) + (int64_t)imm * a.S * pitch + c * LR + fc;
+                const float* mk = a.att_masks + (int64_t)imm * a.S;
+                const int nb = (a.S + XKB - 1) / XKB;
+                uint4 kq[XKB], vq[XKB];
+                float mq[XKB];
+#pragma unroll
+                for (int u = 0; u < XKB; ++u) { const int j = min(u, a.S - 1); kq[u] = xk[j * pitch]; vq[u] = xv[j * pitch]; mq[u] = mk[j]; }
+                for (int b = 0; b < nb; ++b) {
+                    float kind[XKB], pr[XNR][XKB];
+#pragma unroll
+                    for (int u = 0; u < XKB; ++u) kind[u] = b * XKB + u >= a.S ? -INFINITY : (mq[u] == 0.f ? -1e9f : 0.f);
+                    st.scores<XKB>(kq, kind, pr);
+                    if (b + 1 < nb) {
+#pragma unroll
+                        for (int u = 0; u < XKB; ++u) { const int j = min((b + 1) * XKB + u, a.S - 1); kq[u] = xk[j * pitch]; mq[u] = mk[j]; }
+                    }
+                    st.pv<XKB>(vq, pr);
+                    if (b + 1 < nb) {
+#pragma unroll
+                        for (int u = 0; u < XKB; ++u) vq[u] = xv[min((b + 1) * XKB + u, a.S - 1) * pitch];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < XNR; ++i) {
+#pragma clang fp contract(off)
+                    if (i < nr) {
+                        const float inv = 1.f / st.l[i];
+                        reinterpret_cast<uint4*>(tile)[(c0 - r0 + i) * 64 + c * LR + fc] =
+                            make_uint4(pack2(st.o[i][0] * inv, st.o[i][1] * inv), pack2(st.o[i][2] * inv, st.o[i][3] * inv),
+                                       pack2(st.o[i][4] * inv, st.o[i][5] * inv), pack2(st.o[i][6] * inv, st.o[i][7] * inv));
+                    }
+                }
+            }
+            TP_XWAIT();
+            gather_img(tile, A0);
+        }
+        __syncthreads();
+        // ---- output projection, LayerNorm 2 -> A0
+        TP_FRESH_LANE();
+        {
+            char* tile = xb + (xn & 1) * XTILE;
+            ring_tp_start<G>(ring, wp, lane);
+            zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
+            store_tile(tile, acc, P.cob, false);
+            TP_XWAIT();
+            add_tile(tile);
+        }
+        ln_rows(P.n2a, P.n2b, A0);
+        __syncthreads();
+        // ---- FFN, 512 hidden units at a time: this member's columns of h_c = relu(y W1_c^T + b1_c) -> exchange -> Hh;
+        //      acc2 += Hh W2[this member's rows, chunk c]^T
+        TP_FRESH_LANE();
+        f32x4 acc2[MT][NT];
+        zero_acc(acc2);
+        for (int cc = 0; cc < ((a.debug & 4) ? 0 : a.NC); ++cc) {
+            char* tile = xb + (xn & 1) * XTILE;
+            zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
+            store_tile(tile, acc, P.b1 + cc * SD, true);
+            TP_XWAIT();                              // (its first barrier: every wave is past its reads of Hh)
+            gather_img(tile, Hh);
+            __syncthreads();
+            TP_UNIT_BEGIN(); unit_tp<G, true>(acc2, Hh, wp, ring, lane, mt0);
+        }
+        {
+            char* tile = xb + (xn & 1) * XTILE;
+            store_tile(tile, acc2, P.b2, false);
+            TP_XWAIT();
+            add_tile(tile);
+        }
+    }
+    // ---- final LayerNorm -> bf16 rows for the generator (through A0; member 0 writes them out)
+    TP_FRESH_LANE();
+    ln_rows(a.fa, a.fb, A0);
+    __syncthreads();
+    if (c == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = tid + 512 * u, row = q >> 6, ch = q & 63;
+            if (r0 + row < a.rows) *reinterpret_cast<uint4*>(a.y_out + (int64_t)(r0 + row) * SD + 8 * ch) = *reinterpret_cast<const uint4*>(A0 + img_off(row, ch));
+        }
+    }
+#undef TP_XWAIT
+#undef TP_FRESH_LANE
+#undef TP_UNIT_BEGIN
+#undef TP_KEY_ROW
+#undef TP_ISSUE
+}
+
+// tp_wpk[((((c WS + ws) L + l) U + u) 16 + ks) NT + nt) 64 + lane] = the 8 bf16 W_u[row][32 ks + 8 (lane >> 4) ..] with
+// row = c C + 16 tile + (lane & 15) of the unit's 512 output rows (tile = NT ws + nt)
+template <int G>
+__global__ __launch_bounds__(256) void stack_tp_pack_kernel(const __bf16* __restrict__ w16, uint4* __restrict__ wpk, StackPack t) {
+    constexpr int NT = TP<G>::NT, WS = TP<G>::WS, C = TP<G>::C;
+    const int U = 6 + 2 * t.NC;
+    const int64_t total = (int64_t)G * WS * t.L * U * 16 * NT * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        int64_t rest = i >> 6;
+        const int nt = (int)(rest % NT); rest /= NT;
+        const int ks = (int)(rest & 15); rest >>= 4;
+        const int u = (int)(rest % U); rest /= U;
+        const int l = (int)(rest % t.L); rest /= t.L;
+        const int ws = (int)(rest % WS);
+        const int c = (int)(rest / WS);
+        int64_t base; int ld;
+        if (u < 3)       { base = t.off[l][0] + (int64_t)u * SD * SD; ld = SD; }
+        else if (u < 6)  { base = t.off[l][u - 2]; ld = SD; }
+        else {
+            const int cc = (u - 6) >> 1;
+            if (((u - 6) & 1) == 0) { base = t.off[l][4] + (int64_t)cc * SD * SD; ld = SD; }           // W1 rows 512 cc ..
+            else                    { base = t.off[l][5] + (int64_t)cc * SD; ld = t.NC * SD; }          // W2 columns 512 cc ..
+        }
+        const int row = c * C + 16 * (NT * ws + nt) + (lane & 15);
+        wpk[i] = *reinterpret_cast<const uint4*>(w16 + base + (int64_t)row * ld + 32 * ks + 8 * (lane >> 4));
+    }
+}
+
+int stack_tp_degree(int64_t rows) {
+    const int groups = stack_tp_groups(rows);
+    for (int G = 8; G >= 2; G >>= 1)
+        if (groups * G <= 256) return G;
+    return 0;
+}
+size_t stack_tp_packed_bytes(int L, int NC, int G) {
+    const int NT = G == 2 ? 2 : 1, WS = G == 8 ? 4 : 8;
+    return ((size_t)G * WS * L * (6 + 2 * NC) * 16 * NT * 64 + (size_t)16 * NT * 64) * sizeof(uint4);   // + the ring's read-ahead
+}
+int stack_tp_pack(const void* w16, void* wpk, const StackPack& t, int G, hipStream_t s) {
+    const __bf16* w = reinterpret_cast<const __bf16*>(w16);
+    uint4* o = reinterpret_cast<uint4*>(wpk);
+    if (G == 2) hipLaunchKernelGGL(stack_tp_pack_kernel<2>, dim3(2048), dim3(256), 0, s, w, o, t);
+    else if (G == 4) hipLaunchKernelGGL(stack_tp_pack_kernel<4>, dim3(2048), dim3(256), 0, s, w, o, t);
+    else if (G == 8) hipLaunchKernelGGL(stack_tp_pack_kernel<8>, dim3(2048), dim3(256), 0, s, w, o, t);
+    else return ORTK_EINVAL;
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int G>
+static int stack_tp_launch(const StackArgs& b, hipStream_t s) {
+    constexpr size_t lds = TP<G>::LDS;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ORTK_EINVAL;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_stack_tp_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            done[dev] = true;
+        }
+    }
+    // (the pace-makers are the first member of groups 0..7: they must have rows in this launch)
+    const bool pf = b.progress != nullptr && b.tp_groups * G + 8 <= 256 && !(b.debug & 8) && b.rows > 7 * TR;
+    StackArgs c = b;
+    if (!pf) c.progress = nullptr;
+    hipLaunchKernelGGL((decoder_stack_tp_kernel<G>), dim3((unsigned)(b.tp_groups * G + (pf ? 8 : 0))), dim3(512), lds, s, c);
+    return 0;
+}
+
 template <bool SPARSE, int RB>
 static int stack_launch(const StackArgs& b, bool pf, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * RB * SD * 2 + 2 * 32 * 8 * sizeof(float) + (SPARSE ? 8 * SDBUF : 0);
@@ -912,7 +1452,7 @@ int stack_step(const StackArgs& a, hipStream_t s) {
     StackArgs b = a;
     b.nblocks = (int)ortk_cdiv(a.rows, rb);
     const bool pf = !sparse && b.nblocks >= 8 && b.nblocks + 8 <= 256 && a.progress != nullptr && !(a.debug & 8);
-    if (!pf) b.progress = nullptr;
+    if (!pf && !a.tp) b.progress = nullptr;
     // algorithmic bytes of the launch: the weights once (sparse stream: 4 bytes per non-zero), every image's projected
     // memory (K and V) once per layer, every row's cached keys and values once per layer plus the appended position, the
     // residual rows in and the normalised rows out
@@ -925,7 +1465,12 @@ int stack_step(const StackArgs& a, hipStream_t s) {
         (void)prof_begin(PROF_KEY_DECSTACK, 2.0 * a.rows * a.L * U * SD * SD, bytes, s, pm);
     } else pm.live = false;
     int rc;
-    if (sparse) rc = stack_launch<true, 20>(b, pf, s);
+    if (a.tp) {
+        if (sparse || !a.tp_wpk || !a.tp_xbuf || !a.tp_flag || a.tp_groups < 8 || a.tp_groups % 8 || a.tp_groups * a.tp > 256 ||
+            (int64_t)a.tp_groups * TR < a.rows) return ORTK_EINVAL;
+        rc = a.tp == 2 ? stack_tp_launch<2>(b, s) : a.tp == 4 ? stack_tp_launch<4>(b, s) : a.tp == 8 ? stack_tp_launch<8>(b, s) : ORTK_EINVAL;
+    }
+    else if (sparse) rc = stack_launch<true, 20>(b, pf, s);
     else if (rb == 20) rc = stack_launch<false, 20>(b, pf, s);
     else rc = stack_launch<false, 32>(b, pf, s);
     prof_end(pm, s);

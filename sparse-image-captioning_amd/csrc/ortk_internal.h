@@ -102,11 +102,24 @@ struct StackArgs {
     int32_t* progress;             // [16] zeroed at the start of a decode: units begun by the pace-maker of each XCD
     int32_t debug;                 // measurement only: 1 skip self-attention, 2 skip cross-attention, 4 skip the FFN, 8 no L2 prefetchers
     int32_t rb;                    // rows per workgroup: 32 (default) or 20 (256 workgroups for 1 024 images x 5 beams)
+    // column-split form (stack_tp_step): G workgroups of one XCD share 64 rows, each owns 512 / G output columns of every unit
+    int32_t tp;                    // G: 0 (off) | 2 | 4 | 8
+    const uint4* tp_wpk;           // stack_tp_pack() image of the decoder weights
+    char* tp_xbuf;                 // exchange tiles: (groups, 2, 64 x 512 x 4 bytes)
+    int32_t* tp_flag;              // (groups, 32) exchange counters, zeroed at the start of a decode
+    int32_t tp_groups;             // groups of the FULL row count of the decode (a multiple of 8); this launch may use fewer
+    int32_t tp_launch;             // index of this launch within the decode (the counters keep running)
 };
 struct StackPack { int64_t off[STACK_MAXL][6]; int32_t L, NC; };   // element offsets of wqkv, wo, cqw, cow, w1, w2 per layer
 size_t stack_packed_bytes(int L, int NC);
 int stack_pack(const void* w16, void* wpk, const StackPack& t, hipStream_t s);
 int stack_step(const StackArgs& a, hipStream_t s);
+// column-split form: G (0 = not served), weight image bytes, exchange buffer bytes, flag ints for a decode of `rows` rows
+int stack_tp_degree(int64_t rows);
+size_t stack_tp_packed_bytes(int L, int NC, int G);
+int stack_tp_pack(const void* w16, void* wpk, const StackPack& t, int G, hipStream_t s);
+inline int stack_tp_groups(int64_t rows) { return (int)(((rows + 63) / 64 + 7) / 8 * 8); }
+inline size_t stack_tp_xbuf_bytes(int64_t rows) { return (size_t)stack_tp_groups(rows) * 2 * 64 * 512 * 4; }
 // Sparse stream (mostly-zero decoder weights): the non-zeros of every 2 048-weight MFMA fragment group as (position, value) scatter
 // entries, built on the device from the bf16 weights of the call (three launches, no host sync).
 struct SStackBufs { uint2* stream; int32_t *cnt, *nst; int64_t *start, *stats; size_t stream_bytes; };     // stats: {steps, non-zeros}   // stats: {steps, pieces}

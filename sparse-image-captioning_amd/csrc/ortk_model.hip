@@ -1072,6 +1072,8 @@ struct DecodeWS {
     void* wpk = nullptr;               // decoder weights in the stack kernel's streaming order (stack path, dense stream)
     int32_t* progress = nullptr;       // pace-maker counters of the stack kernel's L2 prefetchers
     SStackBufs ss{};                   // the sparse stream and its tables (stack path, sparse stream)
+    int tp = 0;                        // column-split stack kernel: workgroups per group (0 = off), its weight image,
+    void* tp_wpk = nullptr; char* tp_xbuf = nullptr; int32_t* tp_flag = nullptr;      // exchange tiles and counters
     size_t bytes;
 };
 
@@ -1086,13 +1088,17 @@ static bool stack_ok(const ortk_config& c, int64_t rows, int32_t flags) {
     // 29.9 vs 28.3 ms per step).  The SPARSE stream (ORTK_DEC_SPARSE_STREAM) is ~9x shorter and has no such floor.
     // ortk_decode_opts.exec_flags overrides the size rule (parity tests and A/B measurements run both executors).
     if (flags & ORTK_DEC_UNFUSED) return false;
-    if (!(flags & (ORTK_DEC_STACK | ORTK_DEC_SPARSE_STREAM)) && rows < 1600) return false;
+    if (!(flags & (ORTK_DEC_STACK | ORTK_DEC_SPARSE_STREAM | ORTK_DEC_STACK_SPLIT)) && rows < 1600) return false;
     return c.precision == 1 && c.d_model == 512 && c.n_heads == 8 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 &&
            c.share_att_dec == 0 && c.n_layers <= STACK_MAXL && c.seq_len <= 64;     // (seq_len: one lane per cached key)
 }
 
+// workgroups per group of the column-split stack kernel for this decode (0: the plain kernel)
+static int split_degree(bool dense_stack, int32_t flags, int64_t rows) {
+    return (dense_stack && (flags & ORTK_DEC_STACK_SPLIT)) ? stack_tp_degree(rows) : 0;
+}
 static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false, bool sstream = false,
-                         bool train = false) {
+                         bool train = false, int tp = 0) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
     // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
     w.kvdt = (c.precision && H == 8 && d == 512 && S > 8 && S <= 48 && T <= 32 && K <= 16) ? ORTK_BF16 : ORTK_F32;
@@ -1123,7 +1129,13 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     if (beam && c.precision) w.gstats = b.take<float>(rows * (w.ldv / 64) * 2);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
-    if (stack && !sstream) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
+    if (stack && !sstream && tp > 0) {
+        w.tp = tp;
+        w.tp_wpk = b.take_bytes(stack_tp_packed_bytes((int)L, (int)(ff / 512), tp));
+        w.tp_xbuf = reinterpret_cast<char*>(b.take_bytes(stack_tp_xbuf_bytes(rows)));
+        w.tp_flag = b.take<int32_t>((int64_t)stack_tp_groups(rows) * 32);
+        w.progress = b.take<int32_t>(16);
+    } else if (stack && !sstream) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
     if (stack && sstream) {
         const size_t nb = sstack_bytes((int)L, (int)(ff / 512), nullptr, nullptr);
         void* p = b.take_bytes(nb);
@@ -1163,8 +1175,10 @@ extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B,
     if (check_cfg(cfg) || !o || B < 1 || S < 1) return 0;
     const int K = decode_K(o);
     if (K < 1) return 0;
-    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w,
-                             stack_ok(*cfg, (int64_t)B * K, o->exec_flags) && !o->sparse && !o->train, (o->exec_flags & ORTK_DEC_SPARSE_STREAM) != 0, o->train != 0);
+    const bool stack = stack_ok(*cfg, (int64_t)B * K, o->exec_flags) && !o->sparse && !o->train;
+    const bool sstream = (o->exec_flags & ORTK_DEC_SPARSE_STREAM) != 0;
+    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack, sstream, o->train != 0,
+                             split_degree(stack && !sstream, o->exec_flags, (int64_t)B * K));
     return w.bytes;
 }
 
@@ -1243,8 +1257,9 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
 }
 
 // The same position through the one-launch decoder stack: embed, stack kernel, generator.
+struct SplitBufs { int G; const void* wpk; char* xbuf; int32_t* flag; int groups; };      // column-split form (G = 0: off)
 static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w, const void* wpk, const SStackBufs* ss, int32_t* progress, int32_t flags,
-                              int64_t rows, int per_img, int S, int T, int t, const int32_t* kvidx) {
+                              int64_t rows, int per_img, int S, int T, int t, const int32_t* kvidx, const SplitBufs* sp = nullptr) {
     const ortk_config* cfg = c.cfg;
     const float* P = c.P;
     ortk_stream stream = (ortk_stream)c.s;
@@ -1266,6 +1281,10 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
     a.fa = P + o.dec_na; a.fb = P + o.dec_nb; a.att_masks = w.att_masks; a.kvidx = kvidx; a.ldx = o.ckv_slots * o.cw;
     a.rows = (int)rows; a.per_img = per_img; a.S = S; a.T = T; a.t = t; a.L = cfg->n_layers; a.NC = cfg->d_ff / 512; a.eps = 1e-6f;
     a.debug = (flags >> 8) & 0xF;        // ORTK_DEC_DEBUG_*: phase-skipping measurement switches
+    if (sp && sp->G) {
+        a.tp = sp->G; a.tp_wpk = reinterpret_cast<const uint4*>(sp->wpk); a.tp_xbuf = sp->xbuf; a.tp_flag = sp->flag; a.tp_groups = sp->groups;
+        a.tp_launch = t;                 // one launch per position: the exchange counters keep running through the decode
+    }
     TRY(stack_step(a, c.s));
     return gen_gemm(c, o, w, ORTK_BF16, rows);
 }
@@ -1286,7 +1305,8 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (op->train && (op->num_random_sample <= 0 || op->with_greedy || op->sparse)) return ORTK_EINVAL;
     const bool stack = stack_ok(*cfg, (int64_t)B * K, op->exec_flags) && !op->sparse && !op->train;
     const bool sstream = stack && (op->exec_flags & ORTK_DEC_SPARSE_STREAM);
-    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack, sstream, op->train != 0);
+    const int split = split_degree(stack && !sstream, op->exec_flags, (int64_t)B * K);
+    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack, sstream, op->train != 0, split);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     hipStream_t s = ortk_s(stream);
     TRY(make_w16(cfg, o, params, w.w16, stream));
@@ -1298,7 +1318,11 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
             for (int i = 0; i < 6; ++i) tp.off[l][i] = offs[i];
         }
         if (sstream) TRY(sstack_pack(w.w16, w.ss, tp, s));
-        else {
+        else if (w.tp) {
+            TRY(stack_tp_pack(w.w16, w.tp_wpk, tp, w.tp, s));
+            TRY(fill_i32(w.tp_flag, (int64_t)stack_tp_groups((int64_t)B * K) * 32, 0, s));
+            TRY(fill_i32(w.progress, 16, 0, s));
+        } else {
             TRY(stack_pack(w.w16, w.wpk, tp, s));
             TRY(fill_i32(w.progress, 16, 0, s));
         }
@@ -1359,7 +1383,8 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         sb.kvdt = w.kvdt; sb.ckvdt = w.ckvdt; sb.xq16 = w.xq16;
         if (beam && bs.gstats) { sb.gstats = w.gstats; sb.stat_ncols = V; }
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
-        if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
+        const SplitBufs spb{w.tp, w.tp_wpk, w.tp_xbuf, w.tp_flag, stack_tp_groups(rows_full)};
+        if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr, &spb));
         else TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.

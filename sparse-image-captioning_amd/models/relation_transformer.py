@@ -542,11 +542,11 @@ class RelationTransformerModel(CaptionModelBase):
         pptr = self._eff_params_ptr(False, 0)
         # executor choice (ortk_decode_opts.exec_flags): opt["executor"] = "auto" | "unfused" | "stack" | "sparse_stream";
         # ORTK_DEC_STACK=0 / 2 in the environment (read here, on the host side, per call) = "unfused" / "stack"
-        ex = opt.get("executor", {"0": "unfused", "2": "stack"}.get(os.environ.get("ORTK_DEC_STACK", ""), "auto"))
+        ex = opt.get("executor", {"0": "unfused", "2": "stack", "3": "stack_split"}.get(os.environ.get("ORTK_DEC_STACK", ""), "auto"))
         if ex == "auto" and getattr(self, "_sparse_stream", False):
             ex = "sparse_stream"
         o.exec_flags = {"auto": 0, "unfused": L.DEC_UNFUSED, "stack": L.DEC_STACK, "sparse_stream": L.DEC_SPARSE_STREAM,
-                        "stack_rb20": L.DEC_STACK | L.DEC_STACK_RB20,
+                        "stack_rb20": L.DEC_STACK | L.DEC_STACK_RB20, "stack_split": L.DEC_STACK | L.DEC_STACK_SPLIT,
                         "sparse_stream_rb20": L.DEC_SPARSE_STREAM | L.DEC_STACK_RB20}[ex] | (int(opt.get("stack_debug", 0)) & 0xF) << 8
         fresh_plan = getattr(self, "_plans", None) is None
         plan = self._sparse_plans()[0]

@@ -1015,6 +1015,34 @@ def test_decoder_stack_kernel_vs_fp32_and_unfused_executor(P, full_state, n_reg,
     assert (l1 - l0)[same].abs().mean().item() < 0.01
 
 
+@pytest.mark.parametrize("n_img,opt", [(70, {"beam_size": 1}), (70, {"beam_size": 5}), (300, {"beam_size": 5}),
+                                       (150, {"beam_size": 3, "decoding_constraint": 1}), (130, {"num_random_sample": 5, "beam_size": 0, "with_greedy": True, "seed": 7})])
+def test_column_split_stack_kernel_vs_fp32_and_plain_stack(P, full_state, n_img, opt):
+    """The column-split form of the decoder stack kernel (`executor="stack_split"`: groups of 8 / 4 / 2 workgroups of one XCD share
+    64 rows and split every projection's columns; partial results through that XCD's L2) — 70 / 130 / 150 images = 8 workgroups per
+    group (greedy, 6-row sampling, beam 3), 300 x 5 rows = 4 per group, ragged region counts, partial last groups:
+      * teacher-forced in fp32 on the tokens it emits, every log-prob within 0.02 of the one it reported (mean 0.004): the bar of the
+        plain stack kernel (test_decoder_stack_kernel_vs_fp32_and_unfused_executor);
+      * against the plain stack kernel on the same weights: tokens agree up to near-ties, log-probs of agreeing tokens to bf16 noise
+        (the two differ in the LayerNorm summation order only)."""
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
+    m32 = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=0)
+    b = _cuda(H.torch_batch(C.make_inputs(seed=43, n_img=n_img, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    with torch.no_grad():
+        s1, l1 = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt=dict(opt, executor="stack_split"), mode="sample")
+        s0, l0 = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt=dict(opt, executor="stack"), mode="sample")
+        n = min(n_img, 64)
+        rows = s1[:n, 0]
+        tf_in = torch.cat([rows.new_full((rows.size(0), 1), 2), rows], 1)
+        ref = m32(att_feats=b["att_feats"][:n], boxes=b["boxes"][:n], seqs=tf_in, att_masks=b["att_masks"][:n]).gather(2, rows.unsqueeze(2)).squeeze(2)
+    err = (l1[:n, 0] - ref)[rows != 0].abs()
+    assert err.max().item() <= 0.02 and err.mean().item() <= 0.004, (err.max().item(), err.mean().item())
+    same = s1 == s0
+    assert same.float().mean().item() >= 0.85, same.float().mean().item()
+    d = (l1 - l0)[same].abs()
+    assert d.max().item() < 0.25 and d.mean().item() < 0.01, (d.max().item(), d.mean().item())
+
+
 @pytest.mark.parametrize("precision", [0, 1])
 def test_scst_step_at_bench_size_properties(P, full_state, precision):
     """BASELINE configs[3] at its FULL size (256 images, greedy baseline + 5 multinomial rollouts = 1 536 decode rows, then the
