@@ -231,6 +231,7 @@ int ortk_spmm(const ortk_sparse_plan* plan, int32_t block, const ortk_spmm_args*
 #define ORTK_DEC_SPARSE_STREAM 4
 #define ORTK_DEC_STACK_RB20 8
 #define ORTK_DEC_STACK_SPLIT 16
+#define ORTK_DEC_SPLIT_SMALL 32
 typedef struct ortk_decode_opts {
     int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
     int32_t num_random_sample;
@@ -256,6 +257,12 @@ typedef struct ortk_decode_opts {
      *                           and split every projection's output columns (each streams 1/2 .. 1/8 of the weights; partial
      *                           results are exchanged through that XCD's L2).  Dense stream; implies ORTK_DEC_STACK; row counts
      *                           whose groups do not all fit the chip at once (> 8 192 rows) run the plain stack kernel;
+     *   ORTK_DEC_SPLIT_SMALL    automatic choice, but decodes of at most 2 048 rows (where 8 workgroups share a group) take the
+     *                           column-split form: the fastest executor there (100 rows 8.9 vs 10.7 ms unfused, 1 536 rows 11.9
+     *                           vs 14.3).  NOT the default of the library: the members of a group spin on each other, so ALL its
+     *                           workgroups must be resident — two such decodes running on one GPU at the same time (two host
+     *                           threads on two streams, two processes sharing the device) can starve each other for good.  Set
+     *                           it when this decode has the GPU to itself (the Python model does unless told otherwise);
      *   bits 8-11               measurement only: skip self-attention (1) / cross-attention (2) / the FFN (4), no L2 prefetchers (8). */
     int32_t exec_flags;
     /* multinomial only: also decode ONE greedy row per image in the same pass (the SCST baseline of

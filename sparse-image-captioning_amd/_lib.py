@@ -61,7 +61,7 @@ class SpmmArgs(C.Structure):
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
 
 
-DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT = 1, 2, 4, 8, 16      # ortk_decode_opts.exec_flags
+DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL = 1, 2, 4, 8, 16, 32      # ortk_decode_opts.exec_flags
 
 
 class DecodeOpts(C.Structure):

@@ -932,6 +932,14 @@ __device__ __forceinline__ tpu4 load_sc1(const void* p) {
 __device__ __forceinline__ void wait_sc1(tpu4 (&v)[8]) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
 }
+// sum over the 64 lanes by DPP (no LDS crossbar, no lgkmcnt wait): 16-lane rows, then the four row totals through readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_quad1(v);
+    v += dpp_quad2(v);
+    v += dpp_half_mirror(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));      // row_mirror
+    return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
 template <int G> struct RingTP { uint4 f[TP<G>::DEP][TP<G>::NT]; };
 template <int G> __device__ __forceinline__ void ring_tp_start(RingTP<G>& r, const uint4* wp, int lane) {
 #pragma unroll
@@ -1045,7 +1053,7 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         for (int j = 0; j < 4; ++j) { x[i][j] = u0[j]; x[i][4 + j] = u1[j]; }
     }
     // LayerNorm of the 8 rows of this wave -> bf16 rows of an A image (wave reductions only)
-    // (::wave_sum: the float reduction of ortk_common.h — inside namespace ortk the name finds the builder's int overload first)
+    // (NOT wave_sum(): inside namespace ortk that name finds the stream builder's int overload first and silently truncates)
     auto ln_rows = [&](const float* ga, const float* be, char* img) {
 #pragma clang fp contract(off)
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(ga + 8 * lane), g1 = *reinterpret_cast<const f32x4*>(ga + 8 * lane + 4);
@@ -1057,11 +1065,11 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) sm += x[i][j];
-            const float mean = ::wave_sum(sm) * (1.f / SD);
+            const float mean = wave_sum_dpp(sm) * (1.f / SD);
             float q = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = x[i][j] - mean; q = __builtin_fmaf(d, d, q); }
-            const float rinv = 1.f / (sqrtf(::wave_sum(q) * (1.f / (SD - 1))) + a.eps);
+            const float rinv = 1.f / (sqrtf(wave_sum_dpp(q) * (1.f / (SD - 1))) + a.eps);
             float y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = __builtin_fmaf(gv[j] * (x[i][j] - mean), rinv, bv[j]);
@@ -1172,12 +1180,13 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 st.m[0] = -INFINITY; st.l[0] = 0.f;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) st.o[0][d] = 0.f;
-                const int nb = (a.t + SKB - 1) / SKB;
-                uint4 kq[SKB], vq[SKB];
+                constexpr int SKT = G == 2 ? SKB : 6;      // keys per batch: the narrower slices have registers to spare
+                const int nb = (a.t + SKT - 1) / SKT;
+                uint4 kq[SKT], vq[SKT];
 #define TP_ISSUE(B)                                                                           \
                 do {                                                                          \
-                    _Pragma("unroll") for (int u_ = 0; u_ < SKB; ++u_) {                      \
-                        const int j_ = min((B) * SKB + u_, max(a.t - 1, 0));                  \
+                    _Pragma("unroll") for (int u_ = 0; u_ < SKT; ++u_) {                      \
+                        const int j_ = min((B) * SKT + u_, max(a.t - 1, 0));                  \
                         int kr_; TP_KEY_ROW(j_, kr_);                                         \
                         const int64_t ko_ = (int64_t)kr_ * (SD / 8) + c * LR + fc;            \
                         kq[u_] = ck[ko_]; vq[u_] = cv[ko_];                                   \
@@ -1185,15 +1194,15 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 } while (0)
                 if (nb > 0) TP_ISSUE(0);
                 for (int b = 0; b < nb; ++b) {
-                    float kind[SKB], pr[1][SKB];
+                    float kind[SKT], pr[1][SKT];
 #pragma unroll
-                    for (int u = 0; u < SKB; ++u) kind[u] = b * SKB + u < a.t ? 0.f : -INFINITY;
-                    uint4 kc[SKB], vc[SKB];
+                    for (int u = 0; u < SKT; ++u) kind[u] = b * SKT + u < a.t ? 0.f : -INFINITY;
+                    uint4 kc[SKT], vc[SKT];
 #pragma unroll
-                    for (int u = 0; u < SKB; ++u) { kc[u] = kq[u]; vc[u] = vq[u]; }
+                    for (int u = 0; u < SKT; ++u) { kc[u] = kq[u]; vc[u] = vq[u]; }
                     if (b + 1 < nb) TP_ISSUE(b + 1);
-                    st.scores<SKB>(kc, kind, pr);
-                    st.pv<SKB>(vc, pr);
+                    st.scores<SKT>(kc, kind, pr);
+                    st.pv<SKT>(vc, pr);
                 }
                 const uint4 kself[1] = {*reinterpret_cast<const uint4*>(KI + sl_off<G>(row, fc))};
                 const uint4 vself[1] = {*reinterpret_cast<const uint4*>(VI + sl_off<G>(row, fc))};
@@ -1234,7 +1243,56 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         __syncthreads();
         // ---- cross-attention: chunks of up to XNR rows of one image share their key / value loads; one chunk per LR-lane group
         TP_FRESH_LANE();
-        if (!(a.debug & 2)) {
+        if (!(a.debug & 2) && G >= 4) {
+            // narrow slices (16 / 8 lanes per row): one row per lane group, 12 keys per batch — six batches for 36 regions
+            // instead of nine dependent ones (the shared-load form below is bound by that chain, not by its loads)
+            char* tile = xb + (xn & 1) * XTILE;
+            const int rs = lane / LR, fc = lane % LR;
+            constexpr int XKT = 6;
+            const int64_t pitch = a.ldx / 8;
+#pragma unroll 1
+            for (int p0 = 0; p0 < 8; p0 += G) {
+                const int row = 8 * wave + p0 + rs;
+                const int gc = min(r0 + row, a.rows - 1), imm = gc / a.per_img;
+                AttState<1> st;
+                st.q[0] = *reinterpret_cast<const uint4*>(QI + sl_off<G>(row, fc));
+                st.m[0] = -INFINITY; st.l[0] = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) st.o[0][d] = 0.f;
+                const uint4* xk = reinterpret_cast<const uint4*>(P.xk) + (int64_t)imm * a.S * pitch + c * LR + fc;
+                const uint4* xv = reinterpret_cast<const uint4*>(P.xv) + (int64_t)imm * a.S * pitch + c * LR + fc;
+                const float* mk = a.att_masks + (int64_t)imm * a.S;
+                const int nb = (a.S + XKT - 1) / XKT;
+                uint4 kq[XKT], vq[XKT];
+                float mq[XKT];
+#pragma unroll
+                for (int u = 0; u < XKT; ++u) { const int j = min(u, a.S - 1); kq[u] = xk[j * pitch]; vq[u] = xv[j * pitch]; mq[u] = mk[j]; }
+                for (int b = 0; b < nb; ++b) {
+                    float kind[XKT], pr[1][XKT];
+#pragma unroll
+                    for (int u = 0; u < XKT; ++u) kind[u] = b * XKT + u >= a.S ? -INFINITY : (mq[u] == 0.f ? -1e9f : 0.f);
+                    st.scores<XKT>(kq, kind, pr);
+                    if (b + 1 < nb) {
+#pragma unroll
+                        for (int u = 0; u < XKT; ++u) { const int j = min((b + 1) * XKT + u, a.S - 1); kq[u] = xk[j * pitch]; mq[u] = mk[j]; }
+                    }
+                    st.pv<XKT>(vq, pr);
+                    if (b + 1 < nb) {
+#pragma unroll
+                        for (int u = 0; u < XKT; ++u) vq[u] = xv[min((b + 1) * XKT + u, a.S - 1) * pitch];
+                    }
+                }
+                {
+#pragma clang fp contract(off)
+                    const float inv = 1.f / st.l[0];
+                    reinterpret_cast<uint4*>(tile)[row * 64 + c * LR + fc] =
+                        make_uint4(pack2(st.o[0][0] * inv, st.o[0][1] * inv), pack2(st.o[0][2] * inv, st.o[0][3] * inv),
+                                   pack2(st.o[0][4] * inv, st.o[0][5] * inv), pack2(st.o[0][6] * inv, st.o[0][7] * inv));
+                }
+            }
+            TP_XWAIT();
+            gather_img(tile, A0);
+        } else if (!(a.debug & 2)) {
             char* tile = xb + (xn & 1) * XTILE;
             const int rs = lane / LR, fc = lane % LR;
             const int last = min(r0 + TR, a.rows) - 1;

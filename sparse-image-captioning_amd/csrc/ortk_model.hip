@@ -1088,14 +1088,19 @@ static bool stack_ok(const ortk_config& c, int64_t rows, int32_t flags) {
     // 29.9 vs 28.3 ms per step).  The SPARSE stream (ORTK_DEC_SPARSE_STREAM) is ~9x shorter and has no such floor.
     // ortk_decode_opts.exec_flags overrides the size rule (parity tests and A/B measurements run both executors).
     if (flags & ORTK_DEC_UNFUSED) return false;
-    if (!(flags & (ORTK_DEC_STACK | ORTK_DEC_SPARSE_STREAM | ORTK_DEC_STACK_SPLIT)) && rows < 1600) return false;
+    // ORTK_DEC_SPLIT_SMALL: the column-split form serves the small decodes (its groups of 8 workgroups: up to 2 048 rows)
+    const bool small_split = (flags & ORTK_DEC_SPLIT_SMALL) && !(flags & ORTK_DEC_SPARSE_STREAM) && stack_tp_degree(rows) == 8;
+    if (!(flags & (ORTK_DEC_STACK | ORTK_DEC_SPARSE_STREAM | ORTK_DEC_STACK_SPLIT)) && !small_split && rows < 1600) return false;
     return c.precision == 1 && c.d_model == 512 && c.n_heads == 8 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 &&
            c.share_att_dec == 0 && c.n_layers <= STACK_MAXL && c.seq_len <= 64;     // (seq_len: one lane per cached key)
 }
 
 // workgroups per group of the column-split stack kernel for this decode (0: the plain kernel)
 static int split_degree(bool dense_stack, int32_t flags, int64_t rows) {
-    return (dense_stack && (flags & ORTK_DEC_STACK_SPLIT)) ? stack_tp_degree(rows) : 0;
+    if (!dense_stack) return 0;
+    const int G = stack_tp_degree(rows);
+    if (flags & ORTK_DEC_STACK_SPLIT) return G;                                   // whenever its groups fit the chip
+    return ((flags & ORTK_DEC_SPLIT_SMALL) && !(flags & ORTK_DEC_STACK) && G == 8) ? 8 : 0;     // the small decodes only
 }
 static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false, bool sstream = false,
                          bool train = false, int tp = 0) {

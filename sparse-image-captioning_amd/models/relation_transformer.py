@@ -545,7 +545,11 @@ class RelationTransformerModel(CaptionModelBase):
         ex = opt.get("executor", {"0": "unfused", "2": "stack", "3": "stack_split"}.get(os.environ.get("ORTK_DEC_STACK", ""), "auto"))
         if ex == "auto" and getattr(self, "_sparse_stream", False):
             ex = "sparse_stream"
-        o.exec_flags = {"auto": 0, "unfused": L.DEC_UNFUSED, "stack": L.DEC_STACK, "sparse_stream": L.DEC_SPARSE_STREAM,
+        # "auto" lets decodes of <= 2 048 rows take the column-split stack kernel (fastest there) UNLESS another decode may run on
+        # this GPU at the same time: its workgroups spin on each other and must all be resident (ortk.h: ORTK_DEC_SPLIT_SMALL).
+        # `model.exclusive_gpu = False` (two processes on one device) or decode_streams > 1 switch that off.
+        small = L.DEC_SPLIT_SMALL if (getattr(self, "exclusive_gpu", True) and int(opt.get("decode_streams", 0) or 1) <= 1) else 0
+        o.exec_flags = {"auto": small, "unfused": L.DEC_UNFUSED, "stack": L.DEC_STACK, "sparse_stream": L.DEC_SPARSE_STREAM,
                         "stack_rb20": L.DEC_STACK | L.DEC_STACK_RB20, "stack_split": L.DEC_STACK | L.DEC_STACK_SPLIT,
                         "sparse_stream_rb20": L.DEC_SPARSE_STREAM | L.DEC_STACK_RB20}[ex] | (int(opt.get("stack_debug", 0)) & 0xF) << 8
         fresh_plan = getattr(self, "_plans", None) is None

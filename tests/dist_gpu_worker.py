@@ -35,6 +35,7 @@ def build(kind):
 
 def run(kind, data, steps, **kw):
     m = build(kind)
+    m.exclusive_gpu = False        # two ranks share this GPU: no spin-waiting decode kernels (ortk.h: ORTK_DEC_SPLIT_SMALL)
     m.eval()                                               # (no dropout: the two-rank sum must equal the full-batch step)
     tr = NativeTrainer(m, noamopt_warmup=10, sparsity_target=0.5 if kind != "dense" else None, max_train_step=10, **kw)
     losses = []

@@ -1176,22 +1176,21 @@ def test_decode_at_bench_size_properties(P, full_state):
 
 
 def test_decode_executor_is_chosen_by_size(P, full_state):
-    """Default dispatch (ORTK_DEC_STACK unset): decodes of fewer than 1 600 rows run the unfused executor, larger ones the stack
-    kernel — checked through bit-identical outputs against the forced modes."""
-    import os
+    """Default dispatch (no `executor` option): decodes of at most 2 048 rows run the column-split stack kernel when the model has the
+    GPU to itself (`exclusive_gpu`, the default) and the unfused executor when it has not (below 1 600 rows); larger ones the plain
+    stack kernel — checked through bit-identical outputs against the forced modes."""
     m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
-    for n_img, forced in ((40, "0"), (330, "2")):
+    for n_img, exclusive, forced in ((40, True, "stack_split"), (40, False, "unfused"), (330, False, "stack"), (450, True, "stack")):
         b = _cuda(H.torch_batch(C.make_inputs(seed=47, n_img=n_img, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
-        kw = dict(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 5}, mode="sample")
-        with torch.no_grad():
-            os.environ.pop("ORTK_DEC_STACK", None)
-            seq_d, lp_d = m(**kw)
-            os.environ["ORTK_DEC_STACK"] = forced
-            try:
-                seq_f, lp_f = m(**kw)
-            finally:
-                os.environ.pop("ORTK_DEC_STACK", None)
-        assert torch.equal(seq_d, seq_f) and torch.equal(lp_d, lp_f), (n_img, forced)
+        kw = dict(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], mode="sample")
+        m.exclusive_gpu = exclusive
+        try:
+            with torch.no_grad():
+                seq_d, lp_d = m(**kw, opt={"beam_size": 5})
+                seq_f, lp_f = m(**kw, opt={"beam_size": 5, "executor": forced})
+        finally:
+            m.exclusive_gpu = True
+        assert torch.equal(seq_d, seq_f) and torch.equal(lp_d, lp_f), (n_img, exclusive, forced)
 
 
 def test_decoder_stack_kernel_shared_layers_and_long_captions(P):
