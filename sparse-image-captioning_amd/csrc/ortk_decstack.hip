@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 st.m[0] = -INFINITY; st.l[0] = 0.f;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) st.o[0][d] = 0.f;
-                constexpr int SKT = G == 2 ? SKB : 6;      // keys per batch: the narrower slices have registers to spare
+                constexpr int SKT = G == 2 ? SKB : 4;      // keys per batch (measured at 1 536 rows, ms per decode: 2: 11.1, 3 / 4: 10.65, 6: 11.5, 9: 12.1 — registers)
                 const int nb = (a.t + SKT - 1) / SKT;
                 uint4 kq[SKT], vq[SKT];
 #define TP_ISSUE(B)                                                                           \
@@ -1244,11 +1244,11 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         // ---- cross-attention: chunks of up to XNR rows of one image share their key / value loads; one chunk per LR-lane group
         TP_FRESH_LANE();
         if (!(a.debug & 2) && G >= 4) {
-            // narrow slices (16 / 8 lanes per row): one row per lane group, 12 keys per batch — six batches for 36 regions
-            // instead of nine dependent ones (the shared-load form below is bound by that chain, not by its loads)
+            // narrow slices (16 / 8 lanes per row): one row per lane group and all 64 rows of the group in one or two passes — the
+            // shared-load form below leaves two thirds of the lane groups idle there and runs five rows' state per lane
             char* tile = xb + (xn & 1) * XTILE;
             const int rs = lane / LR, fc = lane % LR;
-            constexpr int XKT = 6;
+            constexpr int XKT = 4;
             const int64_t pitch = a.ldx / 8;
 #pragma unroll 1
             for (int p0 = 0; p0 < 8; p0 += G) {
