@@ -965,12 +965,12 @@ def test_bf16_decode_logprob_bound(P, full_state):
         assert (s16[:, 0] == s32[:, 0]).all(-1).float().mean().item() >= 0.6
 
 
-def _decode_both_executors(m, b, opt):
+def _decode_both_executors(m, b, opt, stack_flag="2"):
     """(stack kernel, unfused executor) results of the same mixed-precision decode; ORTK_DEC_STACK is read per call
-    (2 = the stack kernel at any size: by default it only takes decodes of 1 600 rows and more)."""
+    (2 = the plain stack kernel at any size, 3 = its column-split form)."""
     import os
     out = []
-    for flag in ("2", "0"):
+    for flag in (stack_flag, "0"):
         os.environ["ORTK_DEC_STACK"] = flag
         try:
             with torch.no_grad():
@@ -1193,15 +1193,17 @@ def test_decode_executor_is_chosen_by_size(P, full_state):
         assert torch.equal(seq_d, seq_f) and torch.equal(lp_d, lp_f), (n_img, exclusive, forced)
 
 
-def test_decoder_stack_kernel_shared_layers_and_long_captions(P):
-    """ACORT-style configuration on the stack path: decoder layers shared in pairs, 26-token captions (more cached keys than
-    one self-attention batch), d_ff 1024 (two hidden chunks) — against the unfused executor."""
+@pytest.mark.parametrize("stack_flag", ["2", "3"])
+def test_decoder_stack_kernel_shared_layers_and_long_captions(P, stack_flag):
+    """ACORT-style configuration on the stack path (plain kernel and its column-split form): decoder layers shared in pairs,
+    26-token captions (more cached keys than one self-attention batch), d_ff 1024 (two hidden chunks) — against the unfused
+    executor."""
     cfg = dict(C.FULL_CFG, max_seq_length=26, dim_feedforward=1024, share_layer_decoder=(0, 0, 1, 1, 2, 2))
     from sparse_image_captioning_amd.utils.config import Config
     torch.manual_seed(3)
     m = P.get_model("relation_transformer")(Config(**cfg), precision=1).cuda().eval()
     b = _cuda(H.torch_batch(C.make_inputs(seed=43, n_img=33, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
-    (s1, l1), (s0, l0) = _decode_both_executors(m, b, {"beam_size": 5})
+    (s1, l1), (s0, l0) = _decode_both_executors(m, b, {"beam_size": 5}, stack_flag)
     same = s1 == s0
     assert same.float().mean().item() >= 0.85
     assert (l1 - l0)[same].abs().mean().item() < 0.01
