@@ -909,7 +909,7 @@ template <int G> struct TP {
     // k-steps of weight fragments in flight per wave.  The stream is bound by latency x steps in flight, not by bytes, so the
     // narrower streams would want 16 / NT steps (the 64 VGPRs decoder_stack_kernel spends) — measured SLOWER (25.5 vs 23.9 ms per
     // 1 024-image decode): with the full residual rows in registers (64 VGPRs) the deeper ring spills
-    static constexpr int DEP = SPD;
+    static constexpr int DEP = G == 2 ? SPD : 8;     // (G = 4, 8 measured at 1 536 rows, ms per decode: 4 steps 10.65, 8: 10.38, 16: 14.6 — spills)
     static constexpr int SLICE = TR * C * 2;         // bytes of a bf16 slice image
     static constexpr int R2 = 3 * SLICE > 65536 ? 3 * SLICE : 65536;
     static constexpr size_t LDS = 65536 + R2;
@@ -1437,10 +1437,23 @@ __global__ __launch_bounds__(256) void stack_tp_pack_kernel(const __bf16* __rest
     }
 }
 
+// compute units of the current device: every workgroup of a column-split launch must be resident (one per CU: > 80 KB of LDS)
+static int tp_cu_budget() {
+    static std::mutex mu;
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
 int stack_tp_degree(int64_t rows) {
-    const int groups = stack_tp_groups(rows);
+    const int groups = stack_tp_groups(rows), budget = tp_cu_budget();
     for (int G = 8; G >= 2; G >>= 1)
-        if (groups * G <= 256) return G;
+        if (groups * G <= budget) return G;
     return 0;
 }
 size_t stack_tp_packed_bytes(int L, int NC, int G) {
@@ -1475,7 +1488,7 @@ static int stack_tp_launch(const StackArgs& b, hipStream_t s) {
         }
     }
     // (the pace-makers are the first member of groups 0..7: they must have rows in this launch)
-    const bool pf = b.progress != nullptr && b.tp_groups * G + 8 <= 256 && !(b.debug & 8) && b.rows > 7 * TR;
+    const bool pf = b.progress != nullptr && b.tp_groups * G + 8 <= tp_cu_budget() && !(b.debug & 8) && b.rows > 7 * TR;
     StackArgs c = b;
     if (!pf) c.progress = nullptr;
     hipLaunchKernelGGL((decoder_stack_tp_kernel<G>), dim3((unsigned)(b.tp_groups * G + (pf ? 8 : 0))), dim3(512), lds, s, c);
@@ -1524,7 +1537,7 @@ int stack_step(const StackArgs& a, hipStream_t s) {
     } else pm.live = false;
     int rc;
     if (a.tp) {
-        if (sparse || !a.tp_wpk || !a.tp_xbuf || !a.tp_flag || a.tp_groups < 8 || a.tp_groups % 8 || a.tp_groups * a.tp > 256 ||
+        if (sparse || !a.tp_wpk || !a.tp_xbuf || !a.tp_flag || a.tp_groups < 8 || a.tp_groups % 8 || a.tp_groups * a.tp > tp_cu_budget() ||
             (int64_t)a.tp_groups * TR < a.rows) return ORTK_EINVAL;
         rc = a.tp == 2 ? stack_tp_launch<2>(b, s) : a.tp == 4 ? stack_tp_launch<4>(b, s) : a.tp == 8 ? stack_tp_launch<8>(b, s) : ORTK_EINVAL;
     }
