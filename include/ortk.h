@@ -257,9 +257,9 @@ typedef struct ortk_decode_opts {
      *                           and split every projection's output columns (each streams 1/2 .. 1/8 of the weights; partial
      *                           results are exchanged through that XCD's L2).  Dense stream; implies ORTK_DEC_STACK; row counts
      *                           whose groups do not all fit the chip at once (> 8 192 rows) run the plain stack kernel;
-     *   ORTK_DEC_SPLIT_SMALL    automatic choice, but decodes of at most 2 048 rows (where 8 workgroups share a group) take the
-     *                           column-split form: the fastest executor there (100 rows 8.9 vs 10.7 ms unfused, 1 536 rows 11.9
-     *                           vs 14.3).  NOT the default of the library: the members of a group spin on each other, so ALL its
+     *   ORTK_DEC_SPLIT_SMALL    automatic choice, but decodes of at most 4 096 rows (8 workgroups per group up to 2 048 rows, 4
+     *                           above) take the column-split form: the fastest executor there (100 rows 8.2 vs 10.9 ms unfused,
+     *                           1 536 rows 10.9 vs 14.2, 3 500 rows 17.0 vs 17.5 on the plain stack kernel).  NOT the default of the library: the members of a group spin on each other, so ALL its
      *                           workgroups must be resident — two such decodes running on one GPU at the same time (two host
      *                           threads on two streams, two processes sharing the device) can starve each other for good.  Set
      *                           it when this decode has the GPU to itself (the Python model does unless told otherwise);

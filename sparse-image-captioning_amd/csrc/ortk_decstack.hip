@@ -914,7 +914,7 @@ template <int G> struct TP {
     static constexpr int R2 = 3 * SLICE > 65536 ? 3 * SLICE : 65536;
     static constexpr size_t LDS = 65536 + R2;
 };
-constexpr size_t XTILE = (size_t)TR * SD * 4;        // bytes of one exchange tile (fp32 form)
+constexpr size_t XTILE_MIN = (size_t)TR * SD * 4;    // bytes of the fp32 [64 x 512] exchange tile
 
 // slice image [64 rows][LR chunks of 16 B]: chunk' = chunk ^ (row & min(15, LR - 1)) (the accumulator-layout stores of 16 rows
 // of one column tile land on distinct chunks)
@@ -989,8 +989,9 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
     const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = lane0;
     const int U = 6 + 2 * a.NC;
-    // exchanges of one launch: per layer o(self), wo, o(cross), co, NC hidden chunks, w2 (a.debug: phases skipped for measurements)
-    const int NX = a.L * (3 + ((a.debug & 1) ? 0 : 1) + ((a.debug & 2) ? 0 : 1) + ((a.debug & 4) ? 0 : a.NC));
+    // exchanges of one launch: per layer o(self), wo, o(cross), co, the hidden units (all chunks at once), w2 (a.debug: phases
+    // skipped for measurements)
+    const int NX = a.L * (3 + ((a.debug & 1) ? 0 : 1) + ((a.debug & 2) ? 0 : 1) + ((a.debug & 4) ? 0 : 1));
     const int xcd = (int)(blockIdx.x & 7), kk = (int)(blockIdx.x >> 3), c = kk % G, grp = (kk / G) * 8 + xcd;
     if ((int)blockIdx.x >= a.tp_groups * G) {
         // L2 prefetcher of one XCD (as in decoder_stack_kernel): the members of an XCD's groups walk the G x WS weight streams in
@@ -1022,6 +1023,7 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         return;
     }
     int xn = a.tp_launch * NX;              // exchanges this group has completed
+    const size_t XTILE = (size_t)a.tp_xtile;      // bytes of one exchange tile: the fp32 [64 x 512] form or the NC hidden chunks
     char* xb = a.tp_xbuf + (size_t)grp * 2 * XTILE;
     // publish this member's part of tile (xn & 1) and wait for the others'
 #define TP_XWAIT()                                                                                              \
@@ -1374,14 +1376,21 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         TP_FRESH_LANE();
         f32x4 acc2[MT][NT];
         zero_acc(acc2);
-        for (int cc = 0; cc < ((a.debug & 4) ? 0 : a.NC); ++cc) {
+        if (!(a.debug & 4)) {
+            // all NC up-projection units first (the stream holds them back to back), ONE exchange of the [64 x NC 512] hidden
+            // units, then the NC down-projection units, each on its gathered chunk
             char* tile = xb + (xn & 1) * XTILE;
-            zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
-            store_tile(tile, acc, P.b1 + cc * SD, true);
-            TP_XWAIT();                              // (its first barrier: every wave is past its reads of Hh)
-            gather_img(tile, Hh);
-            __syncthreads();
-            TP_UNIT_BEGIN(); unit_tp<G, true>(acc2, Hh, wp, ring, lane, mt0);
+            for (int cc = 0; cc < a.NC; ++cc) {
+                zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
+                store_tile(tile + (size_t)cc * (TR * SD * 2), acc, P.b1 + cc * SD, true);
+            }
+            TP_XWAIT();
+            for (int cc = 0; cc < a.NC; ++cc) {
+                gather_img(tile + (size_t)cc * (TR * SD * 2), Hh);
+                __syncthreads();
+                TP_UNIT_BEGIN(); unit_tp<G, true>(acc2, Hh, wp, ring, lane, mt0);
+                __syncthreads();                     // every wave is past its reads of Hh
+            }
         }
         {
             char* tile = xb + (xn & 1) * XTILE;
@@ -1427,11 +1436,8 @@ __global__ __launch_bounds__(256) void stack_tp_pack_kernel(const __bf16* __rest
         int64_t base; int ld;
         if (u < 3)       { base = t.off[l][0] + (int64_t)u * SD * SD; ld = SD; }
         else if (u < 6)  { base = t.off[l][u - 2]; ld = SD; }
-        else {
-            const int cc = (u - 6) >> 1;
-            if (((u - 6) & 1) == 0) { base = t.off[l][4] + (int64_t)cc * SD * SD; ld = SD; }           // W1 rows 512 cc ..
-            else                    { base = t.off[l][5] + (int64_t)cc * SD; ld = t.NC * SD; }          // W2 columns 512 cc ..
-        }
+        else if (u - 6 < t.NC) { const int cc = u - 6;        base = t.off[l][4] + (int64_t)cc * SD * SD; ld = SD; }           // W1 rows 512 cc .. (all chunks first)
+        else                   { const int cc = u - 6 - t.NC; base = t.off[l][5] + (int64_t)cc * SD; ld = t.NC * SD; }          // W2 columns 512 cc ..
         const int row = c * C + 16 * (NT * ws + nt) + (lane & 15);
         wpk[i] = *reinterpret_cast<const uint4*>(w16 + base + (int64_t)row * ld + 32 * ks + 8 * (lane >> 4));
     }

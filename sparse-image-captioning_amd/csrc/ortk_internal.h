@@ -109,6 +109,7 @@ struct StackArgs {
     int32_t* tp_flag;              // (groups, 32) exchange counters, zeroed at the start of a decode
     int32_t tp_groups;             // groups of the FULL row count of the decode (a multiple of 8); this launch may use fewer
     int32_t tp_launch;             // index of this launch within the decode (the counters keep running)
+    int64_t tp_xtile;              // bytes of one exchange tile (stack_tp_xtile_bytes)
 };
 struct StackPack { int64_t off[STACK_MAXL][6]; int32_t L, NC; };   // element offsets of wqkv, wo, cqw, cow, w1, w2 per layer
 size_t stack_packed_bytes(int L, int NC);
@@ -119,7 +120,9 @@ int stack_tp_degree(int64_t rows);
 size_t stack_tp_packed_bytes(int L, int NC, int G);
 int stack_tp_pack(const void* w16, void* wpk, const StackPack& t, int G, hipStream_t s);
 inline int stack_tp_groups(int64_t rows) { return (int)(((rows + 63) / 64 + 7) / 8 * 8); }
-inline size_t stack_tp_xbuf_bytes(int64_t rows) { return (size_t)stack_tp_groups(rows) * 2 * 64 * 512 * 4; }
+// one exchange tile: [64 x 512] fp32, or the NC hidden chunks of [64 x 512] bf16 that travel together
+inline size_t stack_tp_xtile_bytes(int NC) { const size_t h = (size_t)NC * 64 * 512 * 2, f = (size_t)64 * 512 * 4; return h > f ? h : f; }
+inline size_t stack_tp_xbuf_bytes(int64_t rows, int NC) { return (size_t)stack_tp_groups(rows) * 2 * stack_tp_xtile_bytes(NC); }
 // Sparse stream (mostly-zero decoder weights): the non-zeros of every 2 048-weight MFMA fragment group as (position, value) scatter
 // entries, built on the device from the bf16 weights of the call (three launches, no host sync).
 struct SStackBufs { uint2* stream; int32_t *cnt, *nst; int64_t *start, *stats; size_t stream_bytes; };     // stats: {steps, non-zeros}   // stats: {steps, pieces}

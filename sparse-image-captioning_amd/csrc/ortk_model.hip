@@ -1088,8 +1088,8 @@ static bool stack_ok(const ortk_config& c, int64_t rows, int32_t flags) {
     // 29.9 vs 28.3 ms per step).  The SPARSE stream (ORTK_DEC_SPARSE_STREAM) is ~9x shorter and has no such floor.
     // ortk_decode_opts.exec_flags overrides the size rule (parity tests and A/B measurements run both executors).
     if (flags & ORTK_DEC_UNFUSED) return false;
-    // ORTK_DEC_SPLIT_SMALL: the column-split form serves the small decodes (its groups of 8 workgroups: up to 2 048 rows)
-    const bool small_split = (flags & ORTK_DEC_SPLIT_SMALL) && !(flags & ORTK_DEC_SPARSE_STREAM) && stack_tp_degree(rows) == 8;
+    // ORTK_DEC_SPLIT_SMALL: the column-split form serves the small decodes (groups of 8 workgroups up to 2 048 rows, of 4 up to 4 096)
+    const bool small_split = (flags & ORTK_DEC_SPLIT_SMALL) && !(flags & ORTK_DEC_SPARSE_STREAM) && stack_tp_degree(rows) >= 4;
     if (!(flags & (ORTK_DEC_STACK | ORTK_DEC_SPARSE_STREAM | ORTK_DEC_STACK_SPLIT)) && !small_split && rows < 1600) return false;
     return c.precision == 1 && c.d_model == 512 && c.n_heads == 8 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 &&
            c.share_att_dec == 0 && c.n_layers <= STACK_MAXL && c.seq_len <= 64;     // (seq_len: one lane per cached key)
@@ -1100,7 +1100,7 @@ static int split_degree(bool dense_stack, int32_t flags, int64_t rows) {
     if (!dense_stack) return 0;
     const int G = stack_tp_degree(rows);
     if (flags & ORTK_DEC_STACK_SPLIT) return G;                                   // whenever its groups fit the chip
-    return ((flags & ORTK_DEC_SPLIT_SMALL) && !(flags & ORTK_DEC_STACK) && G == 8) ? 8 : 0;     // the small decodes only
+    return ((flags & ORTK_DEC_SPLIT_SMALL) && !(flags & ORTK_DEC_STACK) && G >= 4) ? G : 0;     // the small decodes only (8 or 4 per group)
 }
 static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false, bool sstream = false,
                          bool train = false, int tp = 0) {
@@ -1137,7 +1137,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     if (stack && !sstream && tp > 0) {
         w.tp = tp;
         w.tp_wpk = b.take_bytes(stack_tp_packed_bytes((int)L, (int)(ff / 512), tp));
-        w.tp_xbuf = reinterpret_cast<char*>(b.take_bytes(stack_tp_xbuf_bytes(rows)));
+        w.tp_xbuf = reinterpret_cast<char*>(b.take_bytes(stack_tp_xbuf_bytes(rows, (int)(ff / 512))));
         w.tp_flag = b.take<int32_t>((int64_t)stack_tp_groups(rows) * 32);
         w.progress = b.take<int32_t>(16);
     } else if (stack && !sstream) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
@@ -1289,6 +1289,7 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
     if (sp && sp->G) {
         a.tp = sp->G; a.tp_wpk = reinterpret_cast<const uint4*>(sp->wpk); a.tp_xbuf = sp->xbuf; a.tp_flag = sp->flag; a.tp_groups = sp->groups;
         a.tp_launch = t;                 // one launch per position: the exchange counters keep running through the decode
+        a.tp_xtile = (int64_t)stack_tp_xtile_bytes(cfg->d_ff / 512);
     }
     TRY(stack_step(a, c.s));
     return gen_gemm(c, o, w, ORTK_BF16, rows);

@@ -1176,11 +1176,12 @@ def test_decode_at_bench_size_properties(P, full_state):
 
 
 def test_decode_executor_is_chosen_by_size(P, full_state):
-    """Default dispatch (no `executor` option): decodes of at most 2 048 rows run the column-split stack kernel when the model has the
+    """Default dispatch (no `executor` option): decodes of at most 4 096 rows run the column-split stack kernel when the model has the
     GPU to itself (`exclusive_gpu`, the default) and the unfused executor when it has not (below 1 600 rows); larger ones the plain
     stack kernel — checked through bit-identical outputs against the forced modes."""
     m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
-    for n_img, exclusive, forced in ((40, True, "stack_split"), (40, False, "unfused"), (330, False, "stack"), (450, True, "stack")):
+    for n_img, exclusive, forced in ((40, True, "stack_split"), (40, False, "unfused"), (330, False, "stack"), (450, True, "stack_split"),
+                                     (830, True, "stack")):
         b = _cuda(H.torch_batch(C.make_inputs(seed=47, n_img=n_img, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
         kw = dict(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], mode="sample")
         m.exclusive_gpu = exclusive
