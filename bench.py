@@ -153,7 +153,9 @@ PARITY = {
             "library's own fp32 parity mode (HIP-bf16 vs HIP-fp32, not against the oracle directly; the fp32 mode is what the "
             "oracle pins): XE loss within 2e-2 of the golden, gradients within 5 % relative L2 of the fp32 path "
             "(test_mixed_precision_gradients_track_fp32_gradients), teacher-forced log-prob error of the decode <= 0.1 over 64 "
-            "images (test_bf16_decode_logprob_bound), valid-position layout == padded layout "
+            "images (test_bf16_decode_logprob_bound; the stack kernels: teacher-forced fp32 log-probs of their own tokens within 0.02, "
+            "test_decoder_stack_kernel_vs_fp32_and_unfused_executor, test_column_split_stack_kernel_vs_fp32_and_plain_stack), "
+            "valid-position layout == padded layout "
             "(test_valid_position_decoder_equals_padded_layout), train-mode dropout replayed through the oracle "
             "(test_train_mode_dropout_vs_oracle, fp32), bench-size determinism / permutation / fused-criterion properties "
             "(test_xe_step_at_bench_size_properties)",
