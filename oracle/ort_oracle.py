@@ -341,7 +341,8 @@ def gumbel_from_hash(seed: int, t: int, rows: int, vocab: int) -> Tensor:
 
 
 def sample_greedy_or_multinomial(P, cfg, att_feats, boxes, att_masks, num_random_sample: int = 0,
-                                 temperature: float = 1.0, decoding_constraint: int = 0, seed: int = 0, drop=None, drop_step=None):
+                                 temperature: float = 1.0, decoding_constraint: int = 0, seed: int = 0, drop=None, drop_step=None,
+                                 scores_out=None):
     """``_generate_captions`` greedy / multinomial branches (transformer.py:507-561).
 
     Multinomial draws use Gumbel-max over ``gumbel_from_hash`` (an exact sampler of
@@ -364,7 +365,10 @@ def sample_greedy_or_multinomial(P, cfg, att_feats, boxes, att_masks, num_random
         if decoding_constraint and t > 0:
             logp = logp.scatter(1, seq[:, t - 1:t], float("-inf"))
         if num_random_sample > 0:
-            it = (logp / temperature + gumbel_from_hash(seed, t, n, logp.size(1))).argmax(-1)
+            z = logp / temperature + gumbel_from_hash(seed, t, n, logp.size(1))
+            if scores_out is not None:          # (tests: the perturbed scores of every step, to show that a flipped token is a near-tie)
+                scores_out.append(z.clone())
+            it = z.argmax(-1)
             lp = logp.gather(1, it[:, None]).squeeze(1)
         else:
             lp, it = logp.max(1)

@@ -444,6 +444,25 @@ def test_non_trigonometric_box_embedding_vs_reference_golden(P, golden):
         close(lp, g5[f"decode_b{bs}/logprobs"], 2e-4)
 
 
+def _assert_flips_are_near_ties(seq, oseq, scores, tol=2e-4):
+    """Where a sampled row of the HIP path leaves the oracle's row, the two tokens at the FIRST differing position are a Gumbel
+    near-tie: the oracle's perturbed score (log-prob / temperature + Gumbel noise, same counter hash on both sides) of the token
+    the HIP path drew is within `tol` of the arg-max.  `scores`: the oracle's per-step perturbed scores (rows, V) — valid for
+    the HIP row up to and including that position because the prefixes agree."""
+    hs, os_ = seq.reshape(-1, seq.size(-1)).cpu(), oseq.reshape(-1, oseq.size(-1))
+    flips = 0
+    for r in range(hs.size(0)):
+        d = (hs[r] != os_[r]).nonzero()
+        if d.numel() == 0:
+            continue
+        t = int(d[0])
+        z = scores[t][r]
+        gap = (z[os_[r, t]] - z[hs[r, t]]).item()
+        assert 0 <= gap <= tol, (r, t, gap)
+        flips += 1
+    return flips
+
+
 def test_multinomial_matches_oracle_and_scst_loss(P, g1):
     """Gumbel-max sampling with the shared counter hash: tokens equal the oracle's; the SCST rollout's differentiable
     log-probs (teacher-forced recompute) give the reference's RewardCriterion value on the reference's own rollout."""
@@ -454,10 +473,12 @@ def test_multinomial_matches_oracle_and_scst_loss(P, g1):
     with torch.no_grad():
         seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"],
                     opt={"num_random_sample": 4, "beam_size": 0, "seed": 11, "temperature": 1.0}, mode="sample")
+        zs = []
         oseq, olp = O.sample_greedy_or_multinomial(H.g1_state(), cfg, cb["att_feats"], cb["boxes"], cb["att_masks"],
-                                                   num_random_sample=4, seed=11)
+                                                   num_random_sample=4, seed=11, scores_out=zs)
     agree = (seq.cpu() == oseq).float().mean().item()
-    assert agree > 0.97, agree            # a Gumbel near-tie may flip a token (fp32 log / exp differ in the last ulp)
+    assert agree > 0.97, agree            # a Gumbel near-tie may flip a token (fp32 log / exp differ in the last ulp) ...
+    _assert_flips_are_near_ties(seq, oseq, zs)      # ... and every flip IS one: the oracle's own scores of the two tokens tie to 2e-4
     rows_equal = (seq.cpu() == oseq).all(-1)
     close(lp.cpu()[rows_equal], olp[rows_equal].numpy(), 2e-4)
     # SCST: teacher-forced log-probs of the reference's rollout == its incremental log-probs; loss value matches
@@ -499,11 +520,14 @@ def test_native_scst_step_vs_oracle(P, g1):
     # ---- oracle rollouts
     Pm = {k: v.clone().requires_grad_() for k, v in H.g1_state().items()}
     with torch.no_grad():
-        oseq, _ = O.sample_greedy_or_multinomial(Pm, cfg, cb["att_feats"], cb["boxes"], cb["att_masks"], num_random_sample=ns, seed=seed)
+        zs = []
+        oseq, _ = O.sample_greedy_or_multinomial(Pm, cfg, cb["att_feats"], cb["boxes"], cb["att_masks"], num_random_sample=ns, seed=seed,
+                                                 scores_out=zs)
         ogreedy, _ = O.sample_greedy_or_multinomial(Pm, cfg, cb["att_feats"], cb["boxes"], cb["att_masks"])
     assert torch.equal(greedy.cpu(), ogreedy), "greedy baseline tokens"
     agree = (seq.cpu() == oseq).float().mean().item()
     assert agree > 0.97, agree                 # a Gumbel near-tie may flip a token
+    _assert_flips_are_near_ties(seq, oseq, zs)
     # ---- reward: the scorer on the HIP path's own tokens (host code, exact), and its baseline structure
     sc_s, sc_b = scorer.score_sequences(refs, seq.cpu(), greedy.cpu(), eos_idx=C.EOS, pad_idx=0)
     np.testing.assert_allclose(reward.cpu().numpy(), (sc_s - sc_b).astype(np.float32), rtol=1e-6, atol=1e-7)
@@ -1538,14 +1562,16 @@ def test_train_mode_sampling_vs_oracle(P, g1):
     Pm = H.g1_state()
     feats, boxes, amask = cb["att_feats"][:, :Sc], cb["boxes"][:, :Sc], cb["att_masks"][:, :Sc]
     with torch.no_grad():
+        zs = []
         oseq, olp = O.sample_greedy_or_multinomial(Pm, cfg, feats, boxes, amask, num_random_sample=ns, seed=gseed,
-                                                   drop=drop_full, drop_step=drop_step)
+                                                   drop=drop_full, drop_step=drop_step, scores_out=zs)
         seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], mode="sample",
                     opt={"num_random_sample": ns, "beam_size": 0, "seed": gseed, "train_mode": True, "drop_seed": drop_seed})
         eseq, _ = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], mode="sample",
                     opt={"num_random_sample": ns, "beam_size": 0, "seed": gseed})
     agree = (seq.cpu() == oseq).float().mean().item()
     assert agree > 0.97, agree                          # (a Gumbel near-tie may flip a token)
+    _assert_flips_are_near_ties(seq, oseq, zs)
     assert not torch.equal(seq, eseq)                   # dropout changed the policy
     same = (seq.cpu() == oseq).all(-1) 
     valid = (oseq != 0) & same[..., None]
