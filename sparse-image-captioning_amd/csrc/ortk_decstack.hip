@@ -1452,7 +1452,10 @@ static int tp_cu_budget() {
     std::lock_guard<std::mutex> g(mu);
     if (!cus[dev]) {
         hipDeviceProp_t prop;
-        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+        // Only the unpartitioned MI355X (256 CUs in 8 XCDs, workgroup i on XCD i % 8) is served: the exchange is coherent
+        // inside ONE XCD's L2, and the members of a group are placed by that mapping.  A partitioned device (DPX / QPX / CPX:
+        // 128 / 64 / 32 CUs, another workgroup -> XCD mapping) runs the other executors.
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256) ? 256 : -1;
     }
     return cus[dev] > 0 ? cus[dev] : 0;
 }
