@@ -1039,19 +1039,22 @@ def test_decoder_stack_kernel_vs_fp32_and_unfused_executor(P, full_state, n_reg,
     assert (l1 - l0)[same].abs().mean().item() < 0.01
 
 
-@pytest.mark.parametrize("n_img,opt", [(70, {"beam_size": 1}), (70, {"beam_size": 5}), (300, {"beam_size": 5}),
-                                       (150, {"beam_size": 3, "decoding_constraint": 1}), (130, {"num_random_sample": 5, "beam_size": 0, "with_greedy": True, "seed": 7})])
-def test_column_split_stack_kernel_vs_fp32_and_plain_stack(P, full_state, n_img, opt):
+@pytest.mark.parametrize("n_img,n_reg,opt", [(70, 36, {"beam_size": 1}), (70, 36, {"beam_size": 5}), (300, 36, {"beam_size": 5}),
+                                             (150, 36, {"beam_size": 3, "decoding_constraint": 1}),
+                                             (130, 36, {"num_random_sample": 5, "beam_size": 0, "with_greedy": True, "seed": 7}),
+                                             (37, 100, {"beam_size": 1}), (520, 100, {"beam_size": 5})])
+def test_column_split_stack_kernel_vs_fp32_and_plain_stack(P, full_state, n_img, n_reg, opt):
     """The column-split form of the decoder stack kernel (`executor="stack_split"`: groups of 8 / 4 / 2 workgroups of one XCD share
     64 rows and split every projection's columns; partial results through that XCD's L2) — 70 / 130 / 150 images = 8 workgroups per
-    group (greedy, 6-row sampling, beam 3), 300 x 5 rows = 4 per group, ragged region counts, partial last groups:
+    group (greedy, 6-row sampling, beam 3), 300 x 5 rows = 4 per group, 520 x 5 rows = 2 per group, ragged region counts (12-36 and
+    33-100 per image), partial last groups:
       * teacher-forced in fp32 on the tokens it emits, every log-prob within 0.02 of the one it reported (mean 0.004): the bar of the
         plain stack kernel (test_decoder_stack_kernel_vs_fp32_and_unfused_executor);
       * against the plain stack kernel on the same weights: tokens agree up to near-ties, log-probs of agreeing tokens to bf16 noise
         (the two differ in the LayerNorm summation order only)."""
     m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=1)
     m32 = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=0)
-    b = _cuda(H.torch_batch(C.make_inputs(seed=43, n_img=n_img, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    b = _cuda(H.torch_batch(C.make_inputs(seed=43, n_img=n_img, n_reg=n_reg, feat=2048, vocab=10001, spi=1, ragged=True)))
     with torch.no_grad():
         s1, l1 = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt=dict(opt, executor="stack_split"), mode="sample")
         s0, l0 = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt=dict(opt, executor="stack"), mode="sample")
