@@ -128,6 +128,13 @@ int ortk_valid_positions_ok(const ortk_config* cfg, int32_t B, int32_t S, int32_
  * written there (ldv >= vocab, multiple of 4).  `train` != 0 enables dropout keyed by `seed`. */
 int ortk_forward(const ortk_config* cfg, const float* params, const ortk_batch* batch, void* ws, size_t ws_bytes,
                  float* logp_out, int64_t ldv, int32_t train, uint64_t seed, ortk_stream stream);
+/* The same in two calls on ONE workspace: phase 1 = weight copies + encoder (batch->seqs may be NULL; R and T still shape the
+ * workspace), phase 2 = decoder + generator on the encoder state phase 1 left there (same params, train, seed); phase 0 = all.
+ * Between the two the encoder memory — (B*S, d_model) rows, *dtype = 0 fp32 / 1 bf16 — can feed a decode of the same images
+ * (ortk_decode_opts.memory): an SCST step (utils/training.py:202-255) then runs its encoder once instead of twice. */
+int ortk_forward_phase(const ortk_config* cfg, const float* params, const ortk_batch* batch, void* ws, size_t ws_bytes,
+                       float* logp_out, int64_t ldv, int32_t train, uint64_t seed, int32_t phase, ortk_stream stream);
+void* ortk_train_workspace_memory(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T, void* ws, int32_t* dtype);
 
 /* Fused criterion on the logits left in `ws` by ortk_forward:
  *   loss = -sum_{r,t} logp[r,t,target]*tok_weight[r,t] / norm      (LanguageModelCriterion losses.py:36-43,
@@ -279,6 +286,10 @@ typedef struct ortk_decode_opts {
      * caches (the fast decode kernels have no dropout). */
     int32_t train;
     uint64_t drop_seed;
+    /* Optional: the encoder memory of these B images, (B*S, d_model) rows in the activation type of cfg->precision (bf16 in mixed
+     * precision, fp32 otherwise), e.g. ortk_train_workspace_memory() after ortk_forward_phase(.., 1, ..).  The decode then skips
+     * its own encoder pass (att_feats / boxes may be NULL).  Not with `train`. */
+    const void* memory;
 } ortk_decode_opts;
 
 size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, const ortk_decode_opts* o);

@@ -68,7 +68,7 @@ class DecodeOpts(C.Structure):
     _fields_ = [("beam_size", C.c_int32), ("num_random_sample", C.c_int32), ("temperature", C.c_float),
                 ("decoding_constraint", C.c_int32), ("length_penalty", C.c_int32), ("length_alpha", C.c_double),
                 ("seed", C.c_uint64), ("sparse", C.POINTER(EllPlanStruct)), ("exec_flags", C.c_int32), ("with_greedy", C.c_int32), ("sample_row_offset", C.c_int64),
-                ("train", C.c_int32), ("drop_seed", C.c_uint64)]
+                ("train", C.c_int32), ("drop_seed", C.c_uint64), ("memory", C.c_void_p)]
 
 
 class GemmArgs(C.Structure):
@@ -118,6 +118,8 @@ SIGNATURES = {
     "ortk_train_workspace_bytes": (_SZ, [_CFG, _I32, _I32, _I32, _I32]),
     "ortk_valid_positions_ok": (_I32, [_CFG, _I32, _I32, _I32, _I32]),
     "ortk_forward": (_I32, [_CFG, _P, C.POINTER(Batch), _P, _SZ, _P, _I64, _I32, _U64, _P]),
+    "ortk_forward_phase": (_I32, [_CFG, _P, C.POINTER(Batch), _P, _SZ, _P, _I64, _I32, _U64, _I32, _P]),
+    "ortk_train_workspace_memory": (_P, [_CFG, _I32, _I32, _I32, _I32, _P, C.POINTER(C.c_int32)]),
     "ortk_loss": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _P]),
     "ortk_loss_external": (_I32, [_CFG, C.POINTER(Batch), _P, _SZ, _P, _P, _I64, _P]),
     "ortk_backward": (_I32, [_CFG, _P, _P, C.POINTER(Batch), _P, _SZ, _I32, _U64, _P]),

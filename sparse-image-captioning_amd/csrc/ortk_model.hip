@@ -661,8 +661,26 @@ extern "C" size_t ortk_train_workspace_bytes(const ortk_config* cfg, int32_t B, 
 
 extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const ortk_batch* bt, void* ws, size_t ws_bytes,
                             float* logp_out, int64_t ldv_out, int32_t train, uint64_t seed, ortk_stream stream) {
+    return ortk_forward_phase(cfg, params, bt, ws, ws_bytes, logp_out, ldv_out, train, seed, 0, stream);
+}
+
+extern "C" void* ortk_train_workspace_memory(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T, void* ws, int32_t* dtype) {
+    if (check_cfg(cfg) || B < 1 || S < 1 || R < 1 || T < 1 || !ws) return nullptr;
+    TrainWS w; carve_train(*cfg, B, S, R, T, ws, w);
+    if (dtype) *dtype = w.adt;
+    return w.mem;
+}
+
+// phase 0: the whole forward.  phase 1: weight copies + encoder only (the memory stays in `ws`: ortk_train_workspace_memory);
+// phase 2: the decoder and generator on the encoder state phase 1 left in the same workspace (same params / train / seed).
+// An SCST step runs its encoder ONCE this way: phase 1, the rollout decode on that memory (ortk_decode_opts.memory), phase 2 on
+// the sampled captions, backward.
+extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, const ortk_batch* bt, void* ws, size_t ws_bytes,
+                                  float* logp_out, int64_t ldv_out, int32_t train, uint64_t seed, int32_t phase, ortk_stream stream) {
+    if (phase < 0 || phase > 2) return ORTK_EINVAL;
     if (int e = check_cfg(cfg)) return e;
-    if (int e = check_batch(cfg, bt, true)) return e;
+    if (int e = check_batch(cfg, bt, phase != 1)) return e;
+    if (phase == 1 && (bt->R < 1 || bt->T < 1 || bt->R % bt->B || bt->T > cfg->seq_len)) return ORTK_EINVAL;     // (they shape the workspace)
     if (!params || !ws) return ORTK_EINVAL;
     Offsets o; build_layout(*cfg, o, nullptr);
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
@@ -675,19 +693,21 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     // (0.14 ms of casts it used to wait behind; the encoder's first attention then waited for it), and the transposed copy,
     // which only the backward reads, is made on the side stream behind it.
     hipEvent_t box_done = nullptr;
-    const bool box_early = c.use_side && !cfg->no_box;
-    if (box_early) TRY(queue_box_bias(c, o, bt->boxes, w.logbias, bt->B, bt->S, &box_done));
-    TRY(make_w16(cfg, o, params, w.w16, stream));
-    if (c.use_side) {
-        if (!box_early) TRY(c.fork());      // (the previous backward on the caller's stream still reads the old copy)
-        TRY(make_w16t(cfg, o, params, w.w16t, (ortk_stream)c.side->s));     // done before the decoder prefix the forward waits for
-        TRY(c.side_mark(nullptr));
-    } else {
-        TRY(make_w16t(cfg, o, params, w.w16t, stream));      // read by the backward that follows this forward
+    const bool box_early = c.use_side && !cfg->no_box && phase != 2;
+    if (phase != 2) {
+        if (box_early) TRY(queue_box_bias(c, o, bt->boxes, w.logbias, bt->B, bt->S, &box_done));
+        TRY(make_w16(cfg, o, params, w.w16, stream));
+        if (c.use_side) {
+            if (!box_early) TRY(c.fork());      // (the previous backward on the caller's stream still reads the old copy)
+            TRY(make_w16t(cfg, o, params, w.w16t, (ortk_stream)c.side->s));     // done before the decoder prefix the forward waits for
+            TRY(c.side_mark(nullptr));
+        } else {
+            TRY(make_w16t(cfg, o, params, w.w16t, stream));      // read by the backward that follows this forward
+        }
     }
     // sparse plans are rebuilt from THIS call's effective weights (a new mask sample per step): no stale images
     if (cfg->sparse_fwd) {
-        TRY(ortk_sparse_build(cfg->sparse_fwd, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
+        if (phase != 2) TRY(ortk_sparse_build(cfg->sparse_fwd, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
         c.ell_f = cfg->sparse_fwd;
     }
     const float* P = params;
@@ -719,16 +739,19 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     // The token side of decoder layer 0 (embedding, self-attention sublayer, cross-attention query) does not depend on the
     // encoder: with the side stream it runs beside the encoder stack (after the geometry bias, which the encoder needs first).
     hipEvent_t prefix_done = nullptr;
-    if (c.use_side) {
+    const bool prefix_side = c.use_side && phase == 0;       // (split phases: the token side has no encoder to run beside)
+    if (prefix_side) {
         TRY(c.fork());                     // the side stream sees the bf16 weight copy
     }
-    TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc,
-                        box_early ? &box_done : nullptr));
+    if (phase != 2)
+        TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc,
+                            box_early ? &box_done : nullptr));
+    if (phase == 1) return c.join();       // (the transposed weight copy of the side stream included)
     {
-        const Ctx cx = c.use_side ? c.on_side() : c;
+        const Ctx cx = prefix_side ? c.on_side() : c;
         TRY(embed_fwd_rows(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, Md, compact ? bt->row_pos : nullptr, T, 0, d,
                            cfg->pad_id, c.p_drop(), c.sub(OP_EMB), cx.s));
-        if (c.use_side) { TRY(self_part(cx, 0, w.dx0)); TRY(c.side_mark(&prefix_done)); }
+        if (prefix_side) { TRY(self_part(cx, 0, w.dx0)); TRY(c.side_mark(&prefix_done)); }
     }
     // decoder
     const int U = o.ckv_slots;            // distinct decoder layers: one K|V slice each in the packed projection
@@ -736,7 +759,7 @@ extern "C" int ortk_forward(const ortk_config* cfg, const float* params, const o
     const float* x = w.dx0;
     for (int l = 0; l < L; ++l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
-        if (l == 0 && c.use_side) TRY(c.wait_ev(prefix_done)); else TRY(self_part(c, l, x));
+        if (l == 0 && prefix_side) TRY(c.wait_ev(prefix_done)); else TRY(self_part(c, l, x));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
         a.qkv_dtype = w.qdt_cross; a.q = (const float*)b.qc; a.ldq = d;
         a.k = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw, w.qdt_cross); a.v = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw + cv, w.qdt_cross);
@@ -1299,7 +1322,9 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
                            const float* att_masks, int32_t B, int32_t S, const ortk_decode_opts* op, void* ws, size_t ws_bytes,
                            int64_t* seq_out, float* logprob_out, float* score_out, ortk_stream stream) {
     if (int e = check_cfg(cfg)) return e;
-    if (!params || !att_feats || (!boxes && !cfg->no_box) || !att_masks || !op || !ws || !seq_out || !logprob_out) return ORTK_EINVAL;
+    if (!params || !op || !att_masks || !ws || !seq_out || !logprob_out) return ORTK_EINVAL;
+    if (!op->memory && (!att_feats || (!boxes && !cfg->no_box))) return ORTK_EINVAL;
+    if (op->memory && op->train) return ORTK_EINVAL;       // (train-mode sampling perturbs the encoder with its own dropout draws)
     if (B < 1 || S < 1 || S > 128) return ORTK_EINVAL;
     const int K = decode_K(op);
     if (K < 1) return ORTK_EINVAL;   // the reference asserts the same option combinations (transformer.py:509,514)
@@ -1349,9 +1374,10 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     // first projection; nothing else of a decode runs there
     c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
-    TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
+    // ortk_decode_opts.memory: the encoder output of these images already exists (the training forward's, ortk_forward_phase 1)
+    if (!op->memory) TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
     c.use_side = false;
-    TRY(fwd_gemm(c, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
+    TRY(fwd_gemm(c, op->memory ? op->memory : w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
 
     const int64_t rows_full = (int64_t)B * K;
     BeamState bs; std::memset(&bs, 0, sizeof(bs));

@@ -568,6 +568,11 @@ class RelationTransformerModel(CaptionModelBase):
         n = max(1, min(n, B))
         if plan is not None and n > 1:
             n = 1       # every chunk's ortk_decode rebuilds the plan's shared buffers on its own stream: not concurrently
+        # opt["memory"]: device address of the encoder memory of THESE images ((B*S, d_model) rows in the activation type of the
+        # precision), e.g. the training forward's (NativeTrainer.scst_step): the decode skips its own encoder pass
+        if opt.get("memory"):
+            o.memory = int(opt["memory"])
+            n = 1
 
         def run(i, b0, b1, stream_ptr, out):
             oi = L.DecodeOpts.from_buffer_copy(o)

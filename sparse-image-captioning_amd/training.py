@@ -96,7 +96,29 @@ class NativeTrainer:
         # decoder to the valid positions only (ortk_batch.cap_off / row_pos); the collate function provides it
         return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight, m.valid_position_tables(data) if self.valid_positions else None)
 
-    def _fwd_bwd(self, batch, norm, train=True, seed=None, after_decoder_half=None):
+    def encode_for_update(self, data, rows, train=False, seed=0):
+        """Phase 1 of the update pass of an SCST step, BEFORE the rollout: bf16 weight copies + encoder on `data`'s images into the
+        training workspace of (B, S, rows, seq_length) — the shapes the update over `rows` sampled captions will use.  Returns the
+        device address of the encoder memory ((B*S, d_model), the precision's activation type) for `opt["memory"]` of the rollout
+        decode; the update then runs `_step(..., encoded=True)`: decoder + criterion + backward on that encoder state."""
+        m, lib = self.model, L.lib()
+        feats, boxes, masks = m._prepare(data["att_feats"], data.get("boxes"), data.get("att_masks"), data.get("att_max_len"))
+        b = m._make_batch(feats, boxes, masks, None, None, None)
+        b.R, b.T = int(rows), int(m.seq_length)
+        m._sparse_plans()
+        nbytes = lib.ortk_train_workspace_bytes(C.byref(m._ccfg), b.B, b.S, b.R, b.T)
+        ws = m._workspace(("train", b.B, b.S, b.R, b.T), nbytes, True)
+        pptr = m._eff_params_ptr(train, seed)
+        L.check(lib.ortk_forward_phase(C.byref(m._ccfg), pptr, C.byref(b), L.ptr(ws), ws.numel(), None, 0, int(train), seed, 1,
+                                       L.stream_ptr()), "ortk_forward_phase(1)")
+        dt = C.c_int32(0)
+        mem = lib.ortk_train_workspace_memory(C.byref(m._ccfg), b.B, b.S, b.R, b.T, L.ptr(ws), C.byref(dt))
+        if not mem:
+            raise L.OrtkError("ortk_train_workspace_memory")
+        self._enc_keep = (feats, boxes, masks, ws)
+        return int(mem)
+
+    def _fwd_bwd(self, batch, norm, train=True, seed=None, after_decoder_half=None, encoded=False):
         """forward + fused criterion + backward into self.grads; returns the seed the dropout / mask draws used.
         `after_decoder_half()`: called between the two backward phases (every gradient at offsets >= _dec_off is final)."""
         m, lib = self.model, L.lib()
@@ -106,8 +128,9 @@ class NativeTrainer:
         nbytes = lib.ortk_train_workspace_bytes(C.byref(m._ccfg), batch.B, batch.S, batch.R, batch.T)
         ws = m._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, True)
         pptr = m._eff_params_ptr(train, seed)
-        L.check(lib.ortk_forward(C.byref(m._ccfg), pptr, C.byref(batch), L.ptr(ws), ws.numel(), None, 0, int(train), seed,
-                                 L.stream_ptr()), "ortk_forward")
+        # encoded: encode_for_update() has run phase 1 of this forward on this workspace (same parameters, mode and seed)
+        L.check(lib.ortk_forward_phase(C.byref(m._ccfg), pptr, C.byref(batch), L.ptr(ws), ws.numel(), None, 0, int(train), seed,
+                                       2 if encoded else 0, L.stream_ptr()), "ortk_forward")
         L.check(lib.ortk_loss(C.byref(m._ccfg), C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(norm), L.ptr(self.loss_dev),
                               L.stream_ptr()), "ortk_loss")
         if self.overlap or after_decoder_half is not None:
@@ -181,7 +204,15 @@ class NativeTrainer:
         kw = dict(att_feats=data["att_feats"], boxes=data.get("boxes"), att_masks=data.get("att_masks"), mode="sample",
                   att_max_len=data.get("att_max_len"))
         drop_seed = None
+        # One encoder pass per step: the update pass below recomputes the rollout's log-probs in the SAME mode as the rollout
+        # (eval-mode model) unless a dropout variant was asked for, so its encoder half runs first, into the training workspace,
+        # and the rollout decodes on that memory (`opt["memory"]`); the update then only runs its decoder half forward.
+        share_encoder = not (train and (sample_dropout or update_dropout)) and not getattr(m, "_sparse_stream", False)
+        mem_opt = {}
         with torch.no_grad():
+            if share_encoder:
+                m.eval()
+                mem_opt = {"memory": self.encode_for_update(data, B * num_samples)}
             if sample_dropout and train:
                 assert sample == "random", "train-mode sampling: multinomial rollouts"
                 drop_seed = m._next_seed()
@@ -192,8 +223,8 @@ class NativeTrainer:
             elif sample == "beam_search":
                 assert num_samples > 1, "beam search needs more than one beam"
                 if baseline == "greedy":
-                    greedy, _ = m(**kw, opt={"beam_size": 1})
-                seq, _ = m(**kw, opt={"beam_size": num_samples})
+                    greedy, _ = m(**kw, opt=dict({"beam_size": 1}, **mem_opt))
+                seq, _ = m(**kw, opt=dict({"beam_size": num_samples}, **mem_opt))
             else:
                 assert sample == "random", sample
                 # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
@@ -201,7 +232,7 @@ class NativeTrainer:
                 seq, _ = m(**kw, opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
                                       # the draws are keyed by the GLOBAL row of the batch: N ranks on their shards sample what
                                       # one process samples on the whole batch
-                                      "sample_row_offset": parallel.rank() * B * (num_samples + (baseline == "greedy"))})
+                                      "sample_row_offset": parallel.rank() * B * (num_samples + (baseline == "greedy")), **mem_opt})
                 if baseline == "greedy":
                     greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
         m.train(was_training)
@@ -223,7 +254,7 @@ class NativeTrainer:
         if drop_seed is not None:
             loss = self._step(tf, mask * reward[:, None], mask, True, seed=drop_seed)
         else:
-            loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout)
+            loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout, encoded=share_encoder)
         return loss, reward, seq, greedy
 
     @staticmethod
@@ -238,7 +269,7 @@ class NativeTrainer:
             return torch.from_numpy(sc_sample - sc_baseline).float()
         return fn
 
-    def _step(self, data, tok_weight, norm_mask, train, seed=None):
+    def _step(self, data, tok_weight, norm_mask, train, seed=None, encoded=False):
         m = self.model
         self.step_count += 1
         if not self._grads_clean:
@@ -259,7 +290,7 @@ class NativeTrainer:
                 self._opt_stream.wait_stream(cur)
                 with torch.cuda.stream(self._opt_stream):
                     self._adam(m._flat[d0:m._n_train], self.grads[d0:], self.m[d0:], self.v[d0:], lr, self.eps, zero=not self.keep_grads)
-        seed = self._fwd_bwd(batch, self.norm_dev, train, seed, after_decoder_half=early)
+        seed = self._fwd_bwd(batch, self.norm_dev, train, seed, after_decoder_half=early, encoded=encoded)
         loss = self.loss_dev.clone()
         if getattr(m, "_sparse_train", False) and (self.step_count == 1 or self.step_count % self.overflow_check_every == 0):
             m.check_sparse_overflow()
