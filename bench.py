@@ -11,7 +11,11 @@ GPU, teacher-forcing XE.  One "step" = zero_grad -> forward (dropout on) -> fuse
 scripts/train_transformer.py:65-81.  Inputs are synthetic and resident in HBM before the timed
 region.  metric = captions/sec = N * B * 5 / step_time  (the reference's "ex/sec", train_transformer.py:85-91).
 
-Other workloads (same JSON contract):  --workload decode|sparse_decode|sparse_xe|scst
+Other workloads (same JSON contract):  --workload decode|sparse_decode|sparse_xe|scst  (+ --variant, see WORKLOADS)
+
+The default one-GPU run also times every other BASELINE config in the same process and carries them, compactly, in the line's
+`workloads` object (ms per step, captions/s, roofline fraction, dominant kernel, CPU baseline); the prose that used to ride on
+the line (parity evidence, kernel descriptions, how the traffic figures are read) lives in profiles/bench_notes.json.
 """
 import argparse
 import ctypes as C
@@ -60,9 +64,10 @@ def synth_batch(B, S, F, V, spi, seq_len, seed, device):
                 att_max_len=S, cap_len=cap_len)
 
 
-def cpu_baseline(workload, cfg_dict, seconds=12.0):
-    """The oracle (parity-pinned CPU restatement of the reference path, torch CPU fp32) timed on this host's cores
-    on a bounded sample of the same workload: 8 images x 5 captions per step (decode: 8 images, beam 5)."""
+def cpu_baseline(workload, cfg_dict, seconds=9.0):
+    """The oracle (parity-pinned CPU restatement of the reference path, torch CPU fp32) timed on this host's cores on a bounded
+    sample of the same workload: 8 images per step — xe: 5 captions each, fwd + bwd + clip + Adam; decode: beam 5; scst: greedy
+    baseline + 5 multinomial rollouts (eval-mode decode; the reference adds dropout, same cost) + teacher-forced update."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import helpers as H
@@ -73,25 +78,42 @@ def cpu_baseline(workload, cfg_dict, seconds=12.0):
     torch.set_num_threads(cores)
     cfg = O.OCfg(**{k: v for k, v in cfg_dict.items() if not k.startswith("prune")})
     P = H.torch_state(H.dense_param_shapes(cfg_dict), 8888, requires_grad=True)
+    Pd = {k: v.detach() for k, v in P.items()}
     B = 8
     b = synth_batch(B, 36, cfg.att_feat_size, cfg.vocab_size, 5, cfg.max_seq_length, 1, "cpu")
     state = {}
     n, t0 = 0, None
     t_start = time.time()
+    kind = "decode" if workload in ("decode", "sparse_decode") else "scst" if workload == "scst" else "xe"
+
+    def update(seqs, weights=None):
+        for p in P.values():
+            p.grad = None
+        logp = O.forward_logp(P, cfg, b["att_feats"], b["boxes"], seqs, b["att_masks"])
+        if weights is None:
+            loss = O.xe_loss(logp, seqs[:, 1:], b["masks"][:, 1:])
+        else:
+            rows = seqs[:, 1:]
+            loss = O.reward_loss(logp.gather(2, rows.unsqueeze(2)).squeeze(2), rows, weights)
+        loss.backward()
+        with torch.no_grad():
+            O.adam_clip_step(P, {k: p.grad for k, p in P.items()}, state, 1e-4)
+
     while True:
-        if workload in ("xe", "sparse_xe", "scst"):
-            for p in P.values():
-                p.grad = None
-            logp = O.forward_logp(P, cfg, b["att_feats"], b["boxes"], b["seqs"], b["att_masks"])
-            loss = O.xe_loss(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
-            loss.backward()
-            with torch.no_grad():
-                O.adam_clip_step(P, {k: p.grad for k, p in P.items()}, state, 1e-4)
+        if kind == "xe":
+            update(b["seqs"])
             units = B * 5
+        elif kind == "decode":
+            with torch.no_grad():
+                O.beam_search(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"], 5)
+            units = B
         else:
             with torch.no_grad():
-                O.beam_search({k: v.detach() for k, v in P.items()}, cfg, b["att_feats"], b["boxes"], b["att_masks"], 5)
-            units = B
+                O.sample_greedy_or_multinomial(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"])
+                seq, _ = O.sample_greedy_or_multinomial(Pd, cfg, b["att_feats"], b["boxes"], b["att_masks"], num_random_sample=5, seed=n)
+            rows = seq.reshape(-1, seq.size(-1))
+            update(torch.cat([rows.new_full((rows.size(0), 1), 2), rows], 1), torch.linspace(-1, 1, rows.size(0)))
+            units = B * 5
         if t0 is None:          # first iteration = warm-up
             t0 = time.time()
             continue
@@ -99,9 +121,9 @@ def cpu_baseline(workload, cfg_dict, seconds=12.0):
         if time.time() - t0 > seconds or time.time() - t_start > 3 * seconds:
             break
     dt = (time.time() - t0) / max(n, 1)
+    what = {"xe": "5 captions each, fwd+bwd+Adam", "decode": "beam-5 decode", "scst": "greedy + 5 rollouts + update"}[kind]
     return {"value": round(units / dt, 2), "unit": "captions/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of {B} images ({'5 captions each, fwd+bwd+Adam' if units != B else 'beam-5 decode'}), "
-                      f"oracle/ort_oracle.py on torch CPU fp32, {cores} threads"}
+            "sample": f"{n} steps of {B} images ({what}), oracle/ort_oracle.py, torch CPU fp32, {cores} threads"}
 
 
 PMC_TAG = "r03"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
@@ -145,21 +167,7 @@ def pmc_traffic(kernel, workload, precision, B):
                               "(separate rocprofv3 --pmc passes of this command), launch-weighted over the same kernels")
 
 
-# Parity evidence carried by the timed mode (tests/, -m gpu; bars in the test sources)
-PARITY = {
-    "fp32": "XE loss within 1e-4 of the reference goldens (observed 2e-6), every gradient within 2e-4*scale, greedy / beam-3 / "
-            "beam-5 tokens exact (tests/test_gpu_model.py: *_vs_reference_golden, full size: test_full_size_config1_*)",
-    "bf16": "timed mode: bf16 MFMA operands, fp32 accumulate / soft-max / LayerNorm / residual / optimizer.  Checked against the "
-            "library's own fp32 parity mode (HIP-bf16 vs HIP-fp32, not against the oracle directly; the fp32 mode is what the "
-            "oracle pins): XE loss within 2e-2 of the golden, gradients within 5 % relative L2 of the fp32 path "
-            "(test_mixed_precision_gradients_track_fp32_gradients), teacher-forced log-prob error of the decode <= 0.1 over 64 "
-            "images (test_bf16_decode_logprob_bound; the stack kernels: teacher-forced fp32 log-probs of their own tokens within 0.02, "
-            "test_decoder_stack_kernel_vs_fp32_and_unfused_executor, test_column_split_stack_kernel_vs_fp32_and_plain_stack), "
-            "valid-position layout == padded layout "
-            "(test_valid_position_decoder_equals_padded_layout), train-mode dropout replayed through the oracle "
-            "(test_train_mode_dropout_vs_oracle, fp32), bench-size determinism / permutation / fused-criterion properties "
-            "(test_xe_step_at_bench_size_properties)",
-}
+NOTES = "profiles/bench_notes.json"       # parity evidence per dtype, kernel descriptions, how `traffic` is read: prose, not on the line
 
 
 def launch_command(n, argv, port):
@@ -193,51 +201,64 @@ def selftest(rank, world, args):
         dist.destroy_process_group()
 
 
-WORKLOAD_NAMES = {
-    "xe": "ORT dense, batch 256 images x 5 captions, teacher-forcing XE fwd+bwd+Adam (BASELINE configs[1])",
-    "sparse_xe": "ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; masked dense GEMM = the reference's flow)",
-    "sparse_xe_kernels": ("ORT 95% supermask-sparse, batch 256, teacher-forcing XE (BASELINE configs[2]; forward and data "
-                          "gradients as sparse products, weight gradients dense)"),
-    "scst": "ORT dense SCST: greedy + 5 multinomial rollouts + teacher-forced update (BASELINE configs[3])",
-    "decode": "ORT dense, cached-KV beam-5 decode, 1024 images",
-    "sparse_decode": ("ORT 95% sparse, cached-KV beam-5 decode, 1024 images (BASELINE configs[4]; decoder stack kernel on the "
-                      "sparse weight stream)"),
-    "sparse_decode_dense_kernels": ("ORT 95% sparse, cached-KV beam-5 decode, 1024 images (BASELINE configs[4]; dense kernels on "
-                                    "zero-filled weights = the reference's flow)"),
+# name -> (BASELINE config, one-line description).  `scst` is the reference's estimator (utils/training.py:216-237: eval-mode greedy
+# baseline, rollouts drawn and differentiated with every dropout on); `scst_nodrop` the dropout-free variant of rounds 1-3.
+WORKLOADS = {
+    "xe": "configs[1]: ORT dense, 256 images x 5 captions, teacher-forcing XE fwd+bwd+clip+Adam",
+    "sparse_xe": "configs[2]: ORT 95% supermask-sparse XE step, masked dense GEMMs (the reference's flow)",
+    "sparse_xe_kernels": "configs[2]: the same step, forward + data-gradient products as sparse kernels (ortk_spmm), weight gradients dense",
+    "sparse_xe_988": "configs[2] at 98.8% (the reference's NNZ 0.7M model): masked dense GEMMs",
+    "sparse_xe_988_kernels": "configs[2] at 98.8%: sparse kernels where the measured crossover says they pay (enable_sparse_kernels('auto'))",
+    "scst": ("configs[3]: ORT dense SCST, the reference's estimator: eval-mode greedy baseline + 5 multinomial rollouts drawn in TRAIN mode "
+             "(dropout on) + teacher-forced update under the same dropout masks"),
+    "scst_nodrop": "configs[3] without dropout: eval-mode greedy + 5 rollouts in one decode pass, eval-mode update (NOT the reference's estimator)",
+    "decode": "ORT dense, cached-KV beam-5 decode, 1024 images (mixed precision)",
+    "decode_fp32": "ORT dense, cached-KV beam-5 decode, 1024 images, fp32 parity mode (token-exact vs the reference)",
+    "sparse_decode": "configs[4]: ORT 95% sparse, cached-KV beam-5 decode, 1024 images, decoder stack kernel on the sparse weight stream",
+    "sparse_decode_dense_kernels": "configs[4]: the same decode as dense kernels on zero-filled weights (the reference's flow)",
+    "sparse_decode_988": "configs[4] at 98.8%: sparse weight stream",
+    "sparse_decode_988_dense_kernels": "configs[4] at 98.8%: dense kernels on zero-filled weights",
 }
 
+# per-image forward work of the dense model (6.354 GFLOP in all): encoder + the packed cross-attention K|V projection do
+# not depend on the caption positions, the decoder stack + generator scale with the decoder rows actually computed
+GFLOP_FWD_ENC, GFLOP_FWD_DEC = 1.680, 4.674
 
-def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
+
+def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, precision=None):
     """Build the model and the synthetic batch of one workload, time `steps` steps after `warmup` (barrier + synchronize on both
     sides, MAX over ranks) and measure the roofline of its dominant kernel with HIP events in extra, untimed steps.
-    `variant`: "" | "kernels" (sparse_xe: sparse products) | "dense_kernels" (sparse_decode: zero-filled dense weights)."""
+    `variant`: "" | "kernels" (sparse_xe: sparse products) | "dense_kernels" (sparse_decode: zero-filled dense weights) | "nodrop"
+    (scst) | "fp32" (decode) | a "988" prefix (98.8 % instead of 95 % zeros)."""
     from sparse_image_captioning_amd.utils.config import ort_config
     from sparse_image_captioning_amd.training import NativeTrainer
     L = pkg._lib
+    precision = precision or ("fp32" if variant == "fp32" else args.precision)
     decode = workload in ("decode", "sparse_decode")
     sparse = workload.startswith("sparse")
-    use_csr = workload == "sparse_xe" and variant == "kernels"
-    sstream = workload == "sparse_decode" and variant != "dense_kernels"
+    keep = 0.012 if "988" in variant else 0.05
+    use_csr = workload == "sparse_xe" and variant.endswith("kernels")
+    sstream = workload == "sparse_decode" and not variant.endswith("dense_kernels")
     B = args.batch or (1024 if decode else 256)
     spi, S = 5, args.regions
     # ORT pruning / SCST commands use drop_prob_src 0.1 (resources/commands_pruning.sh:240,265); dense XE default 0.5
     config = ort_config(drop_prob_src=0.5, prune_type="supermask", max_seq_length=args.max_seq_length)
     torch.manual_seed(8888)     # identical weights (and dropout / mask streams) on every rank
     name = "relation_transformer_prune" if workload == "sparse_xe" else "relation_transformer"
-    model = pkg.get_model(name)(config, precision=args.precision)
+    model = pkg.get_model(name)(config, precision=precision)
     if sparse:
         with torch.no_grad():
-            if workload == "sparse_xe":    # mask logits of a converged supermask run: |m| = 6, 5 % positive -> the
-                # Bernoulli(sigmoid(m)) samples of the training step keep 0.05*0.9975 + 0.95*0.0025 = 5.2 % of the weights
+            if workload == "sparse_xe":    # mask logits of a converged supermask run: |m| = 6, `keep` positive -> the
+                # Bernoulli(sigmoid(m)) samples of the training step keep keep*0.9975 + (1-keep)*0.0025 of the weights (5.2 % / 1.4 %)
                 for _, m in model.all_pruning_masks():
-                    m.copy_(torch.where(torch.rand_like(m) < 0.05, torch.full_like(m, 6.0), torch.full_like(m, -6.0)))
-            else:                                # decode: dense class on densified 95 %-pruned weights (eval_model.py:64-88)
+                    m.copy_(torch.where(torch.rand_like(m) < keep, torch.full_like(m, 6.0), torch.full_like(m, -6.0)))
+            else:                                # decode: dense class on densified pruned weights (eval_model.py:64-88)
                 for n_, p in model.named_parameters():
                     if p.dim() >= 2:
-                        p.mul_((torch.rand_like(p) < 0.05).float())
+                        p.mul_((torch.rand_like(p) < keep).float())
     model = model.to(dev)
-    if use_csr:                              # sparse products (ortk_spmm_ell) for the >= 90 %-sparse weight blocks
-        model.enable_sparse_kernels(0.9, train=True)
+    if use_csr:                              # sparse products (ortk_spmm) for the weight blocks where they pay
+        model.enable_sparse_kernels("auto" if "988" in variant else 0.9, train=True)
     if sstream:
         model.enable_sparse_stream(True)     # the stack kernel pulls the non-zeros of the decoder weights
     batch = synth_batch(B, S, config.att_feat_size, config.vocab_size, spi, config.max_seq_length, 1000 + rank, dev)
@@ -256,14 +277,15 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
         model.train()
         tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000)
         rw = torch.randn(B * 5, device=dev)
+        sample_dropout = variant != "nodrop"
 
         def step():
-            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy", sample_dropout=args.scst_train_sampling)
+            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy", sample_dropout=sample_dropout)
         units_per_step = B * 5
     else:
         model.train()
         tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000,
-                           sparsity_target=0.95 if workload == "sparse_xe" else None, max_train_step=100000,
+                           sparsity_target=(1.0 - keep) if workload == "sparse_xe" else None, max_train_step=100000,
                            overlap_allreduce={"auto": None, "on": True, "off": False}[args.overlap_allreduce])
         tr.valid_positions = not args.padded_positions
 
@@ -295,7 +317,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
     # with every launch on one stream (enable(1): the kernel in isolation).  EVERY rank runs those steps (they contain the
     # data-parallel collectives); only rank 0 records and reports.
     lib = L.lib()
-    key = (4 if args.precision == "bf16" else 0)
+    key = (4 if precision == "bf16" else 0)
     collected = {}
     for level in (2, 1):
         if rank == 0:
@@ -314,46 +336,34 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
     if rank != 0:
         return None
     per_key, iso = collected[2], collected[1]
-    stack = None        # decode: the one-launch-per-position decoder stack (key 16), same HIP-event hook
-    if decode and per_key[16][0]:
-        sn, sms, sfl, sby = per_key[16]
-        gbs_k = sby / (sms * 1e-3) / 1e9
-        stack = {"kernel": ("decoder_stack_kernel<sparse> (ortk_decstack.hip): all decoder layers of one position, rows stationary, the "
-                            "NON-ZEROS of the weights streamed as scatter entries and expanded through LDS" if sstream else
-                            "decoder_stack_kernel (ortk_decstack.hip): all decoder layers of one position, rows stationary, weights streamed"),
-                 "launches_per_step": sn, "avg_launch_us": round(sms * 1e3 / sn, 1),
-                 "algorithmic_bytes_per_launch": round(sby / sn), "achieved": round(gbs_k, 1),
-                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4),
-                 "mfma_tflops": round(sfl / (sms * 1e-3) / 1e12, 1), "ms_per_step": round(sms, 3)}
-        # (sparse_decode on the DENSE stream is the decode workload's kernel: its counters are that profile's)
-        stack["traffic"], stack["traffic_note"] = pmc_traffic("stack", workload if sstream else "decode", args.precision, B)
+    peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     n0, ms0, fl0, by0 = per_key[key]
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
     ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
     ach_iso = iso[key][2] / (iso[key][1] * 1e-3) / 1e12 if iso[key][1] > 0 else 0.0
-    tot_ms = sum(per_key[k][1] for k in (key, key + 1, key + 3))
-    tot_fl = sum(per_key[k][2] for k in (key, key + 1, key + 3))
-    traffic, traffic_note = pmc_traffic("gemm", workload, args.precision, B)
-    gemm = {"kernel": ("gemm_bf16_dma256_kernel<false,false> / gemm_bf16_glds_kernel<false,false,..> / gemm_bf16_dma64_kernel (k-contiguous operands: forward X*W^T, and dY*W on transposed bf16 weight copies; LDS-DMA pipeline)" if args.precision == "bf16"
-                       else "gemm_f32_kernel<false,false> (forward X*W^T)"),
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "schedule": "timed schedule (weight-gradient GEMMs on the side stream beside these launches)",
-            "isolated": {"achieved": round(ach_iso, 2), "frac": round(ach_iso / peak, 4),
-                         "avg_launch_us": round(iso[key][1] * 1e3 / max(iso[key][0], 1), 2),
-                         "schedule": "every launch on one stream"},
-            "launches_per_step": n0, "avg_launch_us": round(ms0 * 1e3 / max(n0, 1), 2),
-            "algorithmic_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3),
-            "all_gemm_layouts": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
-                                 "ms_per_step": round(tot_ms, 3)},
-            "traffic": traffic, "algorithmic_bytes_per_launch": round(by0 / max(n0, 1)), "traffic_note": traffic_note}
+    traffic, _ = pmc_traffic("gemm", workload if not variant else "", precision, B)
+    gemm = {"bound": "mfma", "kernel": "forward-layout GEMMs (gemm_bf16_dma256 / glds / dma64)" if precision == "bf16" else "gemm_f32_kernel (forward layout)",
+            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "launches": n0, "avg_us": round(ms0 * 1e3 / max(n0, 1), 1), "isolated_frac": round(ach_iso / peak, 4),
+            "alg_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 2), "alg_bytes_per_launch": round(by0 / max(n0, 1))}
+    stack = None        # decode: the one-launch-per-position decoder stack (key 16), same HIP-event hook
+    if per_key[16][0]:
+        sn, sms, sfl, sby = per_key[16]
+        gbs_k = sby / (sms * 1e-3) / 1e9
+        st_traffic, _ = pmc_traffic("stack", ("sparse_decode" if sstream else "decode") if decode and "988" not in variant and precision == "bf16" else "", precision, B)
+        stack = {"kernel": ("decoder_stack_kernel<sparse>" if sstream else "decoder_stack_kernel") if decode else "decoder_stack_tp_kernel",
+                 "launches": sn, "avg_us": round(sms * 1e3 / sn, 1), "alg_bytes_per_launch": round(sby / sn), "achieved": round(gbs_k, 1),
+                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4), "traffic": st_traffic,
+                 # (the cached K / V rows are counted per beam: beams share ancestors through the ancestry table, so the algorithmic
+                 #  bytes — and `frac` — are an UPPER bound on the unique bytes; `traffic` is what the counters saw)
+                 "kv_rows_counted": "per beam (upper bound)" if decode else "per row"}
     if decode or use_csr:
-        # the 95 %-sparse step and the cached decode are HBM-bound.  Algorithmic bytes: decode =
-        # 25.7 MB per image (self-KV reads 10.5 + cross-KV 8.0 + logits 7.2) + the weights once per step (18 steps:
-        # 110.9 MB dense bf16, or 4 bytes per non-zero); sparse XE step = activations of the dense step (the bytes
-        # ortk_prof_collect_bytes sums over the GEMM launches of one step) with 4 bytes per non-zero for the weights.
-        nnz_bytes = 2.77e6 * 4
+        # the sparse step and the cached decode are HBM-bound.  Algorithmic bytes: decode = 25.7 MB per image
+        # (self-KV reads 10.5 + cross-KV 8.0 + logits 7.2) + the weights once per step (18 steps: 110.9 MB dense bf16, or 4 bytes
+        # per non-zero); sparse XE step = activations of the dense step with 4 bytes per non-zero for the weights.
+        nnz_bytes = 55.4e6 * keep * 4
         if decode:
-            algo = B * 25.7e6 + config.max_seq_length * (nnz_bytes if sparse else 110.9e6)
+            wbytes = nnz_bytes if sparse else (110.9e6 if precision == "bf16" else 221.8e6)
+            algo = B * 25.7e6 + config.max_seq_length * wbytes
         else:
             # forward + data-gradient products of one step: X (M x K) and Y (M x N) once each in bf16, 4 bytes per non-zero;
             # the dense weight-gradient products read their two operands once and add into fp32 (M rows: 9 216 / 21 760)
@@ -362,54 +372,61 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg):
                       (Md, 1536, 512, 6), (Md, 512, 512, 18), (Md, 2048, 512, 6), (Md, 512, 2048, 6), (Md, 10112, 512, 1)])
             algo = sum(c * (2 * (2 * M * K + 2 * M * N) + (2 * M * K + 2 * M * N + 4 * N * K)) for M, N, K, c in prods) + 3 * nnz_bytes
         gbs = algo / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "whole step (all launches): the path is bandwidth-bound as a whole",
-                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "algorithmic_bytes_per_step": round(algo), "traffic": None,
-                    "dense_gemm_launches_of_the_step": gemm}
+        roofline = {"bound": "hbm", "kernel": "whole step", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "alg_bytes_per_step": round(algo)}
         if stack is not None:
             roofline["dominant_kernel"] = stack
     else:
-        roofline = dict(gemm, bound="mfma")
-        roofline = {k: roofline[k] for k in ["bound"] + [k for k in gemm]}
-    if not decode:
-        # dense-equivalent work of the step (6.354 GFLOP forward per image, x3).  For sparse_xe this is the work
-        # the masked DENSE GEMMs execute (and the weight gradients always do); the sparse products touch 5 % of it.
-        step_tflop = GFLOP_FWD_PER_IMAGE * 3 * B / 1e3
-        if workload != "scst":
-            roofline["whole_step"] = {"dense_equivalent_tflop": round(step_tflop, 3),
-                                      "achieved_tflops": round(step_tflop / (ms_per_step * 1e-3), 2),
-                                      "frac_of_peak": round(step_tflop / (ms_per_step * 1e-3) / peak, 4)}
+        roofline = gemm
+        if stack is not None:
+            roofline["rollout_kernel"] = stack
+    if not decode and workload != "scst":
+        # work the step EXECUTES: the valid-position decoder skips the padded caption positions (same loss and gradients), so the
+        # decoder's share is scaled by the rows it runs; `padded_equivalent` is the reference's (R x 17)-row layout
+        vr = batch.get("_valid_rows")
+        frac_rows = (vr[2] / float(B * spi * (config.max_seq_length - 1))) if vr else 1.0
+        exe = (GFLOP_FWD_ENC + GFLOP_FWD_DEC * frac_rows) * 3 * B / 1e3
+        roofline["whole_step"] = {"executed_tflop": round(exe, 3), "tflops": round(exe / (ms_per_step * 1e-3), 1),
+                                  "frac": round(exe / (ms_per_step * 1e-3) / peak, 4),
+                                  "padded_equivalent_tflop": round(GFLOP_FWD_PER_IMAGE * 3 * B / 1e3, 3)}
     wname = workload + ("_" + variant if variant else "")
     out = {"metric": "captions/sec", "value": round(value, 1), "unit": "captions/sec", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-           "config": {"workload": WORKLOAD_NAMES[wname], "images_per_gpu": B, "regions": S, "captions_per_image": spi,
-                      "parallelism": f"dp{world}" if world > 1 else "single",
-                      "storage": ("fp32 master weights / residual stream / logits; MFMA-operand tensors stored bf16; fp32 accumulate"
-                                  if args.precision == "bf16" else "fp32"),
-                      "sparse_kernels": (os.environ.get("ORTK_SPARSE_FORMAT", "ell16") + " (ortk_spmm)" if use_csr else
-                                         "decoder stack kernel, sparse weight stream (ORTK_DEC_SPARSE_STREAM)" if sstream else None)},
+           "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
+           "config": {"workload": WORKLOADS[wname], "images_per_gpu": B, "regions": S, "captions_per_image": spi,
+                      "parallelism": f"dp{world}" if world > 1 else "single"},
            "roofline": roofline}
     del model
     torch.cuda.empty_cache()
     return out
 
 
+def compact(r):
+    """One extra workload on the headline's line: its time, throughput and roofline in a few dozen bytes."""
+    rf = r["roofline"]
+    k = rf.get("dominant_kernel") or rf.get("rollout_kernel")
+    out = {"ms_per_step": r["ms_per_step"], "value": r["value"], "steps": r["steps"], "dtype": r["dtype"], "workload": r["config"]["workload"],
+           "bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "unit": rf["unit"]}
+    if k:
+        out["kernel"] = {x: k[x] for x in ("kernel", "launches", "avg_us", "frac", "traffic", "alg_bytes_per_launch")}
+    if "whole_step" in rf:
+        out["whole_step_frac"] = rf["whole_step"]["frac"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: > 1 s of timed region at 13 ms per step)")
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: > 1 s of timed region at 12 ms per step)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="xe", choices=("xe", "sparse_xe", "scst", "decode", "sparse_decode"))
+    ap.add_argument("--variant", default="", help="workload variant: kernels | 988 | 988_kernels (sparse_xe), dense_kernels | 988 | "
+                    "988_dense_kernels (sparse_decode), nodrop (scst), fp32 (decode) — see WORKLOADS")
     ap.add_argument("--overlap-allreduce", default="auto", choices=("auto", "on", "off"),
                     help="all-reduce the decoder half of the gradients while the encoder half of the backward runs "
                          "(auto: on when more than one rank)")
-    ap.add_argument("--csr-kernels", "--sparse-kernels", dest="csr_kernels", action="store_true",
-                    help="sparse_xe: sparse products (ortk_spmm, sorted-ELL images rebuilt on the device every call) for the forward "
-                         "and the data gradients instead of MFMA GEMMs on zero-filled weights (the weight gradients stay dense: the "
-                         "straight-through mask gradient needs them at every position)")
-    ap.add_argument("--dense-kernels", action="store_true",
-                    help="sparse_decode: the reference's flow — dense kernels on zero-filled weights — instead of the sparse weight stream")
+    ap.add_argument("--csr-kernels", "--sparse-kernels", dest="csr_kernels", action="store_true", help="= --variant kernels (sparse_xe)")
+    ap.add_argument("--dense-kernels", action="store_true", help="= --variant dense_kernels (sparse_decode)")
     ap.add_argument("--decode-streams", type=int, default=0,
                     help="decode workloads: decode the batch as this many chunks of images on as many streams (0 = one call)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 256; decode 1024)")
@@ -419,9 +436,7 @@ def main():
     ap.add_argument("--padded-positions", action="store_true",
                     help="teacher forcing over all 17 positions of every caption as the reference does (default: the decoder runs on "
                          "the valid positions only; same loss and gradients)")
-    ap.add_argument("--scst-train-sampling", action="store_true",
-                    help="scst: draw the rollouts in TRAIN mode as the reference does (dropout on, generic kernels, separate greedy pass) "
-                         "instead of the default eval-mode rollout + dropout-free update (same policy sampled and differentiated)")
+    ap.add_argument("--scst-train-sampling", action="store_true", help="(kept for old command lines: the scst workload now IS train-mode sampling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="default run on one GPU: do not add the `workloads` object (BASELINE configs[2], [3], [4] timed in this process)")
@@ -441,10 +456,10 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if args.selftest:
         return selftest(rank, world, args)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))       # (a one-rank group too: RCCL under test)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -452,27 +467,41 @@ def main():
     import sparse_image_captioning_amd as pkg
     pkg._lib.require_gpu()
 
-    variant = "kernels" if (args.workload == "sparse_xe" and args.csr_kernels) else (
-        "dense_kernels" if (args.workload == "sparse_decode" and args.dense_kernels) else "")
+    variant = args.variant or ("kernels" if (args.workload == "sparse_xe" and args.csr_kernels) else (
+        "dense_kernels" if (args.workload == "sparse_decode" and args.dense_kernels) else ""))
+    if args.workload + ("_" + variant if variant else "") not in WORKLOADS:
+        sys.exit(f"bench.py: no workload {args.workload} --variant {variant}")
     out = run_workload(args, args.workload, variant, args.steps, args.warmup, rank, world, dev, pkg)
     if rank == 0:
-        out["parity"] = PARITY
+        out["notes"] = NOTES
+        from sparse_image_captioning_amd.utils.config import ORT_DEFAULTS
+        base = {}
+
+        def cpu(kind):
+            if args.no_cpu_baseline or world != 1:
+                return None
+            if kind not in base:
+                base[kind] = cpu_baseline(kind, dict(ORT_DEFAULTS))
+            return base[kind]
         # The other BASELINE configs, timed in this same process with the same contract (fewer steps: the whole default run
         # stays within a couple of minutes).  One GPU only: the driver's scaling runs measure the headline.
-        if args.workload == "xe" and world == 1 and not args.no_extra_workloads and not args.batch:
+        if args.workload == "xe" and not variant and world == 1 and not args.no_extra_workloads and not args.batch:
             extra = {}
-            for wl, var, st, wu in (("sparse_xe", "", 30, 5), ("sparse_xe", "kernels", 20, 3), ("scst", "", 20, 3),
-                                    ("decode", "", 12, 3), ("sparse_decode", "", 12, 3), ("sparse_decode", "dense_kernels", 12, 3)):
-                r = run_workload(args, wl, var, st, wu, rank, world, dev, pkg)
-                extra[wl + ("_" + var if var else "")] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline")}
+            for wl, var, st, wu in (("sparse_xe", "", 20, 3), ("sparse_xe", "kernels", 12, 3), ("sparse_xe", "988", 12, 3),
+                                    ("sparse_xe", "988_kernels", 12, 3), ("scst", "", 12, 3), ("scst", "nodrop", 12, 3),
+                                    ("decode", "", 10, 3), ("decode", "fp32", 3, 1), ("sparse_decode", "", 10, 3),
+                                    ("sparse_decode", "dense_kernels", 10, 3), ("sparse_decode", "988", 10, 3),
+                                    ("sparse_decode", "988_dense_kernels", 10, 3)):
+                c = compact(run_workload(args, wl, var, st, wu, rank, world, dev, pkg))
+                kind = "decode" if "decode" in wl else "scst" if wl == "scst" else "xe"
+                cb = cpu(kind)
+                if cb is not None and kind != "xe":
+                    c["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"], "kind": cb["kind"]}
+                extra[wl + ("_" + var if var else "")] = c
             out["workloads"] = extra
-        if not args.no_cpu_baseline and world == 1:
-            from sparse_image_captioning_amd.utils.config import ORT_DEFAULTS
-            out["cpu_baseline"] = cpu_baseline(args.workload, dict(ORT_DEFAULTS))
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        out["cpu_baseline"] = cpu("decode" if "decode" in args.workload else "scst" if args.workload == "scst" else "xe")
+        print(json.dumps(out, separators=(",", ":")), flush=True)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -28,6 +28,7 @@ extern "C" {
 #define ORTK_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ORTK_ENOSPC (-2)   /* workspace too small */
 #define ORTK_ENOSYS (-3)   /* option not implemented (e.g. ACORT weight sharing) */
+#define ORTK_EEXCHANGE (-4) /* ortk_decode_status: an exchange group of the column-split stack kernel never met (launch not fully resident) */
 
 typedef void* ortk_stream;  /* hipStream_t */
 
@@ -266,11 +267,20 @@ typedef struct ortk_decode_opts {
      *                           whose groups do not all fit the chip at once (> 8 192 rows) run the plain stack kernel;
      *   ORTK_DEC_SPLIT_SMALL    automatic choice, but decodes of at most 4 096 rows (8 workgroups per group up to 2 048 rows, 4
      *                           above) take the column-split form: the fastest executor there (100 rows 8.2 vs 10.9 ms unfused,
-     *                           1 536 rows 10.9 vs 14.2, 3 500 rows 17.0 vs 17.5 on the plain stack kernel).  NOT the default of the library: the members of a group spin on each other, so ALL its
-     *                           workgroups must be resident — two such decodes running on one GPU at the same time (two host
-     *                           threads on two streams, two processes sharing the device) can starve each other for good.  Set
-     *                           it when this decode has the GPU to itself (the Python model does unless told otherwise);
-     *   bits 8-11               measurement only: skip self-attention (1) / cross-attention (2) / the FFN (4), no L2 prefetchers (8). */
+     *                           1 536 rows 10.9 vs 14.2, 3 500 rows 17.0 vs 17.5 on the plain stack kernel).  NOT the default of the
+     *                           library: the members of a group wait for each other, so ALL its workgroups must be resident — two
+     *                           such decodes on one GPU at the same time (two host threads on two streams, two processes sharing
+     *                           the device) can starve each other.  The waits are BOUNDED: a group that never meets raises the
+     *                           decode's status word, the launches run to their end without waiting, the outputs become all-pad
+     *                           captions with NaN log-probs and ortk_decode_status() returns ORTK_EEXCHANGE — no hang, no wrong
+     *                           tokens.  Which exchange a group uses does not depend on where the dispatcher put its members: they
+     *                           report their XCD (HW_REG_XCC_ID) in every launch, and only a group seen on ONE XCD exchanges through
+     *                           that XCD's L2; any other placement takes write-through (sc1) stores — same results, ~1 us more per
+     *                           exchange.  Set the flag when this decode has the GPU to itself (the Python model does unless told
+     *                           otherwise);
+     *   bits 8-15               measurement / tests only: skip self-attention (1) / cross-attention (2) / the FFN (4), no L2
+     *                           prefetchers (8); column-split form: deal the members of a group over different XCDs (16), one member
+     *                           of group 0 never arrives (32). */
     int32_t exec_flags;
     /* multinomial only: also decode ONE greedy row per image in the same pass (the SCST baseline of
      * utils/training.py:220-237): K = num_random_sample + 1, row 0 of each image is the arg-max decode, rows 1.. are
@@ -279,16 +289,22 @@ typedef struct ortk_decode_opts {
     /* multinomial only: index of this call's first output row in the full batch, so that a host that decodes a batch
      * in several chunks (e.g. one per stream) draws the same tokens as one call would (the Gumbel hash is keyed by row) */
     int64_t sample_row_offset;
-    /* multinomial only (num_random_sample > 0, no with_greedy): TRAIN-mode sampling — every dropout of the model is on while
-     * the captions are drawn (the reference samples its SCST rollouts after model.train(), utils/training.py:224-237), keyed
-     * by drop_seed exactly as ortk_forward(train = 1, seed = drop_seed) keys the teacher-forced pass over [BOS, sample]: that
-     * pass then reproduces, token for token, the log-probs of the policy that sampled.  Runs the unfused executor on fp32
-     * caches (the fast decode kernels have no dropout). */
+    /* multinomial only (num_random_sample > 0): TRAIN-mode sampling — every dropout of the model is on while the captions are
+     * drawn (the reference samples its SCST rollouts after model.train(), utils/training.py:224-237), keyed by drop_seed exactly
+     * as ortk_forward(train = 1, seed = drop_seed) keys the teacher-forced pass over [BOS, sample]: that pass then reproduces
+     * the log-probs of the policy that sampled.  Executors: the column-split stack kernel (mixed precision, <= 4 096 rows,
+     * ORTK_DEC_SPLIT_SMALL or ORTK_DEC_STACK_SPLIT: its dropout sites draw the same counter hash) or the unfused executor on fp32
+     * caches.  On the former `with_greedy` is served too: row 0 of every image stays an EVAL-mode row — no dropout, attending to the
+     * eval-mode encoder memory, which this call computes from att_feats — i.e. the reference's separate greedy baseline
+     * (utils/training.py:216-222) rides in the launches of the train-mode rollouts; the other rows of image q draw like rows
+     * q * num_random_sample + k - 1 of the teacher-forced pass.  (ortk_decode_workspace_bytes returns 0 for train + with_greedy where
+     * only the unfused executor applies: run the two decodes separately there.) */
     int32_t train;
     uint64_t drop_seed;
     /* Optional: the encoder memory of these B images, (B*S, d_model) rows in the activation type of cfg->precision (bf16 in mixed
      * precision, fp32 otherwise), e.g. ortk_train_workspace_memory() after ortk_forward_phase(.., 1, ..).  The decode then skips
-     * its own encoder pass (att_feats / boxes may be NULL).  Not with `train`. */
+     * its own encoder pass (att_feats / boxes may be NULL).  With `train` it must be the TRAIN-mode memory under drop_seed
+     * (ortk_forward_phase(train = 1, seed = drop_seed, phase 1)); the eval-mode rows of `with_greedy` still take att_feats / boxes. */
     const void* memory;
 } ortk_decode_opts;
 
@@ -297,6 +313,9 @@ size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S,
 int ortk_decode(const ortk_config* cfg, const float* params, const float* att_feats, const float* boxes,
                 const float* att_masks, int32_t B, int32_t S, const ortk_decode_opts* o, void* ws, size_t ws_bytes,
                 int64_t* seq_out, float* logprob_out, float* score_out, ortk_stream stream);
+/* Status of the ortk_decode that last ran on workspace `ws` (waits for `stream`: the one host synchronisation of the decode API):
+ * 0, or ORTK_EEXCHANGE (see ORTK_DEC_SPLIT_SMALL; only the column-split stack kernel can fail this way). */
+int ortk_decode_status(const void* ws, ortk_stream stream);
 
 /* Encoder only (EncoderDecoder.encode, relation_transformer.py:69-70): memory_out (B,S,d).
  * Workspace: ortk_decode_workspace_bytes(cfg, B, S, {beam_size = 1}). */

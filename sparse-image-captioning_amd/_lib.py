@@ -127,6 +127,7 @@ SIGNATURES = {
     "ortk_arena_decoder_offset": (_I64, [_CFG]),
     "ortk_decode_workspace_bytes": (_SZ, [_CFG, _I32, _I32, C.POINTER(DecodeOpts)]),
     "ortk_decode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, C.POINTER(DecodeOpts), _P, _SZ, _P, _P, _P, _P]),
+    "ortk_decode_status": (_I32, [_P, _P]),
     "ortk_encode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P, _P]),
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),
     "ortk_prof_enable": (_I32, [_I32]),
@@ -211,7 +212,9 @@ def ptr(t):
 def check(code, what):
     if code != 0:
         names = {-1: "ORTK_EINVAL (bad argument / unsupported shape)", -2: "ORTK_ENOSPC (workspace too small)",
-                 -3: "ORTK_ENOSYS (option not implemented)"}
+                 -3: "ORTK_ENOSYS (option not implemented)",
+                 -4: "ORTK_EEXCHANGE (column-split decode: an exchange group never met — the launch was not fully resident; "
+                     "outputs are poisoned; set model.exclusive_gpu = False when the GPU is shared)"}
         raise OrtkError(f"{what} failed: {names.get(code, 'hipError ' + str(code))}")
 
 

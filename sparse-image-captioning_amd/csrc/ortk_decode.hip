@@ -34,6 +34,13 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t n, int64_t v) {
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
 }
+__global__ void decode_poison_kernel(const int32_t* __restrict__ status, int64_t* __restrict__ seq, float* __restrict__ lp, float* __restrict__ score,
+                                     int64_t nseq, int64_t nscore) {
+    if (*status == 0) return;
+    const float nan = __builtin_nanf("");
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nseq; i += (int64_t)gridDim.x * 256) { seq[i] = 0; lp[i] = nan; }
+    if (score) for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nscore; i += (int64_t)gridDim.x * 256) score[i] = nan;
+}
 __global__ void kvidx_init_kernel(int32_t* p, int64_t rows, int row_mult, int tmax) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256)
         p[i] = (int32_t)(i * row_mult * tmax);
@@ -572,6 +579,11 @@ int kv_append(const float* qkv, void* ck, void* cv, int32_t kvdt, int64_t rows, 
               hipStream_t s) {
     if (rows == 0) return 0;
     hipLaunchKernelGGL(kv_append_kernel, dim3(ew_grid(rows * d)), dim3(256), 0, s, qkv, ck, cv, (int)kvdt, rows, d, row_mult, tmax, t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int decode_poison(const int32_t* status, int64_t* seq, float* lp, float* score, int64_t nseq, int64_t nscore, hipStream_t s) {
+    hipLaunchKernelGGL(decode_poison_kernel, dim3(64), dim3(256), 0, s, status, seq, lp, score, nseq, nscore);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -932,6 +932,20 @@ __device__ __forceinline__ tpu4 load_sc1(const void* p) {
 __device__ __forceinline__ void wait_sc1(tpu4 (&v)[8]) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
 }
+// Stores into an exchange tile through its buffer descriptor: plain (the line stays in this XCD's L2: valid only when every member of
+// the group has been SEEN on this XCD, below) or write-through (sc1: valid at any placement — cdna_hip_programming.md Guideline 16 R1:
+// sc1 payload stores, every storing wave's vmcnt(0), the workgroup barrier, one lane's agent-scope counter add; sc1 loads to registers).
+typedef __amdgpu_buffer_rsrc_t tp_rsrc;
+__device__ __forceinline__ void tp_store16(tp_rsrc rs, unsigned off, tpu4 v, bool wt) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+}
+__device__ __forceinline__ void tp_store8(tp_rsrc rs, unsigned off, uint2 v, bool wt) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int tpu2;
+    const tpu2 w = {v.x, v.y};
+    if (wt) __builtin_amdgcn_raw_buffer_store_b64(w, rs, off, 0, 16);
+    else __builtin_amdgcn_raw_buffer_store_b64(w, rs, off, 0, 0);
+}
 // sum over the 64 lanes by DPP (no LDS crossbar, no lgkmcnt wait): 16-lane rows, then the four row totals through readlane
 __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_quad1(v);
@@ -976,10 +990,12 @@ __device__ __forceinline__ void unit_tp(f32x4 (&acc)[TP<G>::MT][TP<G>::NT], cons
 }
 }  // namespace
 
-template <int G>
+// TRAIN: rows draw the dropout of the teacher-forced pass (StackArgs.drop_*); G >= 4 only.
+template <int G, bool TRAIN>
 __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
     using T_ = TP<G>;
     constexpr int C = T_::C, LR = T_::LR, NT = T_::NT, MT = T_::MT, KST = T_::KST;
+    static_assert(!TRAIN || G >= 4, "train-mode rows: one row per lane group in both attention phases");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* A0 = smem;                        // [64 x 512] bf16: LayerNorm output / gathered attention output
     char* QI = smem + 65536;                // this member's query / key / value slices of the current position
@@ -992,7 +1008,12 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
     // exchanges of one launch: per layer o(self), wo, o(cross), co, the hidden units (all chunks at once), w2 (a.debug: phases
     // skipped for measurements)
     const int NX = a.L * (3 + ((a.debug & 1) ? 0 : 1) + ((a.debug & 2) ? 0 : 1) + ((a.debug & 4) ? 0 : 1));
-    const int xcd = (int)(blockIdx.x & 7), kk = (int)(blockIdx.x >> 3), c = kk % G, grp = (kk / G) * 8 + xcd;
+    // members of a group: the workgroups x + 8 k of the launch — dealt to ONE XCD by the dispatcher as observed; that is a speed
+    // assumption only: the XCC ids the members report decide the exchange form below.  (debug 16: consecutive workgroups instead,
+    // i.e. members on DIFFERENT XCDs — the test of that decision)
+    const bool scatter = (a.debug & 16) != 0;
+    const int xcd = (int)(blockIdx.x & 7), kk = (int)(blockIdx.x >> 3);
+    const int c = scatter ? (int)(blockIdx.x % G) : kk % G, grp = scatter ? (int)(blockIdx.x / G) : (kk / G) * 8 + xcd;
     if ((int)blockIdx.x >= a.tp_groups * G) {
         // L2 prefetcher of one XCD (as in decoder_stack_kernel): the members of an XCD's groups walk the G x WS weight streams in
         // step, so without it every fragment load is an L2 miss all of them wait for.  One dword per 128-byte line of the
@@ -1016,25 +1037,54 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
     }
     const bool pace = a.progress != nullptr && blockIdx.x < 8 && tid == 0;
     int unit_no = a.tp_launch * a.L * U;
-    int32_t* flag = a.tp_flag + grp * 32;
+    int32_t* flag = a.tp_flag + grp * TP_FLAG_STRIDE;
     const int r0 = grp * TR;
     if (r0 >= a.rows) {                      // no rows in this launch (the first beam pass): keep the group's counter in step
         if (tid == 0) __hip_atomic_fetch_add(flag, NX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     int xn = a.tp_launch * NX;              // exchanges this group has completed
+    const int xn_first = xn;
     const size_t XTILE = (size_t)a.tp_xtile;      // bytes of one exchange tile: the fp32 [64 x 512] form or the NC hidden chunks
     char* xb = a.tp_xbuf + (size_t)grp * 2 * XTILE;
+    const tp_rsrc xrs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * XTILE), 0x00020000);
+    // ---- placement and residency.  (1) Every member reports the XCD it runs on (HW_REG_XCC_ID) into the group's mask word of this
+    // launch before its first arrival; the FIRST exchange of a launch uses write-through stores, which are valid at any placement;
+    // once it has completed, every member has reported, every thread reads the same final mask, and only a group whose members
+    // all sit on ONE XCD goes on with plain stores (they stay in that XCD's L2, which its CUs share: 1.8 us per exchange instead
+    // of ~3).  (2) The wait is bounded: a member that never arrives (the launch is not fully resident: another kernel holds CUs)
+    // makes the others give up after `spin_max` polls, raise StackArgs.tp_status and run on WITHOUT waiting — the launch (and the
+    // rest of the decode, which sees the word at entry) ends in bounded time with results the host side discards
+    // (ortk_decode poisons its outputs, ortk_decode_status returns ORTK_EEXCHANGE).
+    bool wt = true;                          // write-through exchange stores
+    bool dead = false;                       // (thread 0) stop waiting: the error word is up
+    const int spin_max = (a.debug & 32) ? (1 << 12) : (1 << 20);
+    const bool absent = (a.debug & 32) && grp == 0 && c == G - 1;      // test: this member never arrives
+    if (tid == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15;       // hwreg(HW_REG_XCC_ID, 0, 4)
+        __hip_atomic_fetch_or(flag + 16 + (a.tp_launch & 63), 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = absent || __hip_atomic_load(a.tp_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    }
     // publish this member's part of tile (xn & 1) and wait for the others'
 #define TP_XWAIT()                                                                                              \
     do {                                                                                                         \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
         __syncthreads();                                                                                         \
         if (tid == 0) {                                                                                          \
-            __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                         \
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (xn + 1) * G) __builtin_amdgcn_s_sleep(1); \
+            if (!absent) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            \
+            for (int sp_ = 0; !dead && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (xn + 1) * G; ++sp_) { \
+                __builtin_amdgcn_s_sleep(1);                                                                     \
+                if (sp_ >= spin_max) {                                                                           \
+                    dead = true;                                                                                 \
+                    __hip_atomic_fetch_or(a.tp_status, TP_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                }                                                                                                \
+            }                                                                                                    \
         }                                                                                                        \
         __syncthreads();                                                                                         \
+        if (xn == xn_first) {                                                                                    \
+            const int mk_ = __hip_atomic_load(flag + 16 + (a.tp_launch & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            wt = __builtin_amdgcn_readfirstlane(__popc(mk_)) != 1;                                               \
+        }                                                                                                        \
         ++xn;                                                                                                    \
     } while (0)
 #define TP_FRESH_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
@@ -1043,6 +1093,16 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
     const int mt0 = G == 8 ? 2 * (wave >> 2) : 0;
     const int ws = G == 8 ? (wave & 3) : wave;
     const int tile0 = G == 2 ? 2 * wave : ws;       // column tile (of the slice) of accumulator 0; accumulator nt: tile0 + nt
+    // train-mode rows: the row of the teacher-forced pass whose draws decode row g takes, or -1 (an eval-mode row: the greedy baseline)
+    auto tf_row = [&](int g) -> int {
+        if (a.greedy_stride > 0) { const int q = g / a.greedy_stride, k = g - q * a.greedy_stride; return k == 0 ? -1 : q * (a.greedy_stride - 1) + k - 1; }
+        return g;
+    };
+    const float dp = TRAIN ? a.drop_p : 0.f, ik = TRAIN ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int ns_tf = a.per_img - (a.greedy_stride > 0 ? 1 : 0);       // captions per image in the teacher-forced pass
+    int mtf[MT];                                                       // teacher-forced rows of this lane's accumulator rows
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) mtf[mt] = TRAIN ? tf_row(min(r0 + 16 * (mt0 + mt) + (lane0 & 15), a.rows - 1)) : -1;
 
     // residual rows, row layout: wave w holds rows 8 w .. 8 w + 7, lane l columns 8 l .. 8 l + 7
     float x[8][8];
@@ -1093,8 +1153,10 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
             }
         }
     };
-    // (acc + bias) of this wave's tiles into the exchange tile: fp32 (a residual update) or relu + bf16 (an FFN hidden chunk)
-    auto store_tile = [&](char* tile, const f32x4 (&acc)[MT][NT], const float* bias, bool hidden) {
+    // (acc + bias) of this wave's tiles into the exchange tile at byte offset `toff` of the group's buffer: fp32 (a residual update) or
+    // relu + bf16 (an FFN hidden chunk).  TRAIN: the dropout of that output in the teacher-forced pass — element (row, coff + col) of
+    // its (rows x T, ncols) tensor (the GEMM epilogues' index: ortk_gemm_args.drop_row_stride / _off)
+    auto store_tile = [&](unsigned toff, const f32x4 (&acc)[MT][NT], const float* bias, bool hidden, uint32_t seed, int ncols, int coff) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = c * C + 16 * (tile0 + nt) + 4 * (lane >> 4);
@@ -1104,9 +1166,17 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 const int row = 16 * (mt0 + mt) + (lane & 15);
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + b4[r];
-                if (hidden) *reinterpret_cast<uint2*>(tile + ((size_t)row * SD + col) * 2) = make_uint2(pack2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), pack2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)));
-                else *reinterpret_cast<f32x4*>(tile + ((size_t)row * SD + col) * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+                for (int r = 0; r < 4; ++r) { v[r] = acc[mt][nt][r] + b4[r]; if (hidden) v[r] = fmaxf(v[r], 0.f); }
+                if constexpr (TRAIN) {
+                    if (mtf[mt] >= 0) {
+                        bool kp[4];
+                        ortk_keep4(seed, ((uint64_t)mtf[mt] * (uint64_t)a.T + (uint64_t)a.t) * (uint64_t)ncols + (uint64_t)(coff + col), dp, kp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
+                    }
+                }
+                if (hidden) tp_store8(xrs, toff + (unsigned)(row * SD + col) * 2, make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])), wt);
+                else tp_store16(xrs, toff + (unsigned)(row * SD + col) * 4, (tpu4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, wt);
             }
         }
     };
@@ -1159,14 +1229,19 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         // ---- self-attention over this member's heads: G rows side by side in a wave (LR lanes each); o -> the exchange tile
         TP_FRESH_LANE();
         if (!(a.debug & 1)) {
-            char* tile = xb + (xn & 1) * XTILE;
+            const unsigned toff = (unsigned)((xn & 1) * XTILE);
+            char* tile = xb + toff;
             const int rs = lane / LR, fc = lane % LR;
+            const int hd = (c * LR + fc) >> 3;               // head of this lane's 8 features
             uint4* ck = reinterpret_cast<uint4*>(P.ck);
             uint4* cv = reinterpret_cast<uint4*>(P.cv);
 #pragma unroll 1
             for (int p0 = 0; p0 < 8; p0 += G) {
                 const int row = 8 * wave + p0 + rs;
                 const int g = r0 + row, gc = min(g, a.rows - 1);
+                // TRAIN: probability (row, head, key j) of the teacher-forced (rows, 8, T, T) tensor at query position t
+                const int mrow = TRAIN ? tf_row(gc) : -1;
+                const int64_t sbase = (((int64_t)mrow * 8 + hd) * a.T + a.t) * a.T;
                 int idx[G];                  // this lane: cache rows of keys fc + LR u of its row
 #pragma unroll
                 for (int u = 0; u < G; ++u) { const int j = min(fc + LR * u, a.t); idx[u] = a.kvidx ? a.kvidx[(int64_t)gc * Lk + j] : gc * a.T + j; }
@@ -1204,6 +1279,12 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                     for (int u = 0; u < SKT; ++u) { kc[u] = kq[u]; vc[u] = vq[u]; }
                     if (b + 1 < nb) TP_ISSUE(b + 1);
                     st.scores<SKT>(kc, kind, pr);
+                    if constexpr (TRAIN) {
+                        if (mrow >= 0) {
+#pragma unroll
+                            for (int u = 0; u < SKT; ++u) pr[0][u] = ortk_keep(a.drop_seed[l][0], (uint64_t)(sbase + b * SKT + u), dp) ? pr[0][u] * ik : 0.f;
+                        }
+                    }
                     st.pv<SKT>(vc, pr);
                 }
                 const uint4 kself[1] = {*reinterpret_cast<const uint4*>(KI + sl_off<G>(row, fc))};
@@ -1211,6 +1292,9 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 const float kindself[1] = {0.f};
                 float pself[1][1];
                 st.scores<1>(kself, kindself, pself);
+                if constexpr (TRAIN) {
+                    if (mrow >= 0) pself[0][0] = ortk_keep(a.drop_seed[l][0], (uint64_t)(sbase + a.t), dp) ? pself[0][0] * ik : 0.f;
+                }
                 st.pv<1>(vself, pself);
                 int srow_; TP_KEY_ROW(a.t, srow_);
                 const int64_t slot = (int64_t)srow_ * (SD / 8) + c * LR + fc;
@@ -1218,9 +1302,9 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 {
 #pragma clang fp contract(off)
                     const float inv = 1.f / st.l[0];
-                    reinterpret_cast<uint4*>(tile)[row * 64 + c * LR + fc] =
-                        make_uint4(pack2(st.o[0][0] * inv, st.o[0][1] * inv), pack2(st.o[0][2] * inv, st.o[0][3] * inv),
-                                   pack2(st.o[0][4] * inv, st.o[0][5] * inv), pack2(st.o[0][6] * inv, st.o[0][7] * inv));
+                    tp_store16(xrs, toff + (unsigned)(row * 64 + c * LR + fc) * 16,
+                               (tpu4){pack2(st.o[0][0] * inv, st.o[0][1] * inv), pack2(st.o[0][2] * inv, st.o[0][3] * inv),
+                                      pack2(st.o[0][4] * inv, st.o[0][5] * inv), pack2(st.o[0][6] * inv, st.o[0][7] * inv)}, wt);
                 }
             }
             TP_XWAIT();
@@ -1230,12 +1314,12 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         // ---- output projection: residual update through the exchange, LayerNorm 1 -> A0
         TP_FRESH_LANE();
         {
-            char* tile = xb + (xn & 1) * XTILE;
+            const unsigned toff = (unsigned)((xn & 1) * XTILE);
             ring_tp_start<G>(ring, wp, lane);
             zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
-            store_tile(tile, acc, P.bo, false);
+            store_tile(toff, acc, P.bo, false, a.drop_seed[l][1], SD, 0);
             TP_XWAIT();
-            add_tile(tile);
+            add_tile(xb + toff);
         }
         ln_rows(P.n1a, P.n1b, A0);         // (every wave is past its reads of A0: the exchange's barriers)
         __syncthreads();
@@ -1248,21 +1332,29 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         if (!(a.debug & 2) && G >= 4) {
             // narrow slices (16 / 8 lanes per row): one row per lane group and all 64 rows of the group in one or two passes — the
             // shared-load form below leaves two thirds of the lane groups idle there and runs five rows' state per lane
-            char* tile = xb + (xn & 1) * XTILE;
+            const unsigned toff = (unsigned)((xn & 1) * XTILE);
+            char* tile = xb + toff;
             const int rs = lane / LR, fc = lane % LR;
+            const int hd = (c * LR + fc) >> 3;
             constexpr int XKT = 4;
             const int64_t pitch = a.ldx / 8;
 #pragma unroll 1
             for (int p0 = 0; p0 < 8; p0 += G) {
                 const int row = 8 * wave + p0 + rs;
                 const int gc = min(r0 + row, a.rows - 1), imm = gc / a.per_img;
+                // TRAIN: probability (image, head, caption i, position t, region j) of the teacher-forced (images, 8, ns T, S) tensor; an
+                // eval-mode (greedy) row attends to the EVAL-mode memory's projection
+                const int mrow = TRAIN ? tf_row(gc) : -1;
+                const int64_t cbase = ((((int64_t)(mrow / ns_tf) * 8 + hd) * ns_tf + (mrow % ns_tf)) * a.T + a.t) * a.S;
+                const __bf16* xkb = (TRAIN && mrow < 0 && P.xkg) ? P.xkg : P.xk;
+                const __bf16* xvb = (TRAIN && mrow < 0 && P.xvg) ? P.xvg : P.xv;
                 AttState<1> st;
                 st.q[0] = *reinterpret_cast<const uint4*>(QI + sl_off<G>(row, fc));
                 st.m[0] = -INFINITY; st.l[0] = 0.f;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) st.o[0][d] = 0.f;
-                const uint4* xk = reinterpret_cast<const uint4*>(P.xk) + (int64_t)imm * a.S * pitch + c * LR + fc;
-                const uint4* xv = reinterpret_cast<const uint4*>(P.xv) + (int64_t)imm * a.S * pitch + c * LR + fc;
+                const uint4* xk = reinterpret_cast<const uint4*>(xkb) + (int64_t)imm * a.S * pitch + c * LR + fc;
+                const uint4* xv = reinterpret_cast<const uint4*>(xvb) + (int64_t)imm * a.S * pitch + c * LR + fc;
                 const float* mk = a.att_masks + (int64_t)imm * a.S;
                 const int nb = (a.S + XKT - 1) / XKT;
                 uint4 kq[XKT], vq[XKT];
@@ -1278,6 +1370,12 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
 #pragma unroll
                         for (int u = 0; u < XKT; ++u) { const int j = min((b + 1) * XKT + u, a.S - 1); kq[u] = xk[j * pitch]; mq[u] = mk[j]; }
                     }
+                    if constexpr (TRAIN) {
+                        if (mrow >= 0) {
+#pragma unroll
+                            for (int u = 0; u < XKT; ++u) pr[0][u] = ortk_keep(a.drop_seed[l][2], (uint64_t)(cbase + b * XKT + u), dp) ? pr[0][u] * ik : 0.f;
+                        }
+                    }
                     st.pv<XKT>(vq, pr);
                     if (b + 1 < nb) {
 #pragma unroll
@@ -1287,15 +1385,16 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 {
 #pragma clang fp contract(off)
                     const float inv = 1.f / st.l[0];
-                    reinterpret_cast<uint4*>(tile)[row * 64 + c * LR + fc] =
-                        make_uint4(pack2(st.o[0][0] * inv, st.o[0][1] * inv), pack2(st.o[0][2] * inv, st.o[0][3] * inv),
-                                   pack2(st.o[0][4] * inv, st.o[0][5] * inv), pack2(st.o[0][6] * inv, st.o[0][7] * inv));
+                    tp_store16(xrs, toff + (unsigned)(row * 64 + c * LR + fc) * 16,
+                               (tpu4){pack2(st.o[0][0] * inv, st.o[0][1] * inv), pack2(st.o[0][2] * inv, st.o[0][3] * inv),
+                                      pack2(st.o[0][4] * inv, st.o[0][5] * inv), pack2(st.o[0][6] * inv, st.o[0][7] * inv)}, wt);
                 }
             }
             TP_XWAIT();
             gather_img(tile, A0);
         } else if (!(a.debug & 2)) {
-            char* tile = xb + (xn & 1) * XTILE;
+            const unsigned toff = (unsigned)((xn & 1) * XTILE);
+            char* tile = xb + toff;
             const int rs = lane / LR, fc = lane % LR;
             const int last = min(r0 + TR, a.rows) - 1;
             const int img0 = r0 / a.per_img, img1 = last / a.per_img;
@@ -1349,9 +1448,9 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
 #pragma clang fp contract(off)
                     if (i < nr) {
                         const float inv = 1.f / st.l[i];
-                        reinterpret_cast<uint4*>(tile)[(c0 - r0 + i) * 64 + c * LR + fc] =
-                            make_uint4(pack2(st.o[i][0] * inv, st.o[i][1] * inv), pack2(st.o[i][2] * inv, st.o[i][3] * inv),
-                                       pack2(st.o[i][4] * inv, st.o[i][5] * inv), pack2(st.o[i][6] * inv, st.o[i][7] * inv));
+                        tp_store16(xrs, toff + (unsigned)((c0 - r0 + i) * 64 + c * LR + fc) * 16,
+                                   (tpu4){pack2(st.o[i][0] * inv, st.o[i][1] * inv), pack2(st.o[i][2] * inv, st.o[i][3] * inv),
+                                          pack2(st.o[i][4] * inv, st.o[i][5] * inv), pack2(st.o[i][6] * inv, st.o[i][7] * inv)}, wt);
                     }
                 }
             }
@@ -1362,12 +1461,12 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         // ---- output projection, LayerNorm 2 -> A0
         TP_FRESH_LANE();
         {
-            char* tile = xb + (xn & 1) * XTILE;
+            const unsigned toff = (unsigned)((xn & 1) * XTILE);
             ring_tp_start<G>(ring, wp, lane);
             zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
-            store_tile(tile, acc, P.cob, false);
+            store_tile(toff, acc, P.cob, false, a.drop_seed[l][3], SD, 0);
             TP_XWAIT();
-            add_tile(tile);
+            add_tile(xb + toff);
         }
         ln_rows(P.n2a, P.n2b, A0);
         __syncthreads();
@@ -1379,10 +1478,11 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
         if (!(a.debug & 4)) {
             // all NC up-projection units first (the stream holds them back to back), ONE exchange of the [64 x NC 512] hidden
             // units, then the NC down-projection units, each on its gathered chunk
-            char* tile = xb + (xn & 1) * XTILE;
+            const unsigned toff = (unsigned)((xn & 1) * XTILE);
+            char* tile = xb + toff;
             for (int cc = 0; cc < a.NC; ++cc) {
                 zero_acc(acc); TP_UNIT_BEGIN(); unit_tp<G, true>(acc, A0, wp, ring, lane, mt0);
-                store_tile(tile + (size_t)cc * (TR * SD * 2), acc, P.b1 + cc * SD, true);
+                store_tile(toff + (unsigned)cc * (TR * SD * 2), acc, P.b1 + cc * SD, true, a.drop_seed[l][4], a.NC * SD, cc * SD);
             }
             TP_XWAIT();
             for (int cc = 0; cc < a.NC; ++cc) {
@@ -1393,10 +1493,10 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
             }
         }
         {
-            char* tile = xb + (xn & 1) * XTILE;
-            store_tile(tile, acc2, P.b2, false);
+            const unsigned toff = (unsigned)((xn & 1) * XTILE);
+            store_tile(toff, acc2, P.b2, false, a.drop_seed[l][5], SD, 0);
             TP_XWAIT();
-            add_tile(tile);
+            add_tile(xb + toff);
         }
     }
     // ---- final LayerNorm -> bf16 rows for the generator (through A0; member 0 writes them out)
@@ -1480,7 +1580,7 @@ int stack_tp_pack(const void* w16, void* wpk, const StackPack& t, int G, hipStre
     return 0;
 }
 
-template <int G>
+template <int G, bool TRAIN>
 static int stack_tp_launch(const StackArgs& b, hipStream_t s) {
     constexpr size_t lds = TP<G>::LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -1491,16 +1591,16 @@ static int stack_tp_launch(const StackArgs& b, hipStream_t s) {
     {
         std::lock_guard<std::mutex> g(mu);
         if (!done[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_stack_tp_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_stack_tp_kernel<G, TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
             done[dev] = true;
         }
     }
     // (the pace-makers are the first member of groups 0..7: they must have rows in this launch)
-    const bool pf = b.progress != nullptr && b.tp_groups * G + 8 <= tp_cu_budget() && !(b.debug & 8) && b.rows > 7 * TR;
+    const bool pf = b.progress != nullptr && b.tp_groups * G + 8 <= tp_cu_budget() && !(b.debug & 8) && !(b.debug & 16) && b.rows > 7 * TR;
     StackArgs c = b;
     if (!pf) c.progress = nullptr;
-    hipLaunchKernelGGL((decoder_stack_tp_kernel<G>), dim3((unsigned)(b.tp_groups * G + (pf ? 8 : 0))), dim3(512), lds, s, c);
+    hipLaunchKernelGGL((decoder_stack_tp_kernel<G, TRAIN>), dim3((unsigned)(b.tp_groups * G + (pf ? 8 : 0))), dim3(512), lds, s, c);
     return 0;
 }
 
@@ -1546,10 +1646,14 @@ int stack_step(const StackArgs& a, hipStream_t s) {
     } else pm.live = false;
     int rc;
     if (a.tp) {
-        if (sparse || !a.tp_wpk || !a.tp_xbuf || !a.tp_flag || a.tp_groups < 8 || a.tp_groups % 8 || a.tp_groups * a.tp > tp_cu_budget() ||
-            (int64_t)a.tp_groups * TR < a.rows) return ORTK_EINVAL;
-        rc = a.tp == 2 ? stack_tp_launch<2>(b, s) : a.tp == 4 ? stack_tp_launch<4>(b, s) : a.tp == 8 ? stack_tp_launch<8>(b, s) : ORTK_EINVAL;
+        if (sparse || !a.tp_wpk || !a.tp_xbuf || !a.tp_flag || !a.tp_status || a.tp_groups < 8 || a.tp_groups % 8 || a.tp_groups * a.tp > tp_cu_budget() ||
+            (int64_t)a.tp_groups * TR < a.rows || a.tp_launch < 0 || a.tp_launch >= 64) return ORTK_EINVAL;
+        const bool train = a.drop_p > 0.f;
+        if (train && (a.tp < 4 || a.drop_p >= 1.f || (a.greedy_stride > 0 && a.greedy_stride != a.per_img))) return ORTK_EINVAL;
+        if (train) rc = a.tp == 4 ? stack_tp_launch<4, true>(b, s) : a.tp == 8 ? stack_tp_launch<8, true>(b, s) : ORTK_EINVAL;
+        else rc = a.tp == 2 ? stack_tp_launch<2, false>(b, s) : a.tp == 4 ? stack_tp_launch<4, false>(b, s) : a.tp == 8 ? stack_tp_launch<8, false>(b, s) : ORTK_EINVAL;
     }
+    else if (a.drop_p > 0.f) return ORTK_EINVAL;             // (train-mode rows: the column-split form only)
     else if (sparse) rc = stack_launch<true, 20>(b, pf, s);
     else if (rb == 20) rc = stack_launch<false, 20>(b, pf, s);
     else rc = stack_launch<false, 32>(b, pf, s);

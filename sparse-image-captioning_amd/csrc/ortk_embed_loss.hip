@@ -11,7 +11,7 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ lut, const float* __restrict__ pe,
                                                         float* __restrict__ out, float* __restrict__ keymask, int T, int t0,
                                                         int d, int pad_id, float scale, float drop_p, uint32_t seed,
-                                                        const int32_t* __restrict__ row_pos, int drop_rs, int drop_r0) {
+                                                        const int32_t* __restrict__ row_pos, int drop_rs, int drop_r0, int eval_stride) {
     const int64_t row = blockIdx.x;           // output row; r*T + t, or row_pos[row] in the valid-position layout
     const int64_t prow = row_pos ? (int64_t)row_pos[row] : row;
     const int64_t r = prow / T;
@@ -21,11 +21,16 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const int64_t* __restric
     const float* e = lut + tok * d;
     const float* p = pe + (int64_t)(t0 + t) * d;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    // eval_stride K > 0 (train-mode decode with greedy rows): rows with row % K == 0 are eval-mode rows — no dropout — and row
+    // q K + k (k >= 1) draws like row q (K - 1) + k - 1
+    int64_t drow = row;
+    bool drop = drop_p > 0.f;
+    if (eval_stride > 0) { const int64_t q = row / eval_stride, k = row - q * eval_stride; drop = drop && k != 0; drow = q * (eval_stride - 1) + k - 1; }
     for (int c = threadIdx.x; c < d; c += 128) {
         float v = e[c] * scale + p[c];
         // (draw of output row `row`: its own index, or — a decode step in train mode — that of row*drop_rs + drop_r0 of the
         // teacher-forced pass)
-        if (drop_p > 0.f) v = ortk_keep(seed, (uint64_t)(row * drop_rs + drop_r0) * d + c, drop_p) ? v * inv_keep : 0.f;
+        if (drop) v = ortk_keep(seed, (uint64_t)(drow * drop_rs + drop_r0) * d + c, drop_p) ? v * inv_keep : 0.f;
         out[row * d + c] = v;
     }
 }
@@ -273,12 +278,12 @@ inline unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>(ortk_cdi
 namespace ortk {
 int embed_fwd_rows(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out, float* keymask, int64_t nrows,
                    const int32_t* row_pos, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p, uint32_t seed, hipStream_t s,
-                   int32_t drop_rs, int32_t drop_r0) {
+                   int32_t drop_rs, int32_t drop_r0, int32_t eval_stride) {
     if (!seq || !lut || !pe || !out || nrows < 0 || T < 1 || d < 1) return ORTK_EINVAL;
     if (nrows == 0) return 0;
     const float scale = (float)sqrt((double)d);
     hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)nrows), dim3(128), 0, s, seq, seq_stride, lut, pe, out, keymask, T, t0, d, pad_id,
-                       scale, drop_p, seed, row_pos, drop_rs > 0 ? drop_rs : 1, drop_r0);
+                       scale, drop_p, seed, row_pos, drop_rs > 0 ? drop_rs : 1, drop_r0, eval_stride);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

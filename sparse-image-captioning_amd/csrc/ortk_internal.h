@@ -83,6 +83,7 @@ struct StackLayer {
     const float *n0a, *n0b, *bqkv, *bo, *n1a, *n1b, *cqb, *cob, *n2a, *n2b, *b1, *b2;
     __bf16 *ck, *cv;               // self-attention caches, (cache rows, 512)
     const __bf16 *xk, *xv;         // this layer's K / V columns of the projected memory, row pitch ldx
+    const __bf16 *xkg, *xvg;       // train-mode decode with greedy rows: the same columns of the EVAL-mode memory's projection (or NULL)
 };
 struct StackArgs {
     StackLayer layer[STACK_MAXL];
@@ -100,17 +101,31 @@ struct StackArgs {
     float eps;
     int32_t nblocks;               // compute workgroups (set by stack_step); workgroups beyond are L2 prefetchers
     int32_t* progress;             // [16] zeroed at the start of a decode: units begun by the pace-maker of each XCD
-    int32_t debug;                 // measurement only: 1 skip self-attention, 2 skip cross-attention, 4 skip the FFN, 8 no L2 prefetchers
+    int32_t debug;                 // measurement / test only: 1 skip self-attention, 2 skip cross-attention, 4 skip the FFN, 8 no L2
+                                   // prefetchers; column-split form: 16 deal the members of a group over DIFFERENT XCDs (the placement check
+                                   // must then pick the write-through exchange), 32 one member of group 0 never arrives (the bounded wait
+                                   // must report ORTK_EEXCHANGE instead of hanging)
     int32_t rb;                    // rows per workgroup: 32 (default) or 20 (256 workgroups for 1 024 images x 5 beams)
     // column-split form (stack_tp_step): G workgroups of one XCD share 64 rows, each owns 512 / G output columns of every unit
     int32_t tp;                    // G: 0 (off) | 2 | 4 | 8
     const uint4* tp_wpk;           // stack_tp_pack() image of the decoder weights
     char* tp_xbuf;                 // exchange tiles: (groups, 2, 64 x 512 x 4 bytes)
-    int32_t* tp_flag;              // (groups, 32) exchange counters, zeroed at the start of a decode
+    int32_t* tp_flag;              // (groups, TP_FLAG_STRIDE) per group: [0] the exchange counter, [16 + launch] the XCC ids its members
+                                   // reported in that launch (bit mask); zeroed at the start of a decode
+    int32_t* tp_status;            // [1] decode-wide error word (0 = fine; TP_ERR_*), zeroed at the start of a decode
     int32_t tp_groups;             // groups of the FULL row count of the decode (a multiple of 8); this launch may use fewer
     int32_t tp_launch;             // index of this launch within the decode (the counters keep running)
     int64_t tp_xtile;              // bytes of one exchange tile (stack_tp_xtile_bytes)
+    // train-mode rows (column-split form, G >= 4; ortk_decode_opts.train): every dropout of the decoder draws what the teacher-forced
+    // pass of the same seed draws at (row, position t) — utils/training.py:224-237 samples after model.train()
+    float drop_p;                  // 0: eval mode
+    int32_t greedy_stride;         // K > 0: rows with row % K == 0 are EVAL-mode rows (the greedy baseline: no dropout, memory xkg / xvg);
+                                   // the other rows of image q are rows q (K - 1) + k - 1 of the teacher-forced pass
+    uint32_t drop_seed[STACK_MAXL][6];   // site seeds of layer l: self-attention probabilities, wo output, cross-attention probabilities, co
+                                         // output, FFN hidden units, w2 output (ortk_dropout_site_seed(seed, 3, l, k))
 };
+constexpr int TP_FLAG_STRIDE = 128;        // ints per group in StackArgs.tp_flag
+constexpr int TP_ERR_TIMEOUT = 1;          // a member of an exchange group did not arrive within the spin bound
 struct StackPack { int64_t off[STACK_MAXL][6]; int32_t L, NC; };   // element offsets of wqkv, wo, cqw, cow, w1, w2 per layer
 size_t stack_packed_bytes(int L, int NC);
 int stack_pack(const void* w16, void* wpk, const StackPack& t, hipStream_t s);
@@ -133,13 +148,16 @@ int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStr
 // the valid-position decoder layout of ortk_batch.cap_off / row_pos
 int embed_fwd_rows(const int64_t* seq, int64_t seq_stride, const float* lut, const float* pe, float* out, float* keymask, int64_t nrows,
                    const int32_t* row_pos, int32_t T, int32_t t0, int32_t d, int32_t pad_id, float drop_p, uint32_t seed, hipStream_t s,
-                   int32_t drop_rs = 1, int32_t drop_r0 = 0);
+                   int32_t drop_rs = 1, int32_t drop_r0 = 0, int32_t eval_stride = 0);
 int embed_bwd_rows(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut, int64_t nrows, const int32_t* row_pos, int32_t T,
                    int32_t d, float drop_p, uint32_t seed, hipStream_t s);
 int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight, const float* norm_dev,
               float* loss_dev, int64_t rows, const int32_t* row_pos, int32_t V, int64_t ld, void* dlogits, int32_t dl_dtype, int64_t ld_dl,
               hipStream_t s);
 
+// end of a decode on the column-split stack kernel: if *status != 0 (an exchange group never completed) the outputs become
+// all-pad captions with NaN log-probs and scores — a failed decode cannot pass for a result
+int decode_poison(const int32_t* status, int64_t* seq, float* lp, float* score, int64_t nseq, int64_t nscore, hipStream_t s);
 int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
 int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 // kvidx[g*1 + 0] = g*row_mult*tmax  (index table for the first decoder pass)

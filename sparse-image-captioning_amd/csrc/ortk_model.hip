@@ -1097,6 +1097,8 @@ struct DecodeWS {
     SStackBufs ss{};                   // the sparse stream and its tables (stack path, sparse stream)
     int tp = 0;                        // column-split stack kernel: workgroups per group (0 = off), its weight image,
     void* tp_wpk = nullptr; char* tp_xbuf = nullptr; int32_t* tp_flag = nullptr;      // exchange tiles and counters
+    int32_t* status = nullptr;         // [64] decode status word (ortk_decode_status): ALWAYS the first bytes of the workspace
+    void* ckv_g = nullptr;             // train-mode decode with greedy rows: projection of the EVAL-mode encoder memory
     size_t bytes;
 };
 
@@ -1126,7 +1128,7 @@ static int split_degree(bool dense_stack, int32_t flags, int64_t rows) {
     return ((flags & ORTK_DEC_SPLIT_SMALL) && !(flags & ORTK_DEC_STACK) && G >= 4) ? G : 0;     // the small decodes only (8 or 4 per group)
 }
 static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, void* base, DecodeWS& w, bool stack = false, bool sstream = false,
-                         bool train = false, int tp = 0) {
+                         bool train = false, int tp = 0, bool greedy_rows = false) {
     const int64_t d = c.d_model, ff = c.d_ff, H = c.n_heads, L = c.n_layers, T = c.seq_len;
     // bf16 K / V storage: only when both decode attention kernels that understand it will be the ones dispatched
     w.kvdt = (c.precision && H == 8 && d == 512 && S > 8 && S <= 48 && T <= 32 && K <= 16) ? ORTK_BF16 : ORTK_F32;
@@ -1135,7 +1137,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.xq16 = (c.precision && w.kvdt == ORTK_F32 && S > 48 && attn16_shape_ok(K, S, (int)(d / H))) ? 1 : 0;
     w.ckvdt = w.xq16 ? ORTK_BF16 : w.kvdt;
     if (stack) { w.kvdt = w.ckvdt = ORTK_BF16; w.xq16 = 0; }      // the stack kernel reads bf16 caches at every S
-    if (train) { w.kvdt = w.ckvdt = ORTK_F32; w.xq16 = 0; }       // train-mode sampling: the generic attention kernel (fp32 rows)
+    if (train && !stack) { w.kvdt = w.ckvdt = ORTK_F32; w.xq16 = 0; }       // train-mode sampling, unfused: the generic attention kernel (fp32 rows)
     const size_t kves = ortk_esize(w.kvdt);
     const int64_t Me = (int64_t)B * S, rows = (int64_t)B * K;
     w.ldv = ortk_align(c.vocab, 128);
@@ -1144,6 +1146,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     Bump b{reinterpret_cast<char*>(base), 0};
     auto act = [&](int64_t n) { return b.take_bytes((size_t)n * es); };
     Offsets o; build_layout(c, o, nullptr);
+    w.status = b.take<int32_t>(64);
     w.w16 = c.precision ? b.take_bytes((size_t)o.total * 2) : nullptr;
     w.x0 = b.take<float>(Me * d); w.logbias = b.take<float>(L * B * H * S * S);
     w.enc.y1 = act(Me * d); w.enc.qkv = b.take<float>(Me * 3 * d); w.enc.P = nullptr; w.enc.o = act(Me * d);
@@ -1151,6 +1154,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.enc.xout = w.x0; w.enc.st1 = b.take<float>(Me * 2); w.enc.st2 = w.enc.st1;
     w.mem = b.take_bytes((size_t)Me * d * 4); w.st = b.take<float>(std::max(Me, rows) * 2);
     w.ckv = b.take_bytes((size_t)(Me * L * 2 * d) * ortk_esize(w.ckvdt));
+    if (train && stack && greedy_rows) w.ckv_g = b.take_bytes((size_t)(Me * L * 2 * d) * ortk_esize(w.ckvdt));
     w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = act(rows * d);
     w.qkv = b.take<float>(rows * 3 * d); w.o = act(rows * d); w.q = b.take<float>(rows * d);      // (fp32-sized; holds bf16 when xq16)
     w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
@@ -1161,7 +1165,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
         w.tp = tp;
         w.tp_wpk = b.take_bytes(stack_tp_packed_bytes((int)L, (int)(ff / 512), tp));
         w.tp_xbuf = reinterpret_cast<char*>(b.take_bytes(stack_tp_xbuf_bytes(rows, (int)(ff / 512))));
-        w.tp_flag = b.take<int32_t>((int64_t)stack_tp_groups(rows) * 32);
+        w.tp_flag = b.take<int32_t>((int64_t)stack_tp_groups(rows) * TP_FLAG_STRIDE);
         w.progress = b.take<int32_t>(16);
     } else if (stack && !sstream) { w.wpk = b.take_bytes(stack_packed_bytes((int)L, (int)(ff / 512))); w.progress = b.take<int32_t>(16); }
     if (stack && sstream) {
@@ -1199,15 +1203,44 @@ static int decode_K(const ortk_decode_opts* o) {
     return o->beam_size >= 1 ? o->beam_size : -1;
 }
 
+// Which executor serves a decode call.  Train-mode rows (ortk_decode_opts.train) run on the column-split stack kernel with at least 4
+// workgroups per group (its dropout sites, ortk_decstack.hip) or on the unfused executor; eval-mode (greedy) rows beside them
+// (`with_greedy`) only on the former.  ok = false: the option combination is not served (ORTK_EINVAL).
+struct DecodePlan { bool ok, stack, sstream; int split; };
+static DecodePlan plan_decode(const ortk_config& cfg, int B, int K, const ortk_decode_opts* o) {
+    DecodePlan p{true, false, false, 0};
+    const int64_t rows = (int64_t)B * K;
+    p.stack = stack_ok(cfg, rows, o->exec_flags) && !o->sparse;
+    p.sstream = p.stack && (o->exec_flags & ORTK_DEC_SPARSE_STREAM);
+    p.split = split_degree(p.stack && !p.sstream, o->exec_flags, rows);
+    if (o->train) {
+        if (o->num_random_sample <= 0 || o->sparse) { p.ok = false; return p; }      // multinomial rollouts, dense products
+        if (!(p.stack && !p.sstream && p.split >= 4)) { p.stack = p.sstream = false; p.split = 0; }
+        if (o->with_greedy && !p.stack) p.ok = false;
+    }
+    return p;
+}
+
 extern "C" size_t ortk_decode_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, const ortk_decode_opts* o) {
     if (check_cfg(cfg) || !o || B < 1 || S < 1) return 0;
     const int K = decode_K(o);
     if (K < 1) return 0;
-    const bool stack = stack_ok(*cfg, (int64_t)B * K, o->exec_flags) && !o->sparse && !o->train;
-    const bool sstream = (o->exec_flags & ORTK_DEC_SPARSE_STREAM) != 0;
-    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, stack, sstream, o->train != 0,
-                             split_degree(stack && !sstream, o->exec_flags, (int64_t)B * K));
+    const DecodePlan pl = plan_decode(*cfg, B, K, o);
+    if (!pl.ok) return 0;
+    DecodeWS w; carve_decode(*cfg, B, S, K, o->num_random_sample <= 0 && o->beam_size > 1, nullptr, w, pl.stack, pl.sstream, o->train != 0,
+                             pl.split, o->with_greedy != 0);
     return w.bytes;
+}
+
+// Status of the decode that last ran on workspace `ws` (host synchronisation: waits for `stream`): 0, or ORTK_EEXCHANGE when a
+// workgroup of the column-split stack kernel never met its exchange group (the launch was not fully resident: another kernel
+// held compute units) — the outputs of that decode are all-pad captions with NaN log-probs.
+extern "C" int ortk_decode_status(const void* ws, ortk_stream stream) {
+    if (!ws) return ORTK_EINVAL;
+    int32_t h = 0;
+    if (hipMemcpyAsync(&h, ws, sizeof(h), hipMemcpyDeviceToHost, ortk_s(stream)) != hipSuccess) return ORTK_EINVAL;
+    if (hipStreamSynchronize(ortk_s(stream)) != hipSuccess) return ORTK_EINVAL;
+    return h == 0 ? 0 : ORTK_EEXCHANGE;
 }
 
 // One position of the cached-attention decoder for `rows` rows (transformer.py:172-210 with the caches of :240-273):
@@ -1285,14 +1318,17 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
 }
 
 // The same position through the one-launch decoder stack: embed, stack kernel, generator.
-struct SplitBufs { int G; const void* wpk; char* xbuf; int32_t* flag; int groups; };      // column-split form (G = 0: off)
+struct SplitBufs { int G; const void* wpk; char* xbuf; int32_t* flag; int groups; int32_t* status; };      // column-split form (G = 0: off)
 static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w, const void* wpk, const SStackBufs* ss, int32_t* progress, int32_t flags,
-                              int64_t rows, int per_img, int S, int T, int t, const int32_t* kvidx, const SplitBufs* sp = nullptr) {
+                              int64_t rows, int per_img, int S, int T, int t, const int32_t* kvidx, const SplitBufs* sp = nullptr,
+                              int greedy_stride = 0, const void* ckv_g = nullptr) {
     const ortk_config* cfg = c.cfg;
     const float* P = c.P;
-    ortk_stream stream = (ortk_stream)c.s;
     const int d = cfg->d_model;
-    TRY(ortk_embed_fwd(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, 1, t, d, cfg->pad_id, 0.f, 0, stream));
+    // c.train: every dropout of the position draws what the teacher-forced pass over [BOS, sample] draws at (row, t); rows with
+    // row % greedy_stride == 0 stay in eval mode (the greedy baseline of the same launch)
+    const float pd = c.p_drop();
+    TRY(embed_fwd_rows(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, nullptr, 1, t, d, cfg->pad_id, pd, c.sub(OP_EMB), c.s, T, t, greedy_stride));
     StackArgs a; std::memset(&a, 0, sizeof(a));
     for (int l = 0; l < cfg->n_layers; ++l) {
         const DecOff& e = o.dec[l];
@@ -1302,15 +1338,19 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
         y.ck = reinterpret_cast<__bf16*>(w.cache_k[l]); y.cv = reinterpret_cast<__bf16*>(w.cache_v[l]);
         y.xk = reinterpret_cast<const __bf16*>(w.ckv) + o.ckv_slot[l] * o.cw;
         y.xv = y.xk + o.cv;
+        if (ckv_g) { y.xkg = reinterpret_cast<const __bf16*>(ckv_g) + o.ckv_slot[l] * o.cw; y.xvg = y.xkg + o.cv; }
+        for (int k = 0; k < 6; ++k) a.drop_seed[l][k] = c.sub(dop(l, k));
     }
+    a.drop_p = pd; a.greedy_stride = pd > 0.f ? greedy_stride : 0;
     a.wpk = reinterpret_cast<const uint4*>(wpk); a.progress = progress; a.x_io = w.xa; a.y_out = reinterpret_cast<__bf16*>(w.y);
     if (ss) { a.sstream = ss->stream; a.snst = ss->nst; a.sstart = ss->start; }
     a.rb = (flags & ORTK_DEC_STACK_RB20) ? 20 : 32;
     a.fa = P + o.dec_na; a.fb = P + o.dec_nb; a.att_masks = w.att_masks; a.kvidx = kvidx; a.ldx = o.ckv_slots * o.cw;
     a.rows = (int)rows; a.per_img = per_img; a.S = S; a.T = T; a.t = t; a.L = cfg->n_layers; a.NC = cfg->d_ff / 512; a.eps = 1e-6f;
-    a.debug = (flags >> 8) & 0xF;        // ORTK_DEC_DEBUG_*: phase-skipping measurement switches
+    a.debug = (flags >> 8) & 0xFF;       // phase-skipping measurement switches and the exchange tests (StackArgs.debug)
     if (sp && sp->G) {
         a.tp = sp->G; a.tp_wpk = reinterpret_cast<const uint4*>(sp->wpk); a.tp_xbuf = sp->xbuf; a.tp_flag = sp->flag; a.tp_groups = sp->groups;
+        a.tp_status = sp->status;
         a.tp_launch = t;                 // one launch per position: the exchange counters keep running through the decode
         a.tp_xtile = (int64_t)stack_tp_xtile_bytes(cfg->d_ff / 512);
     }
@@ -1324,7 +1364,8 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (int e = check_cfg(cfg)) return e;
     if (!params || !op || !att_masks || !ws || !seq_out || !logprob_out) return ORTK_EINVAL;
     if (!op->memory && (!att_feats || (!boxes && !cfg->no_box))) return ORTK_EINVAL;
-    if (op->memory && op->train) return ORTK_EINVAL;       // (train-mode sampling perturbs the encoder with its own dropout draws)
+    // (op->memory with op->train: the caller's memory must be the TRAIN-mode encoder output under drop_seed — ortk_forward_phase(train = 1,
+    // seed = drop_seed, phase 1) computes exactly what this call's own train-mode encoder pass would)
     if (B < 1 || S < 1 || S > 128) return ORTK_EINVAL;
     const int K = decode_K(op);
     if (K < 1) return ORTK_EINVAL;   // the reference asserts the same option combinations (transformer.py:509,514)
@@ -1332,14 +1373,18 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (beam && (K > 8 || K > cfg->vocab)) return ORTK_EINVAL;
     if (op->temperature <= 0.f) return ORTK_EINVAL;
     Offsets o; build_layout(*cfg, o, nullptr);
-    // train-mode sampling (dropout on while the captions are drawn): multinomial rollouts only, on the unfused executor
-    if (op->train && (op->num_random_sample <= 0 || op->with_greedy || op->sparse)) return ORTK_EINVAL;
-    const bool stack = stack_ok(*cfg, (int64_t)B * K, op->exec_flags) && !op->sparse && !op->train;
-    const bool sstream = stack && (op->exec_flags & ORTK_DEC_SPARSE_STREAM);
-    const int split = split_degree(stack && !sstream, op->exec_flags, (int64_t)B * K);
-    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack, sstream, op->train != 0, split);
+    // train-mode sampling (dropout on while the captions are drawn): multinomial rollouts only; with the greedy baseline as eval-mode
+    // rows of the same launches when the column-split stack kernel serves the call (plan_decode)
+    const DecodePlan pl = plan_decode(*cfg, B, K, op);
+    if (!pl.ok) return ORTK_EINVAL;
+    const bool stack = pl.stack, sstream = pl.sstream;
+    const int split = pl.split;
+    const bool greedy_rows = op->train && op->with_greedy;         // (=> stack)
+    if (greedy_rows && (!att_feats || (!boxes && !cfg->no_box))) return ORTK_EINVAL;      // their eval-mode encoder pass runs here
+    DecodeWS w; carve_decode(*cfg, B, S, K, beam, ws, w, stack, sstream, op->train != 0, split, greedy_rows);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
     hipStream_t s = ortk_s(stream);
+    TRY(fill_i32(w.status, 64, 0, s));
     TRY(make_w16(cfg, o, params, w.w16, stream));
     if (stack) {
         StackPack tp; tp.L = cfg->n_layers; tp.NC = cfg->d_ff / 512;
@@ -1351,7 +1396,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         if (sstream) TRY(sstack_pack(w.w16, w.ss, tp, s));
         else if (w.tp) {
             TRY(stack_tp_pack(w.w16, w.tp_wpk, tp, w.tp, s));
-            TRY(fill_i32(w.tp_flag, (int64_t)stack_tp_groups((int64_t)B * K) * 32, 0, s));
+            TRY(fill_i32(w.tp_flag, (int64_t)stack_tp_groups((int64_t)B * K) * TP_FLAG_STRIDE, 0, s));
             TRY(fill_i32(w.progress, 16, 0, s));
         } else {
             TRY(stack_pack(w.w16, w.wpk, tp, s));
@@ -1375,6 +1420,14 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
     // ortk_decode_opts.memory: the encoder output of these images already exists (the training forward's, ortk_forward_phase 1)
+    if (greedy_rows) {
+        // the greedy rows attend to the EVAL-mode encoder memory (utils/training.py:216-222 decodes the baseline under model.eval()):
+        // its pass and projection first, then the buffers are free for the train-mode pass
+        Ctx ce = c; ce.train = false; ce.seed = 0;
+        TRY(encoder_forward(ce, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
+        ce.use_side = false;
+        TRY(fwd_gemm(ce, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv_g, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
+    }
     if (!op->memory) TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
     c.use_side = false;
     TRY(fwd_gemm(c, op->memory ? op->memory : w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
@@ -1415,8 +1468,9 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         sb.kvdt = w.kvdt; sb.ckvdt = w.ckvdt; sb.xq16 = w.xq16;
         if (beam && bs.gstats) { sb.gstats = w.gstats; sb.stat_ncols = V; }
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
-        const SplitBufs spb{w.tp, w.tp_wpk, w.tp_xbuf, w.tp_flag, stack_tp_groups(rows_full)};
-        if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr, &spb));
+        const SplitBufs spb{w.tp, w.tp_wpk, w.tp_xbuf, w.tp_flag, stack_tp_groups(rows_full), w.status};
+        if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr, &spb,
+                                          greedy_rows ? K : 0, w.ckv_g));
         else TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.
@@ -1434,6 +1488,8 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         TRY(sample_finalize(ss, s));
         if (score_out) TRY(ortk_fill(score_out, rows_full, 0.f, stream));
     }
+    // the column-split kernel's exchanges are bounded waits: a decode whose groups never met must not pass for a result
+    if (w.tp) TRY(decode_poison(w.status, seq_out, logprob_out, score_out, rows_full * T, rows_full, s));
     return 0;
 }
 

@@ -507,9 +507,9 @@ class RelationTransformerModel(CaptionModelBase):
         kind, alpha = s.split("_")
         return {"wu": 1, "avg": 2}[kind], float(alpha)
 
-    @torch.no_grad()
-    def _decode(self, att_feats, boxes, att_masks, opt):
-        lib = L.lib()
+    def _decode_opts(self, opt):
+        """``opt`` dict of ``mode="sample"`` (transformer.py:471-561) -> (ortk_decode_opts without the sparse plan / memory, rows
+        per image K, executor name)."""
         o = L.DecodeOpts()
         o.num_random_sample = int(opt.get("num_random_sample", 0))
         o.beam_size = int(opt.get("beam_size", 1))
@@ -525,7 +525,8 @@ class RelationTransformerModel(CaptionModelBase):
         # train-mode sampling (ortk_decode_opts.train): dropout on while the captions are drawn, keyed like the teacher-forced
         # pass of seed opt["drop_seed"]; default: follows model.training only when asked (opt["train_mode"])
         if opt.get("train_mode", False):
-            assert o.num_random_sample > 0 and not o.with_greedy, "train-mode sampling: multinomial rollouts without the fused greedy row"
+            # (with_greedy beside train-mode rows: the column-split stack kernel only — an unserved combination raises below)
+            assert o.num_random_sample > 0, "train-mode sampling: multinomial rollouts"
             o.train, o.drop_seed = 1, int(opt["drop_seed"]) & 0xFFFFFFFFFFFFFFFF
         if o.num_random_sample > 0:
             assert o.beam_size < 1, f"Beam size must be < 1, saw {o.beam_size}"      # transformer.py:509
@@ -534,12 +535,6 @@ class RelationTransformerModel(CaptionModelBase):
             assert o.beam_size >= 1, f"Beam size must be >= 1, saw {o.beam_size}"    # transformer.py:514
             assert o.beam_size <= self.vocab_size                                    # transformer.py:482
             K = o.beam_size
-        B, S = att_feats.shape[:2]
-        dev = self._flat.device
-        seq = torch.empty(B, K, self.seq_length, dtype=torch.long, device=dev)
-        lp = torch.empty(B, K, self.seq_length, device=dev)
-        score = torch.empty(B, K, device=dev)
-        pptr = self._eff_params_ptr(False, 0)
         # executor choice (ortk_decode_opts.exec_flags): opt["executor"] = "auto" | "unfused" | "stack" | "sparse_stream";
         # ORTK_DEC_STACK=0 / 2 in the environment (read here, on the host side, per call) = "unfused" / "stack"
         ex = opt.get("executor", {"0": "unfused", "2": "stack", "3": "stack_split"}.get(os.environ.get("ORTK_DEC_STACK", ""), "auto"))
@@ -551,7 +546,29 @@ class RelationTransformerModel(CaptionModelBase):
         small = L.DEC_SPLIT_SMALL if (getattr(self, "exclusive_gpu", True) and int(opt.get("decode_streams", 0) or 1) <= 1) else 0
         o.exec_flags = {"auto": small, "unfused": L.DEC_UNFUSED, "stack": L.DEC_STACK, "sparse_stream": L.DEC_SPARSE_STREAM,
                         "stack_rb20": L.DEC_STACK | L.DEC_STACK_RB20, "stack_split": L.DEC_STACK | L.DEC_STACK_SPLIT,
-                        "sparse_stream_rb20": L.DEC_SPARSE_STREAM | L.DEC_STACK_RB20}[ex] | (int(opt.get("stack_debug", 0)) & 0xF) << 8
+                        "sparse_stream_rb20": L.DEC_SPARSE_STREAM | L.DEC_STACK_RB20}[ex] | (int(opt.get("stack_debug", 0)) & 0xFF) << 8
+        return o, K, ex
+
+    def decode_supported(self, B, S, opt, att_max_len=None):
+        """Whether ``mode="sample"`` serves this option combination for B images of S regions (e.g. train-mode rollouts with the
+        greedy baseline as eval-mode rows of the same launches: the column-split stack kernel only).  No device work."""
+        o, _, ex = self._decode_opts(dict(opt, seed=opt.get("seed", 0)))      # (a probe draws no seed)
+        if getattr(self, "_plans", None) is not None and self._plans[0] is not None and not ex.startswith("sparse_stream"):
+            o.sparse = self._plans[0].ref()
+        if att_max_len is not None:
+            S = min(int(S), int(att_max_len))
+        return L.lib().ortk_decode_workspace_bytes(C.byref(self._ccfg), int(B), int(S), C.byref(o)) != 0
+
+    @torch.no_grad()
+    def _decode(self, att_feats, boxes, att_masks, opt):
+        lib = L.lib()
+        o, K, ex = self._decode_opts(opt)
+        B, S = att_feats.shape[:2]
+        dev = self._flat.device
+        seq = torch.empty(B, K, self.seq_length, dtype=torch.long, device=dev)
+        lp = torch.empty(B, K, self.seq_length, device=dev)
+        score = torch.empty(B, K, device=dev)
+        pptr = self._eff_params_ptr(False, 0)
         fresh_plan = getattr(self, "_plans", None) is None
         plan = self._sparse_plans()[0]
         if plan is not None and not ex.startswith("sparse_stream"):
@@ -574,6 +591,8 @@ class RelationTransformerModel(CaptionModelBase):
             o.memory = int(opt["memory"])
             n = 1
 
+        used_ws = []
+
         def run(i, b0, b1, stream_ptr, out):
             oi = L.DecodeOpts.from_buffer_copy(o)
             oi.sample_row_offset = int(opt.get("sample_row_offset", 0)) + b0 * K
@@ -582,6 +601,7 @@ class RelationTransformerModel(CaptionModelBase):
                 out[i] = -1
                 return
             ws = self._workspace(("decode", b1 - b0, S, K, beam, i), nb, True)
+            used_ws.append(ws)
             out[i] = lib.ortk_decode(C.byref(self._ccfg), pptr, L.ptr(att_feats[b0:b1]), L.ptr(boxes[b0:b1]),
                                      L.ptr(att_masks[b0:b1]), b1 - b0, S, C.byref(oi), L.ptr(ws), ws.numel(), L.ptr(seq[b0:b1]),
                                      L.ptr(lp[b0:b1]), L.ptr(score[b0:b1]), stream_ptr)
@@ -612,6 +632,14 @@ class RelationTransformerModel(CaptionModelBase):
             L.check(r, "ortk_decode")
         if plan is not None and fresh_plan:
             plan.check_overflow()      # (host sync, first decode on a new plan: the images were built from THIS call's weights)
+        # The column-split stack kernel's exchanges are bounded waits (ortk.h: ORTK_DEC_SPLIT_SMALL): a decode whose groups never
+        # met (another kernel held compute units) has poisoned outputs and a status word.  Reading it is a host synchronisation, so
+        # it is read on the first decodes of a model, then every 64th, and whenever opt["check_status"] asks.
+        if (o.exec_flags & (L.DEC_SPLIT_SMALL | L.DEC_STACK_SPLIT)) and ex != "unfused":
+            self._decode_calls = getattr(self, "_decode_calls", 0) + 1
+            if opt.get("check_status", self._decode_calls <= 2 or self._decode_calls % 64 == 0):
+                for ws in used_ws:
+                    L.check(lib.ortk_decode_status(L.ptr(ws), L.stream_ptr()), "ortk_decode (status)")
         return seq, lp, score
 
     def _sample(self, att_feats, boxes, att_masks=None, opt=None, **kwargs):

@@ -175,7 +175,7 @@ class NativeTrainer:
         return self._step(data, tok_w, tok_w, train)
 
     def scst_step(self, data, reward_fn, num_samples=5, baseline="greedy", train=True, sample="random", update_dropout=False,
-                  sample_dropout=False):
+                  sample_dropout=None):
         """SCST step (utils/training.py:202-255): greedy baseline + `num_samples` rollouts (no graph, cached attention), rewards
         from ``reward_fn(sample_seq (N,ns,L), greedy_seq (N,1,L) | None) -> (N*ns,)``, then ONE teacher-forced pass over
         [BOS, sample] with per-token weight mask*reward (RewardCriterion).
@@ -183,58 +183,79 @@ class NativeTrainer:
         ``sample``: "random" = multinomial rollouts (``scst_sample == "random"``, utils/training.py:232-237) or "beam_search" = the
         `num_samples` beams of a beam search (utils/training.py:226-231).
 
-        Which policy is differentiated.  The reference draws its rollouts in TRAIN mode — dropout on in every one of the 18
-        incremental passes — and back-propagates through those very passes, so the log-probs it differentiates are those of
-        the (dropout-perturbed) policy that sampled.  Here the rollout runs on the decode executor WITHOUT dropout (its fast
-        kernels have none) and the log-probs are recomputed by one teacher-forced pass; that pass therefore runs without dropout
-        too (``update_dropout=False``): sampling policy = differentiated policy = the eval-mode model, exactly (teacher-forced
-        and incremental log-probs agree to 3e-6).  ``update_dropout=True`` recomputes under a fresh dropout pattern
-        (rounds 1-2: a regulariser, but then the differentiated policy is not the one that sampled).
+        Which policy is differentiated.  The reference decodes its greedy baseline under ``model.eval()``, then calls
+        ``model.train()`` and draws its rollouts with every dropout on, back-propagating through those very passes
+        (utils/training.py:216-237): the log-probs it differentiates are those of the dropout-perturbed policy that sampled.
 
-        ``sample_dropout=True`` is the reference's own semantics: the rollouts are drawn in TRAIN mode (``ortk_decode_opts.train``:
-        every dropout on, keyed by one seed) and the teacher-forced pass runs with dropout under the SAME seed, so it reproduces
-        the sampling passes' masks position by position and differentiates exactly the dropout-perturbed policy that sampled
-        (tests/test_gpu_model.py::test_train_mode_sampling_vs_oracle).  Costs a separate greedy pass (the baseline is an
-        eval-mode decode, its encoder memory is not the sampled one's) and the generic attention / GEMM kernels in the rollout:
-        the fast decode kernels have no dropout."""
+        ``sample_dropout=True`` — the DEFAULT for multinomial rollouts of a training step (``sample_dropout=None`` and ``train``) —
+        is that estimator: the rollouts are drawn in TRAIN mode (``ortk_decode_opts.train``, every dropout keyed by one seed) and
+        the teacher-forced update pass runs with dropout under the SAME seed, so it reproduces the sampling passes' masks position
+        by position (tests/test_gpu_model.py::test_train_mode_sampling_vs_oracle, ..._on_the_split_kernel).  For a dense model the
+        step costs ONE encoder pass in train mode (phase 1 of the update's forward; the rollout decodes on its memory) plus the
+        eval-mode encoder pass of the greedy baseline, and — where the column-split stack kernel serves the decode (mixed precision,
+        <= 4 096 rows) — ONE decode: the greedy baseline rides as eval-mode rows in the launches of the train-mode rollouts.
+        Elsewhere (fp32 parity mode, masked models) the baseline is its own eval-mode decode.
+
+        ``sample_dropout=False`` is the dropout-free variant: eval-mode rollouts (greedy + samples in one decode pass) and, with
+        ``update_dropout=False``, an eval-mode update — sampling policy = differentiated policy = the eval-mode model (teacher-forced
+        and incremental log-probs agree to 3e-6).  NOT the reference's estimator: no dropout anywhere in the step.
+        ``update_dropout=True`` recomputes under a fresh dropout pattern (rounds 1-2)."""
         m = self.model
         was_training = m.training
         greedy = None
         B = data["att_feats"].size(0)
         kw = dict(att_feats=data["att_feats"], boxes=data.get("boxes"), att_masks=data.get("att_masks"), mode="sample",
                   att_max_len=data.get("att_max_len"))
+        if sample_dropout is None:
+            sample_dropout = bool(train) and sample == "random"
         drop_seed = None
-        # One encoder pass per step: the update pass below recomputes the rollout's log-probs in the SAME mode as the rollout
-        # (eval-mode model) unless a dropout variant was asked for, so its encoder half runs first, into the training workspace,
-        # and the rollout decodes on that memory (`opt["memory"]`); the update then only runs its decoder half forward.
-        share_encoder = not (train and (sample_dropout or update_dropout)) and not getattr(m, "_sparse_stream", False)
-        mem_opt = {}
+        sparse_stream = getattr(m, "_sparse_stream", False)
+        share_encoder = False
         with torch.no_grad():
-            if share_encoder:
-                m.eval()
-                mem_opt = {"memory": self.encode_for_update(data, B * num_samples)}
             if sample_dropout and train:
                 assert sample == "random", "train-mode sampling: multinomial rollouts"
                 drop_seed = m._next_seed()
-                if baseline == "greedy":
-                    greedy, _ = m(**kw, opt={"beam_size": 1})
-                seq, _ = m(**kw, opt={"num_random_sample": num_samples, "beam_size": 0, "train_mode": True, "drop_seed": drop_seed,
-                                      "sample_row_offset": parallel.rank() * B * num_samples})
-            elif sample == "beam_search":
-                assert num_samples > 1, "beam search needs more than one beam"
-                if baseline == "greedy":
-                    greedy, _ = m(**kw, opt=dict({"beam_size": 1}, **mem_opt))
-                seq, _ = m(**kw, opt=dict({"beam_size": num_samples}, **mem_opt))
-            else:
-                assert sample == "random", sample
-                # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
-                # token for token what the two calls of utils/training.py:220-237 return, at half the launches
-                seq, _ = m(**kw, opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
-                                      # the draws are keyed by the GLOBAL row of the batch: N ranks on their shards sample what
-                                      # one process samples on the whole batch
-                                      "sample_row_offset": parallel.rank() * B * (num_samples + (baseline == "greedy")), **mem_opt})
-                if baseline == "greedy":
+                opt = {"num_random_sample": num_samples, "beam_size": 0, "train_mode": True, "drop_seed": drop_seed}
+                # Dense model: the update's encoder half runs first, in TRAIN mode under drop_seed, into the training workspace; the
+                # rollout's train-mode rows decode on that memory.  (Masked models draw a Bernoulli weight mask per training
+                # forward while the rollout runs on the eval-mode masks: their passes share nothing.)
+                share_encoder = not self.masked and not sparse_stream
+                if share_encoder:
+                    m.train()
+                    opt["memory"] = self.encode_for_update(data, B * num_samples, train=True, seed=drop_seed)
+                fused = dict(opt, with_greedy=True, sample_row_offset=parallel.rank() * B * (num_samples + 1))
+                if baseline == "greedy" and share_encoder and m.decode_supported(B, data["att_feats"].size(1), fused, data.get("att_max_len")):
+                    seq, _ = m(**kw, opt=fused)
                     greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
+                else:
+                    if baseline == "greedy":
+                        m.eval()
+                        greedy, _ = m(**kw, opt={"beam_size": 1})
+                    seq, _ = m(**kw, opt=dict(opt, sample_row_offset=parallel.rank() * B * num_samples))
+            else:
+                # One encoder pass per step: the update pass recomputes the rollout's log-probs in the SAME mode as the rollout
+                # (eval-mode model) unless a dropout variant was asked for, so its encoder half runs first, into the training
+                # workspace, and the rollout decodes on that memory (`opt["memory"]`); the update then only runs its decoder half.
+                share_encoder = not (train and update_dropout) and not sparse_stream
+                mem_opt = {}
+                if share_encoder:
+                    m.eval()
+                    mem_opt = {"memory": self.encode_for_update(data, B * num_samples)}
+                if sample == "beam_search":
+                    assert num_samples > 1, "beam search needs more than one beam"
+                    if baseline == "greedy":
+                        greedy, _ = m(**kw, opt=dict({"beam_size": 1}, **mem_opt))
+                    seq, _ = m(**kw, opt=dict({"beam_size": num_samples}, **mem_opt))
+                else:
+                    assert sample == "random", sample
+                    # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
+                    # token for token what the two calls of utils/training.py:220-237 return, at half the launches
+                    seq, _ = m(**kw, opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
+                                          # the draws are keyed by the GLOBAL row of the batch: N ranks on their shards sample what
+                                          # one process samples on the whole batch
+                                          "sample_row_offset": parallel.rank() * B * (num_samples + (baseline == "greedy")), **mem_opt})
+                    if baseline == "greedy":
+                        greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
         m.train(was_training)
         reward = reward_fn(seq, greedy)
         host_reward = not reward.is_cuda
@@ -243,16 +264,18 @@ class NativeTrainer:
         mask = (rows != m.pad_idx).float()
         tf = dict(data)
         tf.pop("cap_len", None); tf.pop("_valid_rows", None)      # (those of the ground-truth captions)
-        if host_reward and self.valid_positions:
+        if host_reward and self.valid_positions and drop_seed is None:
             # The lengths of the SAMPLED captions live on the device.  A reward computed on the host (the CIDEr-D scorer of
             # scst/scorers.py) has already waited for the rollout, so reading them back costs one small copy and the update
             # pass then runs its decoder on the valid positions only (a sampled caption is tokens, EOS, then pads: its
             # weights lie in a prefix).  A device-side reward_fn keeps the whole step free of host synchronisation: padded layout.
+            # (Not with train-mode rollouts: the valid-position layout keys its dropout draws by the COMPACT row, the rollout by
+            # (row, position) of the padded layout — the update must reproduce the rollout's masks, so it stays padded.)
             pos = torch.arange(1, mask.size(1) + 1, device=mask.device, dtype=mask.dtype)
             tf["cap_len"] = (mask * pos).amax(1).clamp_(min=1).to(torch.int64).cpu()       # 1 + index of the last weighted position
         tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
         if drop_seed is not None:
-            loss = self._step(tf, mask * reward[:, None], mask, True, seed=drop_seed)
+            loss = self._step(tf, mask * reward[:, None], mask, True, seed=drop_seed, encoded=share_encoder)
         else:
             loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout, encoded=share_encoder)
         return loss, reward, seq, greedy
@@ -290,16 +313,22 @@ class NativeTrainer:
                 self._opt_stream.wait_stream(cur)
                 with torch.cuda.stream(self._opt_stream):
                     self._adam(m._flat[d0:m._n_train], self.grads[d0:], self.m[d0:], self.v[d0:], lr, self.eps, zero=not self.keep_grads)
-        seed = self._fwd_bwd(batch, self.norm_dev, train, seed, after_decoder_half=early, encoded=encoded)
+        try:
+            seed = self._fwd_bwd(batch, self.norm_dev, train, seed, after_decoder_half=early, encoded=encoded)
+        except BaseException:
+            if self._opt_stream is not None:       # a decoder-half update may already be queued: never leave it racing the caller
+                torch.cuda.current_stream().wait_stream(self._opt_stream)
+            raise
         loss = self.loss_dev.clone()
-        if getattr(m, "_sparse_train", False) and (self.step_count == 1 or self.step_count % self.overflow_check_every == 0):
-            m.check_sparse_overflow()
         parallel.reduce_scalar_sum(loss)            # every rank's partial is already divided by the GLOBAL normaliser
         if early is not None:
+            # (early_adam implies a dense model: no sparse-plan overflow check can raise between the two halves of the update)
             self._adam(m._flat[:d0], self.grads[:d0], self.m[:d0], self.v[:d0], lr, self.eps, zero=not self.keep_grads)
             torch.cuda.current_stream().wait_stream(self._opt_stream)
             self._grads_clean = not self.keep_grads
             return loss
+        if getattr(m, "_sparse_train", False) and (self.step_count == 1 or self.step_count % self.overflow_check_every == 0):
+            m.check_sparse_overflow()
         if self.masked:
             coef = None
             if self.train_masks:
