@@ -234,6 +234,18 @@ typedef struct ortk_spmm_args {
 } ortk_spmm_args;
 int ortk_spmm(const ortk_sparse_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream);
 
+/* Process-wide A/B switches for measurements (the scripts under scratch/); the defaults are the product path and nothing in the library reads the
+ * environment.  Not thread-safe against running calls: set them before the work starts. */
+typedef struct ortk_tuning {
+    int32_t gemm_impl;       /* 0 automatic | 1 register-staged GEMM kernel only | 2 128 x 128 LDS-DMA tiles for every layout | 3 256 x 256 whenever legal */
+    int32_t gemm_t64;        /* 64 x 64 LDS-DMA tiles while the 128 x 128 grid has at most this many workgroups (640; -1 never) */
+    int32_t attn_impl;       /* 0 automatic | 1 wave kernels | 3 fp32-MFMA kernels | 4 small register-only kernels (ortk_attn.hip dispatch) */
+    int32_t attn16_min_lq;   /* fp32-input query blocks shorter than this stay off the bf16-operand attention kernels (33) */
+    int32_t side_stream;     /* 1: the executor queues weight gradients and other independent work on a second stream (default) | 0 */
+} ortk_tuning;
+void ortk_get_tuning(ortk_tuning* out);
+int ortk_set_tuning(const ortk_tuning* t);
+
 #define ORTK_DEC_UNFUSED 1
 #define ORTK_DEC_STACK 2
 #define ORTK_DEC_SPARSE_STREAM 4

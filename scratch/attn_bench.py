@@ -2,6 +2,10 @@ import sys, ctypes as C, os
 sys.path[:0]=["/root/repo"]
 import torch
 import sparse_image_captioning_amd as P
+import os as _os
+if "ORTK_ATTN_IMPL" in _os.environ:      # (the library itself reads no environment: forward the old switch through ortk_set_tuning)
+    P._lib.set_tuning(attn_impl=int(_os.environ["ORTK_ATTN_IMPL"]))
+
 L=P._lib
 def run(name,nkv,H,Lq,Lk,dk,causal,bias,reps=10):
     d=H*dk

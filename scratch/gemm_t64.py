@@ -4,6 +4,10 @@ import sys, ctypes as C, os
 sys.path[:0]=["/root/repo"]
 import torch
 import sparse_image_captioning_amd as P
+import os as _os
+if "ORTK_GEMM_T64" in _os.environ:      # (the library itself reads no environment: forward the old switch through ortk_set_tuning)
+    P._lib.set_tuning(gemm_t64=int(_os.environ["ORTK_GEMM_T64"]))
+
 L=P._lib
 def run(M,N,K,reps=20,epi=True):
     A=torch.randn(M,K,device="cuda").bfloat16(); B=torch.randn(N,K,device="cuda").bfloat16(); Cc=torch.zeros(M,N,device="cuda")

@@ -13,8 +13,9 @@ torch.manual_seed(8888)
 cfg = ort_config(drop_prob_src=0.5, max_seq_length=18)
 m = pkg.get_model("relation_transformer")(cfg, precision="bf16").to(dev).eval()
 b = Bn.synth_batch(B, 36, cfg.att_feat_size, cfg.vocab_size, 5, cfg.max_seq_length, 1000, dev)
-for ex in ("stack_split",):
-    for dbg in (0, 8, 9, 10, 11, 12, 15):
+exs = sys.argv[3].split(",") if len(sys.argv) > 3 else ("stack_split",)
+for ex in exs:
+    for dbg in (0, 1, 2, 4, 7):
         o = {"beam_size": beam, "executor": ex, "stack_debug": dbg}
         with torch.no_grad():
             m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt=o, mode="sample")

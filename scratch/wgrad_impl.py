@@ -4,6 +4,10 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sparse_image_captioning_amd as P
+import os as _os
+if "ORTK_GEMM_IMPL" in _os.environ:      # (the library itself reads no environment: forward the old switch through ortk_set_tuning)
+    P._lib.set_tuning(gemm_impl=int(_os.environ["ORTK_GEMM_IMPL"]))
+
 L = P._lib; L.require_gpu()
 tot = 0.0
 for rows in (16640, 9216):

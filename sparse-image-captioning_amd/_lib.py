@@ -61,6 +61,11 @@ class SpmmArgs(C.Structure):
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
 
 
+class Tuning(C.Structure):
+    _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
+                ("side_stream", C.c_int32)]
+
+
 DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL = 1, 2, 4, 8, 16, 32      # ortk_decode_opts.exec_flags
 
 
@@ -129,6 +134,8 @@ SIGNATURES = {
     "ortk_decode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, C.POINTER(DecodeOpts), _P, _SZ, _P, _P, _P, _P]),
     "ortk_decode_status": (_I32, [_P, _P]),
     "ortk_encode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P, _P]),
+    "ortk_get_tuning": (None, [C.POINTER(Tuning)]),
+    "ortk_set_tuning": (_I32, [C.POINTER(Tuning)]),
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),
     "ortk_prof_enable": (_I32, [_I32]),
     "ortk_prof_collect": (_I32, [_I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -188,6 +195,18 @@ def lib():
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+def set_tuning(**kw):
+    """Measurement switches (include/ortk.h: ortk_tuning), e.g. ``set_tuning(side_stream=0)``; returns the previous values."""
+    t = Tuning()
+    lib().ortk_get_tuning(C.byref(t))
+    old = {f: getattr(t, f) for f, _ in Tuning._fields_}
+    for k, v in kw.items():
+        assert k in old, k
+        setattr(t, k, int(v))
+    check(lib().ortk_set_tuning(C.byref(t)), "ortk_set_tuning")
+    return old
 
 
 def require_gpu():

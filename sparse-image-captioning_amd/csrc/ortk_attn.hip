@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_fwd_wave_kernel(ortk_attn_args a) {
 // One workgroup per pair, one wave per 16-row query tile.  LDS pitches: operands read as [row = M/N index][k]
 // use a pitch = 4 (mod 32) dwords, operands read as [k][n] use a pitch = 16 (mod 32): both conflict-free.
 constexpr int PK_ = 66, PN_ = 80;   // 66 = 2 (mod 32): 16 rows x 2 k-lanes of a half-wave hit 32 distinct banks
-static int attn_impl() { static int v = -1; if (v < 0) { const char* e = getenv("ORTK_ATTN_IMPL"); v = e ? atoi(e) : 0; } return v; }
+static int attn_impl() { return ortk::tuning().attn_impl; }
 typedef __attribute__((ext_vector_type(4))) float f4;
 
 __device__ __forceinline__ float group16_max(float v) {

@@ -21,7 +21,7 @@
 //     rows / columns of the images.
 // The pitch of 72 bf16 (144 B) makes the 16 rows of a ds_read_b128 service group fall on 16 distinct 16-byte slots.
 #include <cstdlib>
-#include "ortk_common.h"
+#include "ortk_internal.h"
 
 namespace {
 
@@ -351,8 +351,7 @@ bool attn16_shape_ok(int Lq, int Lk, int dk) { return (dk == 64 || dk == 32) && 
 
 bool attn16_ok(const ortk_attn_args* a, bool bwd) {
     // fp32 inputs: only the block shapes (the register-only kernels keep the short ones); bf16 inputs: every served shape
-    static int min_lq = -1;
-    if (min_lq < 0) { const char* e = getenv("ORTK_ATTN16_MINLQ"); min_lq = e ? atoi(e) : 33; }
+    const int min_lq = ortk::tuning().attn16_min_lq;
     // (short query blocks over at most 48 keys stay with the register-only kernels; past 48 keys those do not apply)
     if (a->precision != 1 || !attn16_shape_ok(a->Lq, a->Lk, a->dk) || (a->qkv_dtype == 0 && a->Lq < min_lq && a->Lk <= 48)) return false;
     if (a->kv_index || a->kv_group_stride > 0 || a->kv_dtype != 0 || a->k_new || a->v_new) return false;

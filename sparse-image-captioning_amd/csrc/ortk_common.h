@@ -93,6 +93,21 @@ __device__ static inline void ortk_keep4(uint32_t seed, uint64_t idx0, float p, 
         for (int r = 0; r < 4; ++r) k[r] = ortk_keep(seed, idx0 + r, p);
     }
 }
+// The same decisions for element indices below 2^32 (the group's high word is zero), in 32-bit arithmetic, against a precomputed
+// threshold thr = ortk_keep_thr(p): the column-split decoder stack kernel (<= 8 192 rows: every teacher-forced index fits).
+__device__ static inline bool ortk_keep_u32(uint32_t seed, uint32_t idx, uint32_t thr) {
+    const uint32_t h = ortk_mix32((idx >> 2) * 0x9E3779B1u + seed);
+    uint32_t w = h;
+    if (idx & 2) { w = (h ^ 0x68E31DA4u) * 0xB5297A4Du; w ^= w >> 15; }
+    return ((w >> ((idx & 1) * 16)) & 0xFFFFu) >= thr;
+}
+// k[r] = ortk_keep(seed, idx0 + r, p), r = 0..3, idx0 a multiple of 4
+__device__ static inline void ortk_keep4_u32(uint32_t seed, uint32_t idx0, uint32_t thr, bool (&k)[4]) {
+    const uint32_t h = ortk_mix32((idx0 >> 2) * 0x9E3779B1u + seed);
+    uint32_t g = (h ^ 0x68E31DA4u) * 0xB5297A4Du;
+    g ^= g >> 15;
+    k[0] = (h & 0xFFFFu) >= thr; k[1] = (h >> 16) >= thr; k[2] = (g & 0xFFFFu) >= thr; k[3] = (g >> 16) >= thr;
+}
 __host__ static inline uint32_t ortk_subseed(uint64_t seed, uint32_t op) {
     return ortk_mix32((uint32_t)seed ^ ortk_mix32((uint32_t)(seed >> 32) + 0x632BE5ABu) ^ (op * 0x9E3779B1u + 0x7F4A7C15u));
 }

@@ -914,7 +914,7 @@ template <int G> struct TP {
     static constexpr int R2 = 3 * SLICE > 65536 ? 3 * SLICE : 65536;
     static constexpr size_t LDS = 65536 + R2;
 };
-constexpr size_t XTILE_MIN = (size_t)TR * SD * 4;    // bytes of the fp32 [64 x 512] exchange tile
+
 
 // slice image [64 rows][LR chunks of 16 B]: chunk' = chunk ^ (row & min(15, LR - 1)) (the accumulator-layout stores of 16 rows
 // of one column tile land on distinct chunks)
@@ -1093,16 +1093,22 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
     const int mt0 = G == 8 ? 2 * (wave >> 2) : 0;
     const int ws = G == 8 ? (wave & 3) : wave;
     const int tile0 = G == 2 ? 2 * wave : ws;       // column tile (of the slice) of accumulator 0; accumulator nt: tile0 + nt
-    // train-mode rows: the row of the teacher-forced pass whose draws decode row g takes, or -1 (an eval-mode row: the greedy baseline)
-    auto tf_row = [&](int g) -> int {
-        if (a.greedy_stride > 0) { const int q = g / a.greedy_stride, k = g - q * a.greedy_stride; return k == 0 ? -1 : q * (a.greedy_stride - 1) + k - 1; }
-        return g;
-    };
-    const float dp = TRAIN ? a.drop_p : 0.f, ik = TRAIN ? 1.f / (1.f - a.drop_p) : 1.f;
+    // train-mode rows: the row of the teacher-forced pass whose draws decode row g takes, or -1 (an eval-mode row: the greedy baseline);
+    // one table entry per row of the group, behind the images in LDS
+    int* tfrow = reinterpret_cast<int*>(smem + T_::LDS);
+    if constexpr (TRAIN) {
+        if (tid < TR) {
+            const int g = min(r0 + tid, a.rows - 1);
+            int v = g;
+            if (a.greedy_stride > 0) { const int q = g / a.greedy_stride, k = g - q * a.greedy_stride; v = k == 0 ? -1 : q * (a.greedy_stride - 1) + k - 1; }
+            tfrow[tid] = v;
+        }
+        __syncthreads();
+    }
+    // (every teacher-forced element index of a launch this kernel serves — at most 8 192 rows, 64 positions, d_ff 4 096 — is below 2^32)
+    const float ik = TRAIN ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thr = TRAIN ? ortk_keep_thr(a.drop_p) : 0u;
     const int ns_tf = a.per_img - (a.greedy_stride > 0 ? 1 : 0);       // captions per image in the teacher-forced pass
-    int mtf[MT];                                                       // teacher-forced rows of this lane's accumulator rows
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) mtf[mt] = TRAIN ? tf_row(min(r0 + 16 * (mt0 + mt) + (lane0 & 15), a.rows - 1)) : -1;
 
     // residual rows, row layout: wave w holds rows 8 w .. 8 w + 7, lane l columns 8 l .. 8 l + 7
     float x[8][8];
@@ -1168,9 +1174,10 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[mt][nt][r] + b4[r]; if (hidden) v[r] = fmaxf(v[r], 0.f); }
                 if constexpr (TRAIN) {
-                    if (mtf[mt] >= 0) {
+                    const int mtf = tfrow[row];
+                    if (mtf >= 0) {
                         bool kp[4];
-                        ortk_keep4(seed, ((uint64_t)mtf[mt] * (uint64_t)a.T + (uint64_t)a.t) * (uint64_t)ncols + (uint64_t)(coff + col), dp, kp);
+                        ortk_keep4_u32(seed, ((uint32_t)mtf * (uint32_t)a.T + (uint32_t)a.t) * (uint32_t)ncols + (uint32_t)(coff + col), thr, kp);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
                     }
@@ -1240,8 +1247,8 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 const int row = 8 * wave + p0 + rs;
                 const int g = r0 + row, gc = min(g, a.rows - 1);
                 // TRAIN: probability (row, head, key j) of the teacher-forced (rows, 8, T, T) tensor at query position t
-                const int mrow = TRAIN ? tf_row(gc) : -1;
-                const int64_t sbase = (((int64_t)mrow * 8 + hd) * a.T + a.t) * a.T;
+                const int mrow = TRAIN ? tfrow[row] : -1;
+                const uint32_t sbase = (((uint32_t)mrow * 8 + hd) * a.T + a.t) * a.T;
                 int idx[G];                  // this lane: cache rows of keys fc + LR u of its row
 #pragma unroll
                 for (int u = 0; u < G; ++u) { const int j = min(fc + LR * u, a.t); idx[u] = a.kvidx ? a.kvidx[(int64_t)gc * Lk + j] : gc * a.T + j; }
@@ -1282,7 +1289,7 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                     if constexpr (TRAIN) {
                         if (mrow >= 0) {
 #pragma unroll
-                            for (int u = 0; u < SKT; ++u) pr[0][u] = ortk_keep(a.drop_seed[l][0], (uint64_t)(sbase + b * SKT + u), dp) ? pr[0][u] * ik : 0.f;
+                            for (int u = 0; u < SKT; ++u) pr[0][u] = ortk_keep_u32(a.drop_seed[l][0], sbase + b * SKT + u, thr) ? pr[0][u] * ik : 0.f;
                         }
                     }
                     st.pv<SKT>(vc, pr);
@@ -1293,7 +1300,7 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 float pself[1][1];
                 st.scores<1>(kself, kindself, pself);
                 if constexpr (TRAIN) {
-                    if (mrow >= 0) pself[0][0] = ortk_keep(a.drop_seed[l][0], (uint64_t)(sbase + a.t), dp) ? pself[0][0] * ik : 0.f;
+                    if (mrow >= 0) pself[0][0] = ortk_keep_u32(a.drop_seed[l][0], sbase + a.t, thr) ? pself[0][0] * ik : 0.f;
                 }
                 st.pv<1>(vself, pself);
                 int srow_; TP_KEY_ROW(a.t, srow_);
@@ -1344,8 +1351,8 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                 const int gc = min(r0 + row, a.rows - 1), imm = gc / a.per_img;
                 // TRAIN: probability (image, head, caption i, position t, region j) of the teacher-forced (images, 8, ns T, S) tensor; an
                 // eval-mode (greedy) row attends to the EVAL-mode memory's projection
-                const int mrow = TRAIN ? tf_row(gc) : -1;
-                const int64_t cbase = ((((int64_t)(mrow / ns_tf) * 8 + hd) * ns_tf + (mrow % ns_tf)) * a.T + a.t) * a.S;
+                const int mrow = TRAIN ? tfrow[row] : -1;
+                const uint32_t cbase = ((((uint32_t)(mrow / ns_tf) * 8 + hd) * ns_tf + (uint32_t)(mrow % ns_tf)) * a.T + a.t) * a.S;
                 const __bf16* xkb = (TRAIN && mrow < 0 && P.xkg) ? P.xkg : P.xk;
                 const __bf16* xvb = (TRAIN && mrow < 0 && P.xvg) ? P.xvg : P.xv;
                 AttState<1> st;
@@ -1373,7 +1380,7 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                     if constexpr (TRAIN) {
                         if (mrow >= 0) {
 #pragma unroll
-                            for (int u = 0; u < XKT; ++u) pr[0][u] = ortk_keep(a.drop_seed[l][2], (uint64_t)(cbase + b * XKT + u), dp) ? pr[0][u] * ik : 0.f;
+                            for (int u = 0; u < XKT; ++u) pr[0][u] = ortk_keep_u32(a.drop_seed[l][2], cbase + b * XKT + u, thr) ? pr[0][u] * ik : 0.f;
                         }
                     }
                     st.pv<XKT>(vq, pr);
@@ -1582,7 +1589,7 @@ int stack_tp_pack(const void* w16, void* wpk, const StackPack& t, int G, hipStre
 
 template <int G, bool TRAIN>
 static int stack_tp_launch(const StackArgs& b, hipStream_t s) {
-    constexpr size_t lds = TP<G>::LDS;
+    constexpr size_t lds = TP<G>::LDS + (TRAIN ? TR * sizeof(int) : 0);        // (+ the teacher-forced row table)
     static_assert(lds <= 160 * 1024, "LDS budget");
     static std::mutex mu;
     static bool done[64] = {};

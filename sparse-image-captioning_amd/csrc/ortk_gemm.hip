@@ -1439,8 +1439,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         if (want_stats && !(fast4 && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0 && p.K % HBK == 0 && !p.relu &&
                             p.drop_p == 0.f && !p.gate && !p.rowscale && !p.resid && p.stat_ncols > 0 && p.stat_ncols <= p.N))
             return ORTK_EINVAL;
-        static int impl = -1;   // experiments: 1 = register-staged kernel only, 2 = 128^2 DMA tiles only, 3 = 256^2 whenever legal
-        if (impl < 0) { const char* ev = getenv("ORTK_GEMM_IMPL"); impl = ev ? atoi(ev) : 0; }
+        const int impl = ortk::tuning().gemm_impl;   // experiments: 1 = register-staged kernel only, 2 = 128^2 DMA tiles only, 3 = 256^2 whenever legal
         // Measured in the XE step (bench.py, ms/step): register-staged kernel everywhere 17.9; DMA kernels everywhere
         // 21.3 (the k-major layouts lose: dgrad 4.1 vs 3.3 ms, wgrad 4.1 vs 3.4 ms per step in isolation); the DMA kernels
         // therefore serve the forward layout only unless ORTK_GEMM_IMPL >= 2 asks for them everywhere.
@@ -1452,8 +1451,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         // 163 -> 178, 21760x1536x512 87 -> 106).  Decode-sized row counts only (M <= 6 144): inside the training step, beside
         // the side stream's weight gradients, the 9 216- and 16 640-row projections are faster on the big tiles (XE step
         // 12.67 ms with them on the 64 x 64 tiles, 12.51 without).
-        static int t64 = -2;    // ORTK_GEMM_T64: use them while the 128 x 128 grid has at most this many workgroups (-1 = never)
-        if (t64 == -2) { const char* ev = getenv("ORTK_GEMM_T64"); t64 = ev ? atoi(ev) : 640; }
+        const int t64 = ortk::tuning().gemm_t64;     // use them while the 128 x 128 grid has at most this many workgroups (-1 = never)
         if (fast4 && impl != 1 && !want_stats && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && p.K % HBK == 0 &&
             p.drop_p == 0.f && !p.gate && !p.rowscale && (int64_t)tilesM * tilesN <= t64 && p.N <= 2048 && p.M <= 6144) {
             const int tm = (int)ortk_cdiv(p.M, 64), tn = p.N / 64;

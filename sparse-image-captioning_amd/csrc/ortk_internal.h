@@ -4,6 +4,10 @@
 
 namespace ortk {
 
+// process-wide A/B switches (ortk.h: ortk_tuning; defaults = the product path).  Set explicitly through ortk_set_tuning — nothing in
+// the library reads the environment.
+const ortk_tuning& tuning();
+
 // true while bench.py's per-launch GEMM timing is on (the executor then keeps every GEMM on the caller's stream)
 bool ortk_prof_active();
 // ortk_prof_enable(1): additionally, the executor keeps everything on ONE stream (each kernel timed alone); (2): the timed

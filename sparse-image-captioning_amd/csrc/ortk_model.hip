@@ -260,7 +260,7 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
 // tiles on 512 slots, 384 split-K workgroups, ...): the wgrad runs on this stream beside the dgrad on the caller's stream
 // (fork: the side stream waits for the event "dY produced"; lazy join: the caller's stream waits for a wgrad only right
 // before a kernel that OVERWRITES the buffer this wgrad reads, so the side stream may lag by a few kernels).  Mixed
-// precision only (there every dY is one of a few bf16 temporaries); set ORTK_SIDE_STREAM=0 to keep everything on the
+// precision only (there every dY is one of a few bf16 temporaries); ortk_tuning.side_stream = 0 keeps everything on the
 // caller's stream.  Free-running microbenchmark (scratch/gemm_concurrent.py): dgrad + wgrad of w1 172 -> 128 us, of
 // qkv 124 -> 87 us, of the 512 x 512 projections no change.
 struct SideStream {
@@ -269,8 +269,6 @@ struct SideStream {
     int next = 0;
     bool ok = false;
     bool init() {
-        const char* e = getenv("ORTK_SIDE_STREAM");
-        if (e && atoi(e) == 0) return false;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
         for (auto& x : ev) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
@@ -282,6 +280,7 @@ struct SideStream {
 // never share one — the C-ABI's "thread-safe per stream" holds for the executor too.  Created on first use, kept for the
 // life of the process (a handful of entries: one per stream a host ever trains on).
 static SideStream* side_for(hipStream_t caller) {
+    if (!tuning().side_stream) return nullptr;
     static std::mutex mu;
     static std::vector<std::pair<std::pair<int, hipStream_t>, SideStream*>> table;
     int dev = 0;
@@ -590,6 +589,18 @@ using namespace ortk;
 
 // ================================================================================================ C ABI
 extern "C" int ortk_version(void) { return ORTK_VERSION; }
+
+// ------------------------------------------------------------------------------------------------ tuning switches
+namespace ortk {
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1};
+const ortk_tuning& tuning() { return g_tuning; }
+}
+extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
+extern "C" int ortk_set_tuning(const ortk_tuning* t) {
+    if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1) return ORTK_EINVAL;
+    ortk::g_tuning = *t;
+    return 0;
+}
 
 extern "C" int ortk_device_ok(void) {
     int n = 0;

@@ -326,48 +326,59 @@ __global__ __launch_bounds__(256) void ell_count_kernel(const ortk_sparse_block*
     if (lane == 0) cnt[g] = n;
 }
 
-// one workgroup per block: order the columns of every 512-column range by count (descending), chunk lengths, offsets
-__global__ __launch_bounds__(256) void ell_plan_kernel(const ortk_sparse_block* __restrict__ blocks, const int32_t* __restrict__ cnt,
-                                                       int32_t* __restrict__ chunk_ptr, int32_t* __restrict__ chunk_len,
-                                                       int32_t* __restrict__ perm, int32_t* overflow, int gran) {
+// one workgroup per (block, 512-column range): order the range's columns by count (descending); the chunk lengths (the longest
+// member of every 64 columns, rounded up to the entry granule) go to chunk_len.  (Round 3 ran ONE workgroup per block over all its
+// ranges — the generator's 20 ranges took 0.47 ms per build, 1 ms of every sparse training step.)
+__global__ __launch_bounds__(256) void ell_rank_kernel(const ortk_sparse_block* __restrict__ blocks, int nblocks, const int32_t* __restrict__ cnt,
+                                                       int32_t* __restrict__ chunk_len, int32_t* __restrict__ perm, int gran) {
     __shared__ int key[RANGE];
-    __shared__ int lens[256];
-    const ortk_sparse_block bk = blocks[blockIdx.x];
+    int b = 0, first = 0;                       // block of this range, index of the block's first range
+    for (; b < nblocks; ++b) {
+        const int nr = (blocks[b].N + RANGE - 1) / RANGE;
+        if ((int)blockIdx.x < first + nr) break;
+        first += nr;
+    }
+    if (b >= nblocks) return;
+    const ortk_sparse_block bk = blocks[b];
     const int tid = threadIdx.x;
     const int nch = (bk.N + 63) >> 6;
-    for (int n0 = 0; n0 < bk.N; n0 += RANGE) {
-        const int nn = min(RANGE, bk.N - n0);
-        __syncthreads();
-        for (int i = tid; i < RANGE; i += 256) key[i] = i < nn ? cnt[bk.row0 + n0 + i] : -1;
-        __syncthreads();
-        const int slots = min(RANGE, nch * 64 - n0);            // lane slots of this range (the last chunk is padded to 64)
-        for (int i = tid; i < RANGE; i += 256) {
-            if (i < nn) {
-                const int ki = key[i];
-                int rank = 0;
-                for (int j = 0; j < nn; ++j) { const int kj = key[j]; rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0; }
-                perm[(int64_t)bk.chunk0 * 64 + n0 + rank] = n0 + i;
-                if ((rank & 63) == 0) lens[(n0 + rank) >> 6] = (ki + gran - 1) & ~(gran - 1);
-            } else if (i < slots) {
-                perm[(int64_t)bk.chunk0 * 64 + n0 + i] = -1;
-            }
+    const int n0 = ((int)blockIdx.x - first) * RANGE;
+    const int nn = min(RANGE, bk.N - n0);
+    for (int i = tid; i < RANGE; i += 256) key[i] = i < nn ? cnt[bk.row0 + n0 + i] : -1;
+    __syncthreads();
+    const int slots = min(RANGE, nch * 64 - n0);            // lane slots of this range (the last chunk is padded to 64)
+    for (int i = tid; i < RANGE; i += 256) {
+        if (i < nn) {
+            const int ki = key[i];
+            int rank = 0;
+            for (int j = 0; j < nn; ++j) { const int kj = key[j]; rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0; }
+            perm[(int64_t)bk.chunk0 * 64 + n0 + rank] = n0 + i;
+            if ((rank & 63) == 0) chunk_len[bk.chunk0 + ((n0 + rank) >> 6)] = (ki + gran - 1) & ~(gran - 1);
+        } else if (i < slots) {
+            perm[(int64_t)bk.chunk0 * 64 + n0 + i] = -1;
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        int64_t off = bk.stream_offset;
-        const int64_t end = bk.stream_offset + bk.capacity;
-        for (int c = 0; c < nch; ++c) {
-            int l = lens[c];
-            if (off + (int64_t)l * 64 > end) {
-                l = (int)(((end - off) / 64) & ~(int64_t)(gran - 1));
-                if (l < 0) l = 0;
-                *overflow = 1;
-            }
-            chunk_ptr[bk.chunk0 + c] = (int32_t)off;
+}
+// one thread per block: chunk offsets inside the block's share of the entry stream; a block denser than its capacity is cut (and
+// reported through the sticky overflow word)
+__global__ __launch_bounds__(64) void ell_offsets_kernel(const ortk_sparse_block* __restrict__ blocks, int nblocks, int32_t* __restrict__ chunk_ptr,
+                                                         int32_t* __restrict__ chunk_len, int32_t* overflow, int gran) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nblocks) return;
+    const ortk_sparse_block bk = blocks[b];
+    const int nch = (bk.N + 63) >> 6;
+    int64_t off = bk.stream_offset;
+    const int64_t end = bk.stream_offset + bk.capacity;
+    for (int c = 0; c < nch; ++c) {
+        int l = chunk_len[bk.chunk0 + c];
+        if (off + (int64_t)l * 64 > end) {
+            l = (int)(((end - off) / 64) & ~(int64_t)(gran - 1));
+            if (l < 0) l = 0;
+            *overflow = 1;
             chunk_len[bk.chunk0 + c] = l;
-            off += (int64_t)l * 64;
         }
+        chunk_ptr[bk.chunk0 + c] = (int32_t)off;
+        off += (int64_t)l * 64;
     }
 }
 
@@ -795,18 +806,20 @@ extern "C" int ortk_sparse_build(const ortk_sparse_plan* plan, const void* dense
         return 0;
     }
     const int eb = plan->format == ORTK_SP_ELL16 ? 4 : 8;
-    int64_t rows = 0, slots = 0;
+    int64_t rows = 0, slots = 0, ranges = 0;
     for (int i = 0; i < plan->nblocks; ++i) {
         const ortk_sparse_block& b = plan->blocks_host[i];
         if (b.N < 1 || b.N > 16384 || b.K < 1 || b.K > KMAX || b.ld < b.K || b.capacity < 0 || ((b.stream_offset | b.capacity) & 1)) return ORTK_EINVAL;
         if (b.row0 != rows || (int64_t)b.chunk0 * 64 != slots) return ORTK_EINVAL;      // packed, in table order
-        rows += b.N; slots += ortk_cdiv(b.N, 64) * 64;
+        rows += b.N; slots += ortk_cdiv(b.N, 64) * 64; ranges += ortk_cdiv(b.N, RANGE);
     }
     if (rows != plan->total_rows) return ORTK_EINVAL;
     hipLaunchKernelGGL(ell_count_kernel, dim3((unsigned)ortk_cdiv(rows, 4)), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, dense, dtype,
                        plan->count_scratch, rows);
-    hipLaunchKernelGGL(ell_plan_kernel, dim3((unsigned)plan->nblocks), dim3(256), 0, s, plan->blocks_dev, plan->count_scratch,
-                       plan->chunk_ptr, plan->chunk_len, plan->perm, plan->overflow, eb == 4 ? 8 : 4);
+    hipLaunchKernelGGL(ell_rank_kernel, dim3((unsigned)ranges), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, plan->count_scratch,
+                       plan->chunk_len, plan->perm, eb == 4 ? 8 : 4);
+    hipLaunchKernelGGL(ell_offsets_kernel, dim3((unsigned)ortk_cdiv(plan->nblocks, 64)), dim3(64), 0, s, plan->blocks_dev, plan->nblocks,
+                       plan->chunk_ptr, plan->chunk_len, plan->overflow, eb == 4 ? 8 : 4);
     if (eb == 4)
         hipLaunchKernelGGL(ell_fill_kernel<4>, dim3((unsigned)ortk_cdiv(slots, 4)), dim3(256), 0, s, plan->blocks_dev, plan->nblocks, dense,
                            dtype, plan->chunk_ptr, plan->chunk_len, plan->perm, plan->stream, slots);

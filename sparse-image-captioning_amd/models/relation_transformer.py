@@ -289,7 +289,7 @@ class RelationTransformerModel(CaptionModelBase):
         """The arena tensor behind the last ``_eff_params_ptr`` call."""
         return self._flat
 
-    def enable_sparse_kernels(self, min_sparsity=0.9, train=False):
+    def enable_sparse_kernels(self, min_sparsity=0.9, train=False, fmt=None):
         """Run every weight block whose fraction of zeros is >= ``min_sparsity`` as a sparse product (``ortk_spmm``)
         instead of a dense GEMM on the zero-filled weight; ``None`` goes back to dense GEMMs.  Same results as the reference's
         dense-on-zero-filled-weights flow (scripts/eval_model.py:64-88, pruning/masked_layer.py:134-135) up to fp32 summation
@@ -297,8 +297,13 @@ class RelationTransformerModel(CaptionModelBase):
         in mixed precision — the data gradients of the backward through it (the weight gradients stay dense: the
         straight-through mask gradient needs them at every position).  The sparse images are rebuilt on the device inside
         every call from that call's effective weights; only the block selection and the buffer capacities are fixed here
-        (from the CURRENT eval-mode weights) — see :meth:`check_sparse_overflow`."""
+        (from the CURRENT eval-mode weights) — see :meth:`check_sparse_overflow`.
+
+        ``min_sparsity="auto"``: per block, the measured crossover of its shape (``sparse.CROSSOVER``, from
+        ``scratch/spmm_crossover.py`` on MI355X): a block goes sparse only where the sparse product beat the dense MFMA GEMM on
+        zero-filled weights — at 95 % zeros no block does, at the reference's published 98.8 % models most do."""
         self._sparse_min = min_sparsity
+        self._sparse_fmt = {None: None, "ell16": L.SP_ELL16, "gu16": L.SP_GU16, "ell32": L.SP_ELL32}[fmt]      # None: by precision
         self._sparse_train = bool(train) and min_sparsity is not None
         self._plans = None
         self._ccfg.sparse_fwd = None
@@ -331,7 +336,7 @@ class RelationTransformerModel(CaptionModelBase):
             self._eff_params_ptr(False, 0)
             eff = self._eff_params_tensor()
             pf, pb = make_plans(self._ccfg, eff, self._sparse_min, self.precision, backward=self._sparse_train,
-                                density_of=self._train_density if self._sparse_train else None)
+                                fmt=getattr(self, "_sparse_fmt", None), density_of=self._train_density if self._sparse_train else None)
             if pf is not None:       # validate the capacities against the weights they were planned from
                 pf.build(eff[:self._n_train].bfloat16() if self.precision else eff)
                 pf.check_overflow()

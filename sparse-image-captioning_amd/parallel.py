@@ -8,6 +8,15 @@ Only two exchanges exist on the data path:
 import torch
 import torch.distributed as dist
 
+# True: run the collectives of the data path even in a ONE-rank group (identity results).  The 1-GPU test box cannot form a larger
+# RCCL group (RCCL refuses two ranks on one device), so tests/test_gpu_dist.py::test_rccl_one_rank_group sets this to put
+# init_process_group("nccl"), the scalar / arena all-reduces and the asynchronous split all-reduce under test on real RCCL.
+force_collectives = False
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives)
+
 
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -63,7 +72,7 @@ class _StagedWork:
 
 def reduce_scalar_sum(t):
     """In-place SUM over ranks of a (1,) tensor (the loss normaliser)."""
-    if world() > 1:
+    if _active():
         if _staged(t):
             _StagedWork(t).wait()
         else:
@@ -84,7 +93,7 @@ def allreduce_async(t):
 
 def allreduce_arena(*arenas):
     """In-place SUM of flat gradient arenas; one collective per arena (each is one contiguous bucket)."""
-    if world() > 1:
+    if _active():
         for a in arenas:
             if a is not None:
                 if _staged(a):

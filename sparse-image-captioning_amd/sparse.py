@@ -130,14 +130,45 @@ def capacity_for(N, K, max_density):
     return (n + 63) // 64 * 64
 
 
-def select_blocks(ccfg, eff, min_sparsity):
-    """Blocks of the arena ``eff`` whose fraction of zeros is >= ``min_sparsity`` (host syncs: one-off)."""
+# Measured crossover (mixed precision, ELL16 vs this library's dense bf16 GEMM on the same zero-filled weights, MI355X;
+# scratch/spmm_crossover.py -> profiles/r04_spmm_crossover.txt): fraction of zeros from which the sparse product of an (N outputs,
+# K inputs) block beats the dense MFMA GEMM by >= 5 % (the images are rebuilt per call: a tie is a loss) at the row count it runs
+# over — "enc": 9 216 rows (256 images x 36 regions; also the packed cross-attention K|V projection), "dec": 16 640-21 760 rows
+# (the captions' positions), "decode": 5 120 rows (1 024 images x 5 beams).  Keys are the shapes of the PRODUCT: forward blocks
+# (N, K) of the weight, data-gradient blocks (K, N) of its transpose.  1.01 = never measured faster (up to 99.5 % zeros).
+# At 95 % zeros no shape pays (0.65-0.93x of the dense GEMM's speed); at the reference's published 98.8 % models most do.
+CROSSOVER = {
+    "enc": {(512, 2048): 0.98, (512, 512): 0.975, (1536, 512): 0.988, (2048, 512): 0.975, (6144, 512): 0.985,
+            (512, 1536): 0.98, (512, 6144): 0.99},
+    "dec": {(512, 512): 0.975, (1536, 512): 0.985, (2048, 512): 0.985, (512, 2048): 0.995, (10112, 512): 0.975,
+            (512, 1536): 0.995},
+    "decode": {(512, 512): 0.995, (1536, 512): 0.988, (2048, 512): 0.985, (512, 2048): 0.995, (10112, 512): 0.98, (6144, 512): 0.985},
+}
+DEFAULT_CROSSOVER = 0.99
+
+
+def crossover(N, K, cls):
+    return CROSSOVER[cls].get((N, K), DEFAULT_CROSSOVER)
+
+
+def select_blocks(ccfg, eff, min_sparsity, train=False):
+    """Blocks of the arena ``eff`` whose fraction of zeros is >= ``min_sparsity`` — or, with ``"auto"``, those whose forward
+    (``fwd``) / data-gradient (``bwd``) product is past the measured crossover of its shape and row class (host syncs: one-off)."""
+    dec_off = int(L.lib().ortk_arena_decoder_offset(C.byref(ccfg)))
     out = []
     for off, N, K in linear_blocks(ccfg):
         w = eff[off: off + N * K]
         sparsity = 1.0 - float(torch.count_nonzero(w)) / (N * K)
-        if sparsity >= min_sparsity:
-            out.append({"offset": off, "N": N, "K": K, "sparsity": sparsity})
+        if min_sparsity == "auto":
+            # (the packed cross-attention K|V projection lives behind the decoder offset but runs over the encoder's rows)
+            cls = ("enc" if (off < dec_off or N >= 2 * 1536) and N < 8192 else "dec") if train else "decode"
+            # a (512, 10112) data-gradient product is cut into 2 048-input pieces: the (512, 2048) figure of its class
+            fwd = sparsity >= crossover(N, K, cls)
+            bwd = sparsity >= crossover(K, min(N, KMAX), cls)
+        else:
+            fwd = bwd = sparsity >= min_sparsity
+        if fwd or bwd:
+            out.append({"offset": off, "N": N, "K": K, "sparsity": sparsity, "fwd": fwd, "bwd": bwd})
     return out
 
 
@@ -146,8 +177,8 @@ def default_format(precision):
         return L.SP_ELL32
     # Measured on MI355X (scratch/spmm_bench.py): the VALU kernel on sorted ELL is the faster of the two
     # on the decode shapes and on the 2048-input blocks, the MFMA kernel on group unions on the widest outputs; neither beats
-    # the dense MFMA GEMM at 95 %.  ELL16 is the default, ORTK_SPARSE_FORMAT=gu16 selects the other.
-    return {"ell16": L.SP_ELL16, "gu16": L.SP_GU16}[os.environ.get("ORTK_SPARSE_FORMAT", "ell16").lower()]
+    # the dense MFMA GEMM at 95 %.  ELL16 is the default; `enable_sparse_kernels(..., fmt="gu16")` selects the other.
+    return L.SP_ELL16
 
 
 def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None, density_of=None):
@@ -157,27 +188,28 @@ def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None, den
     — (K outputs, N inputs), leading dimension N, at the same offsets of the transposed bf16 copy the executor keeps for its
     data-gradient GEMMs (ELL: a block with more than KMAX inputs — the generator: 10 112 — is cut into KMAX-wide pieces that
     the executor accumulates).  The region embedding (block 0) has no input gradient."""
-    sel = select_blocks(ccfg, eff, min_sparsity)
+    sel = select_blocks(ccfg, eff, min_sparsity, train=backward)
     if not sel:
         return None, None
     fmt = default_format(precision) if fmt is None else fmt
-    dens0 = 1.0 - min_sparsity
+    dens0 = (1.0 - min_sparsity) if min_sparsity != "auto" else 0.0
     # capacity density per block: the planned bound, or — training with Bernoulli(sigmoid(m)) samples, whose density is the
     # MEAN of sigmoid(m), above the eval-mode round(sigmoid(m)) the selection saw — what `density_of(offset, N, K)` expects
     for b in sel:
-        b["dens"] = max(dens0, density_of(b["offset"], b["N"], b["K"])) if density_of is not None else dens0
+        d0 = dens0 if min_sparsity != "auto" else min(1.0, 1.5 * (1.0 - b["sparsity"]) + 0.002)      # (auto: 1.5 x the density seen)
+        b["dens"] = max(d0, density_of(b["offset"], b["N"], b["K"])) if density_of is not None else d0
     first = linear_blocks(ccfg)[0][0]
     gu = fmt == L.SP_GU16
     # (blocks the formats do not take — more than 16 384 outputs: the ELL planner's per-range tables — stay dense)
     ok = (lambda N, K: K <= GKC or N <= 512) if gu else (lambda N, K: K <= KMAX and N <= 16384)
     fwd = [dict(offset=b["offset"], N=b["N"], K=b["K"], ld=b["K"], capacity=capacity_for(b["N"], b["K"], b["dens"]), sparsity=b["sparsity"])
-           for b in sel if ok(b["N"], b["K"])]
+           for b in sel if b["fwd"] and ok(b["N"], b["K"])]
     plan_f = SparsePlan(fwd, fmt, eff.device) if fwd else None
     plan_b = None
     if backward and precision:
         bwd = []
         for b in sel:
-            if b["offset"] == first:
+            if b["offset"] == first or not b["bwd"]:
                 continue
             if gu:
                 if ok(b["K"], b["N"]):

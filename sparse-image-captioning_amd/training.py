@@ -77,7 +77,8 @@ class NativeTrainer:
         # One process, dense model: the decoder half of the arena (64 % of the parameters) takes its Adam update on a second
         # stream as soon as the decoder half of the backward has finished, beside the encoder half (clip_grad_value_ is
         # element-wise, so the split is exact); the gradient arena is cleared by the update itself (ortk_adam_clip_zero).
-        self.early_adam = self.world == 1 and not self.masked and self._dec_off % 4 == 0 and 0 < self._dec_off < self.grads.numel()
+        self.early_adam = (self.world == 1 and not self.masked and not self.overlap and self._dec_off % 4 == 0
+                           and 0 < self._dec_off < self.grads.numel())      # (never beside an exchange of that half)
         self._opt_stream = None
         self._grads_clean = False
         # keep_grads: `self.grads` still holds the step's gradient after the step (tests, diagnostics); default: the update

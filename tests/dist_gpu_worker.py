@@ -1,14 +1,19 @@
 """One rank of tests/test_gpu_dist.py: NativeTrainer steps on its half of a batch, two processes sharing cuda:0, `gloo`
 rendezvous on 127.0.0.1 (RCCL refuses two ranks on one device; the gradient arenas travel through the host, parallel.py).
-Usage: python dist_gpu_worker.py RANK WORLD PORT OUT_DIR MODEL(dense|supermask)"""
+Usage: python dist_gpu_worker.py RANK WORLD PORT OUT_DIR MODEL(dense|supermask) [rccl]
+`rccl`: started by torch.distributed.run with ONE rank — the group is a real RCCL ("nccl") group of one, the collectives of the data
+path run through it (parallel.force_collectives), and the results must equal the plain one-process run."""
 import os
 import sys
 
 rank, world, port, out_dir, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+rccl = len(sys.argv) > 6 and sys.argv[6] == "rccl"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+if not rccl:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required by RCCL on this driver
 
 import numpy as np
 import torch
@@ -60,7 +65,17 @@ if __name__ == "__main__":
     full = {k: v.cuda() for k, v in H.torch_batch(C.make_inputs(seed=5, n_img=4, n_reg=12, feat=C.TINY_CFG["att_feat_size"],
                                                                vocab=C.TINY_CFG["vocab_size"], spi=2)).items()}
     run.reward = torch.linspace(-1.0, 1.0, 4 * 2).cuda()
-    if world > 1:
+    if rccl:
+        # one rank per GPU as the driver launches bench.py: RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run
+        assert int(os.environ["WORLD_SIZE"]) == 1 and int(os.environ["RANK"]) == 0
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        assert dist.get_backend() == "nccl"
+        parallel.force_collectives = True
+        losses, flat, masks, seq = run(kind, full, 2, overlap_allreduce=(kind == "dense"))
+        np.savez(os.path.join(out_dir, f"rccl_{kind}.npz"), losses=losses, flat=flat, masks=masks)
+        dist.barrier()
+        dist.destroy_process_group()
+    elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         mine = parallel.shard_batch(full)
         run.row0 = rank * 2 * 2                              # images per rank x samples per image
