@@ -234,6 +234,40 @@ typedef struct ortk_spmm_args {
 } ortk_spmm_args;
 int ortk_spmm(const ortk_sparse_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Rows-stationary chain of the row-wise operators between two attention calls (csrc/ortk_chain.hip; mixed precision, d_model 512):
+ *
+ *   x  = x_in                                                                 (M, 512) fp32 residual rows
+ *   R  (a_in != NULL):  x += dropout(a_in W_r^T + bias_r)          -> x_mid   SublayerConnection around an attention (transformer.py:293-294)
+ *   L1 (g1 != NULL):    y = LayerNorm(x; g1, b1)                   -> y1 (bf16), st1 {mean, std} per row (transformer.py:338-341)
+ *   S1 (n1 <= 3):       out1[:, 512 i ..] = y W_i^T + bias_s1[512 i ..]       projections of y (packed QKV, cross-attention query)
+ *   F  (NC = d_ff / 512 > 0):  h = dropout(relu(y W1^T + bias_h)) -> h (bf16, (M, d_ff));  x += dropout(h W2^T + bias_o) -> x_out
+ *   L2 (g2 != NULL), S2 (n2 <= 3): as L1 / S1 on the new x            -> y2, st2, out2
+ *
+ * One launch, the rows stay in registers / LDS, the weights stream; every store is what the separate kernels (ortk_layernorm_fwd,
+ * ortk_gemm with its bias / ReLU / dropout / residual epilogue) leave for the backward pass, and the dropout draws are the GEMM
+ * epilogue's (element (row, column) of the (M, N) output under seed_r / seed_h / seed_o), so ortk_backward does not care which
+ * executor ran the forward.  Weights: `n_units` 512 x 512 blocks of the bf16 arena `w16`, in stream order [R] [S1 ..] [W1 chunk c,
+ * W2 chunk c] x NC [S2 ..]; unit = {offset of its first output row (elements), leading dimension}: rows = outputs, 512 inputs from
+ * the offset on.  `units_dev` is a DEVICE array; `packed` a scratch of ortk_chain_packed_bytes(n_units). */
+typedef struct ortk_chain_unit { int64_t offset, ld; } ortk_chain_unit;
+typedef struct ortk_chain_args {
+    const void* w16; const ortk_chain_unit* units_dev; int32_t n_units;
+    void* packed; size_t packed_bytes;
+    int64_t M;
+    const float* x_in;
+    const void* a_in; const float* bias_r; float* x_mid; uint32_t seed_r;
+    const float *g1, *b1; void* y1; float* st1;
+    int32_t n1; const float* bias_s1; void* out1; int64_t ld1;
+    int32_t NC; const float *bias_h, *bias_o; void* h; float* x_out; uint32_t seed_h, seed_o;
+    const float *g2, *b2; void* y2; float* st2;
+    int32_t n2; const float* bias_s2; void* out2; int64_t ld2;
+    float drop_p, eps;
+    int32_t* progress;      /* optional: 16 ints of device scratch (zeroed by the call) -> 8 L2 prefetcher workgroups pace the weight stream */
+} ortk_chain_args;
+size_t ortk_chain_packed_bytes(int32_t n_units);
+int ortk_row_chain(const ortk_chain_args* a, ortk_stream stream);
+
 /* Process-wide A/B switches for measurements (the scripts under scratch/); the defaults are the product path and nothing in the library reads the
  * environment.  Not thread-safe against running calls: set them before the work starts. */
 typedef struct ortk_tuning {
@@ -242,6 +276,7 @@ typedef struct ortk_tuning {
     int32_t attn_impl;       /* 0 automatic | 1 wave kernels | 3 fp32-MFMA kernels | 4 small register-only kernels (ortk_attn.hip dispatch) */
     int32_t attn16_min_lq;   /* fp32-input query blocks shorter than this stay off the bf16-operand attention kernels (33) */
     int32_t side_stream;     /* 1: the executor queues weight gradients and other independent work on a second stream (default) | 0 */
+    int32_t row_chain;       /* 1: forward passes run the row-wise operators between attention calls as rows-stationary chains (ortk_row_chain; default) | 0: one launch per operator */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

@@ -61,9 +61,26 @@ class SpmmArgs(C.Structure):
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
 
 
+class ChainUnit(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("ld", C.c_int64)]
+
+
+class ChainArgs(C.Structure):
+    _fields_ = [("w16", C.c_void_p), ("units_dev", C.c_void_p), ("n_units", C.c_int32), ("packed", C.c_void_p), ("packed_bytes", C.c_size_t),
+                ("M", C.c_int64), ("x_in", C.c_void_p),
+                ("a_in", C.c_void_p), ("bias_r", C.c_void_p), ("x_mid", C.c_void_p), ("seed_r", C.c_uint32),
+                ("g1", C.c_void_p), ("b1", C.c_void_p), ("y1", C.c_void_p), ("st1", C.c_void_p),
+                ("n1", C.c_int32), ("bias_s1", C.c_void_p), ("out1", C.c_void_p), ("ld1", C.c_int64),
+                ("NC", C.c_int32), ("bias_h", C.c_void_p), ("bias_o", C.c_void_p), ("h", C.c_void_p), ("x_out", C.c_void_p),
+                ("seed_h", C.c_uint32), ("seed_o", C.c_uint32),
+                ("g2", C.c_void_p), ("b2", C.c_void_p), ("y2", C.c_void_p), ("st2", C.c_void_p),
+                ("n2", C.c_int32), ("bias_s2", C.c_void_p), ("out2", C.c_void_p), ("ld2", C.c_int64),
+                ("drop_p", C.c_float), ("eps", C.c_float), ("progress", C.c_void_p)]
+
+
 class Tuning(C.Structure):
     _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
-                ("side_stream", C.c_int32)]
+                ("side_stream", C.c_int32), ("row_chain", C.c_int32)]
 
 
 DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL = 1, 2, 4, 8, 16, 32      # ortk_decode_opts.exec_flags
@@ -134,6 +151,8 @@ SIGNATURES = {
     "ortk_decode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, C.POINTER(DecodeOpts), _P, _SZ, _P, _P, _P, _P]),
     "ortk_decode_status": (_I32, [_P, _P]),
     "ortk_encode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P, _P]),
+    "ortk_chain_packed_bytes": (_SZ, [_I32]),
+    "ortk_row_chain": (_I32, [C.POINTER(ChainArgs), _P]),
     "ortk_get_tuning": (None, [C.POINTER(Tuning)]),
     "ortk_set_tuning": (_I32, [C.POINTER(Tuning)]),
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),

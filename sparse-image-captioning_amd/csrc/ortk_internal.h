@@ -15,6 +15,7 @@ bool ortk_prof_active();
 bool ortk_prof_serial();
 // the same measurement hook around a launch that is not an ortk_gemm; ortk_prof_collect(key) then reports it
 constexpr int PROF_KEY_DECSTACK = 16;
+constexpr int PROF_KEY_CHAIN = 17;        // row_chain_kernel launches (ortk_chain.hip)
 struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; };
 bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m);
 void prof_end(const ProfMark& m, hipStream_t s);
@@ -162,6 +163,19 @@ int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride
 // end of a decode on the column-split stack kernel: if *status != 0 (an exchange group never completed) the outputs become
 // all-pad captions with NaN log-probs and scores — a failed decode cannot pass for a result
 int decode_poison(const int32_t* status, int64_t* seq, float* lp, float* score, int64_t nseq, int64_t nscore, hipStream_t s);
+// Rows-stationary chains of row-wise operators (ortk_chain.hip): pack the 512 x 512 weight units of a chain (bf16, device table of
+// descriptors, stream order) into the streaming layout, and run a chain on a packed stream
+size_t chain_packed_bytes(int n_units);
+int chain_rows_per_block(int64_t M, int slots);
+int chain_pack(const void* w16, const ortk_chain_unit* units_dev, int n_units, void* packed, hipStream_t s);
+// all chains of a model in ONE launch: chain i = units [first[i], first[i + 1]) of the table, packed stream at uint4 index base[i]
+constexpr int CH_MAX_UNITS = 192, CH_MAX_CHAINS = 24;
+struct ChainPackTable {
+    int32_t n_chains; int32_t first[CH_MAX_CHAINS + 1]; int64_t base[CH_MAX_CHAINS];
+    struct { int32_t offset, ld; } u[CH_MAX_UNITS];      // element offset of the unit's first output row in the bf16 arena, leading dimension
+};
+int chain_pack_all(const void* w16, void* packed, const ChainPackTable& t, hipStream_t s);
+int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s);
 int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
 int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 // kvidx[g*1 + 0] = g*row_mult*tmax  (index table for the first decoder pass)

@@ -168,6 +168,62 @@ static void build_layout(const ortk_config& c, Offsets& o, std::vector<Entry>* e
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
+// ------------------------------------------------------------------------------------------------ rows-stationary chains
+// The row-wise operators between two attention calls as ONE launch each (ortk_chain.hip): mixed precision, d_model 512, d_ff a
+// multiple of 512, unshared projections, dense products.  Chains of the encoder: E0 = [LN -> Wqkv] of layer 0, EB(l) = [Wo + x ->
+// LN -> FFN + x -> LN of layer l + 1 (or the stack's) -> Wqkv of layer l + 1]; of the decoder: D0 = [LN -> Wqkv] of layer 0,
+// DB(l) = [Wo + x -> LN -> Wcq], DC(l) = [Wco + x -> LN -> FFN + x -> next LN -> next Wqkv].  Their weight units are packed into
+// streaming order once per forward (chain_pack_all, from the bf16 weight copy of the call).
+struct ChainSet {
+    bool on = false;
+    ChainPackTable t;
+    int e0 = -1, eb[MAXLAYERS], d0 = -1, db[MAXLAYERS], dc[MAXLAYERS];
+    size_t bytes = 0;
+    int units(int c) const { return t.first[c + 1] - t.first[c]; }
+    const void* stream_of(const void* pk, int c) const { return reinterpret_cast<const char*>(pk) + (size_t)t.base[c] * 16; }
+};
+static bool chain_cfg_ok(const ortk_config& c, bool ignore_switch = false) {
+    return (ignore_switch || tuning().row_chain) && c.precision == 1 && c.d_model == 512 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 && c.n_heads == 8 &&
+           c.share_att_enc == 0 && c.share_att_dec == 0 && c.n_layers <= 6;
+}
+static void chain_layout(const ortk_config& c, const Offsets& o, bool enc, bool dec, ChainSet& cs, bool sizing = false) {
+    cs.on = chain_cfg_ok(c);
+    cs.bytes = 0;
+    if (!cs.on && !(sizing && chain_cfg_ok(c, true))) return;
+    const int L = c.n_layers, NC = c.d_ff / 512, ff = c.d_ff;
+    ChainPackTable& t = cs.t;
+    t.n_chains = 0; t.first[0] = 0;
+    int nu = 0;
+    int64_t base = 0;
+    auto unit = [&](int64_t off, int ld) { t.u[nu].offset = (int32_t)off; t.u[nu].ld = ld; ++nu; };
+    auto close = [&]() {
+        const int c_ = t.n_chains++;
+        t.base[c_] = base; t.first[c_ + 1] = nu;
+        base += (int64_t)8 * (nu - t.first[c_] + 1) * 16 * 256;           // uint4 per wave and unit: 16 k-steps x 4 tiles x 64 lanes
+        return c_;
+    };
+    auto qkv = [&](int64_t w) { for (int i = 0; i < 3; ++i) unit(w + (int64_t)i * 512 * 512, 512); };
+    auto ffn = [&](int64_t w1, int64_t w2) { for (int k = 0; k < NC; ++k) { unit(w1 + (int64_t)k * 512 * 512, 512); unit(w2 + (int64_t)k * 512, ff); } };
+    if (enc) {
+        qkv(o.enc[0].wqkv); cs.e0 = close();
+        for (int l = 0; l < L; ++l) {
+            unit(o.enc[l].wo, 512); ffn(o.enc[l].w1, o.enc[l].w2);
+            if (l + 1 < L) qkv(o.enc[l + 1].wqkv);
+            cs.eb[l] = close();
+        }
+    }
+    if (dec) {
+        qkv(o.dec[0].wqkv); cs.d0 = close();
+        for (int l = 0; l < L; ++l) {
+            unit(o.dec[l].wo, 512); unit(o.dec[l].cqw, 512); cs.db[l] = close();
+            unit(o.dec[l].cow, 512); ffn(o.dec[l].w1, o.dec[l].w2);
+            if (l + 1 < L) qkv(o.dec[l + 1].wqkv);
+            cs.dc[l] = close();
+        }
+    }
+    cs.bytes = (size_t)base * 16;
+}
+
 struct Bump {
     char* base; size_t off;
     template <typename T> T* take(int64_t n) { return reinterpret_cast<T*>(take_bytes((size_t)n * sizeof(T))); }
@@ -200,6 +256,7 @@ struct TrainWS {
     DecBuf dec[MAXLAYERS];
     // backward temporaries
     float *ga, *gb, *gy; void* gdo /*Q: dO of an attention backward*/; void *gt /*A*/, *gt2 /*A*/, *gt3 /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
+    void* chain_pk = nullptr;               // weight units of the rows-stationary chains in streaming order (chain_layout; mixed precision)
     size_t bytes;
 };
 
@@ -249,6 +306,10 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     w.gdo = c.precision ? act(Mx * d) : nullptr;
     w.gt = act(Mx * d); w.gt2 = act(Mx * d); w.gt3 = act(Mx * d); w.gqkv = act(Mx * 3 * d); w.gh = act(Mx * ff); w.gkv = act(Me * L * 2 * d);
     w.scalar = b.take<float>(64);
+    {   // (sized whatever the tuning switch says: the workspace size is a function of the configuration and the shapes only)
+        ChainSet cs; chain_layout(c, o, true, true, cs, true);
+        if (cs.bytes) w.chain_pk = b.take_bytes(cs.bytes);
+    }
     w.bytes = (b.off + 255) & ~(size_t)255;
 }
 
@@ -527,7 +588,7 @@ static int queue_box_bias(const Ctx& c, const Offsets& o, const float* boxes, fl
 // `box_queued`: the caller has already queued the geometry bias (queue_box_bias; *box_queued = its completion event or NULL)
 static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, const float* boxes, const float* masks, int B, int S,
                            float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem, int qdt = ORTK_F32,
-                           const hipEvent_t* box_queued = nullptr) {
+                           const hipEvent_t* box_queued = nullptr, const ChainSet* cs = nullptr, const void* chain_pk = nullptr) {
     const ortk_config& cfg = *c.cfg;
     const float* P = c.P;
     const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H, A = c.adt;
@@ -548,8 +609,43 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
                  nullptr, 0, plain ? nullptr : masks));
     const float* x = x0;
     const AttMode am = att_mode(cfg.share_att_enc);
+    // rows-stationary chains (ortk_chain.hip) in place of the LayerNorm / projection launches: bf16 Q|K|V and memory, dense products
+    const bool chains = cs && cs->on && cs->e0 >= 0 && chain_pk && qdt == ORTK_BF16 && mem_dt == ORTK_BF16 && A == ORTK_BF16 && !c.ell_f;
+    if (chains) {
+        ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
+        ca.n_units = cs->units(cs->e0); ca.M = Me; ca.x_in = x0;
+        ca.g1 = P + o.enc[0].n0a; ca.b1 = P + o.enc[0].n0b; ca.y1 = bufs[0].y1; ca.st1 = bufs[0].st1;
+        ca.n1 = 3; ca.bias_s1 = P + o.enc[0].bqkv; ca.out1 = bufs[0].qkv; ca.ld1 = 3 * d;
+        ca.eps = 1e-6f;
+        TRY(chain_run(&ca, cs->stream_of(chain_pk, cs->e0), c.s));
+    }
     for (int l = 0; l < L; ++l) {
         const EncOff& e = o.enc[l]; const EncPtrs& b = bufs[l];
+        if (chains) {
+            ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec; a.qkv_dtype = qdt;
+            a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, am.k * d, qdt); a.v = (const float*)off_elems(b.qkv, am.v * d, qdt);
+            a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o; a.o_dtype = A; a.ldo = d;
+            a.kmask = masks; a.bias = plain ? nullptr : logbias + (int64_t)l * B * H * S * S; a.p = b.P;
+            a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
+            if (l == 0) TRY(c.wait_ev(box_done));
+            TRY(ortk_attention_fwd(&a, (ortk_stream)c.s));
+            ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ca.n_units = cs->units(cs->eb[l]); ca.M = Me; ca.x_in = x;
+            ca.a_in = b.o; ca.bias_r = P + e.bo; ca.x_mid = b.xm; ca.seed_r = c.sub(eop(l, 1));
+            ca.g1 = P + e.n1a; ca.b1 = P + e.n1b; ca.y1 = b.y2; ca.st1 = b.st2;
+            ca.NC = ff / 512; ca.bias_h = P + e.b1; ca.bias_o = P + e.b2; ca.h = b.h; ca.x_out = b.xout;
+            ca.seed_h = c.sub(eop(l, 2)); ca.seed_o = c.sub(eop(l, 3));
+            if (l + 1 < L) {
+                ca.g2 = P + o.enc[l + 1].n0a; ca.b2 = P + o.enc[l + 1].n0b; ca.y2 = bufs[l + 1].y1; ca.st2 = bufs[l + 1].st1;
+                ca.n2 = 3; ca.bias_s2 = P + o.enc[l + 1].bqkv; ca.out2 = bufs[l + 1].qkv; ca.ld2 = 3 * d;
+            } else {
+                ca.g2 = P + o.enc_na; ca.b2 = P + o.enc_nb; ca.y2 = mem; ca.st2 = st_mem;
+            }
+            ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+            TRY(chain_run(&ca, cs->stream_of(chain_pk, cs->eb[l]), c.s));
+            x = b.xout;
+            continue;
+        }
         TRY(ln_fwd(c, x, e.n0a, e.n0b, b.y1, A, b.st1, Me));
         TRY(fwd_gemm(c, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, qdt, 3 * d, Me, am.n * d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec; a.qkv_dtype = qdt;
@@ -565,7 +661,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
         TRY(fwd_gemm(c, b.h, A, ff, e.w2, P + e.b2, b.xout, ORTK_F32, d, Me, d, ff, false, c.p_drop(), c.sub(eop(l, 3)), b.xm, d));
         x = b.xout;
     }
-    TRY(ln_fwd(c, x, o.enc_na, o.enc_nb, mem, mem_dt, st_mem, Me));
+    if (!chains) TRY(ln_fwd(c, x, o.enc_na, o.enc_nb, mem, mem_dt, st_mem, Me));
     return 0;
 }
 
@@ -592,7 +688,7 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
@@ -726,6 +822,11 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
     const bool compact = batch_compact(bt);
     if (compact && (logp_out || !w.qdt_self || !w.qdt_cross)) return ORTK_EINVAL;     // fused criterion + bf16-operand attention only
+    // rows-stationary chains: their weight units go into streaming order once per forward (phase 2 finds phase 1's image)
+    ChainSet cs; chain_layout(*cfg, o, true, true, cs);
+    if (cs.on && (!w.chain_pk || c.ell_f)) cs.on = false;
+    const bool dchains = cs.on && w.qdt_self == ORTK_BF16 && w.qdt_cross == ORTK_BF16 && A == ORTK_BF16;
+    if (cs.on && phase != 2) TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.s));
     const int64_t Me = w.Me, Md = compact ? bt->Mc : w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
     const AttMode am = att_mode(cfg->share_att_dec);
@@ -733,8 +834,18 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     // Self-attention sublayer (and the cross-attention query projection) of decoder layer l, on context `cx`'s stream.
     auto self_part = [&](const Ctx& cx, int l, const float* x) -> int {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
-        TRY(ln_fwd(cx, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
-        TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, w.qdt_self, 3 * d, Md, am.n * d, d));
+        if (dchains) {
+            if (l == 0) {             // (layers 1.. get their LayerNorm 0 and Q|K|V from the chain that ends layer l - 1)
+                ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
+                ca.n_units = cs.units(cs.d0); ca.M = Md; ca.x_in = x;
+                ca.g1 = P + e.n0a; ca.b1 = P + e.n0b; ca.y1 = b.y1; ca.st1 = b.st1;
+                ca.n1 = 3; ca.bias_s1 = P + e.bqkv; ca.out1 = b.qkv; ca.ld1 = 3 * d; ca.eps = 1e-6f;
+                TRY(chain_run(&ca, cs.stream_of(w.chain_pk, cs.d0), cx.s));
+            }
+        } else {
+            TRY(ln_fwd(cx, x, e.n0a, e.n0b, b.y1, A, b.st1, Md));
+            TRY(fwd_gemm(cx, b.y1, A, d, e.wqkv, P + e.bqkv, b.qkv, w.qdt_self, 3 * d, Md, am.n * d, d));
+        }
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = cx.prec; a.qkv_dtype = w.qdt_self;
         a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, am.k * d, w.qdt_self); a.v = (const float*)off_elems(b.qkv, am.v * d, w.qdt_self);
         a.ldq = a.ldk = a.ldv = 3 * d; a.o = b.o1; a.o_dtype = A; a.ldo = d;
@@ -742,6 +853,15 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
         a.drop_p = cx.p_drop(); a.drop_seed = cx.sub(dop(l, 0));
         if (compact) { a.q_off = bt->cap_off; a.q_off_stride = 1; a.kv_ragged = 1; }      // a caption's keys are its own (valid) rows
         TRY(ortk_attention_fwd(&a, (ortk_stream)cx.s));
+        if (dchains) {                // [Wo + x -> LayerNorm 1 -> Wcq]
+            ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ca.n_units = cs.units(cs.db[l]); ca.M = Md; ca.x_in = x;
+            ca.a_in = b.o1; ca.bias_r = P + e.bo; ca.x_mid = b.xm1; ca.seed_r = cx.sub(dop(l, 1));
+            ca.g1 = P + e.n1a; ca.b1 = P + e.n1b; ca.y1 = b.y2; ca.st1 = b.st2;
+            ca.n1 = 1; ca.bias_s1 = P + e.cqb; ca.out1 = b.qc; ca.ld1 = d;
+            ca.drop_p = cx.p_drop(); ca.eps = 1e-6f;
+            return chain_run(&ca, cs.stream_of(w.chain_pk, cs.db[l]), cx.s);
+        }
         TRY(fwd_gemm(cx, b.o1, A, d, e.wo, P + e.bo, b.xm1, ORTK_F32, d, Md, d, d, false, cx.p_drop(), cx.sub(dop(l, 1)), x, d));
         TRY(ln_fwd(cx, b.xm1, e.n1a, e.n1b, b.y2, A, b.st2, Md));
         TRY(fwd_gemm(cx, b.y2, A, d, e.cqw, P + e.cqb, b.qc, w.qdt_cross, d, Md, d, d));
@@ -756,7 +876,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     }
     if (phase != 2)
         TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc,
-                            box_early ? &box_done : nullptr));
+                            box_early ? &box_done : nullptr, &cs, w.chain_pk));
     if (phase == 1) return c.join();       // (the transposed weight copy of the side stream included)
     {
         const Ctx cx = prefix_side ? c.on_side() : c;
@@ -779,13 +899,32 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
         if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; }                       // an image's rows: those of its spi captions
         TRY(ortk_attention_fwd(&a, stream));
+        if (dchains) {                // [Wco + x -> LayerNorm 2 -> FFN + x -> LayerNorm 0 of layer l + 1 (or the stack's) -> next Wqkv]
+            ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ca.n_units = cs.units(cs.dc[l]); ca.M = Md; ca.x_in = b.xm1;
+            ca.a_in = b.o2; ca.bias_r = P + e.cob; ca.x_mid = b.xm2; ca.seed_r = c.sub(dop(l, 3));
+            ca.g1 = P + e.n2a; ca.b1 = P + e.n2b; ca.y1 = b.y3; ca.st1 = b.st3;
+            ca.NC = ff / 512; ca.bias_h = P + e.b1; ca.bias_o = P + e.b2; ca.h = b.h; ca.x_out = b.xout;
+            ca.seed_h = c.sub(dop(l, 4)); ca.seed_o = c.sub(dop(l, 5));
+            if (l + 1 < L) {
+                const DecOff& en = o.dec[l + 1]; const DecBuf& bn = w.dec[l + 1];
+                ca.g2 = P + en.n0a; ca.b2 = P + en.n0b; ca.y2 = bn.y1; ca.st2 = bn.st1;
+                ca.n2 = 3; ca.bias_s2 = P + en.bqkv; ca.out2 = bn.qkv; ca.ld2 = 3 * d;
+            } else {
+                ca.g2 = P + o.dec_na; ca.b2 = P + o.dec_nb; ca.y2 = w.dec_out; ca.st2 = w.st_out;
+            }
+            ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+            TRY(chain_run(&ca, cs.stream_of(w.chain_pk, cs.dc[l]), c.s));
+            x = b.xout;
+            continue;
+        }
         TRY(fwd_gemm(c, b.o2, A, d, e.cow, P + e.cob, b.xm2, ORTK_F32, d, Md, d, d, false, c.p_drop(), c.sub(dop(l, 3)), b.xm1, d));
         TRY(ln_fwd(c, b.xm2, e.n2a, e.n2b, b.y3, A, b.st3, Md));
         TRY(fwd_gemm(c, b.y3, A, d, e.w1, P + e.b1, b.h, A, ff, Md, ff, d, true, c.p_drop(), c.sub(dop(l, 4))));
         TRY(fwd_gemm(c, b.h, A, ff, e.w2, P + e.b2, b.xout, ORTK_F32, d, Md, d, ff, false, c.p_drop(), c.sub(dop(l, 5)), b.xm2, d));
         x = b.xout;
     }
-    TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.dec_out, A, w.st_out, Md));
+    if (!dchains) TRY(ln_fwd(c, x, o.dec_na, o.dec_nb, w.dec_out, A, w.st_out, Md));
     const int Vp = (int)w.ldv;     // padded vocabulary (zero weight rows / bias): full GEMM tiles
     if (logp_out) {
         const int Nout = ldv_out >= Vp ? Vp : V;
@@ -1108,6 +1247,7 @@ struct DecodeWS {
     SStackBufs ss{};                   // the sparse stream and its tables (stack path, sparse stream)
     int tp = 0;                        // column-split stack kernel: workgroups per group (0 = off), its weight image,
     void* tp_wpk = nullptr; char* tp_xbuf = nullptr; int32_t* tp_flag = nullptr;      // exchange tiles and counters
+    void* chain_pk = nullptr;          // encoder chains' weight units in streaming order (chain_layout; mixed precision)
     int32_t* status = nullptr;         // [64] decode status word (ortk_decode_status): ALWAYS the first bytes of the workspace
     void* ckv_g = nullptr;             // train-mode decode with greedy rows: projection of the EVAL-mode encoder memory
     size_t bytes;
@@ -1172,6 +1312,10 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     if (beam && c.precision) w.gstats = b.take<float>(rows * (w.ldv / 64) * 2);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
+    {
+        ChainSet cs; chain_layout(c, o, true, false, cs, true);
+        if (cs.bytes) w.chain_pk = b.take_bytes(cs.bytes);
+    }
     if (stack && !sstream && tp > 0) {
         w.tp = tp;
         w.tp_wpk = b.take_bytes(stack_tp_packed_bytes((int)L, (int)(ff / 512), tp));
@@ -1206,7 +1350,7 @@ static int encode_impl(const ortk_config* cfg, const float* params, const float*
     Ctx c{cfg, ortk_s(stream), cfg->precision, 0, false, params, w.w16, w.adt};
     EncPtrs ep[MAXLAYERS];
     for (int l = 0; l < cfg->n_layers; ++l) ep[l] = w.enc;
-    return encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, memory_out, ORTK_F32, w.st);
+    return encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, memory_out, ORTK_F32, w.st);      // (fp32 memory out: no chains)
 }
 
 static int decode_K(const ortk_decode_opts* o) {
@@ -1430,16 +1574,22 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     // first projection; nothing else of a decode runs there
     c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
+    // the encoder's row-wise operators as rows-stationary chains (ortk_chain.hip): bf16 Q|K|V (the buffer is fp32-sized) and memory
+    ChainSet ecs; chain_layout(*cfg, o, true, false, ecs);
+    const bool enc_bf16_attn = cfg->precision && attn16_shape_ok(S, S, d / cfg->n_heads);
+    if (ecs.on && (!w.chain_pk || op->sparse || !enc_bf16_attn || (op->memory && !greedy_rows))) ecs.on = false;
+    if (ecs.on) TRY(chain_pack_all(w.w16, w.chain_pk, ecs.t, s));
+    const int enc_qdt = ecs.on ? ORTK_BF16 : ORTK_F32;
     // ortk_decode_opts.memory: the encoder output of these images already exists (the training forward's, ortk_forward_phase 1)
     if (greedy_rows) {
         // the greedy rows attend to the EVAL-mode encoder memory (utils/training.py:216-222 decodes the baseline under model.eval()):
         // its pass and projection first, then the buffers are free for the train-mode pass
         Ctx ce = c; ce.train = false; ce.seed = 0;
-        TRY(encoder_forward(ce, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
+        TRY(encoder_forward(ce, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st, enc_qdt, nullptr, &ecs, w.chain_pk));
         ce.use_side = false;
         TRY(fwd_gemm(ce, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv_g, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
     }
-    if (!op->memory) TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st));
+    if (!op->memory) TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st, enc_qdt, nullptr, &ecs, w.chain_pk));
     c.use_side = false;
     TRY(fwd_gemm(c, op->memory ? op->memory : w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
 

@@ -875,3 +875,120 @@ def test_gemm_tile_softmax_partials(L, M, V):
     m_row = stats[..., 0].amax(1)
     lse2 = m_row + torch.log((stats[..., 1] * torch.exp(stats[..., 0] - m_row[:, None])).sum(1))
     torch.testing.assert_close(lse2, lse, rtol=1e-6, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ rows-stationary chains (round 4)
+def _keep_mask(L, seed, n, p):
+    """keep / (1 - p) per element of a dropout site, as the kernels draw it (counter hash, element index = row * N + col)."""
+    ones, out = torch.ones(n, device="cuda"), torch.empty(n, device="cuda")
+    L.check(L.lib().ortk_dropout_apply(L.ptr(ones), L.ptr(out), 0, n, p, seed, L.stream_ptr()), "ortk_dropout_apply")
+    return out
+
+
+def _ln_ref(x, g, b, eps=1e-6):
+    mean = x.mean(-1, keepdim=True)
+    sd = x.std(-1, keepdim=True)                      # unbiased (transformer.py:338-341)
+    return g * (x - mean) / (sd + eps) + b, mean.squeeze(-1), sd.squeeze(-1)
+
+
+@pytest.mark.parametrize("M,p,parts", [(1000, 0.1, "R1SFL2S"), (16640, 0.1, "R1SFL2S"), (9216, 0.0, "R1SFL2S"), (777, 0.1, "1S"),
+                                       (2000, 0.1, "R1S"), (5120, 0.0, "R1F2")])
+def test_row_chain_vs_separate_ops(L, M, p, parts):
+    """ortk_row_chain (csrc/ortk_chain.hip: the row-wise operators between two attention calls in ONE rows-stationary launch) against
+    the same chain in torch fp32 on the bf16-rounded operands, with the kernels' own dropout masks: residual streams within 2e-3
+    (fp32 accumulation order), bf16 outputs within one bf16 step, LayerNorm statistics within 1e-4.  Chains: the decoder's
+    [Wo -> LN -> W1 .. W2 -> LN -> Wqkv] at 1 000 / 16 640 rows (33-row blocks, two rounds) and 9 216 rows (36-row blocks), a bare
+    [LN -> W] prefix, [Wo -> LN -> Wcq], and a chain that ends in a LayerNorm (the stack's last layer)."""
+    d, NC = 512, 4
+    ff = NC * d
+    hasR, n1, hasF = "R" in parts, (1 if parts in ("R1S",) else 3 if "1S" in parts else 0), "F" in parts
+    has2, n2 = ("2" in parts), (3 if parts.endswith("2S") else 0)
+    g = torch.Generator().manual_seed(M)
+    nblk = (1 if hasR else 0) + n1 + (2 if hasF else 0) * 1 + n2
+    # one bf16 "arena": [Wr (512,512)] [S1 (n1*512, 512)] [W1 (ff,512)] [W2 (512,ff)] [S2 (n2*512,512)]
+    shapes = []
+    if hasR: shapes.append(("r", d, d))
+    if n1: shapes.append(("s1", n1 * d, d))
+    if hasF: shapes += [("w1", ff, d), ("w2", d, ff)]
+    if n2: shapes.append(("s2", n2 * d, d))
+    W, off, cur = {}, {}, 0
+    for name, N, K in shapes:
+        W[name] = (torch.randn(N, K, generator=g) * (0.5 / math.sqrt(K))).bfloat16()
+        off[name] = cur
+        cur += N * K
+    arena = dev(torch.cat([W[n].reshape(-1) for n, _, _ in shapes]))
+    units = []
+    if hasR: units.append((off["r"], d))
+    units += [(off["s1"] + i * d * d, d) for i in range(n1)]
+    if hasF:
+        for c in range(NC):
+            units += [(off["w1"] + c * d * d, d), (off["w2"] + c * d, ff)]
+    units += [(off["s2"] + i * d * d, d) for i in range(n2)]
+    ut = dev(torch.tensor(units, dtype=torch.int64))
+    x = dev(rnd(M, d, seed=1))
+    a_in = dev(rnd(M, d, seed=2).bfloat16())
+    vec = lambda n, s, sc=0.1: dev(rnd(n, seed=s, scale=sc))
+    br, g1, b1, bs1, bh, bo, g2, b2, bs2 = vec(d, 3), dev(1 + rnd(d, seed=4, scale=0.1)), vec(d, 5), vec(3 * d, 6), vec(ff, 7), vec(d, 8), dev(1 + rnd(d, seed=9, scale=0.1)), vec(d, 10), vec(3 * d, 11)
+    x_mid, x_out = torch.full((M, d), float("nan"), device="cuda"), torch.full((M, d), float("nan"), device="cuda")
+    y1, y2 = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16), torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
+    st1, st2 = torch.zeros(M, 2, device="cuda"), torch.zeros(M, 2, device="cuda")
+    out1 = torch.zeros(M, max(n1, 1) * d, device="cuda", dtype=torch.bfloat16)
+    out2 = torch.zeros(M, max(n2, 1) * d, device="cuda", dtype=torch.bfloat16)
+    h = torch.zeros(M, ff, device="cuda", dtype=torch.bfloat16)
+    a = L.ChainArgs()
+    a.w16, a.units_dev, a.n_units = arena.data_ptr(), ut.data_ptr(), len(units)
+    nb = L.lib().ortk_chain_packed_bytes(len(units))
+    packed = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    a.packed, a.packed_bytes = packed.data_ptr(), nb
+    a.M, a.x_in = M, x.data_ptr()
+    sr, sh, so = 1111, 2222, 3333
+    if hasR:
+        a.a_in, a.bias_r, a.x_mid, a.seed_r = a_in.data_ptr(), br.data_ptr(), x_mid.data_ptr(), sr
+    a.g1, a.b1, a.y1, a.st1 = g1.data_ptr(), b1.data_ptr(), y1.data_ptr(), st1.data_ptr()
+    a.n1 = n1
+    if n1:
+        a.bias_s1, a.out1, a.ld1 = bs1.data_ptr(), out1.data_ptr(), out1.stride(0)
+    if hasF:
+        a.NC, a.bias_h, a.bias_o, a.h, a.x_out, a.seed_h, a.seed_o = NC, bh.data_ptr(), bo.data_ptr(), h.data_ptr(), x_out.data_ptr(), sh, so
+    if has2:
+        a.g2, a.b2, a.y2, a.st2 = g2.data_ptr(), b2.data_ptr(), y2.data_ptr(), st2.data_ptr()
+    a.n2 = n2
+    if n2:
+        a.bias_s2, a.out2, a.ld2 = bs2.data_ptr(), out2.data_ptr(), out2.stride(0)
+    a.drop_p, a.eps = p, 1e-6
+    prog = torch.zeros(16, dtype=torch.int32, device="cuda")
+    if M != 2000:                        # (one case without the L2 prefetcher workgroups)
+        a.progress = prog.data_ptr()
+    L.check(L.lib().ortk_row_chain(C.byref(a), L.stream_ptr()), "ortk_row_chain")
+    torch.cuda.synchronize()
+    # ---- reference (fp32 on the GPU, operands rounded to bf16 where the kernel rounds them)
+    f = lambda t: t.float().cuda()
+    xr = x.clone()
+    one_bf16 = lambda ref: 2.0 ** -7 * ref.abs().clamp(min=1.0)          # one step of an 8-bit mantissa (+ slack for a rounding boundary)
+    if hasR:
+        t = a_in.float() @ f(W["r"]).t() + br
+        if p > 0: t = t * _keep_mask(L, sr, M * d, p).view(M, d)
+        xr = xr + t
+        assert (x_mid - xr).abs().max().item() < 2e-3
+    yr, mean, sd = _ln_ref(xr, g1, b1)
+    assert (st1[:, 0] - mean).abs().max().item() < 1e-4 and (st1[:, 1] - sd).abs().max().item() < 1e-4
+    assert ((y1.float() - yr).abs() <= one_bf16(yr)).all()
+    yb = y1.float()                                     # the kernel's own rounded rows feed the products
+    if n1:
+        ref = yb @ f(W["s1"]).t() + bs1[:n1 * d]
+        assert ((out1.float() - ref).abs() <= one_bf16(ref) + 2e-3).all()
+    if hasF:
+        hr = torch.relu(yb @ f(W["w1"]).t() + bh)
+        if p > 0: hr = hr * _keep_mask(L, sh, M * ff, p).view(M, ff)
+        assert ((h.float() - hr).abs() <= one_bf16(hr) + 2e-3).all()
+        t = h.float() @ f(W["w2"]).t() + bo
+        if p > 0: t = t * _keep_mask(L, so, M * d, p).view(M, d)
+        xr = xr + t
+        assert (x_out - xr).abs().max().item() < 4e-3
+    if has2:
+        yr, mean, sd = _ln_ref(x_out if hasF else xr, g2, b2)
+        assert (st2[:, 0] - mean).abs().max().item() < 1e-4 and (st2[:, 1] - sd).abs().max().item() < 1e-4
+        assert ((y2.float() - yr).abs() <= one_bf16(yr)).all()
+        if n2:
+            ref = y2.float() @ f(W["s2"]).t() + bs2[:n2 * d]
+            assert ((out2.float() - ref).abs() <= one_bf16(ref) + 2e-3).all()
