@@ -268,6 +268,32 @@ typedef struct ortk_chain_args {
 size_t ortk_chain_packed_bytes(int32_t n_units);
 int ortk_row_chain(const ortk_chain_args* a, ortk_stream stream);
 
+/* The backward counterpart: everything between two attention-backward calls except the weight gradients (which reduce over all
+ * rows and stay GEMMs), through the TRANSPOSED bf16 weight copies `w16t` (block (N, K) of the arena stored (K, N) at the same offset):
+ *
+ *   P0 (nin = 1 | 3):  gy = sum_i ain[:, 512 i ..] U_i^T          data gradient of a projection (dq . Wcq; packed dQ|dK|dV . Wqkv)
+ *        (nin = 0):    the operand rows are dz0 (a dropout-masked gradient that already exists)
+ *   LNa (nin > 0):     dx = LayerNorm'(gy; xa, sta, ga) + dresa -> dxa;  daa / dba += parameter gradients;
+ *                      mask_a: dz = dropout-mask(dx; seed_a) -> operand rows of P1 / P2 (+ dza)
+ *   P1 (NC > 0):       gh = gate(hgate) * (dz W2)  -> gh (bf16, (M, d_ff));  gy2 = gh W1        PositionwiseFeedForward backward
+ *   LNb (NC > 0):      as LNa on gy2 with xb, stb, gb, dresb (may be the dxa rows this call has just written) -> dxb, dab, dbb, dzb
+ *   P2 (n2 = 1):       out2 = dz W (through an attention's out-projection) -> bf16 rows
+ *
+ * Same results as ortk_gemm (data-gradient layout, gate epilogue) + ortk_layernorm_bwd_drop; units in stream order
+ * [P0 x nin] [W2^T chunk c, W1^T chunk c] x NC [P2], each a 512 x 512 block of w16t: rows = OUTPUT columns of the product. */
+typedef struct ortk_bchain_args {
+    const void* w16t; const ortk_chain_unit* units_dev; int32_t n_units;
+    void* packed; size_t packed_bytes;
+    int64_t M;
+    int32_t nin; const void* ain; int64_t ld_ain; const void* dz0;
+    const float *xa, *sta, *ga, *dresa; float *dxa, *daa, *dba; void* dza; uint32_t seed_a; int32_t mask_a;
+    int32_t NC; const void* hgate; void* gh; float gate_scale;
+    const float *xb, *stb, *gb, *dresb; float *dxb, *dab, *dbb; void* dzb; uint32_t seed_b; int32_t mask_b;
+    int32_t n2; void* out2;
+    float drop_p, eps;
+} ortk_bchain_args;
+int ortk_row_bchain(const ortk_bchain_args* a, ortk_stream stream);
+
 /* Process-wide A/B switches for measurements (the scripts under scratch/); the defaults are the product path and nothing in the library reads the
  * environment.  Not thread-safe against running calls: set them before the work starts. */
 typedef struct ortk_tuning {
@@ -276,7 +302,8 @@ typedef struct ortk_tuning {
     int32_t attn_impl;       /* 0 automatic | 1 wave kernels | 3 fp32-MFMA kernels | 4 small register-only kernels (ortk_attn.hip dispatch) */
     int32_t attn16_min_lq;   /* fp32-input query blocks shorter than this stay off the bf16-operand attention kernels (33) */
     int32_t side_stream;     /* 1: the executor queues weight gradients and other independent work on a second stream (default) | 0 */
-    int32_t row_chain;       /* 1: forward passes run the row-wise operators between attention calls as rows-stationary chains (ortk_row_chain; default) | 0: one launch per operator */
+    int32_t row_chain;       /* rows-stationary chains (ortk_row_chain / ortk_row_bchain) in the executor: 0 none (one launch per operator) | 1 forward passes
+                                (default) | 2 + the encoder's backward | 3 + the decoder's backward */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

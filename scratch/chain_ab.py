@@ -18,9 +18,9 @@ def timeit(step, n, warm=3):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for wl in ("xe", "scst", "decode"):
+for wl in ("xe",):
     res = {}
-    for rc in (1, 0, 1, 0):
+    for rc in (0, 1, 2, 3, 0, 1, 2, 3):
         pkg._lib.set_tuning(row_chain=rc)
         torch.manual_seed(8888)
         m = pkg.get_model("relation_transformer")(cfg, precision="bf16").to(dev)
@@ -39,4 +39,4 @@ for wl in ("xe", "scst", "decode"):
         res.setdefault(rc, []).append(t)
         del m
         torch.cuda.empty_cache()
-    print(f"{wl}: row_chain on {min(res[1]):.3f} ms   off {min(res[0]):.3f} ms   (runs: {res})", flush=True)
+    print(f"{wl}: " + "  ".join(f"row_chain={k}: {min(v):.3f} ms" for k, v in sorted(res.items())), flush=True)

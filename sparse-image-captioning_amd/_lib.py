@@ -78,6 +78,18 @@ class ChainArgs(C.Structure):
                 ("drop_p", C.c_float), ("eps", C.c_float), ("progress", C.c_void_p)]
 
 
+class BChainArgs(C.Structure):
+    _fields_ = [("w16t", C.c_void_p), ("units_dev", C.c_void_p), ("n_units", C.c_int32), ("packed", C.c_void_p), ("packed_bytes", C.c_size_t),
+                ("M", C.c_int64),
+                ("nin", C.c_int32), ("ain", C.c_void_p), ("ld_ain", C.c_int64), ("dz0", C.c_void_p),
+                ("xa", C.c_void_p), ("sta", C.c_void_p), ("ga", C.c_void_p), ("dresa", C.c_void_p), ("dxa", C.c_void_p), ("daa", C.c_void_p),
+                ("dba", C.c_void_p), ("dza", C.c_void_p), ("seed_a", C.c_uint32), ("mask_a", C.c_int32),
+                ("NC", C.c_int32), ("hgate", C.c_void_p), ("gh", C.c_void_p), ("gate_scale", C.c_float),
+                ("xb", C.c_void_p), ("stb", C.c_void_p), ("gb", C.c_void_p), ("dresb", C.c_void_p), ("dxb", C.c_void_p), ("dab", C.c_void_p),
+                ("dbb", C.c_void_p), ("dzb", C.c_void_p), ("seed_b", C.c_uint32), ("mask_b", C.c_int32),
+                ("n2", C.c_int32), ("out2", C.c_void_p), ("drop_p", C.c_float), ("eps", C.c_float)]
+
+
 class Tuning(C.Structure):
     _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
                 ("side_stream", C.c_int32), ("row_chain", C.c_int32)]
@@ -153,6 +165,7 @@ SIGNATURES = {
     "ortk_encode": (_I32, [_CFG, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P, _P]),
     "ortk_chain_packed_bytes": (_SZ, [_I32]),
     "ortk_row_chain": (_I32, [C.POINTER(ChainArgs), _P]),
+    "ortk_row_bchain": (_I32, [C.POINTER(BChainArgs), _P]),
     "ortk_get_tuning": (None, [C.POINTER(Tuning)]),
     "ortk_set_tuning": (_I32, [C.POINTER(Tuning)]),
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),

@@ -360,6 +360,229 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
 #undef CH_UNIT_BEGIN
 }
 
+// ================================================================================================ backward chains
+// The same idea for the backward pass of the row-wise operators (everything between two attention-backward calls except the
+// weight gradients, which reduce over ALL rows and stay GEMMs on the side stream): data gradients through the TRANSPOSED bf16
+// weight copies, the ReLU / dropout gate of the FFN, the LayerNorm backward on the register-resident gradient rows, the
+// dropout-masked bf16 copy the next sublayer's products (and weight gradients) read.
+//
+//   P0 (nin = 1 | 3):  gy = sum_i ain[:, 512 i ..] . U_i            (dq . Wcq, or the packed dQ|dK|dV . Wqkv: K = 1 536)
+//        or (nin = 0): the A image <- dz0 rows (a masked gradient that already exists)
+//   LNa (nin > 0):     dx = LayerNorm'(gy; x, {mean, std}, gain) + dres  -> dxa;  d gain / d bias += column sums;
+//                      dz = dropout-mask(dx) (site of the NEXT sublayer down the stack) -> A image (+ dza rows)
+//   P1 (NC > 0):       gh_c = gate(h_c) (A . W2^T_c) -> LDS + gh rows;  gy2 += gh_c . W1^T_c        (PositionwiseFeedForward backward)
+//   LNb (NC > 0):      as LNa on gy2 (x = the FFN sublayer's input rows), dres = dresb (may be the dxa rows just written)
+//   P2 (n2 = 1):       out2 = A . U (the masked gradient through an attention out-projection) -> bf16 rows
+//
+// LayerNorm backward (transformer.py:338-341 differentiated; ortk_norm.hip: ln_bwd_kernel): with xc = x - mean, r = 1 / (std + eps),
+// g = gy * gain, n = 512:  dx = r (g - mean(g)) - r^2 sum(g xc) xc / ((n - 1) std) [+ dres];  d gain += sum_rows gy xc r;  d bias += sum_rows gy.
+struct BChainArgs {
+    const uint4* wpk; int32_t n_units; int32_t M, rb;
+    int32_t nin; const __bf16* ain; int32_t ld_ain; const __bf16* dz0;
+    const float *xa, *sta, *ga, *dresa; float *dxa, *daa, *dba; __bf16* dza; uint32_t seed_a; int32_t mask_a;     // mask_a: dz wanted
+    int32_t NC; const __bf16* hgate; __bf16* gh; float gate_scale;
+    const float *xb, *stb, *gb, *dresb; float *dxb, *dab, *dbb; __bf16* dzb; uint32_t seed_b; int32_t mask_b;
+    int32_t n2; __bf16* out2;
+    float drop_p, eps;
+};
+
+__global__ __launch_bounds__(512) void row_bchain_kernel(BChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* A0 = smem;
+    char* H0 = smem + CIMG;
+    char* H1 = smem + 2 * CIMG;
+    float* red1 = reinterpret_cast<float*>(smem + 3 * CIMG);
+    float* red2 = red1 + CRB * 8;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = lane0;
+#define CH_FRESH_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
+    const int r0 = blockIdx.x * a.rb;
+    const int nrow = min(a.rb, a.M - r0);
+    const float ik = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thr = ortk_keep_thr(a.drop_p);
+    const bool drop = a.drop_p > 0.f;
+    const uint4* wp = a.wpk + (int64_t)wave * (a.n_units + 1) * CUNIT;
+    CRing ring;
+    c_ring_start(ring, wp, lane);
+
+    // bf16 rows (M, ld) columns col0 .. col0 + 511 -> an A image (512 threads x 16 B = 8 rows per pass)
+    auto load_img = [&](char* img, const __bf16* src, int ld, int col0) {
+#pragma unroll
+        for (int p = 0; p < CRB / 8; ++p) {
+            const int row = 8 * p + (tid >> 6), ch = tid & 63;
+            const int64_t g = r0 + (row < nrow ? row : 0);
+            *reinterpret_cast<uint4*>(img + c_off(row, ch)) = *reinterpret_cast<const uint4*>(src + g * ld + col0 + 8 * ch);
+        }
+    };
+    // LayerNorm backward on the gradient rows in `gy` (accumulator layout); leaves dx in gy, stores it, adds the parameter gradients,
+    // and (mask) writes the dropout-masked bf16 copy into A0 (+ dz rows).  Two barriers inside; the caller syncs before A0 is read.
+    auto ln_bwd = [&](f32x4 (&gy)[CMT][4], const float* x, const float* stats, const float* gain, const float* dres, float* dxo, float* dap, float* dbp,
+                      __bf16* dzo, uint32_t seed, bool mask) {
+        const int m = lane & 15, q4 = lane >> 4;
+        f32x4 xc[CMT][4];
+        float r[CMT], sd[CMT];
+        {
+            f32x4 pa[4], pb[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { pa[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int mt = 0; mt < CMT; ++mt) {
+                const int row = 16 * mt + m;
+                const bool live = row < nrow;
+                const int64_t g = r0 + (live ? row : 0);
+                const float2 st = *reinterpret_cast<const float2*>(stats + g * 2);
+                sd[mt] = st.y; r[mt] = 1.f / (st.y + a.eps);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + g * CD + 64 * wave + 16 * nt + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xc[mt][nt][e] = xv[e] - st.x;
+                        const float gv = live ? gy[mt][nt][e] : 0.f;          // rows that do not exist add nothing to the parameter gradients
+                        pa[nt][e] += gv * xc[mt][nt][e] * r[mt];
+                        pb[nt][e] += gv;
+                    }
+                }
+            }
+            // column sums over the block's rows: the 16 lanes of a DPP row hold the 16 rows of a tile
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float va = pa[nt][e], vb = pb[nt][e];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) { va += __shfl_xor(va, o, 64); vb += __shfl_xor(vb, o, 64); }
+                    if (m == 0) { atomicAdd(dap + 64 * wave + 16 * nt + 4 * q4 + e, va); atomicAdd(dbp + 64 * wave + 16 * nt + 4 * q4 + e, vb); }
+                }
+        }
+        f32x4 gn[4];
+        c_cols(gain, wave, lane, gn);
+#pragma unroll
+        for (int mt = 0; mt < CMT; ++mt) {
+            float sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gy[mt][nt][e] *= gn[nt][e]; sg += gy[mt][nt][e]; sgx = __builtin_fmaf(gy[mt][nt][e], xc[mt][nt][e], sgx); }
+            sg += __shfl_xor(sg, 16, 64); sg += __shfl_xor(sg, 32, 64);
+            sgx += __shfl_xor(sgx, 16, 64); sgx += __shfl_xor(sgx, 32, 64);
+            if (lane < 16) { red1[(16 * mt + m) * 8 + wave] = sg; red2[(16 * mt + m) * 8 + wave] = sgx; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < CMT; ++mt) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * 8), p1 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * 8 + 4);
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * 8), s1 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * 8 + 4);
+            const float mg = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) * (1.f / CD);
+            const float sx = ((s0[0] + s0[1]) + (s0[2] + s0[3])) + ((s1[0] + s1[1]) + (s1[2] + s1[3]));
+            const float coef = r[mt] * r[mt] * sx / ((float)(CD - 1) * sd[mt]);
+            const int row = 16 * mt + m;
+            const bool live = row < nrow;
+            const int64_t g = r0 + (live ? row : 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = 64 * wave + 16 * nt + 4 * q4;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = r[mt] * (gy[mt][nt][e] - mg) - coef * xc[mt][nt][e];
+                if (dres) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dres + g * CD + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += dv[e];
+                }
+                gy[mt][nt] = o;
+                if (live) *reinterpret_cast<f32x4*>(dxo + g * CD + col) = o;
+                if (mask) {
+                    float z[4] = {o[0], o[1], o[2], o[3]};
+                    if (drop) {
+                        bool kp[4];
+                        ortk_keep4_u32(seed, (uint32_t)g * (uint32_t)CD + (uint32_t)col, thr, kp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z[e] = kp[e] ? z[e] * ik : 0.f;
+                    }
+                    const uint2 pk = make_uint2(c_pack2(z[0], z[1]), c_pack2(z[2], z[3]));
+                    *reinterpret_cast<uint2*>(A0 + c_off(row, col >> 3) + ((col >> 2) & 1) * 8) = pk;
+                    if (dzo && live) *reinterpret_cast<uint2*>(dzo + g * CD + col) = pk;
+                }
+            }
+        }
+        __syncthreads();             // (red1 / red2 are free again; A0 is complete)
+    };
+
+    // ---- P0 / LNa
+    if (a.nin > 0) {
+        load_img(A0, a.ain, a.ld_ain, 0);
+        if (a.nin > 1) { load_img(H0, a.ain, a.ld_ain, CD); load_img(H1, a.ain, a.ld_ain, 2 * CD); }
+        __syncthreads();
+        CH_FRESH_LANE();
+        f32x4 acc[CMT][4];
+        c_zero(acc);
+        c_unit(acc, A0, wp, ring, lane);
+        if (a.nin > 1) { c_unit(acc, H0, wp, ring, lane); c_unit(acc, H1, wp, ring, lane); }
+        __syncthreads();             // every wave is past its reads of the three images
+        ln_bwd(acc, a.xa, a.sta, a.ga, a.dresa, a.dxa, a.daa, a.dba, a.dza, a.seed_a, a.mask_a != 0);
+    } else {
+        load_img(A0, a.dz0, CD, 0);
+        __syncthreads();
+    }
+    // ---- P1 / LNb: the feed-forward sublayer backwards, 512 hidden units at a time
+    if (a.NC > 0) {
+        CH_FRESH_LANE();
+        f32x4 acc2[CMT][4];
+        c_zero(acc2);
+        const int64_t ffn = (int64_t)a.NC * CD;
+        for (int c = 0; c < a.NC; ++c) {
+            char* Hc = (c & 1) ? H1 : H0;
+            f32x4 acc[CMT][4];
+            c_zero(acc);
+            c_unit(acc, A0, wp, ring, lane);
+#pragma unroll
+            for (int mt = 0; mt < CMT; ++mt) {
+                const int row = 16 * mt + (lane & 15);
+                const bool live = row < nrow;
+                const int64_t g = r0 + (live ? row : 0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int col = 64 * wave + 16 * nt + 4 * (lane >> 4);
+                    const uint2 hv = *reinterpret_cast<const uint2*>(a.hgate + g * ffn + c * CD + col);
+                    // gate: h > 0 (ReLU active and the unit kept by its dropout) passes the gradient, scaled by 1 / (1 - p)
+                    const bool k0 = (hv.x & 0x7FFFu) != 0 && !(hv.x & 0x8000u), k1 = (hv.x & 0x7FFF0000u) != 0 && !(hv.x & 0x80000000u);
+                    const bool k2 = (hv.y & 0x7FFFu) != 0 && !(hv.y & 0x8000u), k3 = (hv.y & 0x7FFF0000u) != 0 && !(hv.y & 0x80000000u);
+                    const float v0 = k0 ? acc[mt][nt][0] * a.gate_scale : 0.f, v1 = k1 ? acc[mt][nt][1] * a.gate_scale : 0.f;
+                    const float v2 = k2 ? acc[mt][nt][2] * a.gate_scale : 0.f, v3 = k3 ? acc[mt][nt][3] * a.gate_scale : 0.f;
+                    const uint2 pk = make_uint2(c_pack2(v0, v1), c_pack2(v2, v3));
+                    *reinterpret_cast<uint2*>(Hc + c_off(row, col >> 3) + ((col >> 2) & 1) * 8) = pk;
+                    if (live) *reinterpret_cast<uint2*>(a.gh + g * ffn + c * CD + col) = pk;
+                }
+            }
+            __syncthreads();
+            c_unit(acc2, Hc, wp, ring, lane);
+        }
+        __syncthreads();             // every wave is past its reads of A0 and of the hidden chunks
+        ln_bwd(acc2, a.xb, a.stb, a.gb, a.dresb, a.dxb, a.dab, a.dbb, a.dzb, a.seed_b, a.mask_b != 0);
+    }
+    // ---- P2
+    if (a.n2 > 0) {
+        CH_FRESH_LANE();
+        f32x4 acc[CMT][4];
+        c_zero(acc);
+        c_unit(acc, A0, wp, ring, lane);
+#pragma unroll
+        for (int mt = 0; mt < CMT; ++mt) {
+            const int row = 16 * mt + (lane & 15);
+            if (row < nrow) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int col = 64 * wave + 16 * nt + 4 * (lane >> 4);
+                    *reinterpret_cast<uint2*>(a.out2 + (int64_t)(r0 + row) * CD + col) =
+                        make_uint2(c_pack2(acc[mt][nt][0], acc[mt][nt][1]), c_pack2(acc[mt][nt][2], acc[mt][nt][3]));
+                }
+            }
+        }
+    }
+#undef CH_FRESH_LANE
+}
+
 // out[(((w NU1 + u) 16 + ks) 4 + nt) 64 + lane] = the 8 bf16 W_u[64 w + 16 nt + (lane & 15)][32 ks + 8 (lane >> 4) ..], NU1 = units + 1
 // (the slack unit behind every wave's stream — the ring's read-ahead — is zero-filled)
 struct PackUnit { int64_t offset, ld; };
@@ -483,7 +706,58 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
     return 0;
 }
 
+int bchain_run(const ortk_bchain_args* p, const void* packed, hipStream_t s) {
+    if (!p || !packed || p->M < 1 || p->M > (int64_t)1 << 22) return ORTK_EINVAL;
+    if ((p->nin != 0 && p->nin != 1 && p->nin != 3) || p->NC < 0 || p->NC > 8 || p->n2 < 0 || p->n2 > 1) return ORTK_EINVAL;
+    if (p->nin > 0 && (!p->ain || p->ld_ain < p->nin * CD || p->ld_ain % 8 || !p->xa || !p->sta || !p->ga || !p->dxa || !p->daa || !p->dba)) return ORTK_EINVAL;
+    if (p->nin == 0 && !p->dz0) return ORTK_EINVAL;
+    if (p->NC > 0 && (!p->hgate || !p->gh || !p->xb || !p->stb || !p->gb || !p->dxb || !p->dab || !p->dbb)) return ORTK_EINVAL;
+    if (p->n2 > 0 && !p->out2) return ORTK_EINVAL;
+    if ((p->NC > 0 || p->n2 > 0) && p->nin > 0 && !p->mask_a) return ORTK_EINVAL;       // P1 / P2 read the masked image LNa leaves
+    if (p->n2 > 0 && p->NC > 0 && !p->mask_b) return ORTK_EINVAL;
+    if (p->drop_p < 0.f || p->drop_p >= 1.f) return ORTK_EINVAL;
+    const int n_units = p->nin + 2 * p->NC + p->n2;
+    if (n_units < 1 || n_units != p->n_units) return ORTK_EINVAL;
+    if ((int64_t)p->M * CD >= ((int64_t)1 << 32)) return ORTK_EINVAL;
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ORTK_EINVAL;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_bchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
+            if (e != hipSuccess) return (int)e;
+            done[dev] = true;
+        }
+    }
+    BChainArgs a;
+    a.wpk = reinterpret_cast<const uint4*>(packed); a.n_units = n_units; a.M = (int)p->M; a.rb = chain_rows_per_block(p->M, 256);
+    a.nin = p->nin; a.ain = reinterpret_cast<const __bf16*>(p->ain); a.ld_ain = (int)p->ld_ain; a.dz0 = reinterpret_cast<const __bf16*>(p->dz0);
+    a.xa = p->xa; a.sta = p->sta; a.ga = p->ga; a.dresa = p->dresa; a.dxa = p->dxa; a.daa = p->daa; a.dba = p->dba;
+    a.dza = reinterpret_cast<__bf16*>(p->dza); a.seed_a = p->seed_a; a.mask_a = p->mask_a;
+    a.NC = p->NC; a.hgate = reinterpret_cast<const __bf16*>(p->hgate); a.gh = reinterpret_cast<__bf16*>(p->gh); a.gate_scale = p->gate_scale;
+    a.xb = p->xb; a.stb = p->stb; a.gb = p->gb; a.dresb = p->dresb; a.dxb = p->dxb; a.dab = p->dab; a.dbb = p->dbb;
+    a.dzb = reinterpret_cast<__bf16*>(p->dzb); a.seed_b = p->seed_b; a.mask_b = p->mask_b;
+    a.n2 = p->n2; a.out2 = reinterpret_cast<__bf16*>(p->out2);
+    a.drop_p = p->drop_p; a.eps = p->eps;
+    ProfMark pm;
+    if (ortk_prof_active()) (void)prof_begin(PROF_KEY_CHAIN, 2.0 * p->M * n_units * CD * CD, (double)n_units * CD * CD * 2, s, pm); else pm.live = false;
+    hipLaunchKernelGGL(row_bchain_kernel, dim3((unsigned)ortk_cdiv(p->M, a.rb)), dim3(512), CHAIN_LDS, s, a);
+    prof_end(pm, s);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace ortk
+
+// Operator form of the backward chain (tests, tools): packs the units of this call from `w16t` into `packed`, then runs it.
+extern "C" int ortk_row_bchain(const ortk_bchain_args* p, ortk_stream stream) {
+    if (!p || !p->w16t || !p->units_dev || !p->packed || p->packed_bytes < ortk::chain_packed_bytes(p->n_units)) return ORTK_EINVAL;
+    hipStream_t s = ortk_s(stream);
+    if (int e = ortk::chain_pack(p->w16t, p->units_dev, p->n_units, p->packed, s)) return e;
+    return ortk::bchain_run(p, p->packed, s);
+}
 
 extern "C" size_t ortk_chain_packed_bytes(int32_t n_units) { return n_units < 1 ? 0 : ortk::chain_packed_bytes(n_units); }
 

@@ -176,6 +176,7 @@ struct ChainPackTable {
 };
 int chain_pack_all(const void* w16, void* packed, const ChainPackTable& t, hipStream_t s);
 int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s);
+int bchain_run(const ortk_bchain_args* p, const void* packed, hipStream_t s);
 int fill_i64(int64_t* p, int64_t n, int64_t v, hipStream_t s);
 int fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 // kvidx[g*1 + 0] = g*row_mult*tmax  (index table for the first decoder pass)

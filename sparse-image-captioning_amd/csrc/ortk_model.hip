@@ -178,6 +178,9 @@ struct ChainSet {
     bool on = false;
     ChainPackTable t;
     int e0 = -1, eb[MAXLAYERS], d0 = -1, db[MAXLAYERS], dc[MAXLAYERS];
+    // backward chains (bchain_layout): X = [FFN' -> LN' -> . Wout] on a masked gradient, Y = [dq . Wcq -> LN' -> . Wo],
+    // ZX(l) = [dQKV . Wqkv -> LN' of layer l] + X of layer l - 1, Z0 = the bottom of a stack
+    int bx_top = -1, by[MAXLAYERS], bzx[MAXLAYERS], bz0 = -1, ex_top = -1, ezx[MAXLAYERS], ez0 = -1;
     size_t bytes = 0;
     int units(int c) const { return t.first[c + 1] - t.first[c]; }
     const void* stream_of(const void* pk, int c) const { return reinterpret_cast<const char*>(pk) + (size_t)t.base[c] * 16; }
@@ -223,6 +226,45 @@ static void chain_layout(const ortk_config& c, const Offsets& o, bool enc, bool 
     }
     cs.bytes = (size_t)base * 16;
 }
+// units over the TRANSPOSED bf16 weight copy (block (N, K) of the arena stored (K, N) at the same offset)
+static void bchain_layout(const ortk_config& c, const Offsets& o, ChainSet& cs, bool sizing = false) {
+    cs.on = chain_cfg_ok(c);
+    cs.bytes = 0;
+    if (!cs.on && !(sizing && chain_cfg_ok(c, true))) return;
+    const int L = c.n_layers, NC = c.d_ff / 512, ff = c.d_ff;
+    ChainPackTable& t = cs.t;
+    t.n_chains = 0; t.first[0] = 0;
+    int nu = 0;
+    int64_t base = 0;
+    auto unit = [&](int64_t off, int ld) { t.u[nu].offset = (int32_t)off; t.u[nu].ld = ld; ++nu; };
+    auto close = [&]() {
+        const int c_ = t.n_chains++;
+        t.base[c_] = base; t.first[c_ + 1] = nu;
+        base += (int64_t)8 * (nu - t.first[c_] + 1) * 16 * 256;
+        return c_;
+    };
+    auto zq = [&](int64_t wqkv) { for (int i = 0; i < 3; ++i) unit(wqkv + (int64_t)i * 512, 1536); };          // dQKV . Wqkv: columns 512 i .. of Wqkv^T
+    auto xf = [&](int64_t w1, int64_t w2, int64_t wout) {
+        for (int k = 0; k < NC; ++k) { unit(w2 + (int64_t)k * 512 * 512, 512); unit(w1 + (int64_t)k * 512, ff); }
+        unit(wout, 512);
+    };
+    // decoder
+    xf(o.dec[L - 1].w1, o.dec[L - 1].w2, o.dec[L - 1].cow); cs.bx_top = close();
+    for (int l = L - 1; l >= 0; --l) {
+        unit(o.dec[l].cqw, 512); unit(o.dec[l].wo, 512); cs.by[l] = close();
+        zq(o.dec[l].wqkv);
+        if (l > 0) { xf(o.dec[l - 1].w1, o.dec[l - 1].w2, o.dec[l - 1].cow); cs.bzx[l] = close(); }
+        else cs.bz0 = close();
+    }
+    // encoder
+    xf(o.enc[L - 1].w1, o.enc[L - 1].w2, o.enc[L - 1].wo); cs.ex_top = close();
+    for (int l = L - 1; l >= 0; --l) {
+        zq(o.enc[l].wqkv);
+        if (l > 0) { xf(o.enc[l - 1].w1, o.enc[l - 1].w2, o.enc[l - 1].wo); cs.ezx[l] = close(); }
+        else cs.ez0 = close();
+    }
+    cs.bytes = (size_t)base * 16;
+}
 
 struct Bump {
     char* base; size_t off;
@@ -257,6 +299,8 @@ struct TrainWS {
     // backward temporaries
     float *ga, *gb, *gy; void* gdo /*Q: dO of an attention backward*/; void *gt /*A*/, *gt2 /*A*/, *gt3 /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
     void* chain_pk = nullptr;               // weight units of the rows-stationary chains in streaming order (chain_layout; mixed precision)
+    void* chain_pk_b = nullptr;             // ... of the backward chains (bchain_layout, from the transposed copy)
+    void* gh2 = nullptr;                    // second FFN hidden-gradient buffer: the backward chains alternate (a weight gradient still reads the other)
     size_t bytes;
 };
 
@@ -309,6 +353,8 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     {   // (sized whatever the tuning switch says: the workspace size is a function of the configuration and the shapes only)
         ChainSet cs; chain_layout(c, o, true, true, cs, true);
         if (cs.bytes) w.chain_pk = b.take_bytes(cs.bytes);
+        ChainSet bs; bchain_layout(c, o, bs, true);
+        if (bs.bytes) { w.chain_pk_b = b.take_bytes(bs.bytes); w.gh2 = act(Mx * ff); }
     }
     w.bytes = (b.off + 255) & ~(size_t)255;
 }
@@ -1021,6 +1067,25 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     int gt_i = 0;
     void* gt_cur = w.gt;
     auto gt_new = [&]() { gt_i = (gt_i + 1) % 3; gt_cur = gt_pool[gt_i]; return gt_cur; };
+    // Backward chains (ortk_chain.hip): everything between two attention-backward calls except the weight gradients in one
+    // rows-stationary launch each.  Mixed precision, bf16 Q / K / V / dO in all three attention stacks, dense products.
+    ChainSet bs; bchain_layout(*cfg, o, bs);
+    const bool bch_any = bs.on && w.chain_pk_b && A == ORTK_BF16 && w.qdt_self == ORTK_BF16 && w.qdt_cross == ORTK_BF16 && w.qdt_enc == ORTK_BF16 &&
+                         !c.ell_b && !cfg->sparse_fwd;
+    // ortk_tuning.row_chain: 1 = forward chains only, 2 = + the encoder's backward (one round of workgroups at 9 216 rows), 3 = + the decoder's
+    const bool bch_enc = bch_any && tuning().row_chain >= 2, bch = bch_any && tuning().row_chain >= 3;
+    if (bch_enc && phase != 2) TRY(chain_pack_all(w.w16t, w.chain_pk_b, bs.t, c.s));
+    const int NCc = ff / 512;
+    int gh_i = 0;
+    auto gh_new = [&]() { gh_i ^= 1; return gh_i ? w.gh2 : w.gh; };
+    // X = [FFN' -> LayerNorm' -> . Wout] of one layer, standalone (the top of a stack) or as the tail of a ZX chain: the fields of `ca`
+    auto x_part = [&](ortk_bchain_args& ca, const void* hrow, void* ghbuf, const float* xrows, const float* strows, int64_t na, int64_t nb,
+                      const float* dres, float* dxo, void* dzo, uint32_t seed, void* dO) {
+        ca.NC = NCc; ca.hgate = hrow; ca.gh = ghbuf; ca.gate_scale = inv_keep;
+        ca.xb = xrows; ca.stb = strows; ca.gb = params + na; ca.dresb = dres; ca.dxb = dxo; ca.dab = G + na; ca.dbb = G + nb;
+        ca.dzb = dzo; ca.seed_b = seed; ca.mask_b = 1;
+        ca.n2 = 1; ca.out2 = dO;
+    };
     if (phase != 2) {
     // ---- decoder half: generator, decoder stack, token embedding, cross-attention K/V projections; leaves the gradient
     // of the encoder memory in w.gy.  Every gradient at arena offsets >= ortk_arena_decoder_offset is final afterwards.
@@ -1029,6 +1094,86 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     TRY(wgrad_gemm(c, w.dlogits, A, w.ldv, w.dec_out, A, d, G + o.gen_w, G + o.gen_b, Md, Vp, d));
     TRY(dgrad_gemm(c, w.dlogits, A, w.ldv, o.gen_w, w.gy, ORTK_F32, d, Md, Vp, d));
     TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md, gt_new(), dop(L - 1, 5)));
+    if (bch) {
+        // cur = gradient of the FFN sublayer's INPUT rows (xm2) of the layer in hand, oth = the other fp32 buffer; dtA / dtB = the masked
+        // bf16 gradients the weight gradients of W2 / Wco read; ghb = the FFN hidden gradient (W1's weight gradient)
+        float* cur = dx2; float* oth = dx;
+        void* dtA = gt_cur; void* dtB = gt_new(); void* ghb = gh_new();
+        {   // X of the top layer, on the masked gradient the final LayerNorm's backward left
+            const DecOff& e = o.dec[L - 1]; const DecBuf& b = w.dec[L - 1];
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ca.n_units = bs.units(bs.bx_top); ca.M = Md; ca.nin = 0; ca.dz0 = dtA;
+            x_part(ca, b.h, ghb, b.xm2, b.st3, e.n2a, e.n2b, dx, cur, dtB, c.sub(dop(L - 1, 3)), w.gdo);
+            ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+            TRY(c.before_write(dtB)); TRY(c.before_write(ghb));
+            TRY(bchain_run(&ca, bs.stream_of(w.chain_pk_b, bs.bx_top), c.s));
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
+            const float* xin = l == 0 ? w.dx0 : w.dec[l - 1].xout;
+            TRY(wgrad_gemm(c, dtA, A, d, b.h, A, ff, G + e.w2, G + e.b2, Md, d, ff));
+            TRY(wgrad_gemm(c, ghb, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
+            TRY(wgrad_gemm(c, dtB, A, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
+            // cross-attention backward: dO = w.gdo (the chain's last product) -> dq, dK | dV
+            void* dq = gt_new();
+            ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
+            a.qkv_dtype = w.qdt_cross; a.q = (const float*)b.qc; a.ldq = d;
+            a.k = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw, w.qdt_cross); a.v = (const float*)off_elems(w.ckv, o.ckv_slot[l] * cw + cv, w.qdt_cross);
+            a.ldk = a.ldv = U * cw;
+            a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
+            a.d_o = (const float*)w.gdo; a.lddo = d; a.dq = dq; a.lddq = d; a.dqkv_dtype = A;
+            a.d_k = off_elems(w.gkv, gslot[l] * cw, A); a.dv = off_elems(w.gkv, gslot[l] * cw + gdv, A);
+            a.lddk = a.lddv = ldg;
+            if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; }
+            TRY(c.before_write(dq));
+            TRY(ortk_attention_bwd(&a, stream));
+            TRY(wgrad_gemm(c, dq, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
+            // Y: [dq . Wcq -> LayerNorm 1' (+ cur) -> masked copy -> . Wo]
+            void* dtD = gt_new();
+            {
+                ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+                ca.n_units = bs.units(bs.by[l]); ca.M = Md; ca.nin = 1; ca.ain = dq; ca.ld_ain = d;
+                ca.xa = b.xm1; ca.sta = b.st2; ca.ga = params + e.n1a; ca.dresa = cur; ca.dxa = oth; ca.daa = G + e.n1a; ca.dba = G + e.n1b;
+                ca.dza = dtD; ca.seed_a = c.sub(dop(l, 1)); ca.mask_a = 1;
+                ca.n2 = 1; ca.out2 = w.gdo;
+                ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+                TRY(c.before_write(dtD));
+                TRY(bchain_run(&ca, bs.stream_of(w.chain_pk_b, bs.by[l]), c.s));
+            }
+            TRY(wgrad_gemm(c, dtD, A, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
+            // self-attention backward: dO = w.gdo -> packed dQ | dK | dV
+            std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
+            a.qkv_dtype = w.qdt_self; a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, amd.k * d, w.qdt_self);
+            a.v = (const float*)off_elems(b.qkv, amd.v * d, w.qdt_self); a.ldq = a.ldk = a.ldv = 3 * d;
+            a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
+            a.d_o = (const float*)w.gdo; a.lddo = d; a.dqkv_dtype = A;
+            a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, amd.gk * d, A); a.dv = off_elems(w.gqkv, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+            if (compact) { a.q_off = bt->cap_off; a.q_off_stride = 1; a.kv_ragged = 1; }
+            TRY(c.before_write(w.gqkv));
+            TRY(ortk_attention_bwd(&a, stream));
+            TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
+            // Z (+ X of the layer below): [dQKV . Wqkv -> LayerNorm 0' (+ oth) -> masked copy] [-> FFN' -> LayerNorm 2' -> masked copy -> . Wco]
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ca.M = Md; ca.nin = 3; ca.ain = w.gqkv; ca.ld_ain = 3 * d;
+            ca.xa = xin; ca.sta = b.st1; ca.ga = params + e.n0a; ca.dresa = oth; ca.dxa = cur; ca.daa = G + e.n0a; ca.dba = G + e.n0b;
+            ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+            if (l > 0) {
+                const DecOff& en = o.dec[l - 1]; const DecBuf& bn = w.dec[l - 1];
+                dtA = gt_new(); void* dtBn = gt_new(); ghb = gh_new();
+                ca.n_units = bs.units(bs.bzx[l]);
+                ca.dza = dtA; ca.seed_a = c.sub(dop(l - 1, 5)); ca.mask_a = 1;
+                x_part(ca, bn.h, ghb, bn.xm2, bn.st3, en.n2a, en.n2b, cur, oth, dtBn, c.sub(dop(l - 1, 3)), w.gdo);
+                TRY(c.before_write(dtA)); TRY(c.before_write(dtBn)); TRY(c.before_write(ghb));
+                TRY(bchain_run(&ca, bs.stream_of(w.chain_pk_b, bs.bzx[l]), c.s));
+                dtB = dtBn;
+                std::swap(cur, oth);          // cur = gradient of xm2 of layer l - 1 (what the chain wrote last)
+            } else {
+                ca.n_units = bs.units(bs.bz0);
+                TRY(bchain_run(&ca, bs.stream_of(w.chain_pk_b, bs.bz0), c.s));
+                dx = cur; dx2 = oth;           // the gradient of the embedded tokens
+            }
+        }
+    } else
     for (int l = L - 1; l >= 0; --l) {
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         const float* xin = l == 0 ? w.dx0 : w.dec[l - 1].xout;
@@ -1123,6 +1268,56 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     };
     dx = w.ga; dx2 = w.gb;
     TRY(ln_bwd(c, w.gy, w.enc[L - 1].xout, G, o.enc_na, o.enc_nb, w.st_mem, nullptr, dx, Me, gt_new(), eop(L - 1, 3)));
+    if (bch_enc) {
+        // cur = gradient of the FFN sublayer's input rows (xm) of the layer in hand; oth = the other fp32 buffer
+        float* cur = dx2; float* oth = dx;
+        void* dtA = gt_cur; void* dtB = gt_new(); void* ghb = gh_new();
+        {
+            const EncOff& e = o.enc[L - 1]; const EncBuf& b = w.enc[L - 1];
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ca.n_units = bs.units(bs.ex_top); ca.M = Me; ca.nin = 0; ca.dz0 = dtA;
+            x_part(ca, b.h, ghb, b.xm, b.st2, e.n1a, e.n1b, dx, cur, dtB, c.sub(eop(L - 1, 1)), w.gdo);
+            ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+            TRY(c.before_write(dtB)); TRY(c.before_write(ghb));
+            TRY(bchain_run(&ca, bs.stream_of(w.chain_pk_b, bs.ex_top), c.s));
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            const EncOff& e = o.enc[l]; const EncBuf& b = w.enc[l];
+            const float* xin = l == 0 ? w.x0 : w.enc[l - 1].xout;
+            TRY(wgrad_gemm(c, dtA, A, d, b.h, A, ff, G + e.w2, G + e.b2, Me, d, ff));
+            TRY(wgrad_gemm(c, ghb, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
+            TRY(wgrad_gemm(c, dtB, A, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
+            ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
+            a.qkv_dtype = w.qdt_enc; a.q = (const float*)b.qkv; a.k = (const float*)off_elems(b.qkv, ame.k * d, w.qdt_enc);
+            a.v = (const float*)off_elems(b.qkv, ame.v * d, w.qdt_enc); a.ldq = a.ldk = a.ldv = 3 * d;
+            a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
+            a.d_o = (const float*)w.gdo; a.lddo = d; a.dqkv_dtype = A;
+            a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, ame.gk * d, A); a.dv = off_elems(w.gqkv, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+            a.dscore = cfg->no_box ? nullptr : w.dscore + (int64_t)l * B * H * S * S;
+            TRY(c.before_write(w.gqkv));
+            TRY(ortk_attention_bwd(&a, stream));
+            if (l == 1 && box_split) TRY(box_grad(1, L - 1));
+            TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ca.M = Me; ca.nin = 3; ca.ain = w.gqkv; ca.ld_ain = 3 * d;
+            ca.xa = xin; ca.sta = b.st1; ca.ga = params + e.n0a; ca.dresa = cur; ca.dxa = oth; ca.daa = G + e.n0a; ca.dba = G + e.n0b;
+            ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+            if (l > 0) {
+                const EncOff& en = o.enc[l - 1]; const EncBuf& bn = w.enc[l - 1];
+                dtA = gt_new(); void* dtBn = gt_new(); ghb = gh_new();
+                ca.n_units = bs.units(bs.ezx[l]);
+                ca.dza = dtA; ca.seed_a = c.sub(eop(l - 1, 3)); ca.mask_a = 1;
+                x_part(ca, bn.h, ghb, bn.xm, bn.st2, en.n1a, en.n1b, oth, cur, dtBn, c.sub(eop(l - 1, 1)), w.gdo);
+                TRY(c.before_write(dtA)); TRY(c.before_write(dtBn)); TRY(c.before_write(ghb));
+                TRY(bchain_run(&ca, bs.stream_of(w.chain_pk_b, bs.ezx[l]), c.s));
+                dtB = dtBn;
+            } else {
+                ca.n_units = bs.units(bs.ez0);
+                TRY(bchain_run(&ca, bs.stream_of(w.chain_pk_b, bs.ez0), c.s));
+                dx = oth; dx2 = cur;           // the gradient of the embedded regions (att_embed's output)
+            }
+        }
+    } else
     for (int l = L - 1; l >= 0; --l) {
         const EncOff& e = o.enc[l]; const EncBuf& b = w.enc[l];
         const float* xin = l == 0 ? w.x0 : w.enc[l - 1].xout;

@@ -992,3 +992,111 @@ def test_row_chain_vs_separate_ops(L, M, p, parts):
         if n2:
             ref = y2.float() @ f(W["s2"]).t() + bs2[:n2 * d]
             assert ((out2.float() - ref).abs() <= one_bf16(ref) + 2e-3).all()
+
+
+def _ln_bwd_ref(gy, x, gain, eps=1e-6):
+    n = x.size(-1)
+    mean, sd = x.mean(-1, keepdim=True), x.std(-1, keepdim=True)
+    r, xc = 1.0 / (sd + eps), x - mean
+    g = gy * gain
+    dx = r * (g - g.mean(-1, keepdim=True)) - r * r * (g * xc).sum(-1, keepdim=True) * xc / ((n - 1) * sd)
+    return dx, (gy * xc * r).sum(0), gy.sum(0), torch.cat([mean, sd], 1)
+
+
+@pytest.mark.parametrize("M,p,kind", [(1000, 0.1, "ZX"), (16640, 0.1, "ZX"), (9216, 0.0, "ZX"), (3000, 0.1, "X"), (2000, 0.1, "Y"), (777, 0.1, "Z")])
+def test_row_bchain_vs_reference(L, M, p, kind):
+    """ortk_row_bchain (the backward of the row-wise operators between two attention-backward calls in ONE rows-stationary launch:
+    data gradients through the transposed weights, FFN gate, LayerNorm backward, masked bf16 copies) against the same chain in torch
+    fp32 on the bf16-rounded operands with the kernels' own dropout masks.  kind: ZX = [dQKV . Wqkv -> LN' -> FFN' -> LN' -> . Wco]
+    (the decoder's longest chain, 12 units), X = its tail on an existing masked gradient, Y = [dq . Wcq -> LN' -> . Wo], Z = the
+    bottom of the stack ([dQKV . Wqkv -> LN'], no masked copy)."""
+    d, NC = 512, 4
+    ff = NC * d
+    g = torch.Generator().manual_seed(M + 7)
+    nin = {"ZX": 3, "X": 0, "Y": 1, "Z": 3}[kind]
+    hasF, n2 = kind in ("ZX", "X"), (0 if kind == "Z" else 1)
+    mk = lambda N, K: (torch.randn(N, K, generator=g) * (0.5 / math.sqrt(N))).bfloat16()
+    Win = mk(nin * d, d) if nin else None                   # (nin*512 outputs, 512 inputs): dX = dY . W
+    W2, W1, Wo = mk(d, ff), mk(ff, d), mk(d, d)
+    # the transposed bf16 arena the chain streams (what cast_bf16_transposed leaves): block (N, K) stored as (K, N)
+    parts, off, cur = [], {}, 0
+    for name, W in (("in", Win), ("w2", W2), ("w1", W1), ("o", Wo)):
+        if W is None: continue
+        parts.append(W.t().contiguous().reshape(-1)); off[name] = cur; cur += W.numel()
+    arena_t = dev(torch.cat(parts))
+    units = [(off["in"] + i * d, nin * d) for i in range(nin)]
+    if hasF:
+        for c in range(NC):
+            units += [(off["w2"] + c * d * d, d), (off["w1"] + c * d, ff)]
+    if n2: units.append((off["o"], d))
+    ut = dev(torch.tensor(units, dtype=torch.int64))
+    ain = dev(rnd(M, max(nin, 1) * d, seed=1).bfloat16())
+    dz0 = dev(rnd(M, d, seed=2).bfloat16())
+    xa, xb = dev(rnd(M, d, seed=3)), dev(rnd(M, d, seed=4))
+    ga, gb = dev(1 + rnd(d, seed=5, scale=0.1)), dev(1 + rnd(d, seed=6, scale=0.1))
+    dresa, dresb_ext = dev(rnd(M, d, seed=7)), dev(rnd(M, d, seed=8))
+    hrow = torch.relu(rnd(M, ff, seed=9)) * (torch.rand(M, ff, generator=g) < 0.9).float()        # post-ReLU, post-dropout hidden units
+    hgate = dev(hrow.bfloat16())
+    sta = torch.cat([xa.mean(1, keepdim=True), xa.std(1, keepdim=True)], 1).contiguous()
+    stb = torch.cat([xb.mean(1, keepdim=True), xb.std(1, keepdim=True)], 1).contiguous()
+    nanf = lambda *s: torch.full(s, float("nan"), device="cuda")
+    dxa, dxb = nanf(M, d), nanf(M, d)
+    daa, dba, dab, dbb = (torch.zeros(d, device="cuda") for _ in range(4))
+    dza, dzb = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16), torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
+    gh = torch.zeros(M, ff, device="cuda", dtype=torch.bfloat16)
+    out2 = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
+    a = L.BChainArgs()
+    a.w16t, a.units_dev, a.n_units = arena_t.data_ptr(), ut.data_ptr(), len(units)
+    nb = L.lib().ortk_chain_packed_bytes(len(units))
+    packed = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    a.packed, a.packed_bytes, a.M = packed.data_ptr(), nb, M
+    sa, sb = 4321, 8765
+    a.nin = nin
+    if nin:
+        a.ain, a.ld_ain = ain.data_ptr(), ain.stride(0)
+        a.xa, a.sta, a.ga, a.dresa, a.dxa, a.daa, a.dba = xa.data_ptr(), sta.data_ptr(), ga.data_ptr(), dresa.data_ptr(), dxa.data_ptr(), daa.data_ptr(), dba.data_ptr()
+        a.mask_a = 0 if kind == "Z" else 1
+        a.dza, a.seed_a = dza.data_ptr(), sa
+    else:
+        a.dz0 = dz0.data_ptr()
+    if hasF:
+        a.NC, a.hgate, a.gh, a.gate_scale = NC, hgate.data_ptr(), gh.data_ptr(), 1.0 / (1.0 - p)
+        dresb = dxa if nin else dresb_ext
+        a.xb, a.stb, a.gb, a.dresb, a.dxb, a.dab, a.dbb = xb.data_ptr(), stb.data_ptr(), gb.data_ptr(), dresb.data_ptr(), dxb.data_ptr(), dab.data_ptr(), dbb.data_ptr()
+        a.mask_b, a.dzb, a.seed_b = 1, dzb.data_ptr(), sb
+    a.n2 = n2
+    if n2: a.out2 = out2.data_ptr()
+    a.drop_p, a.eps = p, 1e-6
+    L.check(L.lib().ortk_row_bchain(C.byref(a), L.stream_ptr()), "ortk_row_bchain")
+    torch.cuda.synchronize()
+    # ---- reference
+    f = lambda t: t.float().cuda()
+    one_bf16 = lambda ref: 2.0 ** -7 * ref.abs().clamp(min=1.0)
+    km = lambda seed: (_keep_mask(L, seed, M * d, p).view(M, d) if p > 0 else 1.0)
+    if nin:
+        gy = ain.float() @ f(Win)
+        dx, da, db, _ = _ln_bwd_ref(gy, xa, ga)
+        dx = dx + dresa
+        assert (dxa - dx).abs().max().item() < 3e-3 * max(1.0, dx.abs().max().item())
+        scale = max(1.0, da.abs().max().item())
+        assert (daa - da).abs().max().item() < 2e-3 * scale and (dba - db).abs().max().item() < 2e-3 * max(1.0, db.abs().max().item())
+        if kind == "Z":
+            return
+        zr = dxa * km(sa)                                    # (from the kernel's own dx: the products below take its rounded rows)
+        assert ((dza.float() - zr).abs() <= one_bf16(zr)).all()
+        dzin = dza.float()
+    else:
+        dzin = dz0.float()
+    if hasF:
+        ghr = (dzin @ f(W2)) * (hgate.float() > 0).float() * (1.0 / (1.0 - p))
+        assert ((gh.float() - ghr).abs() <= one_bf16(ghr) + 2e-3).all()
+        gy2 = gh.float() @ f(W1)
+        dx, da, db, _ = _ln_bwd_ref(gy2, xb, gb)
+        dx = dx + (dxa if nin else dresb_ext)
+        assert (dxb - dx).abs().max().item() < 3e-3 * max(1.0, dx.abs().max().item())
+        assert (dab - da).abs().max().item() < 2e-3 * max(1.0, da.abs().max().item()) and (dbb - db).abs().max().item() < 2e-3 * max(1.0, db.abs().max().item())
+        zr = dxb * km(sb)
+        assert ((dzb.float() - zr).abs() <= one_bf16(zr)).all()
+        dzin = dzb.float()
+    ref = dzin @ f(Wo)
+    assert ((out2.float() - ref).abs() <= one_bf16(ref) + 2e-3).all()
