@@ -126,7 +126,7 @@ def cpu_baseline(workload, cfg_dict, seconds=9.0):
             "sample": f"{n} steps of {B} images ({what}), oracle/ort_oracle.py, torch CPU fp32, {cores} threads"}
 
 
-PMC_TAG = "r03"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
+PMC_TAG = "r04"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
 
 
 def pmc_traffic(kernel, workload, precision, B):
@@ -327,7 +327,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         if rank == 0:
             n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             rec = {}
-            for k in (key, key + 1, key + 3, 16):
+            for k in (key, key + 1, key + 3, 16, 17):
                 lib.ortk_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl))
                 lib.ortk_prof_collect_bytes(k, C.byref(by))
                 rec[k] = (n.value, ms.value, fl.value, by.value)
@@ -356,6 +356,12 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
                  # (the cached K / V rows are counted per beam: beams share ancestors through the ancestry table, so the algorithmic
                  #  bytes — and `frac` — are an UPPER bound on the unique bytes; `traffic` is what the counters saw)
                  "kv_rows_counted": "per beam (upper bound)" if decode else "per row"}
+    chain = None        # rows-stationary chains of the forward pass (key 17): weights streamed out of L2 per workgroup; HBM-side figure
+    if per_key[17][0]:
+        cn, cms, cfl, cby = per_key[17]
+        chain = {"kernel": "row_chain_kernel", "launches": cn, "avg_us": round(cms * 1e3 / cn, 1), "alg_bytes_per_launch": round(cby / cn),
+                 "achieved": round(cby / (cms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(cby / (cms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                 "mfma_tflops": round(cfl / (cms * 1e-3) / 1e12, 1)}
     if decode or use_csr:
         # the sparse step and the cached decode are HBM-bound.  Algorithmic bytes: decode = 25.7 MB per image
         # (self-KV reads 10.5 + cross-KV 8.0 + logits 7.2) + the weights once per step (18 steps: 110.9 MB dense bf16, or 4 bytes
@@ -380,6 +386,8 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         roofline = gemm
         if stack is not None:
             roofline["rollout_kernel"] = stack
+    if chain is not None:
+        roofline["chain_kernel"] = chain
     if not decode and workload != "scst":
         # work the step EXECUTES: the valid-position decoder skips the padded caption positions (same loss and gradients), so the
         # decoder's share is scaled by the rows it runs; `padded_equivalent` is the reference's (R x 17)-row layout
@@ -405,10 +413,13 @@ def compact(r):
     """One extra workload on the headline's line: its time, throughput and roofline in a few dozen bytes."""
     rf = r["roofline"]
     k = rf.get("dominant_kernel") or rf.get("rollout_kernel")
-    out = {"ms_per_step": r["ms_per_step"], "value": r["value"], "steps": r["steps"], "dtype": r["dtype"], "workload": r["config"]["workload"],
+    # (the one-line description of every workload name is in WORKLOADS here and in profiles/bench_notes.json, not on the line)
+    out = {"ms_per_step": r["ms_per_step"], "value": r["value"], "steps": r["steps"], "dtype": r["dtype"], "config": r["config"]["workload"].split(":")[0],
            "bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "unit": rf["unit"]}
     if k:
         out["kernel"] = {x: k[x] for x in ("kernel", "launches", "avg_us", "frac", "traffic", "alg_bytes_per_launch")}
+    if "chain_kernel" in rf:
+        out["chains"] = {x: rf["chain_kernel"][x] for x in ("launches", "avg_us", "mfma_tflops")}
     if "whole_step" in rf:
         out["whole_step_frac"] = rf["whole_step"]["frac"]
     return out

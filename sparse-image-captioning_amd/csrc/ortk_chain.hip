@@ -699,7 +699,12 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
     a.drop_p = p->drop_p; a.eps = p->eps;
     const unsigned grid = (unsigned)(ortk_cdiv(p->M, a.rb) + a.npf);
     ProfMark pm;
-    if (ortk_prof_active()) (void)prof_begin(PROF_KEY_CHAIN, 2.0 * p->M * n_units * CD * CD, (double)n_units * CD * CD * 2, s, pm); else pm.live = false;
+    if (ortk_prof_active()) {
+        // algorithmic HBM bytes: the weights once + every row tensor the chain reads or writes
+        const double rowb = 2048.0 + (p->a_in ? 1024 + 2048 : 0) + (p->g1 ? (p->y1 ? 1024 : 0) + 8 : 0) + p->n1 * 1024.0 +
+                            (p->NC ? p->NC * 1024.0 + 2048 + 2048 : 0) + (p->g2 ? (p->y2 ? 1024 : 0) + 8 : 0) + p->n2 * 1024.0;
+        (void)prof_begin(PROF_KEY_CHAIN, 2.0 * p->M * n_units * CD * CD, (double)n_units * CD * CD * 2 + rowb * p->M, s, pm);
+    } else pm.live = false;
     hipLaunchKernelGGL(row_chain_kernel, dim3(grid), dim3(512), CHAIN_LDS, s, a);
     prof_end(pm, s);
     ORTK_CHECK_LAUNCH();
