@@ -56,6 +56,24 @@ def _staged(t):
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
+class _Bf16Work:
+    """SUM all-reduce of an fp32 arena THROUGH bf16: half the bytes on the links (xGMI rings are per-link bound: 153 GB/s x 7), fp32
+    again on arrival.  An option of NativeTrainer (`allreduce_dtype="bf16"`), not the default: every rank's addend is rounded to 8
+    bits of mantissa before the sum, which is standard gradient compression but not the reference's arithmetic."""
+
+    def __init__(self, t, async_op):
+        self.t = t
+        self.h = t.detach().to(torch.bfloat16)
+        if _staged(t):
+            self.h = self.h.cpu()
+        self.work = dist.all_reduce(self.h, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.t.copy_(self.h.to(self.t.device, torch.float32))
+
+
 class _StagedWork:
     """all-reduce of a device tensor through a host copy: the copy out waits for the work queued on the current stream (what
     the RCCL collective does on its own stream), ``wait()`` copies the sum back."""
@@ -80,23 +98,27 @@ def reduce_scalar_sum(t):
     return t
 
 
-def allreduce_async(t):
+def allreduce_async(t, dtype=None):
     """Start an in-place SUM all-reduce of `t` (a contiguous slice of the gradient arena) and return its handle
     (``.wait()`` makes the current stream wait for it), or None when there is nothing to exchange.  With the nccl (= RCCL)
     backend the collective first waits for the work already queued on the current stream, then runs on its own stream."""
     if not (dist.is_available() and dist.is_initialized()):
         return None
+    if dtype == "bf16":
+        return _Bf16Work(t, True)
     if _staged(t):
         return _StagedWork(t)
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 
-def allreduce_arena(*arenas):
-    """In-place SUM of flat gradient arenas; one collective per arena (each is one contiguous bucket)."""
+def allreduce_arena(*arenas, dtype=None):
+    """In-place SUM of flat gradient arenas; one collective per arena (each is one contiguous bucket).  dtype="bf16": through bf16."""
     if _active():
         for a in arenas:
             if a is not None:
-                if _staged(a):
+                if dtype == "bf16" and a.numel() > 1:
+                    _Bf16Work(a, False).wait()
+                elif _staged(a):
                     _StagedWork(a).wait()
                 else:
                     dist.all_reduce(a, op=dist.ReduceOp.SUM)

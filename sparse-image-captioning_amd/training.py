@@ -28,7 +28,7 @@ def noam_rate(step, d_model, factor, warmup):
 class NativeTrainer:
     def __init__(self, model, noamopt_factor=1.0, noamopt_warmup=20000, grad_clip=0.1, betas=(0.9, 0.98), eps=1e-9,
                  prune_supermask_lr=100.0, mask_eps=1e-2, sparsity_target=None, sparsity_weight=None, max_train_step=1,
-                 overlap_allreduce=None, keep_grads=False):
+                 overlap_allreduce=None, keep_grads=False, allreduce_dtype=None):
         L.require_gpu()
         self.model = model
         self.dev = model._flat.device
@@ -66,6 +66,9 @@ class NativeTrainer:
             self.sparsity_weight = sparsity_weight if (sparsity_weight is not None and sparsity_weight >= 0) else (
                 max(5.0, 1.5 / (1.0 - sparsity_target)) if sparsity_target is not None else 0.0)
             self.max_train_step = max_train_step
+        # gradient exchange dtype: None = fp32 (the sum the reference's single process computes), "bf16" = half the bytes on the links
+        assert allreduce_dtype in (None, "fp32", "bf16"), allreduce_dtype
+        self.allreduce_dtype = "bf16" if allreduce_dtype == "bf16" else None
         self.world = parallel.world()
         # Data-parallel overlap: the decoder half of the backward finishes first, so its 154 MB of gradients are all-reduced
         # (RCCL, on the collective's own stream) while the encoder half still runs.  Dense models only: the masked variants
@@ -139,7 +142,7 @@ class NativeTrainer:
                 L.check(lib.ortk_backward_phase(C.byref(m._ccfg), pptr, L.ptr(self.grads), C.byref(batch), L.ptr(ws), ws.numel(),
                                                 int(train), seed, phase, L.stream_ptr()), "ortk_backward_phase")
                 if phase == 1 and self.overlap:      # the collective waits for the work queued so far, then runs beside phase 2
-                    self._pending = parallel.allreduce_async(self.grads[self._dec_off:])
+                    self._pending = parallel.allreduce_async(self.grads[self._dec_off:], dtype=self.allreduce_dtype)
                 if phase == 1 and after_decoder_half is not None:
                     after_decoder_half()
         else:
@@ -151,12 +154,12 @@ class NativeTrainer:
         # RCCL over xGMI (SUM; every rank's loss is already divided by the GLOBAL norm): one flat 222 MB bucket, or — with the
         # overlap — the decoder half already in flight and the 80 MB encoder half now
         if self.overlap:
-            parallel.allreduce_arena(self.grads[:self._dec_off])
+            parallel.allreduce_arena(self.grads[:self._dec_off], dtype=self.allreduce_dtype)
             if self._pending is not None:
                 self._pending.wait()
                 self._pending = None
             return
-        parallel.allreduce_arena(self.grads, self.dm if (self.masked and self.train_masks) else None)
+        parallel.allreduce_arena(self.grads, self.dm if (self.masked and self.train_masks) else None, dtype=self.allreduce_dtype)
 
     def _adam(self, p, g, m, v, lr, eps, zero=False):
         t = self.step_count

@@ -43,8 +43,13 @@ def _worker(rank, world, port, out_dir):
     pending = parallel.allreduce_async(arena[split:])
     parallel.allreduce_arena(arena[:split], loss_t)
     pending.wait()
+    # the bf16 exchange option (NativeTrainer(allreduce_dtype="bf16")): same sum to 8 bits of mantissa per addend
+    a16 = torch.cat([P[n].grad.reshape(-1) for n in names])
+    p16 = parallel.allreduce_async(a16[split:], dtype="bf16")
+    parallel.allreduce_arena(a16[:split], dtype="bf16")
+    p16.wait()
     if rank == 0:
-        np.savez(os.path.join(out_dir, "dp.npz"), arena=arena.numpy(), loss=loss_t.numpy())
+        np.savez(os.path.join(out_dir, "dp.npz"), arena=arena.numpy(), loss=loss_t.numpy(), arena_bf16=a16.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,6 +70,7 @@ def test_two_rank_data_parallel_equals_full_batch(tmp_path):
     ref = torch.cat([P[n].grad.reshape(-1) for n in sorted(P)]).numpy()
     assert abs(float(got["loss"][0]) - loss.item()) < 1e-5
     np.testing.assert_allclose(got["arena"], ref, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(got["arena_bf16"], ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())       # bf16 addends
 
 
 def test_shard_batch_single_process():

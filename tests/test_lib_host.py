@@ -55,16 +55,18 @@ def test_struct_sizes_match_header():
     prog = r'''
     #include <stdio.h>
     #include "ortk.h"
-    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ortk_config), sizeof(ortk_batch), sizeof(ortk_decode_opts),
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ortk_config), sizeof(ortk_batch), sizeof(ortk_decode_opts),
                            sizeof(ortk_gemm_args), sizeof(ortk_attn_args), sizeof(ortk_sparse_block), sizeof(ortk_sparse_plan),
-                           sizeof(ortk_spmm_args)); return 0; }'''
+                           sizeof(ortk_spmm_args), sizeof(ortk_chain_unit), sizeof(ortk_chain_args), sizeof(ortk_bchain_args),
+                           sizeof(ortk_tuning)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     L = P._lib
     assert [int(x) for x in out] == [C.sizeof(L.Config), C.sizeof(L.Batch), C.sizeof(L.DecodeOpts), C.sizeof(L.GemmArgs),
-                                     C.sizeof(L.AttnArgs), C.sizeof(L.EllBlock), C.sizeof(L.EllPlanStruct), C.sizeof(L.SpmmArgs)]
+                                     C.sizeof(L.AttnArgs), C.sizeof(L.EllBlock), C.sizeof(L.EllPlanStruct), C.sizeof(L.SpmmArgs),
+                                     C.sizeof(L.ChainUnit), C.sizeof(L.ChainArgs), C.sizeof(L.BChainArgs), C.sizeof(L.Tuning)]
 
 
 @pytest.mark.parametrize("cfg", [Cm.TINY_CFG, Cm.FULL_CFG])
