@@ -304,6 +304,8 @@ typedef struct ortk_tuning {
     int32_t side_stream;     /* 1: the executor queues weight gradients and other independent work on a second stream (default) | 0 */
     int32_t row_chain;       /* rows-stationary chains (ortk_row_chain / ortk_row_bchain) in the executor: 0 none (one launch per operator) | 1 forward passes
                                 (default) | 2 + the encoder's backward | 3 + the decoder's backward */
+    int32_t chain_wide;      /* 0 (default) | 1: forward chains run the four-wave 76-row form of the kernel where that saves a round of workgroups
+                                (measured slower: one wave per SIMD does not keep the matrix pipe fed; profiles/r04_row_chains.txt) */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

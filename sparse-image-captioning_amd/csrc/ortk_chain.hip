@@ -360,6 +360,296 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
 #undef CH_UNIT_BEGIN
 }
 
+// ================================================================================================ wide form of the forward chain
+// OPT-IN (ortk_tuning.chain_wide; off by default: measured slower, profiles/r04_row_chains.txt).
+// The kernel above is bound by the weight stream per compute unit, whatever the rows a workgroup holds — but with 8 waves (two per
+// SIMD: 256 registers each) it cannot hold more than 48 rows' accumulators, so 16 640 decoder rows need TWO rounds of workgroups and
+// every compute unit streams the chain's weights twice.  This form runs FOUR waves (one per SIMD: the whole 512-entry register
+// file, accumulators in the AGPR half), each wave owns 128 output columns (8 column tiles) of up to 76 rows (5 row tiles):
+// 16 640 rows = 256 workgroups x 65 rows = ONE round; the decode's 36 864 encoder rows take two rounds instead of three.  Two LDS
+// images (A operand + one FFN hidden chunk, an extra barrier per chunk), rows past the 76th of a tile read the neighbouring image
+// (don't-cares) and are never written.
+constexpr int WMT = 5, WNW = 4, WNT = 8, WCW = 16 * WNT, WRB = 76;
+#ifndef WSPD_
+#define WSPD_ 2
+#endif
+constexpr int WSPD = WSPD_;                 // k-steps of weight fragments in flight per wave (8 KB each)
+constexpr int WKSTEP = WNT * CFRAG;         // uint4 per k-step of one wave
+constexpr int WUNIT = 16 * WKSTEP;          // uint4 per unit of one wave (128 KB)
+constexpr int WIMG = WRB * 1024;            // bytes of an image (76 rows); MFMA tiles cover 80
+constexpr size_t WIDE_LDS = (size_t)WIMG + 80 * 1024 + 2 * (16 * WMT) * WNW * sizeof(float);
+
+struct WRing { uint4 f[WSPD][WNT]; };
+__device__ __forceinline__ void w_ring_start(WRing& r, const uint4* wp, int lane) {
+#pragma unroll
+    for (int s = 0; s < WSPD; ++s)
+#pragma unroll
+        for (int nt = 0; nt < WNT; ++nt) r.f[s][nt] = wp[s * WKSTEP + nt * CFRAG + lane];
+}
+__device__ __forceinline__ void w_unit(f32x4 (&acc)[WMT][WNT], const char* A, const uint4*& wp, WRing& r, int lane) {
+    const int m = lane & 15, kg = lane >> 4;
+#pragma unroll 1
+    for (int it = 0; it < 16 / WSPD; ++it) {
+#pragma unroll
+        for (int s = 0; s < WSPD; ++s) {
+            const int ks = it * WSPD + s;
+            bf16x8 av[WMT];
+#pragma unroll
+            for (int mt = 0; mt < WMT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, 4 * ks + kg));
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, r.f[s][nt]);
+#pragma unroll
+                for (int mt = 0; mt < WMT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[mt], acc[mt][nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt) r.f[s][nt] = wp[(ks + WSPD) * WKSTEP + nt * CFRAG + lane];
+            __builtin_amdgcn_sched_barrier(0);      // the refill is issued HERE (the scheduler otherwise sinks every load to the loop's end)
+        }
+    }
+    wp += WUNIT;
+}
+// an FFN up-projection unit is streamed as TWO half units (8 groups each): group g of half h holds k-steps 2g and 2g + 1 of the
+// wave's column tiles 4h .. 4h + 3 — the hidden chunk's accumulators are 80 registers instead of 160 beside the 160 of the
+// down-projection's running sum
+__device__ __forceinline__ void w_unit_half(f32x4 (&acc)[WMT][4], const char* A, const uint4*& wp, WRing& r, int lane) {
+    const int m = lane & 15, kg = lane >> 4;
+#pragma unroll 1
+    for (int it = 0; it < 8 / WSPD; ++it) {
+#pragma unroll
+        for (int s = 0; s < WSPD; ++s) {
+            const int g = it * WSPD + s;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                bf16x8 av[WMT];
+#pragma unroll
+                for (int mt = 0; mt < WMT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, 4 * (2 * g + k2) + kg));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, r.f[s][4 * k2 + j]);
+#pragma unroll
+                    for (int mt = 0; mt < WMT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[mt], acc[mt][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt) r.f[s][nt] = wp[(g + WSPD) * WKSTEP + nt * CFRAG + lane];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    wp += 8 * WKSTEP;
+}
+__device__ __forceinline__ void w_zero(f32x4 (&a)[WMT][WNT]) {
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) a[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void w_cols(const float* p, int wave, int lane, f32x4 (&v)[WNT]) {
+#pragma unroll
+    for (int nt = 0; nt < WNT; ++nt) v[nt] = *reinterpret_cast<const f32x4*>(p + WCW * wave + 16 * nt + 4 * (lane >> 4));
+}
+
+__global__ __launch_bounds__(256) void row_chain_wide_kernel(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* A0 = smem;
+    char* H0 = smem + WIMG;
+    float* red1 = reinterpret_cast<float*>(smem + WIMG + 80 * 1024);
+    float* red2 = red1 + 16 * WMT * WNW;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = lane0;
+#define CH_FRESH_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
+    const int r0 = blockIdx.x * a.rb;
+    const int nrow = min(a.rb, a.M - r0);
+    const float ik = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thr = ortk_keep_thr(a.drop_p);
+    const bool drop = a.drop_p > 0.f;
+    const uint4* wp = a.wpk + (int64_t)wave * (a.n_units + 1) * WUNIT;
+    WRing ring;
+    w_ring_start(ring, wp, lane);
+
+    // ONE register image of the block's rows: a product's accumulators, then (in place) the fp32 residual rows the LayerNorm reads
+    f32x4 xa[WMT][WNT];
+    auto load_x = [&](const float* src) {
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt) {
+            const int row = 16 * mt + (lane & 15);
+            const int64_t g = r0 + (row < nrow ? row : 0);
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt) xa[mt][nt] = *reinterpret_cast<const f32x4*>(src + g * CD + WCW * wave + 16 * nt + 4 * (lane >> 4));
+        }
+    };
+    // xa = src rows + dropout(xa + bias), stored to dst
+    auto resid = [&](const float* biasp, uint32_t seed, const float* src, float* dst) {
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt) {
+            const int row = 16 * mt + (lane & 15);
+            const uint32_t g = (uint32_t)(r0 + (row < nrow ? row : 0));
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt) {
+                const int col = WCW * wave + 16 * nt + 4 * (lane >> 4);
+                const f32x4 x = *reinterpret_cast<const f32x4*>(src + (int64_t)g * CD + col);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(biasp + col);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = xa[mt][nt][r] + bias[r];
+                if (drop) {
+                    bool kp[4];
+                    ortk_keep4_u32(seed, g * (uint32_t)CD + (uint32_t)col, thr, kp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xa[mt][nt][r] = x[r] + v[r];
+                if (row < nrow) *reinterpret_cast<f32x4*>(dst + (int64_t)g * CD + col) = xa[mt][nt];
+            }
+        }
+    };
+    auto layer_norm = [&](const float* ga, const float* be, __bf16* yout, float* stats) {
+        const int m = lane & 15;
+        float mean[WMT];
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt) {
+            float s = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += xa[mt][nt][r];
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if (lane < 16) red1[(16 * mt + m) * WNW + wave] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * WNW);
+            mean[mt] = ((p0[0] + p0[1]) + (p0[2] + p0[3])) * (1.f / CD);
+            float q = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = xa[mt][nt][r] - mean[mt]; q = __builtin_fmaf(d, d, q); }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (lane < 16) red2[(16 * mt + m) * WNW + wave] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * WNW);
+            const float var = ((p0[0] + p0[1]) + (p0[2] + p0[3])) * (1.f / (CD - 1));
+            const float sd = sqrtf(var);
+            const float rinv = 1.f / (sd + a.eps);
+            const int row = 16 * mt + m;
+            if (stats && wave == 0 && lane < 16 && row < nrow) *reinterpret_cast<float2*>(stats + (int64_t)(r0 + row) * 2) = make_float2(mean[mt], sd);
+#pragma unroll
+            for (int nt = 0; nt < WNT; ++nt) {
+                const int col = WCW * wave + 16 * nt + 4 * (lane >> 4);
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ga + col), b4 = *reinterpret_cast<const f32x4*>(be + col);
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = a4[r] * (xa[mt][nt][r] - mean[mt]) * rinv + b4[r];
+                const uint2 pk = make_uint2(c_pack2(y[0], y[1]), c_pack2(y[2], y[3]));
+                if (row < WRB) *reinterpret_cast<uint2*>(A0 + c_off(row, col >> 3) + ((col >> 2) & 1) * 8) = pk;
+                if (yout && row < nrow) *reinterpret_cast<uint2*>(yout + (int64_t)(r0 + row) * CD + col) = pk;
+            }
+        }
+    };
+    auto project = [&](int n, const float* biasp, __bf16* out, int ld) {
+        for (int i = 0; i < n; ++i) {
+            w_zero(xa);
+            w_unit(xa, A0, wp, ring, lane);
+#pragma unroll
+            for (int mt = 0; mt < WMT; ++mt) {
+                const int row = 16 * mt + (lane & 15);
+#pragma unroll
+                for (int nt = 0; nt < WNT; ++nt) {
+                    const int col = WCW * wave + 16 * nt + 4 * (lane >> 4);
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(biasp + i * CD + col);
+                    if (row < nrow)
+                        *reinterpret_cast<uint2*>(out + (int64_t)(r0 + row) * ld + i * CD + col) =
+                            make_uint2(c_pack2(xa[mt][nt][0] + bias[0], xa[mt][nt][1] + bias[1]), c_pack2(xa[mt][nt][2] + bias[2], xa[mt][nt][3] + bias[3]));
+                }
+            }
+        }
+    };
+
+    const float* xsrc = a.x_in;
+    if (a.a_in) {
+        for (int row = tid >> 6; row < WRB; row += WNW) {
+            const int ch = tid & 63;
+            const int64_t g = r0 + (row < nrow ? row : 0);
+            *reinterpret_cast<uint4*>(A0 + c_off(row, ch)) = *reinterpret_cast<const uint4*>(a.a_in + g * CD + 8 * ch);
+        }
+        __syncthreads();
+        CH_FRESH_LANE();
+        w_zero(xa);
+        w_unit(xa, A0, wp, ring, lane);
+        resid(a.bias_r, a.seed_r, a.x_in, a.x_mid);
+        xsrc = a.x_mid;
+        __syncthreads();
+    } else {
+        load_x(a.x_in);
+    }
+    if (a.g1) {
+        CH_FRESH_LANE();
+        layer_norm(a.g1, a.b1, a.y1, a.st1);
+        __syncthreads();
+        CH_FRESH_LANE();
+        project(a.n1, a.bias_s1, a.out1, a.ld1);
+    }
+    if (a.NC > 0) {
+        CH_FRESH_LANE();
+        w_zero(xa);
+        const uint32_t ffn = (uint32_t)a.NC * CD;
+        for (int c = 0; c < a.NC; ++c) {
+#pragma unroll 1
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 hacc[WMT][4];
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                w_unit_half(hacc, A0, wp, ring, lane);
+                if (c > 0 && hf == 0) __syncthreads();          // every wave is past its reads of the previous hidden chunk
+#pragma unroll
+                for (int mt = 0; mt < WMT; ++mt) {
+                    const int row = 16 * mt + (lane & 15);
+                    const uint32_t g = (uint32_t)(r0 + (row < nrow ? row : 0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = WCW * wave + 64 * hf + 16 * j + 4 * (lane >> 4);
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias_h + c * CD + col);
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(hacc[mt][j][r] + bias[r], 0.f);
+                        if (drop) {
+                            bool kp[4];
+                            ortk_keep4_u32(a.seed_h, g * ffn + (uint32_t)(c * CD + col), thr, kp);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
+                        }
+                        const uint2 pk = make_uint2(c_pack2(v[0], v[1]), c_pack2(v[2], v[3]));
+                        if (row < WRB) *reinterpret_cast<uint2*>(H0 + c_off(row, col >> 3) + ((col >> 2) & 1) * 8) = pk;
+                        if (row < nrow) *reinterpret_cast<uint2*>(a.h + (int64_t)(r0 + row) * ffn + c * CD + col) = pk;
+                    }
+                }
+            }
+            __syncthreads();
+            w_unit(xa, H0, wp, ring, lane);
+        }
+        resid(a.bias_o, a.seed_o, xsrc, a.x_out);
+        __syncthreads();
+    } else if (a.g2) {
+        load_x(xsrc);                        // (not kept across the projections above)
+    }
+    if (a.g2) {
+        CH_FRESH_LANE();
+        layer_norm(a.g2, a.b2, a.y2, a.st2);
+        __syncthreads();
+        CH_FRESH_LANE();
+        project(a.n2, a.bias_s2, a.out2, a.ld2);
+    }
+#undef CH_FRESH_LANE
+}
+
 // ================================================================================================ backward chains
 // The same idea for the backward pass of the row-wise operators (everything between two attention-backward calls except the
 // weight gradients, which reduce over ALL rows and stay GEMMs on the side stream): data gradients through the TRANSPOSED bf16
@@ -585,18 +875,33 @@ __global__ __launch_bounds__(512) void row_bchain_kernel(BChainArgs a) {
 
 // out[(((w NU1 + u) 16 + ks) 4 + nt) 64 + lane] = the 8 bf16 W_u[64 w + 16 nt + (lane & 15)][32 ks + 8 (lane >> 4) ..], NU1 = units + 1
 // (the slack unit behind every wave's stream — the ring's read-ahead — is zero-filled)
+// The wide kernel's stream (form 1): out[(((w NU1 + u) 16 + g) 8 + j) 64 + lane] = W_u[128 w + 16 j + (lane & 15)][32 g + 8 (lane >> 4) ..], four
+// waves; an FFN up-projection unit (form 2) as two half units: group g = 8 h + g8 holds k-steps 2 g8 + (j >> 2) of column tiles 4 h + (j & 3).
+// Same bytes per chain as the 8-wave stream.
 struct PackUnit { int64_t offset, ld; };
+__device__ __forceinline__ int64_t pack_src(int form, int w, int q, int64_t ld) {
+    const int lane = q & 63;
+    int nt, ks, col0;
+    if (form == 0) { nt = (q >> 6) & 3; ks = q >> 8; col0 = 64 * w; }
+    else {
+        const int j = (q >> 6) & 7, g = q >> 9;
+        col0 = 128 * w;
+        if (form == 2) { ks = 2 * (g & 7) + (j >> 2); nt = 4 * (g >> 3) + (j & 3); }
+        else { ks = g; nt = j; }
+    }
+    return (int64_t)(col0 + 16 * nt + (lane & 15)) * ld + 32 * ks + 8 * (lane >> 4);
+}
 __global__ __launch_bounds__(256) void chain_pack_kernel(const __bf16* __restrict__ w16, uint4* __restrict__ out, const PackUnit* __restrict__ units,
-                                                         int n_units) {
-    const int64_t per_wave = (int64_t)(n_units + 1) * CUNIT, total = 8 * per_wave;
+                                                         int n_units, int wide, int n_r, int n1, int NC) {
+    const int64_t usz = wide ? WUNIT : CUNIT;
+    const int64_t per_wave = (int64_t)(n_units + 1) * usz, total = (wide ? 4 : 8) * per_wave;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int w = (int)(i / per_wave);
         const int64_t rest = i - (int64_t)w * per_wave;
-        const int u = (int)(rest / CUNIT), q = (int)(rest % CUNIT);
+        const int u = (int)(rest / usz), q = (int)(rest % usz);
         if (u >= n_units) { out[i] = make_uint4(0, 0, 0, 0); continue; }
-        const int lane = q & 63, nt = (q >> 6) & 3, ks = q >> 8;
         const PackUnit pu = units[u];
-        out[i] = *reinterpret_cast<const uint4*>(w16 + pu.offset + (int64_t)(64 * w + 16 * nt + (lane & 15)) * pu.ld + 32 * ks + 8 * (lane >> 4));
+        out[i] = *reinterpret_cast<const uint4*>(w16 + pu.offset + pack_src(chain_unit_form(wide != 0, u, n_r, n1, NC), w, q, pu.ld));
     }
 }
 
@@ -610,15 +915,15 @@ __global__ __launch_bounds__(256) void chain_pack_all_kernel(const __bf16* __res
             rest -= sz;
         }
         const int n = t.first[c + 1] - t.first[c];
-        const int64_t per_wave = (int64_t)(n + 1) * CUNIT;
+        const int64_t usz = t.form[t.first[c]] ? WUNIT : CUNIT;              // a chain is wide or not as a whole
+        const int64_t per_wave = (int64_t)(n + 1) * usz;
         const int w = (int)(rest / per_wave);
         const int64_t r2 = rest - (int64_t)w * per_wave;
-        const int u = (int)(r2 / CUNIT), q = (int)(r2 % CUNIT);
+        const int u = (int)(r2 / usz), q = (int)(r2 % usz);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (u < n) {
-            const int lane = q & 63, nt = (q >> 6) & 3, ks = q >> 8;
             const auto pu = t.u[t.first[c] + u];
-            v = *reinterpret_cast<const uint4*>(w16 + (int64_t)pu.offset + (int64_t)(64 * w + 16 * nt + (lane & 15)) * pu.ld + 32 * ks + 8 * (lane >> 4));
+            v = *reinterpret_cast<const uint4*>(w16 + (int64_t)pu.offset + pack_src(t.form[t.first[c] + u], w, q, pu.ld));
         }
         out[t.base[c] + rest] = v;
     }
@@ -637,11 +942,17 @@ int chain_rows_per_block(int64_t M, int slots) {
     return (int)std::min<int64_t>(CRB, std::max<int64_t>(rb, 1));
 }
 
-int chain_pack(const void* w16, const ortk_chain_unit* units_dev, int n_units, void* packed, hipStream_t s) {
+bool chain_wide(int64_t M) {
+    if (!tuning().chain_wide) return false;
+    return ortk_cdiv(ortk_cdiv(M, (int64_t)WRB), 256) < ortk_cdiv(ortk_cdiv(M, (int64_t)CRB), 256);
+}
+
+int chain_pack(const void* w16, const ortk_chain_unit* units_dev, int n_units, void* packed, hipStream_t s, bool wide, int n_r, int n1, int NC) {
     if (!w16 || !units_dev || n_units < 1 || !packed) return ORTK_EINVAL;
     static_assert(sizeof(PackUnit) == sizeof(ortk_chain_unit), "unit descriptor");
+    static_assert(WUNIT == 2 * CUNIT, "both streams take the same bytes per unit");
     hipLaunchKernelGGL(chain_pack_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const __bf16*>(w16), reinterpret_cast<uint4*>(packed),
-                       reinterpret_cast<const PackUnit*>(units_dev), n_units);
+                       reinterpret_cast<const PackUnit*>(units_dev), n_units, wide ? 1 : 0, n_r, n1, NC);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
@@ -677,17 +988,20 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
     {
         std::lock_guard<std::mutex> g(mu);
         if (!done[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS);
             if (e != hipSuccess) return (int)e;
             done[dev] = true;
         }
     }
+    const bool wide = !p->progress && chain_wide(p->M);      // (the caller packed the stream for the same rule)
     ChainArgs a;
     a.wpk = reinterpret_cast<const uint4*>(packed); a.n_units = n_units;
     // with a progress array the grid starts with 8 L2 prefetcher workgroups (one per XCD): 248 compute workgroups per round
     a.progress = p->progress; a.npf = p->progress ? 8 : 0; a.slots = 256 - a.npf;
     if (p->progress && hipMemsetAsync(p->progress, 0, 16 * sizeof(int32_t), s) != hipSuccess) return ORTK_EINVAL;
     a.M = (int)p->M; a.rb = chain_rows_per_block(p->M, a.slots);
+    if (wide) a.rb = (int)std::min<int64_t>(WRB, ortk_cdiv(p->M, ortk_cdiv(ortk_cdiv(p->M, (int64_t)WRB), 256) * 256));
     a.x_in = p->x_in;
     a.a_in = reinterpret_cast<const __bf16*>(p->a_in); a.bias_r = p->bias_r; a.x_mid = p->x_mid; a.seed_r = p->seed_r;
     a.g1 = p->g1; a.b1 = p->b1; a.y1 = reinterpret_cast<__bf16*>(p->y1); a.st1 = p->st1;
@@ -705,7 +1019,8 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
                             (p->NC ? p->NC * 1024.0 + 2048 + 2048 : 0) + (p->g2 ? (p->y2 ? 1024 : 0) + 8 : 0) + p->n2 * 1024.0;
         (void)prof_begin(PROF_KEY_CHAIN, 2.0 * p->M * n_units * CD * CD, (double)n_units * CD * CD * 2 + rowb * p->M, s, pm);
     } else pm.live = false;
-    hipLaunchKernelGGL(row_chain_kernel, dim3(grid), dim3(512), CHAIN_LDS, s, a);
+    if (wide) hipLaunchKernelGGL(row_chain_wide_kernel, dim3(grid), dim3(256), WIDE_LDS, s, a);
+    else hipLaunchKernelGGL(row_chain_kernel, dim3(grid), dim3(512), CHAIN_LDS, s, a);
     prof_end(pm, s);
     ORTK_CHECK_LAUNCH();
     return 0;
@@ -770,6 +1085,7 @@ extern "C" size_t ortk_chain_packed_bytes(int32_t n_units) { return n_units < 1 
 extern "C" int ortk_row_chain(const ortk_chain_args* p, ortk_stream stream) {
     if (!p || !p->w16 || !p->units_dev || !p->packed || p->packed_bytes < ortk::chain_packed_bytes(p->n_units)) return ORTK_EINVAL;
     hipStream_t s = ortk_s(stream);
-    if (int e = ortk::chain_pack(p->w16, p->units_dev, p->n_units, p->packed, s)) return e;
+    const bool wide = !p->progress && ortk::chain_wide(p->M);
+    if (int e = ortk::chain_pack(p->w16, p->units_dev, p->n_units, p->packed, s, wide, p->a_in ? 1 : 0, p->n1, p->NC)) return e;
     return ortk::chain_run(p, p->packed, s);
 }

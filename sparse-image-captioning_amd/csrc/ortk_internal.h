@@ -167,13 +167,22 @@ int decode_poison(const int32_t* status, int64_t* seq, float* lp, float* score, 
 // descriptors, stream order) into the streaming layout, and run a chain on a packed stream
 size_t chain_packed_bytes(int n_units);
 int chain_rows_per_block(int64_t M, int slots);
-int chain_pack(const void* w16, const ortk_chain_unit* units_dev, int n_units, void* packed, hipStream_t s);
+int chain_pack(const void* w16, const ortk_chain_unit* units_dev, int n_units, void* packed, hipStream_t s, bool wide = false, int n_r = 0, int n1 = 0, int NC = 0);
 // all chains of a model in ONE launch: chain i = units [first[i], first[i + 1]) of the table, packed stream at uint4 index base[i]
 constexpr int CH_MAX_UNITS = 192, CH_MAX_CHAINS = 24;
 struct ChainPackTable {
     int32_t n_chains; int32_t first[CH_MAX_CHAINS + 1]; int64_t base[CH_MAX_CHAINS];
     struct { int32_t offset, ld; } u[CH_MAX_UNITS];      // element offset of the unit's first output row in the bf16 arena, leading dimension
+    uint8_t form[CH_MAX_UNITS];                          // 0: 8-wave stream | 1: 4-wave (wide) stream | 2: wide, FFN up-projection (two half units)
 };
+// the 76-row form of the forward chain kernel serves M rows in fewer rounds of workgroups than the 48-row form (and is switched on)
+bool chain_wide(int64_t M);
+// form of unit `u` of a forward chain with `n_r` (0 | 1) leading out-projection units, n1 projections behind the first LayerNorm and NC FFN chunks
+__host__ __device__ inline uint8_t chain_unit_form(bool wide, int u, int n_r, int n1, int NC) {
+    if (!wide) return 0;
+    const int k = u - n_r - n1;
+    return (k >= 0 && k < 2 * NC && !(k & 1)) ? 2 : 1;
+}
 int chain_pack_all(const void* w16, void* packed, const ChainPackTable& t, hipStream_t s);
 int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s);
 int bchain_run(const ortk_bchain_args* p, const void* packed, hipStream_t s);

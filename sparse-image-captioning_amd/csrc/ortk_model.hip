@@ -189,7 +189,9 @@ static bool chain_cfg_ok(const ortk_config& c, bool ignore_switch = false) {
     return (ignore_switch || tuning().row_chain) && c.precision == 1 && c.d_model == 512 && c.d_ff % 512 == 0 && c.d_ff / 512 <= 8 && c.n_heads == 8 &&
            c.share_att_enc == 0 && c.share_att_dec == 0 && c.n_layers <= 6;
 }
-static void chain_layout(const ortk_config& c, const Offsets& o, bool enc, bool dec, ChainSet& cs, bool sizing = false) {
+// Me / Md: the rows the encoder's / the decoder's chains will run on (they pick the 48- or the 76-row form of the kernel, and with it the
+// streaming order of the units: ortk::chain_wide)
+static void chain_layout(const ortk_config& c, const Offsets& o, bool enc, bool dec, ChainSet& cs, int64_t Me, int64_t Md, bool sizing = false) {
     cs.on = chain_cfg_ok(c);
     cs.bytes = 0;
     if (!cs.on && !(sizing && chain_cfg_ok(c, true))) return;
@@ -198,30 +200,34 @@ static void chain_layout(const ortk_config& c, const Offsets& o, bool enc, bool 
     t.n_chains = 0; t.first[0] = 0;
     int nu = 0;
     int64_t base = 0;
-    auto unit = [&](int64_t off, int ld) { t.u[nu].offset = (int32_t)off; t.u[nu].ld = ld; ++nu; };
-    auto close = [&]() {
+    auto unit = [&](int64_t off, int ld) { t.u[nu].offset = (int32_t)off; t.u[nu].ld = ld; t.form[nu] = 0; ++nu; };
+    // n_r / n1 / nc: the chain's shape (ortk_chain_args), which fixes the form of each of its units
+    auto close = [&](bool wide, int n_r, int n1, int nc) {
         const int c_ = t.n_chains++;
         t.base[c_] = base; t.first[c_ + 1] = nu;
-        base += (int64_t)8 * (nu - t.first[c_] + 1) * 16 * 256;           // uint4 per wave and unit: 16 k-steps x 4 tiles x 64 lanes
+        for (int u = t.first[c_]; u < nu; ++u) t.form[u] = chain_unit_form(wide, u - t.first[c_], n_r, n1, nc);
+        base += (int64_t)8 * (nu - t.first[c_] + 1) * 16 * 256;           // uint4 per unit (+ one of slack): 16 k-steps x 32 column tiles x 64 lanes
         return c_;
     };
     auto qkv = [&](int64_t w) { for (int i = 0; i < 3; ++i) unit(w + (int64_t)i * 512 * 512, 512); };
     auto ffn = [&](int64_t w1, int64_t w2) { for (int k = 0; k < NC; ++k) { unit(w1 + (int64_t)k * 512 * 512, 512); unit(w2 + (int64_t)k * 512, ff); } };
     if (enc) {
-        qkv(o.enc[0].wqkv); cs.e0 = close();
+        const bool wide = Me > 0 && chain_wide(Me);
+        qkv(o.enc[0].wqkv); cs.e0 = close(wide, 0, 3, 0);
         for (int l = 0; l < L; ++l) {
             unit(o.enc[l].wo, 512); ffn(o.enc[l].w1, o.enc[l].w2);
             if (l + 1 < L) qkv(o.enc[l + 1].wqkv);
-            cs.eb[l] = close();
+            cs.eb[l] = close(wide, 1, 0, NC);
         }
     }
     if (dec) {
-        qkv(o.dec[0].wqkv); cs.d0 = close();
+        const bool wide = Md > 0 && chain_wide(Md);
+        qkv(o.dec[0].wqkv); cs.d0 = close(wide, 0, 3, 0);
         for (int l = 0; l < L; ++l) {
-            unit(o.dec[l].wo, 512); unit(o.dec[l].cqw, 512); cs.db[l] = close();
+            unit(o.dec[l].wo, 512); unit(o.dec[l].cqw, 512); cs.db[l] = close(wide, 1, 1, 0);
             unit(o.dec[l].cow, 512); ffn(o.dec[l].w1, o.dec[l].w2);
             if (l + 1 < L) qkv(o.dec[l + 1].wqkv);
-            cs.dc[l] = close();
+            cs.dc[l] = close(wide, 1, 0, NC);
         }
     }
     cs.bytes = (size_t)base * 16;
@@ -236,7 +242,7 @@ static void bchain_layout(const ortk_config& c, const Offsets& o, ChainSet& cs, 
     t.n_chains = 0; t.first[0] = 0;
     int nu = 0;
     int64_t base = 0;
-    auto unit = [&](int64_t off, int ld) { t.u[nu].offset = (int32_t)off; t.u[nu].ld = ld; ++nu; };
+    auto unit = [&](int64_t off, int ld) { t.u[nu].offset = (int32_t)off; t.u[nu].ld = ld; t.form[nu] = 0; ++nu; };
     auto close = [&]() {
         const int c_ = t.n_chains++;
         t.base[c_] = base; t.first[c_ + 1] = nu;
@@ -351,7 +357,7 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     w.gt = act(Mx * d); w.gt2 = act(Mx * d); w.gt3 = act(Mx * d); w.gqkv = act(Mx * 3 * d); w.gh = act(Mx * ff); w.gkv = act(Me * L * 2 * d);
     w.scalar = b.take<float>(64);
     {   // (sized whatever the tuning switch says: the workspace size is a function of the configuration and the shapes only)
-        ChainSet cs; chain_layout(c, o, true, true, cs, true);
+        ChainSet cs; chain_layout(c, o, true, true, cs, 0, 0, true);
         if (cs.bytes) w.chain_pk = b.take_bytes(cs.bytes);
         ChainSet bs; bchain_layout(c, o, bs, true);
         if (bs.bytes) { w.chain_pk_b = b.take_bytes(bs.bytes); w.gh2 = act(Mx * ff); }
@@ -734,7 +740,7 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 0};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
@@ -869,7 +875,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     const bool compact = batch_compact(bt);
     if (compact && (logp_out || !w.qdt_self || !w.qdt_cross)) return ORTK_EINVAL;     // fused criterion + bf16-operand attention only
     // rows-stationary chains: their weight units go into streaming order once per forward (phase 2 finds phase 1's image)
-    ChainSet cs; chain_layout(*cfg, o, true, true, cs);
+    ChainSet cs; chain_layout(*cfg, o, true, true, cs, w.Me, batch_compact(bt) ? bt->Mc : w.Md);
     if (cs.on && (!w.chain_pk || c.ell_f)) cs.on = false;
     const bool dchains = cs.on && w.qdt_self == ORTK_BF16 && w.qdt_cross == ORTK_BF16 && A == ORTK_BF16;
     if (cs.on && phase != 2) TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.s));
@@ -1508,7 +1514,7 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
     {
-        ChainSet cs; chain_layout(c, o, true, false, cs, true);
+        ChainSet cs; chain_layout(c, o, true, false, cs, 0, 0, true);
         if (cs.bytes) w.chain_pk = b.take_bytes(cs.bytes);
     }
     if (stack && !sstream && tp > 0) {
@@ -1770,7 +1776,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;
     c.use_side = c.side != nullptr;
     // the encoder's row-wise operators as rows-stationary chains (ortk_chain.hip): bf16 Q|K|V (the buffer is fp32-sized) and memory
-    ChainSet ecs; chain_layout(*cfg, o, true, false, ecs);
+    ChainSet ecs; chain_layout(*cfg, o, true, false, ecs, Me, 0);
     const bool enc_bf16_attn = cfg->precision && attn16_shape_ok(S, S, d / cfg->n_heads);
     if (ecs.on && (!w.chain_pk || op->sparse || !enc_bf16_attn || (op->memory && !greedy_rows))) ecs.on = false;
     if (ecs.on) TRY(chain_pack_all(w.w16, w.chain_pk, ecs.t, s));

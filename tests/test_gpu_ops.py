@@ -891,14 +891,18 @@ def _ln_ref(x, g, b, eps=1e-6):
     return g * (x - mean) / (sd + eps) + b, mean.squeeze(-1), sd.squeeze(-1)
 
 
-@pytest.mark.parametrize("M,p,parts", [(1000, 0.1, "R1SFL2S"), (16640, 0.1, "R1SFL2S"), (9216, 0.0, "R1SFL2S"), (777, 0.1, "1S"),
-                                       (2000, 0.1, "R1S"), (5120, 0.0, "R1F2")])
-def test_row_chain_vs_separate_ops(L, M, p, parts):
+@pytest.mark.parametrize("M,p,parts,pf", [(1000, 0.1, "R1SFL2S", 1), (16640, 0.1, "R1SFL2S", 1), (9216, 0.0, "R1SFL2S", 1), (777, 0.1, "1S", 1),
+                                          (2000, 0.1, "R1S", 0), (5120, 0.0, "R1F2", 1),
+                                          # the 76-row (four-wave) form of the kernel: chosen where it saves a round of workgroups
+                                          (16640, 0.1, "R1SFL2S", 0), (12300, 0.1, "R1SFL2S", 0), (19456, 0.0, "R1F2", 0), (13000, 0.1, "R1S", 0),
+                                          (36864, 0.1, "1S", 0)])
+def test_row_chain_vs_separate_ops(L, M, p, parts, pf):
     """ortk_row_chain (csrc/ortk_chain.hip: the row-wise operators between two attention calls in ONE rows-stationary launch) against
     the same chain in torch fp32 on the bf16-rounded operands, with the kernels' own dropout masks: residual streams within 2e-3
     (fp32 accumulation order), bf16 outputs within one bf16 step, LayerNorm statistics within 1e-4.  Chains: the decoder's
     [Wo -> LN -> W1 .. W2 -> LN -> Wqkv] at 1 000 / 16 640 rows (33-row blocks, two rounds) and 9 216 rows (36-row blocks), a bare
-    [LN -> W] prefix, [Wo -> LN -> Wcq], and a chain that ends in a LayerNorm (the stack's last layer)."""
+    [LN -> W] prefix, [Wo -> LN -> Wcq], and a chain that ends in a LayerNorm (the stack's last layer); the same shapes through the
+    four-wave 76-row form (65-, 49-, 76-, 51- and 72-row blocks: whole and partial row tiles)."""
     d, NC = 512, 4
     ff = NC * d
     hasR, n1, hasF = "R" in parts, (1 if parts in ("R1S",) else 3 if "1S" in parts else 0), "F" in parts
@@ -957,10 +961,14 @@ def test_row_chain_vs_separate_ops(L, M, p, parts):
         a.bias_s2, a.out2, a.ld2 = bs2.data_ptr(), out2.data_ptr(), out2.stride(0)
     a.drop_p, a.eps = p, 1e-6
     prog = torch.zeros(16, dtype=torch.int32, device="cuda")
-    if M != 2000:                        # (one case without the L2 prefetcher workgroups)
+    if pf:                               # with the L2 prefetcher workgroups (always the 48-row form)
         a.progress = prog.data_ptr()
-    L.check(L.lib().ortk_row_chain(C.byref(a), L.stream_ptr()), "ortk_row_chain")
-    torch.cuda.synchronize()
+    L.set_tuning(chain_wide=0 if pf else 1)          # (the 76-row form is opt-in; it is taken where it saves a round: 12 289 .. 19 456 rows, 36 864)
+    try:
+        L.check(L.lib().ortk_row_chain(C.byref(a), L.stream_ptr()), "ortk_row_chain")
+        torch.cuda.synchronize()
+    finally:
+        L.set_tuning(chain_wide=0)
     # ---- reference (fp32 on the GPU, operands rounded to bf16 where the kernel rounds them)
     f = lambda t: t.float().cuda()
     xr = x.clone()
