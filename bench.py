@@ -353,9 +353,9 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         stack = {"kernel": ("decoder_stack_kernel<sparse>" if sstream else "decoder_stack_kernel") if decode else "decoder_stack_tp_kernel",
                  "launches": sn, "avg_us": round(sms * 1e3 / sn, 1), "alg_bytes_per_launch": round(sby / sn), "achieved": round(gbs_k, 1),
                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4), "traffic": st_traffic,
-                 # (the cached K / V rows are counted per beam: beams share ancestors through the ancestry table, so the algorithmic
-                 #  bytes — and `frac` — are an UPPER bound on the unique bytes; `traffic` is what the counters saw)
-                 "kv_rows_counted": "per beam (upper bound)" if decode else "per row"}
+                 # (beam search: the cached K / V rows are the UNIQUE rows each pass references — beams share ancestors through the
+                 #  ancestry table; the beam step counts them on the device, ortk_prof_collect_bytes adds them in)
+                 "kv_rows_counted": "unique" if decode else "per row"}
     chain = None        # rows-stationary chains of the forward pass (key 17): weights streamed out of L2 per workgroup; HBM-side figure
     if per_key[17][0]:
         cn, cms, cfl, cby = per_key[17]

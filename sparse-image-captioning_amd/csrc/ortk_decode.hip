@@ -352,7 +352,16 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
         const int q = idx / (t + 1), u = idx - q * (t + 1);
         const int parent = win_i[q] / V;
         const int64_t srow = t == 0 ? img : row0 + parent;
-        st.kvidx[nxt][(row0 + q) * (t + 2) + u] = st.kvidx[cur][srow * (t + 1) + u];   // ancestors' cache rows
+        const int32_t v = st.kvidx[cur][srow * (t + 1) + u];
+        st.kvidx[nxt][(row0 + q) * (t + 2) + u] = v;                                   // ancestors' cache rows
+        if (st.uniq) {      // measurement only: is this the first of the image's new beams that references cache row v?
+            bool first = true;
+            for (int q2 = 0; q2 < q; ++q2) {
+                const int64_t s2 = t == 0 ? img : row0 + win_i[q2] / V;
+                if (st.kvidx[cur][s2 * (t + 1) + u] == v) first = false;
+            }
+            if (first) atomicAdd(st.uniq, 1ull);
+        }
     }
     __shared__ int end_slot[MAXB];
     if (tid < b) {

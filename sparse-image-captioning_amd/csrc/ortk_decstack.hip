@@ -1635,7 +1635,10 @@ static int stack_launch(const StackArgs& b, bool pf, hipStream_t s) {
 int stack_step(const StackArgs& a, hipStream_t s) {
     if (a.rows < 1 || a.S < 1 || a.S > 128 || a.t < 0 || a.t >= 64 || a.per_img < 1 || a.L < 1 || a.L > STACK_MAXL || a.NC < 1) return ORTK_EINVAL;
     const bool sparse = a.sstream != nullptr;
-    const int rb = (sparse || a.rb == 20) ? 20 : 32;        // (the sparse stream's fragment buffers leave LDS for 20-row images)
+    // (the sparse stream's fragment buffers leave LDS for 20-row images.  Whole-image 30-row blocks — with 5 beams a 32-row block cuts
+    // every third image in two and both workgroups read its projected memory — were measured SLOWER at 1 024 x 5 rows, 18.69 vs 18.50
+    // ms per decode, same tokens: 171 instead of 160 workgroups stream the weights out of the L2s, and that stream is the bound)
+    const int rb = (sparse || a.rb == 20) ? 20 : 32;
     StackArgs b = a;
     b.nblocks = (int)ortk_cdiv(a.rows, rb);
     const bool pf = !sparse && b.nblocks >= 8 && b.nblocks + 8 <= 256 && a.progress != nullptr && !(a.debug & 8);
@@ -1647,9 +1650,13 @@ int stack_step(const StackArgs& a, hipStream_t s) {
     if (ortk_prof_active()) {
         const double U = 6 + 2 * a.NC, imgs = (double)ortk_cdiv(a.rows, a.per_img);
         const double wbytes = U * SD * SD * (sparse ? 0.05 * 4.0 : 2.0);       // (sparse: priced at the 95 % of BASELINE configs[4])
-        const double bytes = a.L * (wbytes + imgs * a.S * 2.0 * SD * 2 + (double)a.rows * (a.t + 1) * 2.0 * SD * 2) +
-                             (double)a.rows * SD * (4 + 2);
+        // cached keys / values: every row's t positions — or, with a counter of the UNIQUE rows the beams of this pass reference
+        // (StackArgs.uniq_slot: beams share ancestors through the ancestry table), that count — plus the appended position per row
+        const bool uq = a.uniq_slot > 0 && a.kvidx;
+        const double cached = uq ? (double)a.rows : (double)a.rows * (a.t + 1);
+        const double bytes = a.L * (wbytes + imgs * a.S * 2.0 * SD * 2 + cached * 2.0 * SD * 2) + (double)a.rows * SD * (4 + 2);
         (void)prof_begin(PROF_KEY_DECSTACK, 2.0 * a.rows * a.L * U * SD * SD, bytes, s, pm);
+        if (uq) { pm.slot = a.uniq_slot - 1; pm.per_count = a.L * 2.0 * SD * 2; }
     } else pm.live = false;
     int rc;
     if (a.tp) {

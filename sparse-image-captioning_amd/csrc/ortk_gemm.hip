@@ -1283,7 +1283,10 @@ template <bool TA, bool TB> gemm16_fn pick16(int adt, int bdt, bool fast) {
 // accumulated per kernel instance (precision, transA, transB).  Disabled by default; the timed region of bench.py
 // never runs with it on.  This is the only process-global state in the library.
 namespace {
-struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; int slot; double per_count; };
+constexpr int PROF_SLOTS = 1 << 16;
+unsigned long long* g_prof_slots = nullptr;      // device counters (ortk::prof_slot)
+int g_prof_slot_next = 0;
 bool g_prof_on = false;
 bool g_prof_serial = false;    // level 1: the executor keeps every launch on the caller's stream (kernels timed in isolation)
 std::mutex g_prof_mu;          // decode chunks may be driven by several host threads
@@ -1305,9 +1308,17 @@ bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m)
 void prof_end(const ProfMark& m, hipStream_t s) {
     if (!m.live) return;
     (void)hipEventRecord(m.b, s);
-    ProfRec rec{m.a, m.b, m.key, m.flops, m.bytes};
+    ProfRec rec{m.a, m.b, m.key, m.flops, m.bytes, m.slot, m.per_count};
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof->push_back(rec);
+}
+unsigned long long* prof_slot(int* index) {
+    if (index) *index = -1;
+    if (!g_prof_on || !g_prof_slots || !index) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_slot_next >= PROF_SLOTS) return nullptr;
+    *index = g_prof_slot_next++;
+    return g_prof_slots + *index;
 }
 }  // namespace ortk
 
@@ -1315,6 +1326,9 @@ extern "C" int ortk_prof_enable(int32_t on) {
     if (!g_prof) g_prof = new std::vector<ProfRec>();
     for (auto& r : *g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof->clear();
+    if (on && !g_prof_slots && hipMalloc(reinterpret_cast<void**>(&g_prof_slots), PROF_SLOTS * sizeof(unsigned long long)) != hipSuccess) g_prof_slots = nullptr;
+    if (on && g_prof_slots && hipMemset(g_prof_slots, 0, PROF_SLOTS * sizeof(unsigned long long)) != hipSuccess) return ORTK_EINVAL;
+    g_prof_slot_next = 0;
     g_prof_on = on != 0;
     g_prof_serial = on == 1;
     return 0;
@@ -1336,7 +1350,17 @@ extern "C" int ortk_prof_collect(int32_t key, int64_t* launches, double* total_m
 extern "C" int ortk_prof_collect_bytes(int32_t key, double* total_bytes) {
     if (!g_prof || !total_bytes) return ORTK_EINVAL;
     *total_bytes = 0;
-    for (auto& r : *g_prof) if (r.key == key) *total_bytes += r.bytes;
+    // (the counters of the slots: the caller has synchronised — ortk_prof_collect waits for every event — and this copy waits as well)
+    std::vector<unsigned long long> slots;
+    if (g_prof_slots && g_prof_slot_next > 0) {
+        slots.resize((size_t)g_prof_slot_next);
+        if (hipMemcpy(slots.data(), g_prof_slots, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ORTK_EINVAL;
+    }
+    for (auto& r : *g_prof) {
+        if (r.key != key) continue;
+        *total_bytes += r.bytes;
+        if (r.slot >= 0 && (size_t)r.slot < slots.size()) *total_bytes += r.per_count * (double)slots[(size_t)r.slot];
+    }
     return 0;
 }
 

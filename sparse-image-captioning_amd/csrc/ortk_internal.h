@@ -16,9 +16,13 @@ bool ortk_prof_serial();
 // the same measurement hook around a launch that is not an ortk_gemm; ortk_prof_collect(key) then reports it
 constexpr int PROF_KEY_DECSTACK = 16;
 constexpr int PROF_KEY_CHAIN = 17;        // row_chain_kernel launches (ortk_chain.hip)
-struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; };
+struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; int slot = -1; double per_count = 0.0; };
 bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m);
 void prof_end(const ProfMark& m, hipStream_t s);
+// A device counter a launch's algorithmic bytes depend on (the beam step counts the UNIQUE cache rows of the next decoder pass into it:
+// beams share ancestors through the ancestry table): ortk_prof_collect_bytes adds ProfMark.per_count x the counter's final value.
+// nullptr (and *index = -1) when profiling is off or the slots are used up.
+unsigned long long* prof_slot(int* index);
 
 // copy the new token's K and V (columns d..3d of the packed QKV row) into the self-attention cache
 int kv_append(const float* qkv, void* cache_k, void* cache_v, int32_t kv_dtype, int64_t rows, int32_t d, int32_t row_mult, int32_t tmax,
@@ -57,6 +61,7 @@ struct BeamState {
     int32_t tmax;             // cache time capacity
     // optional soft-max partials of the logit rows (ortk_gemm_args.tile_stats): {max, sum exp} per block of 64 columns
     const float* gstats; int32_t nblk;
+    unsigned long long* uniq = nullptr;   // measurement only (prof_slot): += the distinct cache rows the images' new beams reference at positions 0..t
 };
 // fused = true: `logp` holds raw logits and the log-soft-max of (logits * scale) is taken inside the step
 int beam_step(const BeamState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false, float scale = 1.f, bool fast_exp = false);
@@ -106,6 +111,7 @@ struct StackArgs {
     float eps;
     int32_t nblocks;               // compute workgroups (set by stack_step); workgroups beyond are L2 prefetchers
     int32_t* progress;             // [16] zeroed at the start of a decode: units begun by the pace-maker of each XCD
+    int32_t uniq_slot;             // measurement only: prof_slot index + 1 of the counter of unique cache rows this pass references (0: none)
     int32_t debug;                 // measurement / test only: 1 skip self-attention, 2 skip cross-attention, 4 skip the FFN, 8 no L2
                                    // prefetchers; column-split form: 16 deal the members of a group over DIFFERENT XCDs (the placement check
                                    // must then pick the write-through exchange), 32 one member of group 0 never arrives (the bounded wait

@@ -1677,7 +1677,7 @@ static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64
 struct SplitBufs { int G; const void* wpk; char* xbuf; int32_t* flag; int groups; int32_t* status; };      // column-split form (G = 0: off)
 static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w, const void* wpk, const SStackBufs* ss, int32_t* progress, int32_t flags,
                               int64_t rows, int per_img, int S, int T, int t, const int32_t* kvidx, const SplitBufs* sp = nullptr,
-                              int greedy_stride = 0, const void* ckv_g = nullptr) {
+                              int greedy_stride = 0, const void* ckv_g = nullptr, int uniq_slot = 0) {
     const ortk_config* cfg = c.cfg;
     const float* P = c.P;
     const int d = cfg->d_model;
@@ -1704,6 +1704,7 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
     a.fa = P + o.dec_na; a.fb = P + o.dec_nb; a.att_masks = w.att_masks; a.kvidx = kvidx; a.ldx = o.ckv_slots * o.cw;
     a.rows = (int)rows; a.per_img = per_img; a.S = S; a.T = T; a.t = t; a.L = cfg->n_layers; a.NC = cfg->d_ff / 512; a.eps = 1e-6f;
     a.debug = (flags >> 8) & 0xFF;       // phase-skipping measurement switches and the exchange tests (StackArgs.debug)
+    a.uniq_slot = uniq_slot;
     if (sp && sp->G) {
         a.tp = sp->G; a.tp_wpk = reinterpret_cast<const uint4*>(sp->wpk); a.tp_xbuf = sp->xbuf; a.tp_flag = sp->flag; a.tp_groups = sp->groups;
         a.tp_status = sp->status;
@@ -1820,6 +1821,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         ss.row_offset = op->sample_row_offset;
         TRY(sample_init(ss, cfg->bos_id, s));
     }
+    int uniq_slot = 0;          // (profiling only) counter of the unique cache rows the NEXT pass references, filled by this pass's beam step
     for (int t = 0; t < T; ++t) {
         // rows of this pass: the first beam pass runs one row per image (transformer.py:488), then b per image
         const bool first_beam = beam && t == 0;
@@ -1832,12 +1834,13 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
         const SplitBufs spb{w.tp, w.tp_wpk, w.tp_xbuf, w.tp_flag, stack_tp_groups(rows_full), w.status};
         if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr, &spb,
-                                          greedy_rows ? K : 0, w.ckv_g));
+                                          greedy_rows ? K : 0, w.ckv_g, uniq_slot));
         else TRY(decoder_step(c, o, sb, rows, B, per_img, row_mult, S, T, t, beam ? w.kvidx[t & 1] : nullptr));
         // first-step log-probs are plain log_softmax; later beam steps re-normalise logp / temperature
         // (transformer.py:488 vs caption_model.py:218); greedy / multinomial never rescale the log-probs themselves.
         const float scale = (beam && t > 0) ? 1.f / op->temperature : 1.f;
         const bool fast_exp = cfg->precision == 1;                     // (the fp32 parity mode keeps libm's expf)
+        if (beam && stack && ortk_prof_active()) { int ix = -1; bs.uniq = prof_slot(&ix); uniq_slot = ix + 1; }
         if (beam) TRY(beam_step(bs, w.logits, t, s, true, scale, fast_exp));     // log-soft-max fused into the candidate scan
         else if (V <= 256 * 40) TRY(sample_step(ss, w.logits, t, s, true, fast_exp));     // log-soft-max fused (scale is 1 on this branch)
         else {

@@ -1848,3 +1848,45 @@ def test_column_split_exchange_placement_check_and_bounded_wait(P, full_state):
         with torch.no_grad():
             s3, l3 = m(**kw, opt=dict(opt, executor="stack_split", check_status=True))
         assert torch.equal(s0, s3) and torch.equal(l0, l3)
+
+
+def test_stack_kernel_algorithmic_bytes_count_unique_cache_rows(P, margin_state):
+    """The decode line's `alg_bytes_per_launch` for the stack kernel (bench.py: key 16 of the HIP-event hook) counts the UNIQUE cache
+    rows a beam-search pass references — the beam step counts them on the device while it re-threads the ancestry table — not one
+    row per beam and position.  Checked exactly where the count is known: captions of at most 2 tokens = two launches, the second
+    one reads the single cache row of each image (all beams descend from the image's first pass); and bounded at the full length:
+    at least one chain of rows per image, at most one per beam."""
+    from sparse_image_captioning_amd import _lib as L
+    import ctypes as Ct
+    n_img, S, b, Lyr, d, NC = 40, 36, 5, 6, 512, 4
+    U = 6 + 2 * NC
+    fixed = lambda rows, imgs: Lyr * (U * d * d * 2.0 + imgs * S * 2.0 * d * 2) + rows * d * 6.0     # weights, projected memory, rows in / out
+    kv = Lyr * 2.0 * d * 2                                                                          # one cached row (K and V) of all layers
+    data = _cuda(H.torch_batch(C.make_inputs(seed=5, n_img=n_img, n_reg=S, feat=2048, vocab=10001, spi=1)))
+
+    def run(T):
+        m = _model(P, "relation_transformer", C.FULL_CFG, margin_state, precision=1, max_seq_length=T)
+        kw = dict(att_feats=data["att_feats"], boxes=data["boxes"], att_masks=data["att_masks"], mode="sample")
+        with torch.no_grad():
+            m(**kw, opt={"beam_size": b, "executor": "stack"})          # (weights packed, workspace sized)
+            L.lib().ortk_prof_enable(2)
+            try:
+                m(**kw, opt={"beam_size": b, "executor": "stack"})
+                torch.cuda.synchronize()
+                n, ms, fl, by = Ct.c_int64(), Ct.c_double(), Ct.c_double(), Ct.c_double()
+                L.check(L.lib().ortk_prof_collect(16, Ct.byref(n), Ct.byref(ms), Ct.byref(fl)), "collect")
+                L.check(L.lib().ortk_prof_collect_bytes(16, Ct.byref(by)), "collect_bytes")
+            finally:
+                L.lib().ortk_prof_enable(0)
+        return n.value, by.value
+
+    n, by = run(2)
+    assert n == 2
+    rows = n_img * b
+    want = (fixed(n_img, n_img) + n_img * kv) + (fixed(rows, n_img) + (n_img + rows) * kv)      # pass 0: append only; pass 1: 1 unique row per image + the appends
+    assert abs(by - want) <= 1e-9 * want, (by, want)
+    n, by = run(18)
+    assert n == 18
+    base = fixed(n_img, n_img) + n_img * kv + 17 * (fixed(rows, n_img) + rows * kv)
+    lo, hi = base + kv * n_img * sum(range(1, 18)), base + kv * (n_img + rows * sum(range(2, 18)))
+    assert lo < by < hi, (lo, by, hi)
