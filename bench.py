@@ -286,7 +286,8 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         model.train()
         tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000,
                            sparsity_target=(1.0 - keep) if workload == "sparse_xe" else None, max_train_step=100000,
-                           overlap_allreduce={"auto": None, "on": True, "off": False}[args.overlap_allreduce])
+                           overlap_allreduce={"auto": None, "on": True, "off": False}[args.overlap_allreduce],
+                           allreduce_dtype=args.allreduce_dtype)
         tr.valid_positions = not args.padded_positions
 
         def step():
@@ -402,7 +403,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
            "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
            "config": {"workload": WORKLOADS[wname], "images_per_gpu": B, "regions": S, "captions_per_image": spi,
-                      "parallelism": f"dp{world}" if world > 1 else "single"},
+                      "parallelism": (f"dp{world}" + ("+bf16-allreduce" if args.allreduce_dtype == "bf16" else "")) if world > 1 else "single"},
            "roofline": roofline}
     del model
     torch.cuda.empty_cache()
@@ -433,6 +434,8 @@ def main():
     ap.add_argument("--workload", default="xe", choices=("xe", "sparse_xe", "scst", "decode", "sparse_decode"))
     ap.add_argument("--variant", default="", help="workload variant: kernels | 988 | 988_kernels (sparse_xe), dense_kernels | 988 | "
                     "988_dense_kernels (sparse_decode), nodrop (scst), fp32 (decode) — see WORKLOADS")
+    ap.add_argument("--allreduce-dtype", default="fp32", choices=("fp32", "bf16"),
+                    help="N > 1: gradient arenas cross xGMI in fp32 (default: the sum is exact up to order) or rounded to bf16 (half the bytes)")
     ap.add_argument("--overlap-allreduce", default="auto", choices=("auto", "on", "off"),
                     help="all-reduce the decoder half of the gradients while the encoder half of the backward runs "
                          "(auto: on when more than one rank)")
