@@ -1379,8 +1379,15 @@ __global__ __launch_bounds__(512) void decoder_stack_tp_kernel(StackArgs a) {
                     }
                     if constexpr (TRAIN) {
                         if (mrow >= 0) {
+                            if (XKT == 4 && (a.S & 3) == 0) {        // (uniform) the batch is one aligned group of four: one hash evaluation
+                                bool kp[4];
+                                ortk_keep4_u32(a.drop_seed[l][2], cbase + b * XKT, thr, kp);
 #pragma unroll
-                            for (int u = 0; u < XKT; ++u) pr[0][u] = ortk_keep_u32(a.drop_seed[l][2], cbase + b * XKT + u, thr) ? pr[0][u] * ik : 0.f;
+                                for (int u = 0; u < XKT; ++u) pr[0][u] = kp[u & 3] ? pr[0][u] * ik : 0.f;
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < XKT; ++u) pr[0][u] = ortk_keep_u32(a.drop_seed[l][2], cbase + b * XKT + u, thr) ? pr[0][u] * ik : 0.f;
+                            }
                         }
                     }
                     st.pv<XKT>(vq, pr);
