@@ -306,6 +306,8 @@ typedef struct ortk_tuning {
                                 (default) | 2 + the encoder's backward | 3 + the decoder's backward */
     int32_t chain_wide;      /* 0 (default) | 1: forward chains run the four-wave 76-row form of the kernel where that saves a round of workgroups
                                 (measured slower: one wave per SIMD does not keep the matrix pipe fed; profiles/r04_row_chains.txt) */
+    int32_t spmm_alias;      /* 1 (default): ELL products with more than 512 input columns and one output range per workgroup keep their output
+                                tile over the staged X planes (two workgroups per compute unit instead of one) | 0 */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

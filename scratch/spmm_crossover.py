@@ -55,7 +55,12 @@ for sp in (0.95, 0.975, 0.988, 0.995):
             a.M, a.N, a.K, a.precision, a.a_dtype, a.b_dtype, a.c_dtype = M, N, K, 1, 1, 1, (0 if len(pieces) > 1 else 1); a.bias = L.ptr(bias)
             f_d = lambda: lib.ortk_gemm(C.byref(a), L.stream_ptr())
             f_build = lambda: ell.build(W16)
-            te, td, tb = t_us([f_ell, f_d, f_build])
+            def f_ell_plain():           # (K > 512: the form with the output tile beside the planes, one workgroup per CU)
+                L.set_tuning(spmm_alias=0)
+                f_ell()
+                L.set_tuning(spmm_alias=1)
+            te, td, tb, tp = t_us([f_ell, f_d, f_build, f_ell_plain] if K > 512 else [f_ell, f_d, f_build])[:4] + ([None] if K <= 512 else [])
             table[f"{sp}/{N}x{K}/{M}"] = (round(te, 1), round(td, 1), round(tb, 1))
-            print(f"sp={sp:5.3f} N={N:6d} K={K:5d} M={M:6d}: ell16 {te:7.1f} us  dense {td:7.1f} us  ell16/dense {te / td:5.2f}  build {tb:6.1f} us", flush=True)
+            print(f"sp={sp:5.3f} N={N:6d} K={K:5d} M={M:6d}: ell16 {te:7.1f} us  dense {td:7.1f} us  ell16/dense {te / td:5.2f}  build {tb:6.1f} us" +
+                  (f"  (tile beside the planes {tp:7.1f} us)" if tp is not None else ""), flush=True)
 print("JSON " + json.dumps(table))

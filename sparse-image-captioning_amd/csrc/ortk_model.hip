@@ -191,6 +191,31 @@ static bool chain_cfg_ok(const ortk_config& c, bool ignore_switch = false) {
 }
 // Me / Md: the rows the encoder's / the decoder's chains will run on (they pick the 48- or the 76-row form of the kernel, and with it the
 // streaming order of the units: ortk::chain_wide)
+// Which forward last built a data-gradient plan's images (the plan's buffers belong to the model, not to a workspace): the forward
+// queues the build beside its own work, the backward rebuilds only when another forward — a second autograd graph, another mask
+// sample — has done so since.  Host-side bookkeeping in call order = stream order on the caller's stream.
+struct BwdPlanOwner { const ortk_sparse_plan* plan; const void* ws; uint64_t seed; int train; };
+static std::mutex g_bwd_owner_mu;
+static BwdPlanOwner g_bwd_owner[8] = {};
+static void bwd_plan_built_by(const ortk_sparse_plan* plan, const void* ws, uint64_t seed, int train) {
+    std::lock_guard<std::mutex> g(g_bwd_owner_mu);
+    int slot = 0;
+    for (int i = 0; i < 8; ++i) { if (g_bwd_owner[i].plan == plan) { slot = i; break; } if (!g_bwd_owner[i].plan) slot = i; }
+    g_bwd_owner[slot] = BwdPlanOwner{plan, ws, seed, train};
+}
+static bool bwd_plan_is_of(const ortk_sparse_plan* plan, const void* ws, uint64_t seed, int train) {
+    std::lock_guard<std::mutex> g(g_bwd_owner_mu);
+    for (const auto& o : g_bwd_owner) if (o.plan == plan) return o.ws == ws && o.seed == seed && o.train == train;
+    return false;
+}
+static bool plan_hits_chain(const ortk_sparse_plan* plan, const ChainSet& cs) {
+    if (!plan || !cs.on) return false;
+    const int nu = cs.t.first[cs.t.n_chains];
+    for (int i = 0; i < plan->nblocks; ++i)
+        for (int u = 0; u < nu; ++u)
+            if (plan->blocks_host[i].src_offset == cs.t.u[u].offset) return true;       // (a block starts where its first unit starts)
+    return false;
+}
 static void chain_layout(const ortk_config& c, const Offsets& o, bool enc, bool dec, ChainSet& cs, int64_t Me, int64_t Md, bool sizing = false) {
     cs.on = chain_cfg_ok(c);
     cs.bytes = 0;
@@ -662,7 +687,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     const float* x = x0;
     const AttMode am = att_mode(cfg.share_att_enc);
     // rows-stationary chains (ortk_chain.hip) in place of the LayerNorm / projection launches: bf16 Q|K|V and memory, dense products
-    const bool chains = cs && cs->on && cs->e0 >= 0 && chain_pk && qdt == ORTK_BF16 && mem_dt == ORTK_BF16 && A == ORTK_BF16 && !c.ell_f;
+    const bool chains = cs && cs->on && cs->e0 >= 0 && chain_pk && qdt == ORTK_BF16 && mem_dt == ORTK_BF16 && A == ORTK_BF16;
     if (chains) {
         ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
         ca.n_units = cs->units(cs->e0); ca.M = Me; ca.x_in = x0;
@@ -740,7 +765,7 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 0};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 0, 1};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
@@ -865,10 +890,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
         }
     }
     // sparse plans are rebuilt from THIS call's effective weights (a new mask sample per step): no stale images
-    if (cfg->sparse_fwd) {
-        if (phase != 2) TRY(ortk_sparse_build(cfg->sparse_fwd, cfg->precision ? (const void*)w.w16 : (const void*)params, cfg->precision ? ORTK_BF16 : ORTK_F32, stream));
-        c.ell_f = cfg->sparse_fwd;
-    }
+    c.ell_f = cfg->sparse_fwd;        // (built below, once it is known who uses it first)
     const float* P = params;
     const int d = cfg->d_model, ff = cfg->d_ff, H = cfg->n_heads, L = cfg->n_layers, dk = d / H, V = cfg->vocab, A = w.adt;
     const int B = bt->B, S = bt->S, R = bt->R, T = bt->T, spi = R / B;
@@ -876,8 +898,24 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     if (compact && (logp_out || !w.qdt_self || !w.qdt_cross)) return ORTK_EINVAL;     // fused criterion + bf16-operand attention only
     // rows-stationary chains: their weight units go into streaming order once per forward (phase 2 finds phase 1's image)
     ChainSet cs; chain_layout(*cfg, o, true, true, cs, w.Me, batch_compact(bt) ? bt->Mc : w.Md);
-    if (cs.on && (!w.chain_pk || c.ell_f)) cs.on = false;
+    // (a sparse forward plan that takes a product of a chain switches the chains off; one over the other products — region embedding,
+    //  K|V projection of the memory, generator — or a data-gradient plan alone leaves them on)
+    if (cs.on && (!w.chain_pk || plan_hits_chain(c.ell_f, cs))) cs.on = false;
     const bool dchains = cs.on && w.qdt_self == ORTK_BF16 && w.qdt_cross == ORTK_BF16 && A == ORTK_BF16;
+    hipEvent_t fplan_done = nullptr;
+    if (cfg->sparse_fwd && phase != 2) {
+        // With the chains on, no product of a layer is in the plan; unless the region embedding is, its first user is the K|V
+        // projection of the memory, after the encoder: the build (0.2 ms) then runs beside the encoder on the side stream.
+        const void* src = cfg->precision ? (const void*)w.w16 : (const void*)params;
+        const int sdt = cfg->precision ? ORTK_BF16 : ORTK_F32;
+        if (cs.on && c.use_side && Ctx::ell_block(c.ell_f, o.att_w, cfg->d_model, cfg->feat) < 0) {
+            TRY(c.fork());                        // (the bf16 weight copy is made on the caller's stream)
+            TRY(ortk_sparse_build(cfg->sparse_fwd, src, sdt, (ortk_stream)c.side->s));
+            TRY(c.side_mark(&fplan_done));
+        } else {
+            TRY(ortk_sparse_build(cfg->sparse_fwd, src, sdt, stream));
+        }
+    }
     if (cs.on && phase != 2) TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.s));
     const int64_t Me = w.Me, Md = compact ? bt->Mc : w.Md;
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
@@ -930,11 +968,24 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
         TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc,
                             box_early ? &box_done : nullptr, &cs, w.chain_pk));
     if (phase == 1) return c.join();       // (the transposed weight copy of the side stream included)
+    TRY(c.wait_ev(fplan_done));
     {
         const Ctx cx = prefix_side ? c.on_side() : c;
         TRY(embed_fwd_rows(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, Md, compact ? bt->row_pos : nullptr, T, 0, d,
                            cfg->pad_id, c.p_drop(), c.sub(OP_EMB), cx.s));
         if (prefix_side) { TRY(self_part(cx, 0, w.dx0)); TRY(c.side_mark(&prefix_done)); }
+    }
+    // the data-gradient plan's images (from this call's transposed weights: this step's mask sample) are built beside the forward
+    // — 0.2 ms the backward used to start with — behind everything the forward waits for on the side stream
+    hipEvent_t bplan_done = nullptr;
+    if (phase != 2 && cfg->precision && cfg->sparse_bwd && w.w16t) {
+        if (c.use_side) {
+            TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, (ortk_stream)c.side->s));
+            TRY(c.side_mark(&bplan_done));
+        } else {
+            TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, stream));
+        }
+        bwd_plan_built_by(cfg->sparse_bwd, ws, seed, train != 0);
     }
     // decoder
     const int U = o.ckv_slots;            // distinct decoder layers: one K|V slice each in the packed projection
@@ -985,6 +1036,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     } else {
         TRY(fwd_gemm(c, w.dec_out, A, d, o.gen_w, P + o.gen_b, w.logits, ORTK_F32, w.ldv, Md, Vp, d));
     }
+    TRY(c.wait_ev(bplan_done));            // (long finished: orders the backward, a later call on this stream, behind the build)
     return 0;
 }
 
@@ -1039,7 +1091,10 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         // Rebuilt HERE from this workspace's transposed bf16 weights (the mask sample of THIS graph's forward): the plan's
         // buffers are shared by every workspace of the model, so another forward (a second autograd graph, another seed) may
         // have rebuilt them since.  Phase 2 of a split backward reuses phase 1's build.
-        if (phase != 2) TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, stream));
+        if (phase != 2 && !bwd_plan_is_of(cfg->sparse_bwd, ws, seed, train != 0)) {
+            TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, stream));
+            bwd_plan_built_by(cfg->sparse_bwd, ws, seed, train != 0);
+        }
         c.ell_b = cfg->sparse_bwd;
     }
     c.side = (c.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(c.s) : nullptr;

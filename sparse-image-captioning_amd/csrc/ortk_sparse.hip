@@ -21,6 +21,7 @@
 //   MFMA GEMM at 95 % (profiles/r02_spmm_*).
 #include <algorithm>
 #include "ortk_common.h"
+#include "ortk_internal.h"
 
 namespace {
 
@@ -117,17 +118,23 @@ __device__ __forceinline__ void fma_entry8(const unsigned char* planes, u32x2 w,
 // NT: threads per workgroup (512 on short grids: one chunk per wave instead of two halves the latency of a workgroup).
 // A workgroup stages its X tile once and then walks `rpw` consecutive 512-column ranges (long grids: the staging and the
 // redundant X reads are shared by up to 4 ranges).
+// ALIAS (one range per workgroup, rpw == 1): the staged output tile lies OVER the planes — every wave keeps the accumulators of its
+// chunks (fixed assignment: chunk w, w + waves, ..) in registers until the whole workgroup is done gathering — so a 2 048-column tile
+// takes 64 KB instead of 97 and two workgroups share a compute unit: one stages its X tile while the other gathers (the wide-input
+// data-gradient products, one workgroup per CU before, were a chain of stage -> gather -> store per compute unit).
 constexpr int MAXRPW = 32;
-template <typename XT, int KT, int NT>
+template <typename XT, int KT, int NT, bool ALIAS>
 __global__ __launch_bounds__(NT) void spmm_ell_kernel(SpmmP p, int rpw, int ngroups) {
     constexpr bool F32 = sizeof(XT) == 4;
     constexpr int RB = F32 ? 8 : 16;
     constexpr int NPAIR = RB / 2;
     constexpr int PB = KT * 16;
+    constexpr int CPW = ALIAS ? (RANGE / 64) / (NT / 64) : 1;      // chunks per wave held in registers
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* planes = smem;
-    float* sOut = reinterpret_cast<float*>(smem + 2 * PB);
-    int* sNext = reinterpret_cast<int*>(sOut + RB * OP);
+    constexpr size_t TILE_B = (size_t)RB * OP * sizeof(float);
+    float* sOut = reinterpret_cast<float*>(smem + (ALIAS ? 0 : 2 * PB));
+    int* sNext = reinterpret_cast<int*>(smem + (ALIAS ? ((size_t)2 * PB > TILE_B ? (size_t)2 * PB : TILE_B) : (size_t)2 * PB + TILE_B));
     const int tid = threadIdx.x, lane = tid & 63;
     const int rg0 = (blockIdx.x % ngroups) * rpw;
     const int64_t m0 = (int64_t)(blockIdx.x / ngroups) * RB;
@@ -183,13 +190,9 @@ __global__ __launch_bounds__(NT) void spmm_ell_kernel(SpmmP p, int rpw, int ngro
         if (rg >= p.nranges) break;
         // ---- lane = output column; chunks of this range are taken longest first
         const int c_begin = rg * (RANGE / 64), c_end = min(p.nchunks, c_begin + RANGE / 64);
-        for (;;) {
-            int c = 0;
-            if (lane == 0) c = atomicAdd(sNext + ri, 1);
-            c = __builtin_amdgcn_readfirstlane(c) + c_begin;
-            if (c >= c_end) break;
+        // acc[r] = the chunk's 64 output columns (lane = column) of row r of the tile
+        auto run_chunk = [&](int c, float (&acc)[RB]) {
             const int len = p.chunk_len[c];
-            float acc[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) acc[r] = 0.f;
             if (len > 0) {
@@ -227,11 +230,37 @@ __global__ __launch_bounds__(NT) void spmm_ell_kernel(SpmmP p, int rpw, int ngro
                     }
                 }
             }
+        };
+        auto put_chunk = [&](int c, const float (&acc)[RB]) {
             const int col = p.perm[c * 64 + lane];
             if (col >= 0) {
                 const int nloc = col - rg * RANGE;
 #pragma unroll
                 for (int r = 0; r < RB; ++r) sOut[r * OP + nloc] = acc[r];
+            }
+        };
+        if constexpr (ALIAS) {
+            float hold[CPW][RB];
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci) {
+                const int c = c_begin + ci * (NT / 64) + (tid >> 6);
+                if (c < c_end) run_chunk(c, hold[ci]);
+            }
+            __syncthreads();                      // every wave is done with the planes the tile overwrites
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci) {
+                const int c = c_begin + ci * (NT / 64) + (tid >> 6);
+                if (c < c_end) put_chunk(c, hold[ci]);
+            }
+        } else {
+            for (;;) {
+                int c = 0;
+                if (lane == 0) c = atomicAdd(sNext + ri, 1);
+                c = __builtin_amdgcn_readfirstlane(c) + c_begin;
+                if (c >= c_end) break;
+                float acc[RB];
+                run_chunk(c, acc);
+                put_chunk(c, acc);
             }
         }
         __syncthreads();
@@ -764,11 +793,15 @@ bool plan_ok(const ortk_sparse_plan* p) {
 template <typename XT, int KT>
 int launch_spmm(const SpmmP& p, hipStream_t s) {
     constexpr int RB = sizeof(XT) == 4 ? 8 : 16;
-    const size_t lds = (size_t)2 * KT * 16 + (size_t)RB * OP * sizeof(float) + MAXRPW * sizeof(int);
+    const size_t tile_b = (size_t)RB * OP * sizeof(float);
+    const size_t lds = (size_t)2 * KT * 16 + tile_b + MAXRPW * sizeof(int);
+    const size_t lds_alias = std::max((size_t)2 * KT * 16, tile_b) + MAXRPW * sizeof(int);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alias);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alias);
         attr = true;
     }
     const int64_t tiles = ortk_cdiv(p.a.M, RB);
@@ -776,8 +809,17 @@ int launch_spmm(const SpmmP& p, hipStream_t s) {
     const int rpw = tiles * p.nranges > 2048 ? std::min(4, p.nranges) : 1;
     const int ngroups = (int)ortk_cdiv(p.nranges, rpw);
     const dim3 grid((unsigned)(tiles * ngroups));
-    if (tiles * ngroups <= 640) hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 512>), grid, dim3(512), lds, s, p, rpw, ngroups);
-    else hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 256>), grid, dim3(256), lds, s, p, rpw, ngroups);
+    // one range per workgroup: the output tile over the planes (wide inputs: two workgroups per compute unit instead of one)
+    // (wide inputs only: with 512 input columns the planes are 16 KB, three workgroups share a CU either way, and the held tile measured
+    //  no faster)
+    const bool alias = rpw == 1 && KT > 512 && ortk::tuning().spmm_alias != 0;
+    if (tiles * ngroups <= 640) {
+        if (alias) hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 512, true>), grid, dim3(512), lds_alias, s, p, rpw, ngroups);
+        else hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 512, false>), grid, dim3(512), lds, s, p, rpw, ngroups);
+    } else {
+        if (alias) hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 256, true>), grid, dim3(256), lds_alias, s, p, rpw, ngroups);
+        else hipLaunchKernelGGL((spmm_ell_kernel<XT, KT, 256, false>), grid, dim3(256), lds, s, p, rpw, ngroups);
+    }
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -138,11 +138,11 @@ def capacity_for(N, K, max_density):
 # (N, K) of the weight, data-gradient blocks (K, N) of its transpose.  1.01 = never measured faster (up to 99.5 % zeros).
 # At 95 % zeros no shape pays (0.65-0.93x of the dense GEMM's speed); at the reference's published 98.8 % models most do.
 CROSSOVER = {
-    "enc": {(512, 2048): 0.98, (512, 512): 0.975, (1536, 512): 0.988, (2048, 512): 0.975, (6144, 512): 0.985,
-            (512, 1536): 0.98, (512, 6144): 0.99},
-    "dec": {(512, 512): 0.975, (1536, 512): 0.985, (2048, 512): 0.985, (512, 2048): 0.995, (10112, 512): 0.975,
-            (512, 1536): 0.995},
-    "decode": {(512, 512): 0.995, (1536, 512): 0.988, (2048, 512): 0.985, (512, 2048): 0.995, (10112, 512): 0.98, (6144, 512): 0.985},
+    "enc": {(512, 2048): 0.975, (512, 512): 0.975, (1536, 512): 0.988, (2048, 512): 0.975, (6144, 512): 0.98,
+            (512, 1536): 0.975, (512, 6144): 0.98},
+    "dec": {(512, 512): 0.975, (1536, 512): 0.985, (2048, 512): 0.98, (512, 2048): 0.985, (10112, 512): 0.975,
+            (512, 1536): 0.975},
+    "decode": {(512, 512): 0.99, (1536, 512): 0.985, (2048, 512): 0.985, (512, 2048): 0.995, (10112, 512): 0.975, (6144, 512): 0.98},
 }
 DEFAULT_CROSSOVER = 0.99
 
@@ -151,19 +151,33 @@ def crossover(N, K, cls):
     return CROSSOVER[cls].get((N, K), DEFAULT_CROSSOVER)
 
 
-def select_blocks(ccfg, eff, min_sparsity, train=False):
+def chains_serve(ccfg, precision):
+    """Whether the executor's forward pass runs the row-wise operators of the layers as rows-stationary chains — dense products on
+    the zero-filled weights, one launch per chain (csrc/ortk_model.hip: chain_cfg_ok)."""
+    t = L.Tuning()
+    L.lib().ortk_get_tuning(C.byref(t))
+    return (bool(precision) and t.row_chain >= 1 and ccfg.d_model == 512 and ccfg.d_ff % 512 == 0 and ccfg.d_ff // 512 <= 8 and
+            ccfg.n_heads == 8 and not ccfg.share_att_enc and not ccfg.share_att_dec and ccfg.n_layers <= 6)
+
+
+def select_blocks(ccfg, eff, min_sparsity, train=False, precision=0):
     """Blocks of the arena ``eff`` whose fraction of zeros is >= ``min_sparsity`` — or, with ``"auto"``, those whose forward
-    (``fwd``) / data-gradient (``bwd``) product is past the measured crossover of its shape and row class (host syncs: one-off)."""
+    (``fwd``) / data-gradient (``bwd``) product is past the measured crossover of its shape and row class (host syncs: one-off).
+    Training with ``"auto"``: the products inside the layers stay with the forward chains where those run (one launch per chain
+    beats per-operator sparse products: 12.6 vs 13.1 ms per step at 98.8 %); their data gradients still go sparse where that pays."""
     dec_off = int(L.lib().ortk_arena_decoder_offset(C.byref(ccfg)))
+    blocks = linear_blocks(ccfg)
+    chains = train and min_sparsity == "auto" and chains_serve(ccfg, precision)
     out = []
-    for off, N, K in linear_blocks(ccfg):
+    for off, N, K in blocks:
         w = eff[off: off + N * K]
         sparsity = 1.0 - float(torch.count_nonzero(w)) / (N * K)
         if min_sparsity == "auto":
             # (the packed cross-attention K|V projection lives behind the decoder offset but runs over the encoder's rows)
             cls = ("enc" if (off < dec_off or N >= 2 * 1536) and N < 8192 else "dec") if train else "decode"
             # a (512, 10112) data-gradient product is cut into 2 048-input pieces: the (512, 2048) figure of its class
-            fwd = sparsity >= crossover(N, K, cls)
+            # (with the chains: only the K|V projection of the memory and the generator, whose plan is then built beside the encoder)
+            fwd = sparsity >= crossover(N, K, cls) and not (chains and N < 6144)
             bwd = sparsity >= crossover(K, min(N, KMAX), cls)
         else:
             fwd = bwd = sparsity >= min_sparsity
@@ -188,7 +202,7 @@ def make_plans(ccfg, eff, min_sparsity, precision, backward=False, fmt=None, den
     — (K outputs, N inputs), leading dimension N, at the same offsets of the transposed bf16 copy the executor keeps for its
     data-gradient GEMMs (ELL: a block with more than KMAX inputs — the generator: 10 112 — is cut into KMAX-wide pieces that
     the executor accumulates).  The region embedding (block 0) has no input gradient."""
-    sel = select_blocks(ccfg, eff, min_sparsity, train=backward)
+    sel = select_blocks(ccfg, eff, min_sparsity, train=backward, precision=precision)
     if not sel:
         return None, None
     fmt = default_format(precision) if fmt is None else fmt
