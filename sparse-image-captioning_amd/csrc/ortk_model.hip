@@ -1798,14 +1798,21 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     hipStream_t s = ortk_s(stream);
     TRY(fill_i32(w.status, 64, 0, s));
     TRY(make_w16(cfg, o, params, w.w16, stream));
+    // (the bf16 weight copy exists from here on in stream order: what the side stream's builders wait for)
+    SideStream* const side0 = (w.adt == ORTK_BF16 && !ortk_prof_serial()) ? side_for(s) : nullptr;
+    hipEvent_t w16_done = nullptr;
+    if (side0 && stack && sstream) {
+        w16_done = side0->take();
+        if (hipEventRecord(w16_done, s) != hipSuccess) return ORTK_EINVAL;
+    }
+    StackPack tp; tp.L = cfg->n_layers; tp.NC = cfg->d_ff / 512;
+    for (int l = 0; l < cfg->n_layers; ++l) {
+        const DecOff& e = o.dec[l];
+        const int64_t offs[6] = {e.wqkv, e.wo, e.cqw, e.cow, e.w1, e.w2};
+        for (int i = 0; i < 6; ++i) tp.off[l][i] = offs[i];
+    }
     if (stack) {
-        StackPack tp; tp.L = cfg->n_layers; tp.NC = cfg->d_ff / 512;
-        for (int l = 0; l < cfg->n_layers; ++l) {
-            const DecOff& e = o.dec[l];
-            const int64_t offs[6] = {e.wqkv, e.wo, e.cqw, e.cow, e.w1, e.w2};
-            for (int i = 0; i < 6; ++i) tp.off[l][i] = offs[i];
-        }
-        if (sstream) TRY(sstack_pack(w.w16, w.ss, tp, s));
+        if (sstream) { /* the sparse weight stream is built beside the encoder pass, below */ }
         else if (w.tp) {
             TRY(stack_tp_pack(w.w16, w.tp_wpk, tp, w.tp, s));
             TRY(fill_i32(w.tp_flag, (int64_t)stack_tp_groups((int64_t)B * K) * TP_FLAG_STRIDE, 0, s));
@@ -1847,6 +1854,18 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         TRY(fwd_gemm(ce, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv_g, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
     }
     if (!op->memory) TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st, enc_qdt, nullptr, &ecs, w.chain_pk));
+    // the decoder's sparse weight stream (count / scan / fill: 0.37 ms): on the side stream behind the geometry bias, beside the encoder
+    // pass, which does not read it; the first decoder position waits for it
+    hipEvent_t sstream_done = nullptr;
+    if (stack && sstream) {
+        if (c.use_side && w16_done) {
+            if (hipStreamWaitEvent(c.side->s, w16_done, 0) != hipSuccess) return ORTK_EINVAL;     // (NOT a fork: the encoder pass is queued already)
+            TRY(sstack_pack(w.w16, w.ss, tp, c.side->s));
+            TRY(c.side_mark(&sstream_done));
+        } else {
+            TRY(sstack_pack(w.w16, w.ss, tp, s));
+        }
+    }
     c.use_side = false;
     TRY(fwd_gemm(c, op->memory ? op->memory : w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
 
@@ -1877,6 +1896,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         TRY(sample_init(ss, cfg->bos_id, s));
     }
     int uniq_slot = 0;          // (profiling only) counter of the unique cache rows the NEXT pass references, filled by this pass's beam step
+    TRY(c.wait_ev(sstream_done));
     for (int t = 0; t < T; ++t) {
         // rows of this pass: the first beam pass runs one row per image (transformer.py:488), then b per image
         const bool first_beam = beam && t == 0;
