@@ -318,6 +318,7 @@ int ortk_set_tuning(const ortk_tuning* t);
 #define ORTK_DEC_STACK_RB20 8
 #define ORTK_DEC_STACK_SPLIT 16
 #define ORTK_DEC_SPLIT_SMALL 32
+#define ORTK_DEC_SPARSE_GATHER 64
 typedef struct ortk_decode_opts {
     int32_t beam_size;            /* 1 = greedy; >1 = beam search; <1 with num_random_sample > 0 = multinomial */
     int32_t num_random_sample;
@@ -338,6 +339,10 @@ typedef struct ortk_decode_opts {
      *                           linears on zero-filled weights, scripts/eval_model.py:64-88): the stack kernel streams their
      *                           NON-ZEROS (rebuilt on the device from the weights of the call, no host sync; correct at any
      *                           density, faster than the dense stream above ~80 % zeros); implies ORTK_DEC_STACK;
+     *   ORTK_DEC_SPARSE_GATHER  with ORTK_DEC_SPARSE_STREAM: the non-zeros as per-output-column gather lists over transposed operand
+     *                           images instead of scatter entries expanded for the matrix cores — work proportional to the
+     *                           non-zeros (the longest column of each group of 64); pays from ~97 % zeros, the reference's published
+     *                           97.5 / 98.8 / 99.1 % models; same results up to fp32 summation order;
      *   ORTK_DEC_STACK_RB20     dense stream with 20-row workgroups (measurement);
      *   ORTK_DEC_STACK_SPLIT    the column-split form of the stack kernel: groups of 2 / 4 / 8 workgroups of one XCD share 64 rows
      *                           and split every projection's output columns (each streams 1/2 .. 1/8 of the weights; partial

@@ -95,7 +95,7 @@ class Tuning(C.Structure):
                 ("side_stream", C.c_int32), ("row_chain", C.c_int32), ("chain_wide", C.c_int32), ("spmm_alias", C.c_int32)]
 
 
-DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL = 1, 2, 4, 8, 16, 32      # ortk_decode_opts.exec_flags
+DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL, DEC_SPARSE_GATHER = 1, 2, 4, 8, 16, 32, 64      # ortk_decode_opts.exec_flags
 
 
 class DecodeOpts(C.Structure):

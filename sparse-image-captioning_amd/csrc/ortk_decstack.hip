@@ -220,6 +220,98 @@ __device__ __forceinline__ void unit_sparse(f32x4 (&acc)[2][4], const char* A, c
     sp += (int64_t)nst * 64;
 }
 
+// ------------------------------------------------------------------------------------------------ gather form of the sparse unit
+// From ~97 % zeros on (the reference's published 97.5 / 98.8 / 99.1 % models) even the scatter stream above does work that no
+// non-zero asks for: 16 k-steps of 8 MFMAs per unit whatever the density.  Here a unit is a per-COLUMN list product instead (the
+// shape of ortk_sparse.hip's ELL kernel): lane = one of the wave's 64 output columns, its non-zeros arrive in pairs {k1, k2, w1, w2},
+// and the A operand sits in LDS TRANSPOSED — three planes of 8 rows, slot(k) = the 8 rows' bf16 values of input column k — so that
+// one ds_read_b128 per plane fetches a non-zero's operand for 8 rows and one v_dot2_f32_bf16 per row multiplies a pair.  A wave
+// runs as many pairs as its longest column has (padded with zero weights).  The 24 row sums of a lane's column then go through a
+// 2.5-KB per-wave LDS tile into the MFMA accumulator layout the rest of the kernel works in (8 rows per pass).
+constexpr int GPB = SD * 16;                 // bytes of one plane (512 slots of 16 B)
+constexpr int GPL = 3 * GPB;                 // one transposed image: rows 0..23 (24 KB)
+constexpr int GTP = 80;                      // fp32 pitch of the 8-row transposition tile (2-way bank conflicts on the b128 reads at most)
+constexpr int GTB = 8 * GTP * 4;             // bytes of a wave's tile
+__device__ __forceinline__ int g_slot(int k) { return (k & ~7) | (((k & 7) + (k >> 3)) & 7); }      // (spreads a slot's neighbours over the banks)
+struct GRing { uint2 e[4]; };
+__device__ __forceinline__ void gring_start(GRing& r, const uint2* sp, int lane) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r.e[s] = sp[s * 64 + lane];
+}
+struct GRows { uint4 a[3], b[3]; };
+__device__ __forceinline__ void g_gather(const char* P, unsigned int offs, GRows& r) {
+    const unsigned int o1 = offs & 0xFFFFu, o2 = offs >> 16;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        r.a[h] = *reinterpret_cast<const uint4*>(P + h * GPB + o1);
+        r.b[h] = *reinterpret_cast<const uint4*>(P + h * GPB + o2);
+    }
+}
+__device__ __forceinline__ void g_fma(const GRows& r, unsigned int w, float (&g)[24]) {
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const unsigned int ad[4] = {r.a[h].x, r.a[h].y, r.a[h].z, r.a[h].w}, bd[4] = {r.b[h].x, r.b[h].y, r.b[h].z, r.b[h].w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            // dword d of a slot = rows (2d, 2d + 1) of that input column: low halves -> row 2d, high halves -> row 2d + 1
+            g[8 * h + 2 * d] = dot2(__builtin_amdgcn_perm(bd[d], ad[d], 0x05040100u), w, g[8 * h + 2 * d]);
+            g[8 * h + 2 * d + 1] = dot2(__builtin_amdgcn_perm(bd[d], ad[d], 0x07060302u), w, g[8 * h + 2 * d + 1]);
+        }
+    }
+}
+// acc += A . W_u^T for the wave's 64 columns; np pairs (a multiple of 4) of this (wave, unit); P = the transposed A image; T = the wave's tile
+__device__ __forceinline__ void unit_gather(f32x4 (&acc)[2][4], const char* P, char* T, const uint2*& sp, int np, GRing& E, int lane) {
+    float g[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) g[i] = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < np; j += 4) {
+        GRows r0, r1;
+        g_gather(P, E.e[0].x, r0);
+        g_gather(P, E.e[1].x, r1);
+        g_fma(r0, E.e[0].y, g); E.e[0] = sp[(j + 4) * 64 + lane];
+        g_gather(P, E.e[2].x, r0);
+        g_fma(r1, E.e[1].y, g); E.e[1] = sp[(j + 5) * 64 + lane];
+        g_gather(P, E.e[3].x, r1);
+        g_fma(r0, E.e[2].y, g); E.e[2] = sp[(j + 6) * 64 + lane];
+        g_fma(r1, E.e[3].y, g); E.e[3] = sp[(j + 7) * 64 + lane];     // (past the unit: the next unit's pairs; past the stream: zeroed slack)
+    }
+    sp += (int64_t)np * 64;
+    const int m = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float*>(T + (i * GTP + lane) * 4) = g[8 * p + i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the wave's LDS writes have landed (one wave owns T)
+        __builtin_amdgcn_wave_barrier();
+        const int rl = m - 8 * (p & 1);
+        if (rl >= 0 && rl < 8) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[p >> 1][nt] += *reinterpret_cast<const f32x4*>(T + (rl * GTP + 16 * nt + 4 * q4) * 4);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// the transposed form of an A image (all 512 threads, thread = input column k; rows RB.. are zeros)
+template <int RB>
+__device__ __forceinline__ void build_planes(const char* img, char* P, int tid) {
+    const int k = tid;
+    const char* src = img + (k & 7) * 2;
+    char* dst = P + g_slot(k) * 16;
+    // (one plane at a time: 8 values live instead of 24 — unrolled over the planes the compiler spilled 16 registers around every call)
+#pragma unroll 1
+    for (int h = 0; h < 3; ++h) {
+        unsigned int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * h + i;
+            v[i] = r < RB ? (unsigned int)*reinterpret_cast<const unsigned short*>(src + img_off(r, k >> 3)) : 0u;
+        }
+        *reinterpret_cast<uint4*>(dst + h * GPB) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+}
+
 __device__ __forceinline__ void zero(f32x4 (&a)[2][4]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -391,8 +483,10 @@ struct AttState {
 // sparse stream uses: its cost per workgroup no longer depends on L2 bandwidth shared with the others, so more, smaller
 // workgroups only shorten the attention phases).  Rows RB .. 31 of the two MFMA row tiles do not exist: their operand reads
 // land in whatever follows the image in LDS, their accumulators are never stored.
-template <bool SPARSE, int RB>
+// GATHER (with SPARSE, RB <= 24): the units as per-column gather lists over transposed A images (above) instead of the scatter stream.
+template <bool SPARSE, int RB, bool GATHER = false>
 __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
+    static_assert(!GATHER || (SPARSE && RB <= 24), "gather form: sparse stream, at most 24 rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IMG = RB * SD * 2;  // bytes of one bf16 A image
     char* A0 = smem;                  // LayerNorm output / attention output: the A operand of the next projection
@@ -452,7 +546,17 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
     char* D = smem + 4 * IMG + 2 * 32 * 8 * 4 + wave * SDBUF;      // this wave's fragment buffer
     SRing E;
     uint4 F[2][4];
-    if constexpr (SPARSE) {
+    // gather form: transposed images of A0 (PA) and of the FFN hidden chunk (PH), the wave's transposition tile, the pair ring
+    char* PA = smem + 4 * IMG + 2 * 32 * 8 * 4;
+    char* PH = PA + GPL;
+    char* GT = PH + GPL + wave * GTB;
+    GRing GE;
+    if constexpr (GATHER) {
+        auto uni64 = [](uint64_t v) { return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        nstp = (cint_ptr)(uintptr_t)uni64((uint64_t)(uintptr_t)(a.snst + wave * a.L * U));
+        sp = a.sstream + (int64_t)a.sstart[wave] * 64;
+        gring_start(GE, sp, lane);
+    } else if constexpr (SPARSE) {
         auto uni64 = [](uint64_t v) { return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
         nstp = (cint_ptr)(uintptr_t)uni64((uint64_t)(uintptr_t)(a.snst + wave * a.L * U));
         sp = a.sstream + (int64_t)a.sstart[wave] * 64;
@@ -469,11 +573,15 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
 #define STACK_UNIT(ACC, AIMG, NEXT)                                                                    \
     do {                                                                                               \
         STACK_UNIT_BEGIN();                                                                            \
-        if constexpr (SPARSE) { const int nst_ = *nstp++; unit_sparse<NEXT>(ACC, AIMG, D, sp, nst_, E, F, lane); } \
+        if constexpr (GATHER) { const int np_ = *nstp++; unit_gather(ACC, (AIMG) == A0 ? PA : PH, GT, sp, np_, GE, lane); } \
+        else if constexpr (SPARSE) { const int nst_ = *nstp++; unit_sparse<NEXT>(ACC, AIMG, D, sp, nst_, E, F, lane); } \
         else unit_gemm<NEXT>(ACC, AIMG, wp, ring, lane);                                               \
     } while (0)
 #define STACK_RESTART()                                                                                \
-    do { if constexpr (SPARSE) s_unit_cold(D, E, F, lane); else ring_start(ring, wp, lane); } while (0)
+    do { if constexpr (GATHER) gring_start(GE, sp, lane); else if constexpr (SPARSE) s_unit_cold(D, E, F, lane); else ring_start(ring, wp, lane); } while (0)
+// gather form: a freshly published A image (behind the barrier that publishes it) gets its transposed planes
+#define STACK_PUBLISH(AIMG)                                                                            \
+    do { if constexpr (GATHER) { build_planes<RB>(AIMG, (AIMG) == A0 ? PA : PH, tid); __syncthreads(); } } while (0)
 
 #define STACK_SYNC() __syncthreads()
     for (int l = 0; l < a.L; ++l) {
@@ -484,6 +592,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         layer_norm<false>(x, P.n0a, P.n0b, a.eps, red1, red2, wave, lane, y);
         store_img_plain<RB>(A0, y, wave, lane);
         STACK_SYNC();
+        STACK_PUBLISH(A0);
         // ---- packed QKV: three units -> q (A1), k (KN), v (VN)
         STACK_FRESH_LANE();
         load_cols(P.bqkv, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, true); store_img<RB>(A1, acc, bias, false, wave, lane);
@@ -561,6 +670,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
             }
         }
         STACK_SYNC();
+        STACK_PUBLISH(A0);
         // ---- output projection + residual, LayerNorm 1 -> A0
         STACK_FRESH_LANE();
         STACK_RESTART();
@@ -572,6 +682,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         layer_norm<false>(x, P.n1a, P.n1b, a.eps, red1, red2, wave, lane, y);       // (its barriers: every wave is done reading A0)
         store_img_plain<RB>(A0, y, wave, lane);
         STACK_SYNC();
+        STACK_PUBLISH(A0);
         // ---- cross-attention query -> A1
         STACK_FRESH_LANE();
         load_cols(P.cqb, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, false); store_img<RB>(A1, acc, bias, false, wave, lane);
@@ -622,6 +733,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
             }
         }
         STACK_SYNC();
+        STACK_PUBLISH(A0);
         // ---- output projection + residual, LayerNorm 2 -> A0
         STACK_FRESH_LANE();
         STACK_RESTART();
@@ -633,6 +745,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
         layer_norm<false>(x, P.n2a, P.n2b, a.eps, red1, red2, wave, lane, y);
         store_img_plain<RB>(A0, y, wave, lane);
         STACK_SYNC();
+        STACK_PUBLISH(A0);
         STACK_FRESH_LANE();
         // ---- FFN, 512 hidden units at a time: h_c = relu(y W1_c^T + b1_c) -> LDS, acc2 += h_c W2[:, c]^T
         f32x4 acc2[2][4];
@@ -641,6 +754,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
             char* Hc = (c & 1) ? KN : A1;
             load_cols(P.b1 + c * SD, wave, lane, bias); zero(acc); STACK_UNIT(acc, A0, true); store_img<RB>(Hc, acc, bias, true, wave, lane);
             STACK_SYNC();
+            STACK_PUBLISH(Hc);
             STACK_UNIT(acc2, Hc, true);
         }
         load_cols(P.b2, wave, lane, bias);
@@ -666,6 +780,7 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
 #undef STACK_SYNC
 #undef STACK_UNIT
 #undef STACK_RESTART
+#undef STACK_PUBLISH
 }
 
 // wpk[((((w L + l) U + u) 16 + ks) 4 + nt) 64 + lane] = the 8 bf16 W_u[64 w + 16 nt + (lane & 15)][32 ks + 8 (lane >> 4) ..]
@@ -881,6 +996,106 @@ int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStr
     hipLaunchKernelGGL(sstack_scan_kernel, dim3(1), dim3(64), 0, s, b.cnt, b.nst, b.start, b.stats, LU);
     ORTK_CHECK_LAUNCH();
     hipLaunchKernelGGL(sstack_fill_kernel, dim3(items), dim3(256), 0, s, w, b.cnt, b.nst, b.start, b.stream, t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ gather-list builder
+// Stream of the gather form: per wave, per unit, np pair rows of 64 lanes x {off1 | off2 << 16, w1 | w2 << 16}: lane = output column
+// 64 w + lane of the unit, its non-zeros in input order, two per row, off = byte offset of the input column's slot in a plane; np = the
+// longest column of the wave's 64, in pairs, rounded up to the ring's four (the rest: zero weights at slot 0).  Same buffers as the
+// scatter stream (SStackBufs: cnt = first pair row of every (wave, unit), nst = its pair rows).
+namespace {
+__device__ __forceinline__ void gstack_row(const StackPack& t, int w, int l, int u, int lane, int64_t& base) {
+    int ld;
+    if (u < 3)       { base = t.off[l][0] + (int64_t)u * SD * SD; ld = SD; }
+    else if (u < 6)  { base = t.off[l][u - 2]; ld = SD; }
+    else {
+        const int c = (u - 6) >> 1;
+        if (((u - 6) & 1) == 0) { base = t.off[l][4] + (int64_t)c * SD * SD; ld = SD; }
+        else                    { base = t.off[l][5] + (int64_t)c * SD; ld = t.NC * SD; }
+    }
+    base += (int64_t)(64 * w + lane) * ld;          // the 512 inputs of this lane's output column
+}
+}  // namespace
+// one wave per (w, lu): np[w LU + lu] = pair rows of the unit, np[8 LU + ..] = its non-zeros
+__global__ __launch_bounds__(256) void gstack_count_kernel(const __bf16* __restrict__ w16, int32_t* __restrict__ np, StackPack t) {
+    const int U = 6 + 2 * t.NC, LU = t.L * U;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= 8 * LU) return;
+    const int lu = item % LU, w = item / LU;
+    int64_t base; gstack_row(t, w, lu / U, lu % U, lane, base);
+    int n = 0;
+    for (int q = 0; q < SD / 8; ++q) {
+        const uint4 f = *reinterpret_cast<const uint4*>(w16 + base + 8 * q);
+        const unsigned int d[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n += ((d[i] & 0x00007FFFu) ? 1 : 0) + ((d[i] & 0x7FFF0000u) ? 1 : 0);
+    }
+    int mx = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    const int tot = wave_sum(n);
+    if (lane == 0) { np[item] = ((mx + 1) / 2 + 3) & ~3; np[8 * LU + item] = tot; }
+}
+// thread w: first[w LU + lu] (relative to the wave's stream), start[w]; stats = {pair rows in all, non-zeros}
+__global__ void gstack_scan_kernel(const int32_t* __restrict__ np, int32_t* __restrict__ first, int64_t* __restrict__ start, int64_t* __restrict__ stats, int LU) {
+    __shared__ int64_t tot[8], nzs[8];
+    const int w = threadIdx.x;
+    if (w < 8) {
+        int64_t run = 0, z = 0;
+        for (int lu = 0; lu < LU; ++lu) { first[w * LU + lu] = (int)run; run += np[w * LU + lu]; z += np[8 * LU + w * LU + lu]; }
+        tot[w] = run; nzs[w] = z;
+    }
+    __syncthreads();
+    if (w == 0) {
+        int64_t run = 0, z = 0;
+        for (int i = 0; i < 8; ++i) { start[i] = run; run += tot[i] + SSLACK; z += nzs[i]; }
+        stats[0] = run; stats[1] = z;
+    }
+}
+__global__ __launch_bounds__(256) void gstack_fill_kernel(const __bf16* __restrict__ w16, const int32_t* __restrict__ first, const int32_t* __restrict__ nst,
+                                                         const int64_t* __restrict__ start, uint2* __restrict__ stream, StackPack t) {
+    const int U = 6 + 2 * t.NC, LU = t.L * U;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= 8 * LU) return;
+    const int lu = item % LU, w = item / LU;
+    int64_t base; gstack_row(t, w, lu / U, lu % U, lane, base);
+    uint2* out = stream + (start[w] + first[item]) * 64 + lane;
+    const int np = nst[item];
+    int j = 0, have = 0;
+    unsigned int o1 = 0, w1 = 0;
+    const unsigned short* row = reinterpret_cast<const unsigned short*>(w16 + base);
+    for (int q = 0; q < SD / 8; ++q) {
+        const uint4 f = *reinterpret_cast<const uint4*>(row + 8 * q);
+        const unsigned int d[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned int h = (i & 1) ? d[i >> 1] >> 16 : d[i >> 1] & 0xFFFFu;
+            if (h & 0x7FFFu) {
+                const unsigned int off = (unsigned int)g_slot(8 * q + i) * 16u;
+                if (!have) { o1 = off; w1 = h; have = 1; }
+                else { out[(int64_t)j * 64] = make_uint2(o1 | (off << 16), w1 | (h << 16)); ++j; have = 0; }
+            }
+        }
+    }
+    if (have) { out[(int64_t)j * 64] = make_uint2(o1, w1); ++j; }           // (second half: weight 0 at slot 0)
+    for (; j < np; ++j) out[(int64_t)j * 64] = make_uint2(0u, 0u);
+    // behind the wave's last unit: the ring's look-ahead
+    if (lu == LU - 1) for (int i = 0; i < SSLACK; ++i) out[(int64_t)(np + i) * 64] = make_uint2(0u, 0u);
+}
+int gstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStream_t s) {
+    const int LU = t.L * (6 + 2 * t.NC);
+    const __bf16* w = reinterpret_cast<const __bf16*>(w16);
+    const unsigned items = (unsigned)ortk_cdiv(8 * LU, 4);
+    // (b.cnt holds 8 LU 16 ints: first[8 LU] at its head, the count kernel's {pair rows, non-zeros}[2 x 8 LU] behind it; b.nst = the pair rows)
+    int32_t* np = b.cnt + 8 * LU;
+    hipLaunchKernelGGL(gstack_count_kernel, dim3(items), dim3(256), 0, s, w, np, t);
+    ORTK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gstack_scan_kernel, dim3(1), dim3(64), 0, s, np, b.cnt, b.start, b.stats, LU);
+    ORTK_CHECK_LAUNCH();
+    if (hipMemcpyAsync(b.nst, np, (size_t)8 * LU * sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return ORTK_EINVAL;
+    hipLaunchKernelGGL(gstack_fill_kernel, dim3(items), dim3(256), 0, s, w, b.cnt, b.nst, b.start, b.stream, t);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
@@ -1618,9 +1833,9 @@ static int stack_tp_launch(const StackArgs& b, hipStream_t s) {
     return 0;
 }
 
-template <bool SPARSE, int RB>
+template <bool SPARSE, int RB, bool GATHER = false>
 static int stack_launch(const StackArgs& b, bool pf, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * RB * SD * 2 + 2 * 32 * 8 * sizeof(float) + (SPARSE ? 8 * SDBUF : 0);
+    constexpr size_t lds = (size_t)4 * RB * SD * 2 + 2 * 32 * 8 * sizeof(float) + (GATHER ? 2 * GPL + 8 * GTB : SPARSE ? 8 * SDBUF : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     // (per device: the attribute belongs to the function on ONE device; a process that drives several GPUs sets it on each)
     static std::mutex mu;
@@ -1630,12 +1845,12 @@ static int stack_launch(const StackArgs& b, bool pf, hipStream_t s) {
     {
         std::lock_guard<std::mutex> g(mu);
         if (!done[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_stack_kernel<SPARSE, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_stack_kernel<SPARSE, RB, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
             done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((decoder_stack_kernel<SPARSE, RB>), dim3((unsigned)(b.nblocks + (pf ? 8 : 0))), dim3(512), lds, s, b);
+    hipLaunchKernelGGL((decoder_stack_kernel<SPARSE, RB, GATHER>), dim3((unsigned)(b.nblocks + (pf ? 8 : 0))), dim3(512), lds, s, b);
     return 0;
 }
 
@@ -1675,6 +1890,7 @@ int stack_step(const StackArgs& a, hipStream_t s) {
         else rc = a.tp == 2 ? stack_tp_launch<2, false>(b, s) : a.tp == 4 ? stack_tp_launch<4, false>(b, s) : a.tp == 8 ? stack_tp_launch<8, false>(b, s) : ORTK_EINVAL;
     }
     else if (a.drop_p > 0.f) return ORTK_EINVAL;             // (train-mode rows: the column-split form only)
+    else if (sparse && a.gather) rc = stack_launch<true, 20, true>(b, pf, s);
     else if (sparse) rc = stack_launch<true, 20>(b, pf, s);
     else if (rb == 20) rc = stack_launch<false, 20>(b, pf, s);
     else rc = stack_launch<false, 32>(b, pf, s);

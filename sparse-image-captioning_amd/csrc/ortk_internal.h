@@ -99,6 +99,7 @@ struct StackArgs {
     StackLayer layer[STACK_MAXL];
     const uint4* wpk;              // stack_pack() image of the decoder weights (dense stream)
     const uint2* sstream;          // sparse stream (sstack_pack): per wave, steps of 64 lanes x 2 scatter entries
+    int32_t gather;                // the sparse stream holds per-column gather lists (gstack_pack) instead: decoder_stack_kernel<true, 20, true>
     const int32_t* snst;           //   [8][L * U] steps of every (wave, unit) (multiples of 4)
     const int64_t* sstart;         //   [8] first step of every wave's stream
     const float* x_io;             // (rows, 512) embedded tokens of this position
@@ -154,6 +155,7 @@ inline size_t stack_tp_xbuf_bytes(int64_t rows, int NC) { return (size_t)stack_t
 struct SStackBufs { uint2* stream; int32_t *cnt, *nst; int64_t *start, *stats; size_t stream_bytes; };     // stats: {steps, non-zeros}   // stats: {steps, pieces}
 size_t sstack_bytes(int L, int NC, SStackBufs* carve, void* base);          // worst-case (fully dense weights) capacity
 int sstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStream_t s);
+int gstack_pack(const void* w16, const SStackBufs& b, const StackPack& t, hipStream_t s);       // gather lists in the same buffers
 
 // embedding / fused criterion over an explicit list of (caption, position) rows (row_pos[i] = r*T + t; NULL = all R*T rows in order):
 // the valid-position decoder layout of ortk_batch.cap_off / row_pos

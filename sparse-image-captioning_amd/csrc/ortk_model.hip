@@ -1617,12 +1617,13 @@ static int decode_K(const ortk_decode_opts* o) {
 // Which executor serves a decode call.  Train-mode rows (ortk_decode_opts.train) run on the column-split stack kernel with at least 4
 // workgroups per group (its dropout sites, ortk_decstack.hip) or on the unfused executor; eval-mode (greedy) rows beside them
 // (`with_greedy`) only on the former.  ok = false: the option combination is not served (ORTK_EINVAL).
-struct DecodePlan { bool ok, stack, sstream; int split; };
+struct DecodePlan { bool ok, stack, sstream; int split; bool gather = false; };
 static DecodePlan plan_decode(const ortk_config& cfg, int B, int K, const ortk_decode_opts* o) {
     DecodePlan p{true, false, false, 0};
     const int64_t rows = (int64_t)B * K;
     p.stack = stack_ok(cfg, rows, o->exec_flags) && !o->sparse;
     p.sstream = p.stack && (o->exec_flags & ORTK_DEC_SPARSE_STREAM);
+    p.gather = p.sstream && (o->exec_flags & ORTK_DEC_SPARSE_GATHER);
     p.split = split_degree(p.stack && !p.sstream, o->exec_flags, rows);
     if (o->train) {
         if (o->num_random_sample <= 0 || o->sparse) { p.ok = false; return p; }      // multinomial rollouts, dense products
@@ -1754,7 +1755,7 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
     }
     a.drop_p = pd; a.greedy_stride = pd > 0.f ? greedy_stride : 0;
     a.wpk = reinterpret_cast<const uint4*>(wpk); a.progress = progress; a.x_io = w.xa; a.y_out = reinterpret_cast<__bf16*>(w.y);
-    if (ss) { a.sstream = ss->stream; a.snst = ss->nst; a.sstart = ss->start; }
+    if (ss) { a.sstream = ss->stream; a.snst = ss->nst; a.sstart = ss->start; a.gather = (flags & ORTK_DEC_SPARSE_GATHER) ? 1 : 0; }
     a.rb = (flags & ORTK_DEC_STACK_RB20) ? 20 : 32;
     a.fa = P + o.dec_na; a.fb = P + o.dec_nb; a.att_masks = w.att_masks; a.kvidx = kvidx; a.ldx = o.ckv_slots * o.cw;
     a.rows = (int)rows; a.per_img = per_img; a.S = S; a.T = T; a.t = t; a.L = cfg->n_layers; a.NC = cfg->d_ff / 512; a.eps = 1e-6f;
@@ -1860,10 +1861,10 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
     if (stack && sstream) {
         if (c.use_side && w16_done) {
             if (hipStreamWaitEvent(c.side->s, w16_done, 0) != hipSuccess) return ORTK_EINVAL;     // (NOT a fork: the encoder pass is queued already)
-            TRY(sstack_pack(w.w16, w.ss, tp, c.side->s));
+            TRY(pl.gather ? gstack_pack(w.w16, w.ss, tp, c.side->s) : sstack_pack(w.w16, w.ss, tp, c.side->s));
             TRY(c.side_mark(&sstream_done));
         } else {
-            TRY(sstack_pack(w.w16, w.ss, tp, s));
+            TRY(pl.gather ? gstack_pack(w.w16, w.ss, tp, s) : sstack_pack(w.w16, w.ss, tp, s));
         }
     }
     c.use_side = false;

@@ -316,14 +316,19 @@ class RelationTransformerModel(CaptionModelBase):
         ``include/ortk.h``): the kernel pulls only the non-zeros of the decoder weights (rebuilt on the device inside every
         ``ortk_decode`` from that call's weights) instead of the zero-filled dense matrices the reference multiplies by
         (scripts/eval_model.py:64-88).  Correct at any density; pays above ~80 % zeros.  ``on="auto"`` measures the
-        decoder's zero fraction once (host sync) and switches the stream on when it is >= 0.8."""
+        decoder's zero fraction once (host sync) and switches the stream on when it is >= 0.8 — and from 97 % zeros on in its
+        gather form (``ORTK_DEC_SPARSE_GATHER``: per-column gather lists, work proportional to the non-zeros; ``on="gather"``
+        forces that form)."""
+        gather = on == "gather"
         if on == "auto":
             self._eff_params_ptr(False, 0)          # (the `_prune` variant materialises s*W)
             eff = self._eff_params_tensor()
             dec = [e for e in self._entries if ".decoder.layers." in e["name"] and len(e["shape"]) >= 2]
             nz = sum(int(torch.count_nonzero(eff[e["offset"]:e["offset"] + e["numel"]])) for e in dec)
-            on = nz <= 0.2 * sum(e["numel"] for e in dec)
+            tot = sum(e["numel"] for e in dec)
+            on, gather = nz <= 0.2 * tot, nz <= 0.03 * tot
         self._sparse_stream = bool(on)
+        self._sparse_gather = bool(on) and gather
         return self._sparse_stream
 
     def _sparse_plans(self):
@@ -544,21 +549,22 @@ class RelationTransformerModel(CaptionModelBase):
         # ORTK_DEC_STACK=0 / 2 in the environment (read here, on the host side, per call) = "unfused" / "stack"
         ex = opt.get("executor", {"0": "unfused", "2": "stack", "3": "stack_split"}.get(os.environ.get("ORTK_DEC_STACK", ""), "auto"))
         if ex == "auto" and getattr(self, "_sparse_stream", False):
-            ex = "sparse_stream"
+            ex = "sparse_gather" if getattr(self, "_sparse_gather", False) else "sparse_stream"
         # "auto" lets decodes of <= 2 048 rows take the column-split stack kernel (fastest there) UNLESS another decode may run on
         # this GPU at the same time: its workgroups spin on each other and must all be resident (ortk.h: ORTK_DEC_SPLIT_SMALL).
         # `model.exclusive_gpu = False` (two processes on one device) or decode_streams > 1 switch that off.
         small = L.DEC_SPLIT_SMALL if (getattr(self, "exclusive_gpu", True) and int(opt.get("decode_streams", 0) or 1) <= 1) else 0
         o.exec_flags = {"auto": small, "unfused": L.DEC_UNFUSED, "stack": L.DEC_STACK, "sparse_stream": L.DEC_SPARSE_STREAM,
                         "stack_rb20": L.DEC_STACK | L.DEC_STACK_RB20, "stack_split": L.DEC_STACK | L.DEC_STACK_SPLIT,
-                        "sparse_stream_rb20": L.DEC_SPARSE_STREAM | L.DEC_STACK_RB20}[ex] | (int(opt.get("stack_debug", 0)) & 0xFF) << 8
+                        "sparse_stream_rb20": L.DEC_SPARSE_STREAM | L.DEC_STACK_RB20,
+                        "sparse_gather": L.DEC_SPARSE_STREAM | L.DEC_SPARSE_GATHER}[ex] | (int(opt.get("stack_debug", 0)) & 0xFF) << 8
         return o, K, ex
 
     def decode_supported(self, B, S, opt, att_max_len=None):
         """Whether ``mode="sample"`` serves this option combination for B images of S regions (e.g. train-mode rollouts with the
         greedy baseline as eval-mode rows of the same launches: the column-split stack kernel only).  No device work."""
         o, _, ex = self._decode_opts(dict(opt, seed=opt.get("seed", 0)))      # (a probe draws no seed)
-        if getattr(self, "_plans", None) is not None and self._plans[0] is not None and not ex.startswith("sparse_stream"):
+        if getattr(self, "_plans", None) is not None and self._plans[0] is not None and not ex.startswith("sparse_"):
             o.sparse = self._plans[0].ref()
         if att_max_len is not None:
             S = min(int(S), int(att_max_len))
@@ -576,7 +582,7 @@ class RelationTransformerModel(CaptionModelBase):
         pptr = self._eff_params_ptr(False, 0)
         fresh_plan = getattr(self, "_plans", None) is None
         plan = self._sparse_plans()[0]
-        if plan is not None and not ex.startswith("sparse_stream"):
+        if plan is not None and not ex.startswith("sparse_"):
             o.sparse = plan.ref()
         else:
             plan = None
