@@ -216,7 +216,7 @@ WORKLOADS = {
     "decode_fp32": "ORT dense, cached-KV beam-5 decode, 1024 images, fp32 parity mode (token-exact vs the reference)",
     "sparse_decode": "configs[4]: ORT 95% sparse, cached-KV beam-5 decode, 1024 images, decoder stack kernel on the sparse weight stream",
     "sparse_decode_dense_kernels": "configs[4]: the same decode as dense kernels on zero-filled weights (the reference's flow)",
-    "sparse_decode_988": "configs[4] at 98.8%: sparse weight stream, gather form (per-column lists; auto from 97% zeros on)",
+    "sparse_decode_988": "configs[4] at 98.8%: sparse weight stream, gather form (per-column lists; auto from 98.5% zeros on)",
     "sparse_decode_988_scatter": "configs[4] at 98.8%: sparse weight stream, scatter form (the 95% kernel)",
     "sparse_decode_988_dense_kernels": "configs[4] at 98.8%: dense kernels on zero-filled weights",
 }
@@ -261,7 +261,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
     if use_csr:                              # sparse products (ortk_spmm) for the weight blocks where they pay
         model.enable_sparse_kernels("auto" if "988" in variant else 0.9, train=True)
     if sstream:
-        # the stack kernel pulls the non-zeros of the decoder weights ("988": auto picks the gather form of the stream from 97 % zeros on)
+        # the stack kernel pulls the non-zeros of the decoder weights ("988": auto picks the gather form of the stream from 98.5 % zeros on)
         model.enable_sparse_stream(True if variant == "988_scatter" else "auto" if "988" in variant else True)
     batch = synth_batch(B, S, config.att_feat_size, config.vocab_size, spi, config.max_seq_length, 1000 + rank, dev)
 

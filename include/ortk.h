@@ -341,8 +341,9 @@ typedef struct ortk_decode_opts {
      *                           density, faster than the dense stream above ~80 % zeros); implies ORTK_DEC_STACK;
      *   ORTK_DEC_SPARSE_GATHER  with ORTK_DEC_SPARSE_STREAM: the non-zeros as per-output-column gather lists over transposed operand
      *                           images instead of scatter entries expanded for the matrix cores — work proportional to the
-     *                           non-zeros (the longest column of each group of 64); pays from ~97 % zeros, the reference's published
-     *                           97.5 / 98.8 / 99.1 % models; same results up to fp32 summation order;
+     *                           non-zeros (the longest column of each group of 64); pays from ~98.5 % zeros on (the reference's published
+     *                           98.8 / 99.1 % models; at 97.5 % the scatter stream is the faster one); same results up to fp32
+     *                           summation order;
      *   ORTK_DEC_STACK_RB20     dense stream with 20-row workgroups (measurement);
      *   ORTK_DEC_STACK_SPLIT    the column-split form of the stack kernel: groups of 2 / 4 / 8 workgroups of one XCD share 64 rows
      *                           and split every projection's output columns (each streams 1/2 .. 1/8 of the weights; partial

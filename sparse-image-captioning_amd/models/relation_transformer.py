@@ -316,7 +316,7 @@ class RelationTransformerModel(CaptionModelBase):
         ``include/ortk.h``): the kernel pulls only the non-zeros of the decoder weights (rebuilt on the device inside every
         ``ortk_decode`` from that call's weights) instead of the zero-filled dense matrices the reference multiplies by
         (scripts/eval_model.py:64-88).  Correct at any density; pays above ~80 % zeros.  ``on="auto"`` measures the
-        decoder's zero fraction once (host sync) and switches the stream on when it is >= 0.8 — and from 97 % zeros on in its
+        decoder's zero fraction once (host sync) and switches the stream on when it is >= 0.8 — and from 98.5 % zeros on (measured crossover, scratch/gather_crossover.py) in its
         gather form (``ORTK_DEC_SPARSE_GATHER``: per-column gather lists, work proportional to the non-zeros; ``on="gather"``
         forces that form)."""
         gather = on == "gather"
@@ -326,7 +326,7 @@ class RelationTransformerModel(CaptionModelBase):
             dec = [e for e in self._entries if ".decoder.layers." in e["name"] and len(e["shape"]) >= 2]
             nz = sum(int(torch.count_nonzero(eff[e["offset"]:e["offset"] + e["numel"]])) for e in dec)
             tot = sum(e["numel"] for e in dec)
-            on, gather = nz <= 0.2 * tot, nz <= 0.03 * tot
+            on, gather = nz <= 0.2 * tot, nz <= 0.015 * tot
         self._sparse_stream = bool(on)
         self._sparse_gather = bool(on) and gather
         return self._sparse_stream
