@@ -304,8 +304,8 @@ typedef struct ortk_tuning {
     int32_t side_stream;     /* 1: the executor queues weight gradients and other independent work on a second stream (default) | 0 */
     int32_t row_chain;       /* rows-stationary chains (ortk_row_chain / ortk_row_bchain) in the executor: 0 none (one launch per operator) | 1 forward passes
                                 (default) | 2 + the encoder's backward | 3 + the decoder's backward */
-    int32_t chain_wide;      /* 0 (default) | 1: forward chains run the four-wave 76-row form of the kernel where that saves a round of workgroups
-                                (measured slower: one wave per SIMD does not keep the matrix pipe fed; profiles/r04_row_chains.txt) */
+    int32_t chain_wide;      /* 1 (default): forward chains of 12 289 .. 19 456 rows run the 76-row form of the kernel — one round of workgroups
+                                instead of two (profiles/r04_row_chains.txt) | 0: the 48-row form everywhere */
     int32_t spmm_alias;      /* 1 (default): ELL products with more than 512 input columns and one output range per workgroup keep their output
                                 tile over the staged X planes (two workgroups per compute unit instead of one) | 0 */
 } ortk_tuning;

@@ -361,23 +361,28 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
 }
 
 // ================================================================================================ wide form of the forward chain
-// OPT-IN (ortk_tuning.chain_wide; off by default: measured slower, profiles/r04_row_chains.txt).
-// The kernel above is bound by the weight stream per compute unit, whatever the rows a workgroup holds — but with 8 waves (two per
-// SIMD: 256 registers each) it cannot hold more than 48 rows' accumulators, so 16 640 decoder rows need TWO rounds of workgroups and
-// every compute unit streams the chain's weights twice.  This form runs FOUR waves (one per SIMD: the whole 512-entry register
-// file, accumulators in the AGPR half), each wave owns 128 output columns (8 column tiles) of up to 76 rows (5 row tiles):
-// 16 640 rows = 256 workgroups x 65 rows = ONE round; the decode's 36 864 encoder rows take two rounds instead of three.  Two LDS
-// images (A operand + one FFN hidden chunk, an extra barrier per chunk), rows past the 76th of a tile read the neighbouring image
-// (don't-cares) and are never written.
-constexpr int WMT = 5, WNW = 4, WNT = 8, WCW = 16 * WNT, WRB = 76;
+// OPT-IN / DEFAULT: see ortk_tuning.chain_wide (profiles/r04_row_chains.txt).
+// The kernel above is bound by the weight stream per compute unit (~104 GB/s out of L2 whatever the rows a workgroup holds), and with
+// three 48-row LDS images it cannot hold more than 48 rows: 16 640 decoder rows need TWO rounds of workgroups, every compute unit
+// streams the chain's weights twice.  This form holds up to 76 rows (5 row tiles) in the SAME eight waves — wave w = 64 output
+// columns, two waves per SIMD as above —: 16 640 rows = 256 workgroups x 65 rows = ONE round, the decode's 36 864 encoder rows two
+// rounds instead of three.  What makes it fit: TWO LDS images (the A operand + ONE FFN hidden chunk: an extra barrier per chunk);
+// one register image of the block's rows (a product's accumulators become, in place, the fp32 residual rows the LayerNorm reads:
+// 80 VGPRs); an FFN up-projection unit streamed as two half units so that the hidden chunk's accumulators are 40 registers beside the
+// 80 of the down-projection's running sum.  Rows past the 76th of a tile read the neighbouring LDS bytes (don't-cares) and are never
+// written.  (A first version with FOUR waves of 128 columns — one per SIMD, accumulators in AGPRs — measured slower than two rounds of
+// the 48-row kernel: one wave per SIMD does not keep the matrix pipe fed.)
+constexpr int WMT = 5, WNW = 8, WNT = 4, WCW = 16 * WNT, WRB = 76;
 #ifndef WSPD_
-#define WSPD_ 2
+#define WSPD_ 4
 #endif
-constexpr int WSPD = WSPD_;                 // k-steps of weight fragments in flight per wave (8 KB each)
+constexpr int WSPD = WSPD_;                 // k-steps of weight fragments in flight per wave (4 KB each)
 constexpr int WKSTEP = WNT * CFRAG;         // uint4 per k-step of one wave
-constexpr int WUNIT = 16 * WKSTEP;          // uint4 per unit of one wave (128 KB)
-constexpr int WIMG = WRB * 1024;            // bytes of an image (76 rows); MFMA tiles cover 80
-constexpr size_t WIDE_LDS = (size_t)WIMG + 80 * 1024 + 2 * (16 * WMT) * WNW * sizeof(float);
+constexpr int WUNIT = 16 * WKSTEP;          // uint4 per unit of one wave (64 KB)
+constexpr int WIMG = WRB * 1024;            // bytes of an image (76 rows); MFMA tiles cover 80: rows 76.. of A0 read H0, of H0 the red arrays
+constexpr size_t WIDE_LDS = (size_t)2 * WIMG + 2 * (16 * WMT) * WNW * sizeof(float);
+static_assert(2 * (16 * WMT) * WNW * sizeof(float) >= 4 * 1024, "the tile rows past the second image stay inside the allocation");
+static_assert(WIDE_LDS <= 160 * 1024, "LDS budget");
 
 struct WRing { uint4 f[WSPD][WNT]; };
 __device__ __forceinline__ void w_ring_start(WRing& r, const uint4* wp, int lane) {
@@ -404,15 +409,13 @@ __device__ __forceinline__ void w_unit(f32x4 (&acc)[WMT][WNT], const char* A, co
             }
 #pragma unroll
             for (int nt = 0; nt < WNT; ++nt) r.f[s][nt] = wp[(ks + WSPD) * WKSTEP + nt * CFRAG + lane];
-            __builtin_amdgcn_sched_barrier(0);      // the refill is issued HERE (the scheduler otherwise sinks every load to the loop's end)
         }
     }
     wp += WUNIT;
 }
-// an FFN up-projection unit is streamed as TWO half units (8 groups each): group g of half h holds k-steps 2g and 2g + 1 of the
-// wave's column tiles 4h .. 4h + 3 — the hidden chunk's accumulators are 80 registers instead of 160 beside the 160 of the
-// down-projection's running sum
-__device__ __forceinline__ void w_unit_half(f32x4 (&acc)[WMT][4], const char* A, const uint4*& wp, WRing& r, int lane) {
+// an FFN up-projection unit is streamed as TWO half units (8 groups of four fragments each): group g of half h holds k-steps 2g and
+// 2g + 1 of the wave's column tiles 2h, 2h + 1 — the hidden chunk's accumulators are 40 registers instead of 80
+__device__ __forceinline__ void w_unit_half(f32x4 (&acc)[WMT][2], const char* A, const uint4*& wp, WRing& r, int lane) {
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll 1
     for (int it = 0; it < 8 / WSPD; ++it) {
@@ -425,15 +428,14 @@ __device__ __forceinline__ void w_unit_half(f32x4 (&acc)[WMT][4], const char* A,
 #pragma unroll
                 for (int mt = 0; mt < WMT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, 4 * (2 * g + k2) + kg));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, r.f[s][4 * k2 + j]);
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, r.f[s][2 * k2 + j]);
 #pragma unroll
                     for (int mt = 0; mt < WMT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[mt], acc[mt][j], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int nt = 0; nt < WNT; ++nt) r.f[s][nt] = wp[(g + WSPD) * WKSTEP + nt * CFRAG + lane];
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     wp += 8 * WKSTEP;
@@ -449,11 +451,11 @@ __device__ __forceinline__ void w_cols(const float* p, int wave, int lane, f32x4
     for (int nt = 0; nt < WNT; ++nt) v[nt] = *reinterpret_cast<const f32x4*>(p + WCW * wave + 16 * nt + 4 * (lane >> 4));
 }
 
-__global__ __launch_bounds__(256) void row_chain_wide_kernel(ChainArgs a) {
+__global__ __launch_bounds__(512) void row_chain_wide_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* A0 = smem;
     char* H0 = smem + WIMG;
-    float* red1 = reinterpret_cast<float*>(smem + WIMG + 80 * 1024);
+    float* red1 = reinterpret_cast<float*>(smem + 2 * WIMG);
     float* red2 = red1 + 16 * WMT * WNW;
     const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = lane0;
@@ -520,8 +522,8 @@ __global__ __launch_bounds__(256) void row_chain_wide_kernel(ChainArgs a) {
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < WMT; ++mt) {
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * WNW);
-            mean[mt] = ((p0[0] + p0[1]) + (p0[2] + p0[3])) * (1.f / CD);
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * WNW), p1 = *reinterpret_cast<const f32x4*>(red1 + (16 * mt + m) * WNW + 4);
+            mean[mt] = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) * (1.f / CD);
             float q = 0.f;
 #pragma unroll
             for (int nt = 0; nt < WNT; ++nt)
@@ -533,8 +535,8 @@ __global__ __launch_bounds__(256) void row_chain_wide_kernel(ChainArgs a) {
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < WMT; ++mt) {
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * WNW);
-            const float var = ((p0[0] + p0[1]) + (p0[2] + p0[3])) * (1.f / (CD - 1));
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * WNW), p1 = *reinterpret_cast<const f32x4*>(red2 + (16 * mt + m) * WNW + 4);
+            const float var = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) * (1.f / (CD - 1));
             const float sd = sqrtf(var);
             const float rinv = 1.f / (sd + a.eps);
             const int row = 16 * mt + m;
@@ -602,11 +604,11 @@ __global__ __launch_bounds__(256) void row_chain_wide_kernel(ChainArgs a) {
         for (int c = 0; c < a.NC; ++c) {
 #pragma unroll 1
             for (int hf = 0; hf < 2; ++hf) {
-                f32x4 hacc[WMT][4];
+                f32x4 hacc[WMT][2];
 #pragma unroll
                 for (int i = 0; i < WMT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 2; ++j) hacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 w_unit_half(hacc, A0, wp, ring, lane);
                 if (c > 0 && hf == 0) __syncthreads();          // every wave is past its reads of the previous hidden chunk
 #pragma unroll
@@ -614,8 +616,8 @@ __global__ __launch_bounds__(256) void row_chain_wide_kernel(ChainArgs a) {
                     const int row = 16 * mt + (lane & 15);
                     const uint32_t g = (uint32_t)(r0 + (row < nrow ? row : 0));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = WCW * wave + 64 * hf + 16 * j + 4 * (lane >> 4);
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = WCW * wave + 32 * hf + 16 * j + 4 * (lane >> 4);
                         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias_h + c * CD + col);
                         float v[4];
 #pragma unroll
@@ -875,26 +877,21 @@ __global__ __launch_bounds__(512) void row_bchain_kernel(BChainArgs a) {
 
 // out[(((w NU1 + u) 16 + ks) 4 + nt) 64 + lane] = the 8 bf16 W_u[64 w + 16 nt + (lane & 15)][32 ks + 8 (lane >> 4) ..], NU1 = units + 1
 // (the slack unit behind every wave's stream — the ring's read-ahead — is zero-filled)
-// The wide kernel's stream (form 1): out[(((w NU1 + u) 16 + g) 8 + j) 64 + lane] = W_u[128 w + 16 j + (lane & 15)][32 g + 8 (lane >> 4) ..], four
-// waves; an FFN up-projection unit (form 2) as two half units: group g = 8 h + g8 holds k-steps 2 g8 + (j >> 2) of column tiles 4 h + (j & 3).
-// Same bytes per chain as the 8-wave stream.
+// The wide kernel's stream: full units (form 1) as above; an FFN up-projection unit (form 2) as two half units: group g = 8 h + g8 of four
+// fragments holds k-steps 2 g8 + (j >> 1) of the wave's column tiles 2 h + (j & 1).  Same bytes per chain and wave.
 struct PackUnit { int64_t offset, ld; };
 __device__ __forceinline__ int64_t pack_src(int form, int w, int q, int64_t ld) {
     const int lane = q & 63;
     int nt, ks, col0;
-    if (form == 0) { nt = (q >> 6) & 3; ks = q >> 8; col0 = 64 * w; }
-    else {
-        const int j = (q >> 6) & 7, g = q >> 9;
-        col0 = 128 * w;
-        if (form == 2) { ks = 2 * (g & 7) + (j >> 2); nt = 4 * (g >> 3) + (j & 3); }
-        else { ks = g; nt = j; }
-    }
+    col0 = 64 * w;
+    if (form != 2) { nt = (q >> 6) & 3; ks = q >> 8; }                         // (the wide kernel's full units stream like the 48-row kernel's)
+    else { const int j = (q >> 6) & 3, g = q >> 8; ks = 2 * (g & 7) + (j >> 1); nt = 2 * (g >> 3) + (j & 1); }
     return (int64_t)(col0 + 16 * nt + (lane & 15)) * ld + 32 * ks + 8 * (lane >> 4);
 }
 __global__ __launch_bounds__(256) void chain_pack_kernel(const __bf16* __restrict__ w16, uint4* __restrict__ out, const PackUnit* __restrict__ units,
                                                          int n_units, int wide, int n_r, int n1, int NC) {
-    const int64_t usz = wide ? WUNIT : CUNIT;
-    const int64_t per_wave = (int64_t)(n_units + 1) * usz, total = (wide ? 4 : 8) * per_wave;
+    const int64_t usz = CUNIT;
+    const int64_t per_wave = (int64_t)(n_units + 1) * usz, total = 8 * per_wave;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int w = (int)(i / per_wave);
         const int64_t rest = i - (int64_t)w * per_wave;
@@ -915,7 +912,7 @@ __global__ __launch_bounds__(256) void chain_pack_all_kernel(const __bf16* __res
             rest -= sz;
         }
         const int n = t.first[c + 1] - t.first[c];
-        const int64_t usz = t.form[t.first[c]] ? WUNIT : CUNIT;              // a chain is wide or not as a whole
+        const int64_t usz = CUNIT;
         const int64_t per_wave = (int64_t)(n + 1) * usz;
         const int w = (int)(rest / per_wave);
         const int64_t r2 = rest - (int64_t)w * per_wave;
@@ -944,13 +941,16 @@ int chain_rows_per_block(int64_t M, int slots) {
 
 bool chain_wide(int64_t M) {
     if (!tuning().chain_wide) return false;
-    return ortk_cdiv(ortk_cdiv(M, (int64_t)WRB), 256) < ortk_cdiv(ortk_cdiv(M, (int64_t)CRB), 256);
+    // ONE round of 76-row blocks instead of two of 48-row blocks (12 289 .. 19 456 rows: the training decoder's 16 640): 187 vs 221 us
+    // on the 13-unit chain.  Two rounds instead of three (36 864 rows, the decode's encoder) measured slower, 380 vs 353 us: a 76-row
+    // round costs 12 us per unit (MFMA + operand reads + weight stream barely overlap with two waves per SIMD) against 7.5.
+    return ortk_cdiv(ortk_cdiv(M, (int64_t)WRB), 256) == 1 && ortk_cdiv(ortk_cdiv(M, (int64_t)CRB), 256) == 2;
 }
 
 int chain_pack(const void* w16, const ortk_chain_unit* units_dev, int n_units, void* packed, hipStream_t s, bool wide, int n_r, int n1, int NC) {
     if (!w16 || !units_dev || n_units < 1 || !packed) return ORTK_EINVAL;
     static_assert(sizeof(PackUnit) == sizeof(ortk_chain_unit), "unit descriptor");
-    static_assert(WUNIT == 2 * CUNIT, "both streams take the same bytes per unit");
+    static_assert(WUNIT == CUNIT, "both streams take the same bytes per unit and wave");
     hipLaunchKernelGGL(chain_pack_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const __bf16*>(w16), reinterpret_cast<uint4*>(packed),
                        reinterpret_cast<const PackUnit*>(units_dev), n_units, wide ? 1 : 0, n_r, n1, NC);
     ORTK_CHECK_LAUNCH();
@@ -1019,7 +1019,7 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
                             (p->NC ? p->NC * 1024.0 + 2048 + 2048 : 0) + (p->g2 ? (p->y2 ? 1024 : 0) + 8 : 0) + p->n2 * 1024.0;
         (void)prof_begin(PROF_KEY_CHAIN, 2.0 * p->M * n_units * CD * CD, (double)n_units * CD * CD * 2 + rowb * p->M, s, pm);
     } else pm.live = false;
-    if (wide) hipLaunchKernelGGL(row_chain_wide_kernel, dim3(grid), dim3(256), WIDE_LDS, s, a);
+    if (wide) hipLaunchKernelGGL(row_chain_wide_kernel, dim3(grid), dim3(512), WIDE_LDS, s, a);
     else hipLaunchKernelGGL(row_chain_kernel, dim3(grid), dim3(512), CHAIN_LDS, s, a);
     prof_end(pm, s);
     ORTK_CHECK_LAUNCH();

@@ -902,7 +902,7 @@ def test_row_chain_vs_separate_ops(L, M, p, parts, pf):
     (fp32 accumulation order), bf16 outputs within one bf16 step, LayerNorm statistics within 1e-4.  Chains: the decoder's
     [Wo -> LN -> W1 .. W2 -> LN -> Wqkv] at 1 000 / 16 640 rows (33-row blocks, two rounds) and 9 216 rows (36-row blocks), a bare
     [LN -> W] prefix, [Wo -> LN -> Wcq], and a chain that ends in a LayerNorm (the stack's last layer); the same shapes through the
-    four-wave 76-row form (65-, 49-, 76-, 51- and 72-row blocks: whole and partial row tiles)."""
+    76-row form of the kernel (65-, 49-, 76- and 51-row blocks: whole and partial row tiles; 36 864 rows stay on the 48-row form)."""
     d, NC = 512, 4
     ff = NC * d
     hasR, n1, hasF = "R" in parts, (1 if parts in ("R1S",) else 3 if "1S" in parts else 0), "F" in parts
@@ -963,12 +963,10 @@ def test_row_chain_vs_separate_ops(L, M, p, parts, pf):
     prog = torch.zeros(16, dtype=torch.int32, device="cuda")
     if pf:                               # with the L2 prefetcher workgroups (always the 48-row form)
         a.progress = prog.data_ptr()
-    L.set_tuning(chain_wide=0 if pf else 1)          # (the 76-row form is opt-in; it is taken where it saves a round: 12 289 .. 19 456 rows, 36 864)
-    try:
-        L.check(L.lib().ortk_row_chain(C.byref(a), L.stream_ptr()), "ortk_row_chain")
-        torch.cuda.synchronize()
-    finally:
-        L.set_tuning(chain_wide=0)
+    # (the 76-row form is the default where ONE round of its blocks replaces two of the 48-row form: 12 289 .. 19 456 rows; the cases with
+    #  the prefetcher workgroups and the row counts outside that range run the 48-row form)
+    L.check(L.lib().ortk_row_chain(C.byref(a), L.stream_ptr()), "ortk_row_chain")
+    torch.cuda.synchronize()
     # ---- reference (fp32 on the GPU, operands rounded to bf16 where the kernel rounds them)
     f = lambda t: t.float().cuda()
     xr = x.clone()
