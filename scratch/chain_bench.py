@@ -35,9 +35,9 @@ def gemm(A, B, Cc, M, N, K, **kw):
     return a
 
 
-PF = len(sys.argv) < 2 or sys.argv[1] not in ("nopf", "wide")
-if len(sys.argv) > 1 and sys.argv[1] == "wide":            # no prefetchers, the 76-row form where it saves a round
-    L.set_tuning(chain_wide=1)
+PF = len(sys.argv) < 2 or sys.argv[1] not in ("nopf", "wide", "narrow")
+if len(sys.argv) > 1 and sys.argv[1] in ("wide", "narrow"):            # no prefetchers; the 76-row form where it saves a round | never
+    L.set_tuning(chain_wide=1 if sys.argv[1] == "wide" else 0)
 for M in (5120, 9216, 16640, 21760, 36864):
     g = torch.Generator().manual_seed(1)
     Wr = (torch.randn(d, d, generator=g) * 0.02).bfloat16().cuda(); W1 = (torch.randn(ff, d, generator=g) * 0.02).bfloat16().cuda()

@@ -391,21 +391,26 @@ __device__ __forceinline__ void w_ring_start(WRing& r, const uint4* wp, int lane
 #pragma unroll
         for (int nt = 0; nt < WNT; ++nt) r.f[s][nt] = wp[s * WKSTEP + nt * CFRAG + lane];
 }
+// (the A operand of the NEXT k-step is requested before the MFMAs of this one: with two waves per SIMD and 20 MFMAs per k-step the
+//  LDS round trip of five ds_read_b128 was otherwise exposed once per k-step)
 __device__ __forceinline__ void w_unit(f32x4 (&acc)[WMT][WNT], const char* A, const uint4*& wp, WRing& r, int lane) {
     const int m = lane & 15, kg = lane >> 4;
+    bf16x8 av[2][WMT];
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt) av[0][mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, kg));
 #pragma unroll 1
     for (int it = 0; it < 16 / WSPD; ++it) {
 #pragma unroll
         for (int s = 0; s < WSPD; ++s) {
             const int ks = it * WSPD + s;
-            bf16x8 av[WMT];
+            const int kn = ks + 1 < 16 ? ks + 1 : ks;                  // (the last step re-reads its own slice: no branch in the loop)
 #pragma unroll
-            for (int mt = 0; mt < WMT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, 4 * ks + kg));
+            for (int mt = 0; mt < WMT; ++mt) av[(s + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, 4 * kn + kg));
 #pragma unroll
             for (int nt = 0; nt < WNT; ++nt) {
                 const bf16x8 b = __builtin_bit_cast(bf16x8, r.f[s][nt]);
 #pragma unroll
-                for (int mt = 0; mt < WMT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[mt], acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < WMT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[s & 1][mt], acc[mt][nt], 0, 0, 0);
             }
 #pragma unroll
             for (int nt = 0; nt < WNT; ++nt) r.f[s][nt] = wp[(ks + WSPD) * WKSTEP + nt * CFRAG + lane];
@@ -417,6 +422,9 @@ __device__ __forceinline__ void w_unit(f32x4 (&acc)[WMT][WNT], const char* A, co
 // 2g + 1 of the wave's column tiles 2h, 2h + 1 — the hidden chunk's accumulators are 40 registers instead of 80
 __device__ __forceinline__ void w_unit_half(f32x4 (&acc)[WMT][2], const char* A, const uint4*& wp, WRing& r, int lane) {
     const int m = lane & 15, kg = lane >> 4;
+    bf16x8 av[2][WMT];
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt) av[0][mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, kg));
 #pragma unroll 1
     for (int it = 0; it < 8 / WSPD; ++it) {
 #pragma unroll
@@ -424,14 +432,14 @@ __device__ __forceinline__ void w_unit_half(f32x4 (&acc)[WMT][2], const char* A,
             const int g = it * WSPD + s;
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                bf16x8 av[WMT];
+                const int ks = 2 * g + k2, kn = ks + 1 < 16 ? ks + 1 : ks;
 #pragma unroll
-                for (int mt = 0; mt < WMT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, 4 * (2 * g + k2) + kg));
+                for (int mt = 0; mt < WMT; ++mt) av[(k2 + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(A + c_off(16 * mt + m, 4 * kn + kg));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const bf16x8 b = __builtin_bit_cast(bf16x8, r.f[s][2 * k2 + j]);
 #pragma unroll
-                    for (int mt = 0; mt < WMT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[mt], acc[mt][j], 0, 0, 0);
+                    for (int mt = 0; mt < WMT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, av[k2 & 1][mt], acc[mt][j], 0, 0, 0);
                 }
             }
 #pragma unroll
