@@ -362,7 +362,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
     chain = None        # rows-stationary chains of the forward pass (key 17): weights streamed out of L2 per workgroup; HBM-side figure
     if per_key[17][0]:
         cn, cms, cfl, cby = per_key[17]
-        chain = {"kernel": "row_chain_kernel", "launches": cn, "avg_us": round(cms * 1e3 / cn, 1), "alg_bytes_per_launch": round(cby / cn),
+        chain = {"kernel": "row_chain_kernel / row_chain_wide_kernel", "launches": cn, "avg_us": round(cms * 1e3 / cn, 1), "alg_bytes_per_launch": round(cby / cn),
                  "achieved": round(cby / (cms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(cby / (cms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                  "mfma_tflops": round(cfl / (cms * 1e-3) / 1e12, 1)}
     if decode or use_csr:
