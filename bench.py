@@ -507,7 +507,7 @@ def main():
                                     ("sparse_xe", "988_kernels", 12, 3), ("scst", "", 12, 3), ("scst", "nodrop", 12, 3),
                                     ("decode", "", 10, 3), ("decode", "fp32", 3, 1), ("sparse_decode", "", 10, 3),
                                     ("sparse_decode", "dense_kernels", 10, 3), ("sparse_decode", "988", 10, 3),
-                                    ("sparse_decode", "988_dense_kernels", 10, 3)):
+                                    ("sparse_decode", "988_scatter", 10, 3), ("sparse_decode", "988_dense_kernels", 10, 3)):
                 c = compact(run_workload(args, wl, var, st, wu, rank, world, dev, pkg))
                 kind = "decode" if "decode" in wl else "scst" if wl == "scst" else "xe"
                 cb = cpu(kind)
