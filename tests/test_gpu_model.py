@@ -1316,24 +1316,26 @@ def test_sparse_weight_stream_vs_dense_stream(P, full_state, keep):
         assert (ld - ls)[same].abs().max().item() < 2e-3, (keep, opt, (ld - ls)[same].abs().max().item())
 
 
-@pytest.mark.parametrize("keep", [0.012, 0.05, 0.3])
+@pytest.mark.parametrize("keep", [0.012, 0.05, 0.3, 1.0])
 def test_sparse_gather_lists_vs_dense_stream(P, margin_state, keep):
     """The GATHER form of the sparse stream (ORTK_DEC_SPARSE_GATHER: per-column lists of {input, weight} pairs over transposed
     operand images, v_dot2 accumulation, csrc/ortk_decstack.hip) against the stack kernel on the dense stream, same zero-filled
     weights, 70 ragged images: same bf16 operands, fp32 sums in another order — tokens agree up to near-ties, log-probs of agreeing
-    hypotheses to summation noise; at 98.8 % zeros (its range), 95 % and 70 % (correct at any density: a column's list just grows).
+    hypotheses to summation noise; at 98.8 % zeros (its range), 95 %, 70 % and NO zeros (correct at any density: a column's list just grows).
     Weights with real decision margins (margin_state): with the flat log-probs of unit random weights any change of the
     summation order re-ranks a fifth of the beams."""
     m = _pruned_dense_model(P, margin_state, keep)
     b = _cuda(H.torch_batch(C.make_inputs(seed=43, n_img=70, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
-    for opt, min_tok in (({"beam_size": 1}, 0.99), ({"beam_size": 5}, 0.97), ({"beam_size": 3, "decoding_constraint": 1}, 0.97),
-                         ({"num_random_sample": 3, "beam_size": 0, "seed": 7}, 0.97)):
+    cases = (({"beam_size": 1}, 0.99), ({"beam_size": 5}, 0.97), ({"beam_size": 3, "decoding_constraint": 1}, 0.97),
+             ({"num_random_sample": 3, "beam_size": 0, "seed": 7}, 0.97))
+    for opt, min_tok in (cases if keep < 1.0 else cases[:2]):          # (no zero at all: 256 pair rows per unit — the lists' worst case)
         sd, ld = _decode_ex(m, b, opt, "stack")
         ss, ls = _decode_ex(m, b, opt, "sparse_gather")
         same = (sd == ss).all(-1)
         assert same.float().mean().item() >= min_tok - 0.04, (keep, opt, same.float().mean().item())
         assert (sd == ss).float().mean().item() >= min_tok - 0.02, (keep, opt)
-        assert (ld - ls)[same].abs().max().item() < 5e-3, (keep, opt, (ld - ls)[same].abs().max().item())
+        # (512-term sums in another order on real-margin weights: 7e-3 with no zero at all, the bf16-noise bar of the other decode tests is 0.02)
+        assert (ld - ls)[same].abs().max().item() < (5e-3 if keep < 0.5 else 2e-2), (keep, opt, (ld - ls)[same].abs().max().item())
     # auto: the stream from 80 % zeros on, its gather form from 98.5 %
     assert m.enable_sparse_stream("auto") is (keep <= 0.2) and m._sparse_gather == (keep <= 0.015)
     m.enable_sparse_stream(False)
