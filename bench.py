@@ -207,7 +207,7 @@ WORKLOADS = {
     "xe": "configs[1]: ORT dense, 256 images x 5 captions, teacher-forcing XE fwd+bwd+clip+Adam",
     "sparse_xe": "configs[2]: ORT 95% supermask-sparse XE step, masked dense GEMMs (the reference's flow)",
     "sparse_xe_kernels": "configs[2]: the same step, forward + data-gradient products as sparse kernels (ortk_spmm), weight gradients dense",
-    "sparse_xe_988": "configs[2] at 98.8% (the reference's NNZ 0.7M model): masked dense GEMMs",
+    "sparse_xe_988": "configs[2] at 98.8%: the reference's NNZ 0.7M model, masked dense GEMMs",
     "sparse_xe_988_kernels": "configs[2] at 98.8%: sparse kernels where the measured crossover says they pay (enable_sparse_kernels('auto'))",
     "scst": ("configs[3]: ORT dense SCST, the reference's estimator: eval-mode greedy baseline + 5 multinomial rollouts drawn in TRAIN mode "
              "(dropout on) + teacher-forced update under the same dropout masks"),
@@ -417,12 +417,12 @@ def compact(r):
     rf = r["roofline"]
     k = rf.get("dominant_kernel") or rf.get("rollout_kernel")
     # (the one-line description of every workload name is in WORKLOADS here and in profiles/bench_notes.json, not on the line)
-    out = {"ms_per_step": r["ms_per_step"], "value": r["value"], "steps": r["steps"], "dtype": r["dtype"], "config": r["config"]["workload"].split(":")[0],
+    out = {"ms_per_step": r["ms_per_step"], "value": r["value"], "dtype": r["dtype"], "config": r["config"]["workload"].split(":")[0],
            "bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "unit": rf["unit"]}
     if k:
-        out["kernel"] = {x: k[x] for x in ("kernel", "launches", "avg_us", "frac", "traffic", "alg_bytes_per_launch")}
+        out["kernel"] = {x: k[x] for x in ("kernel", "avg_us", "frac", "traffic", "alg_bytes_per_launch")}
     if "chain_kernel" in rf:
-        out["chains"] = {x: rf["chain_kernel"][x] for x in ("launches", "avg_us", "mfma_tflops")}
+        out["chains"] = {x: rf["chain_kernel"][x] for x in ("launches", "avg_us")}
     if "whole_step" in rf:
         out["whole_step_frac"] = rf["whole_step"]["frac"]
     return out
@@ -512,7 +512,7 @@ def main():
                 kind = "decode" if "decode" in wl else "scst" if wl == "scst" else "xe"
                 cb = cpu(kind)
                 if cb is not None and kind != "xe":
-                    c["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"], "kind": cb["kind"]}
+                    c["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"]}        # (kind "port": the oracle, bench_notes.json)
                 extra[wl + ("_" + var if var else "")] = c
             out["workloads"] = extra
         out["cpu_baseline"] = cpu("decode" if "decode" in args.workload else "scst" if args.workload == "scst" else "xe")
