@@ -259,7 +259,7 @@ typedef struct ortk_chain_args {
     const void* a_in; const float* bias_r; float* x_mid; uint32_t seed_r;
     const float *g1, *b1; void* y1; float* st1;
     int32_t n1; const float* bias_s1; void* out1; int64_t ld1;
-    int32_t NC; const float *bias_h, *bias_o; void* h; float* x_out; uint32_t seed_h, seed_o;
+    int32_t NC; const float *bias_h, *bias_o; void* h; float* x_out; uint32_t seed_h, seed_o;    /* h, y1, y2, st1, st2 may be NULL: not kept (inference) */
     const float *g2, *b2; void* y2; float* st2;
     int32_t n2; const float* bias_s2; void* out2; int64_t ld2;
     float drop_p, eps;

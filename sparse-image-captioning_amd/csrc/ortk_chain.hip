@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
                     }
                     const uint2 pk = make_uint2(c_pack2(v[0], v[1]), c_pack2(v[2], v[3]));
                     *reinterpret_cast<uint2*>(Hc + c_off(row, col >> 3) + ((col >> 2) & 1) * 8) = pk;
-                    if (row < nrow) *reinterpret_cast<uint2*>(a.h + (int64_t)(r0 + row) * ffn + c * CD + col) = pk;
+                    if (a.h && row < nrow) *reinterpret_cast<uint2*>(a.h + (int64_t)(r0 + row) * ffn + c * CD + col) = pk;
                 }
             }
             __syncthreads();
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(512) void row_chain_wide_kernel(ChainArgs a) {
                         }
                         const uint2 pk = make_uint2(c_pack2(v[0], v[1]), c_pack2(v[2], v[3]));
                         if (row < WRB) *reinterpret_cast<uint2*>(H0 + c_off(row, col >> 3) + ((col >> 2) & 1) * 8) = pk;
-                        if (row < nrow) *reinterpret_cast<uint2*>(a.h + (int64_t)(r0 + row) * ffn + c * CD + col) = pk;
+                        if (a.h && row < nrow) *reinterpret_cast<uint2*>(a.h + (int64_t)(r0 + row) * ffn + c * CD + col) = pk;
                     }
                 }
             }
@@ -984,7 +984,7 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
     if (p->a_in && (!p->bias_r || !p->x_mid)) return ORTK_EINVAL;
     if (p->n1 > 0 && (!p->bias_s1 || !p->out1 || p->ld1 < p->n1 * CD || p->ld1 % 4)) return ORTK_EINVAL;
     if (p->n2 > 0 && (!p->bias_s2 || !p->out2 || p->ld2 < p->n2 * CD || p->ld2 % 4)) return ORTK_EINVAL;
-    if (p->NC > 0 && (!p->g1 || !p->bias_h || !p->bias_o || !p->h || !p->x_out)) return ORTK_EINVAL;
+    if (p->NC > 0 && (!p->g1 || !p->bias_h || !p->bias_o || !p->x_out)) return ORTK_EINVAL;      // (h NULL: inference, the hidden units are not kept)
     if (p->drop_p < 0.f || p->drop_p >= 1.f) return ORTK_EINVAL;
     const int n_units = (p->a_in ? 1 : 0) + p->n1 + 2 * p->NC + p->n2;
     if (n_units < 1 || n_units != p->n_units) return ORTK_EINVAL;
@@ -1024,7 +1024,7 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
     if (ortk_prof_active()) {
         // algorithmic HBM bytes: the weights once + every row tensor the chain reads or writes
         const double rowb = 2048.0 + (p->a_in ? 1024 + 2048 : 0) + (p->g1 ? (p->y1 ? 1024 : 0) + 8 : 0) + p->n1 * 1024.0 +
-                            (p->NC ? p->NC * 1024.0 + 2048 + 2048 : 0) + (p->g2 ? (p->y2 ? 1024 : 0) + 8 : 0) + p->n2 * 1024.0;
+                            (p->NC ? (p->h ? p->NC * 1024.0 : 0.0) + 2048 + 2048 : 0) + (p->g2 ? (p->y2 ? 1024 : 0) + 8 : 0) + p->n2 * 1024.0;
         (void)prof_begin(PROF_KEY_CHAIN, 2.0 * p->M * n_units * CD * CD, (double)n_units * CD * CD * 2 + rowb * p->M, s, pm);
     } else pm.live = false;
     if (wide) hipLaunchKernelGGL(row_chain_wide_kernel, dim3(grid), dim3(512), WIDE_LDS, s, a);

@@ -665,7 +665,8 @@ static int queue_box_bias(const Ctx& c, const Offsets& o, const float* boxes, fl
 // `box_queued`: the caller has already queued the geometry bias (queue_box_bias; *box_queued = its completion event or NULL)
 static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, const float* boxes, const float* masks, int B, int S,
                            float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem, int qdt = ORTK_F32,
-                           const hipEvent_t* box_queued = nullptr, const ChainSet* cs = nullptr, const void* chain_pk = nullptr) {
+                           const hipEvent_t* box_queued = nullptr, const ChainSet* cs = nullptr, const void* chain_pk = nullptr,
+                           bool keep = true) {       // keep = false (decode): the chains do not store what only a backward would read
     const ortk_config& cfg = *c.cfg;
     const float* P = c.P;
     const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H, A = c.adt;
@@ -691,7 +692,7 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     if (chains) {
         ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
         ca.n_units = cs->units(cs->e0); ca.M = Me; ca.x_in = x0;
-        ca.g1 = P + o.enc[0].n0a; ca.b1 = P + o.enc[0].n0b; ca.y1 = bufs[0].y1; ca.st1 = bufs[0].st1;
+        ca.g1 = P + o.enc[0].n0a; ca.b1 = P + o.enc[0].n0b; ca.y1 = keep ? bufs[0].y1 : nullptr; ca.st1 = keep ? bufs[0].st1 : nullptr;
         ca.n1 = 3; ca.bias_s1 = P + o.enc[0].bqkv; ca.out1 = bufs[0].qkv; ca.ld1 = 3 * d;
         ca.eps = 1e-6f;
         TRY(chain_run(&ca, cs->stream_of(chain_pk, cs->e0), c.s));
@@ -709,14 +710,14 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
             ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
             ca.n_units = cs->units(cs->eb[l]); ca.M = Me; ca.x_in = x;
             ca.a_in = b.o; ca.bias_r = P + e.bo; ca.x_mid = b.xm; ca.seed_r = c.sub(eop(l, 1));
-            ca.g1 = P + e.n1a; ca.b1 = P + e.n1b; ca.y1 = b.y2; ca.st1 = b.st2;
-            ca.NC = ff / 512; ca.bias_h = P + e.b1; ca.bias_o = P + e.b2; ca.h = b.h; ca.x_out = b.xout;
+            ca.g1 = P + e.n1a; ca.b1 = P + e.n1b; ca.y1 = keep ? b.y2 : nullptr; ca.st1 = keep ? b.st2 : nullptr;
+            ca.NC = ff / 512; ca.bias_h = P + e.b1; ca.bias_o = P + e.b2; ca.h = keep ? b.h : nullptr; ca.x_out = b.xout;
             ca.seed_h = c.sub(eop(l, 2)); ca.seed_o = c.sub(eop(l, 3));
             if (l + 1 < L) {
-                ca.g2 = P + o.enc[l + 1].n0a; ca.b2 = P + o.enc[l + 1].n0b; ca.y2 = bufs[l + 1].y1; ca.st2 = bufs[l + 1].st1;
+                ca.g2 = P + o.enc[l + 1].n0a; ca.b2 = P + o.enc[l + 1].n0b; ca.y2 = keep ? bufs[l + 1].y1 : nullptr; ca.st2 = keep ? bufs[l + 1].st1 : nullptr;
                 ca.n2 = 3; ca.bias_s2 = P + o.enc[l + 1].bqkv; ca.out2 = bufs[l + 1].qkv; ca.ld2 = 3 * d;
             } else {
-                ca.g2 = P + o.enc_na; ca.b2 = P + o.enc_nb; ca.y2 = mem; ca.st2 = st_mem;
+                ca.g2 = P + o.enc_na; ca.b2 = P + o.enc_nb; ca.y2 = mem; ca.st2 = keep ? st_mem : nullptr;
             }
             ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
             TRY(chain_run(&ca, cs->stream_of(chain_pk, cs->eb[l]), c.s));
@@ -1850,11 +1851,11 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         // the greedy rows attend to the EVAL-mode encoder memory (utils/training.py:216-222 decodes the baseline under model.eval()):
         // its pass and projection first, then the buffers are free for the train-mode pass
         Ctx ce = c; ce.train = false; ce.seed = 0;
-        TRY(encoder_forward(ce, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st, enc_qdt, nullptr, &ecs, w.chain_pk));
+        TRY(encoder_forward(ce, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st, enc_qdt, nullptr, &ecs, w.chain_pk, false));
         ce.use_side = false;
         TRY(fwd_gemm(ce, w.mem, A, d, o.ckv_w, P + o.ckv_b, w.ckv_g, w.ckvdt, o.ckv_slots * o.cw, Me, (int)(o.ckv_slots * o.cw), d));
     }
-    if (!op->memory) TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st, enc_qdt, nullptr, &ecs, w.chain_pk));
+    if (!op->memory) TRY(encoder_forward(c, o, att_feats, boxes, att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st, enc_qdt, nullptr, &ecs, w.chain_pk, false));
     // the decoder's sparse weight stream (count / scan / fill: 0.37 ms): on the side stream behind the geometry bias, beside the encoder
     // pass, which does not read it; the first decoder position waits for it
     hipEvent_t sstream_done = nullptr;
