@@ -305,7 +305,8 @@ typedef struct ortk_tuning {
     int32_t row_chain;       /* rows-stationary chains (ortk_row_chain / ortk_row_bchain) in the executor: 0 none (one launch per operator) | 1 forward passes
                                 (default) | 2 + the encoder's backward | 3 + the decoder's backward */
     int32_t chain_wide;      /* 1 (default): forward chains of 12 289 .. 19 456 rows run the 76-row form of the kernel — one round of workgroups
-                                instead of two (profiles/r04_row_chains.txt) | 0: the 48-row form everywhere */
+                                instead of two (profiles/r04_row_chains.txt) | 0: the 48-row form everywhere | 2: the 76-row form wherever it saves
+                                a round (A/B: two instead of three at the decode's 36 864 encoder rows measures the same) */
     int32_t spmm_alias;      /* 1 (default): ELL products with more than 512 input columns and one output range per workgroup keep their output
                                 tile over the staged X planes (two workgroups per compute unit instead of one) | 0 */
 } ortk_tuning;

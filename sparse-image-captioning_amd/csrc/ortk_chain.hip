@@ -952,6 +952,7 @@ bool chain_wide(int64_t M) {
     // ONE round of 76-row blocks instead of two of 48-row blocks (12 289 .. 19 456 rows: the training decoder's 16 640): 187 vs 221 us
     // on the 13-unit chain.  Two rounds instead of three (36 864 rows, the decode's encoder) measured slower, 380 vs 353 us: a 76-row
     // round costs 12 us per unit (MFMA + operand reads + weight stream barely overlap with two waves per SIMD) against 7.5.
+    if (tuning().chain_wide == 2) return ortk_cdiv(ortk_cdiv(M, (int64_t)WRB), 256) < ortk_cdiv(ortk_cdiv(M, (int64_t)CRB), 256);      // (A/B: wherever it saves a round)
     return ortk_cdiv(ortk_cdiv(M, (int64_t)WRB), 256) == 1 && ortk_cdiv(ortk_cdiv(M, (int64_t)CRB), 256) == 2;
 }
 
