@@ -294,21 +294,28 @@ __device__ __forceinline__ void unit_gather(f32x4 (&acc)[2][4], const char* P, c
     }
 }
 // the transposed form of an A image (all 512 threads, thread = input column k; rows RB.. are zeros)
+// LDS transpose read (gfx950): lane 4q + p of a 16-lane group supplies the address of 4 consecutive bf16 of "row" q (segment p); it
+// receives element (lane & 15) of each of the group's 4 rows
+__device__ __forceinline__ uint2 g_tr_read(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+    const bf16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_ __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
 template <int RB>
 __device__ __forceinline__ void build_planes(const char* img, char* P, int tid) {
-    const int k = tid;
-    const char* src = img + (k & 7) * 2;
-    char* dst = P + g_slot(k) * 16;
-    // (one plane at a time: 8 values live instead of 24 — unrolled over the planes the compiler spilled 16 registers around every call)
-#pragma unroll 1
-    for (int h = 0; h < 3; ++h) {
-        unsigned int v[8];
+    static_assert(RB % 4 == 0 && RB <= 24, "four image rows per transpose read");
+    // 32 groups of 16 lanes, one per 16 input columns: a transpose read turns 4 image rows x 16 columns into 4 rows of ONE column per
+    // lane — half a slot — instead of one 2-byte read per element (20 per thread: the builds were 1.1 ms of a 16.3-ms decode)
+    const int lr = tid & 15, q = lr >> 2, pp = lr & 3, k0 = 16 * (tid >> 4);
+    const int ks = k0 + 4 * pp;                                // the columns this lane SUPPLIES (of row 4 b + q)
+    const char* src = img + (ks & 7) * 2;
+    char* dst = P + g_slot(k0 + lr) * 16;                      // the column this lane RECEIVES
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = 8 * h + i;
-            v[i] = r < RB ? (unsigned int)*reinterpret_cast<const unsigned short*>(src + img_off(r, k >> 3)) : 0u;
-        }
-        *reinterpret_cast<uint4*>(dst + h * GPB) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    for (int h = 0; h < 3; ++h) {
+        uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+        if (8 * h < RB) lo = g_tr_read(src + img_off(8 * h + q, ks >> 3));
+        if (8 * h + 4 < RB) hi = g_tr_read(src + img_off(8 * h + 4 + q, ks >> 3));
+        *reinterpret_cast<uint4*>(dst + h * GPB) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
 }
 
