@@ -541,8 +541,19 @@ __global__ __launch_bounds__(512) void decoder_stack_kernel(StackArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int g = min(r0 + 16 * mt + m, a.rows - 1);
+        if (a.tok) {        // Embeddings (transformer.py:366-373: lut(x) * sqrt(d_model)) + positional encoding, same arithmetic as embed_fwd_kernel
+            const float* e = a.lut + a.tok[g] * SD;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) x[mt][nt] = *reinterpret_cast<const f32x4*>(a.x_io + (int64_t)g * SD + 64 * wave + 16 * nt + 4 * q4);
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = 64 * wave + 16 * nt + 4 * q4;
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(e + col), pv = *reinterpret_cast<const f32x4*>(a.pe_t + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[mt][nt][r] = ev[r] * a.emb_scale + pv[r];
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) x[mt][nt] = *reinterpret_cast<const f32x4*>(a.x_io + (int64_t)g * SD + 64 * wave + 16 * nt + 4 * q4);
+        }
     }
     // dense stream state
     const uint4* wp = a.wpk + (int64_t)wave * a.L * U * 16 * KSTEP;

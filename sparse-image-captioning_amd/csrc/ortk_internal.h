@@ -102,7 +102,8 @@ struct StackArgs {
     int32_t gather;                // the sparse stream holds per-column gather lists (gstack_pack) instead: decoder_stack_kernel<true, 20, true>
     const int32_t* snst;           //   [8][L * U] steps of every (wave, unit) (multiples of 4)
     const int64_t* sstart;         //   [8] first step of every wave's stream
-    const float* x_io;             // (rows, 512) embedded tokens of this position
+    const float* x_io;             // (rows, 512) embedded tokens of this position — or, with `tok`, not read:
+    const int64_t* tok; const float* lut; const float* pe_t; float emb_scale;      // x = lut[tok[row]] * emb_scale + pe_t (eval mode: the embedding launch folded into the kernel's first load)
     __bf16* y_out;                 // (rows, 512) final LayerNorm output: the generator's operand
     const float *fa, *fb;          // final LayerNorm
     const float* att_masks;        // (images, S)

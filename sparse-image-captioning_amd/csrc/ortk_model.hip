@@ -1741,8 +1741,11 @@ static int decoder_stack_step(const Ctx& c, const Offsets& o, const StepBufs& w,
     // c.train: every dropout of the position draws what the teacher-forced pass over [BOS, sample] draws at (row, t); rows with
     // row % greedy_stride == 0 stay in eval mode (the greedy baseline of the same launch)
     const float pd = c.p_drop();
-    TRY(embed_fwd_rows(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, nullptr, 1, t, d, cfg->pad_id, pd, c.sub(OP_EMB), c.s, T, t, greedy_stride));
+    // (eval mode on the plain kernel: the embedding is the kernel's first load — one launch less per position)
+    const bool fold_embed = pd == 0.f && !(sp && sp->G);
+    if (!fold_embed) TRY(embed_fwd_rows(w.it, 1, P + o.lut, P + o.pe, w.xa, nullptr, rows, nullptr, 1, t, d, cfg->pad_id, pd, c.sub(OP_EMB), c.s, T, t, greedy_stride));
     StackArgs a; std::memset(&a, 0, sizeof(a));
+    if (fold_embed) { a.tok = w.it; a.lut = P + o.lut; a.pe_t = P + o.pe + (int64_t)t * d; a.emb_scale = (float)std::sqrt((double)d); }
     for (int l = 0; l < cfg->n_layers; ++l) {
         const DecOff& e = o.dec[l];
         StackLayer& y = a.layer[l];
