@@ -6,7 +6,8 @@ ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], 
 # steps end with adam_clip_kernel
 ends = [i for i, e in enumerate(ev) if "adam_clip" in e[3]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 4        # step index (0-based); the last steps of a bench run are the serialised roofline steps
-a, b = ends[k - 1] + 1, ends[k] + 1
+APS = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # Adam launches per step (2: the decoder half goes early on its own stream)
+a, b = ends[APS * k - 1] + 1, ends[APS * (k + 1) - 1] + 1
 g = ev[a:b]
 t0, t1 = g[0][0], max(e[1] for e in g)
 print("kernels in the step:", len(g), "span ms %.3f" % ((t1 - t0) / 1e6))
