@@ -186,8 +186,14 @@ __device__ __forceinline__ void s_unit_cold(char* D, const SRing& E, uint4 (&F)[
     s_scatter(D, E.e[0]);
     s_frags(D, F[0], lane);
 }
+// nstp = steps of the unit (a multiple of SSPD) | its REAL steps << 16: the all-pad steps that round a unit up to the ring's four
+// (a k-step that overflows its 128 entries costs one real step more — 7 % of the wave-units at 95 % zeros, so 45 % of the units have
+// a wave with 20 steps instead of 16 and every other wave waits for it at the next barrier) skip their MFMAs.  (Skipping their
+// scatter / clear / fragment reads as well — four more wave-uniform branches per step — breaks the software pipeline: 700 us per
+// position against 593.)
 template <bool NEXT>
-__device__ __forceinline__ void unit_sparse(f32x4 (&acc)[2][4], const char* A, char* D, const uint2*& sp, int nst, SRing& E, uint4 (&F)[2][4], int lane) {
+__device__ __forceinline__ void unit_sparse(f32x4 (&acc)[2][4], const char* A, char* D, const uint2*& sp, int nstp, SRing& E, uint4 (&F)[2][4], int lane) {
+    const int nst = nstp & 0xFFFF, nreal = nstp >> 16;
     const int m = lane & 15, kg = lane >> 4;
     bf16x8 a[2][2];
     {
@@ -209,11 +215,13 @@ __device__ __forceinline__ void unit_sparse(f32x4 (&acc)[2][4], const char* A, c
                 a[p ^ 1][1] = *reinterpret_cast<const bf16x8*>(A + img_off(16 + m, 4 * ks + kg));
             }
             E.e[s] = sp[(g + s + SSPD) * 64 + lane];                // (past the unit: the next unit's steps; past the stream: zeroed slack)
+            if (g + s < nreal) {                                    // (wave-uniform; an all-pad step's fragments are zeros)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, F[p][nt]);
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[p][0], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[p][1], acc[1][nt], 0, 0, 0);
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, F[p][nt]);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[p][0], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[p][1], acc[1][nt], 0, 0, 0);
+                }
             }
         }
     }
@@ -901,8 +909,9 @@ __global__ void sstack_scan_kernel(int32_t* __restrict__ cnt, int32_t* __restric
                 cnt[i] = (int)(run + st);
                 st += steps_of(c);
             }
+            const int real = st;
             st = (st + SSPD - 1) / SSPD * SSPD;
-            nst[w * LU + lu] = st;
+            nst[w * LU + lu] = st | (real << 16);
             run += st;
         }
         tot[w] = run; nzs[w] = z;
@@ -978,7 +987,7 @@ __global__ __launch_bounds__(256) void sstack_fill_kernel(const __bf16* __restri
         __builtin_amdgcn_wave_barrier();
     }
     if (ks == 15) {
-        const int64_t ustart = start[w] + first[item - 15], uend = ustart + nst[w * LU + lu];
+        const int64_t ustart = start[w] + first[item - 15], uend = ustart + (nst[w * LU + lu] & 0xFFFF);
         uint2* us = stream + (start[w] + first[item] + ns) * 64;
         for (int64_t st = start[w] + first[item] + ns; st < uend; ++st, us += 64)
             us[lane] = make_uint2((unsigned int)(2048 + 2 * lane) << 16, (unsigned int)(2048 + 2 * lane + 1) << 16);
