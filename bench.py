@@ -66,8 +66,10 @@ def synth_batch(B, S, F, V, spi, seq_len, seed, device):
 
 def cpu_baseline(workload, cfg_dict, seconds=9.0):
     """The oracle (parity-pinned CPU restatement of the reference path, torch CPU fp32) timed on this host's cores on a bounded
-    sample of the same workload: 8 images per step — xe: 5 captions each, fwd + bwd + clip + Adam; decode: beam 5; scst: greedy
-    baseline + 5 multinomial rollouts (eval-mode decode; the reference adds dropout, same cost) + teacher-forced update."""
+    sample of the same workload.  xe: BASELINE configs[0] EXACTLY — 4 images x 5 captions per step, fwd + bwd + clip + Adam (the
+    reference's own CPU-runnable case); decode: beam 5 on 8 images per step; scst: greedy baseline + 5
+    multinomial rollouts (eval-mode decode; the reference adds dropout, same cost) + teacher-forced update on 8 images per step.
+    `cores` = the threads used, `host_threads` = what the host offers."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import helpers as H
@@ -79,12 +81,12 @@ def cpu_baseline(workload, cfg_dict, seconds=9.0):
     cfg = O.OCfg(**{k: v for k, v in cfg_dict.items() if not k.startswith("prune")})
     P = H.torch_state(H.dense_param_shapes(cfg_dict), 8888, requires_grad=True)
     Pd = {k: v.detach() for k, v in P.items()}
-    B = 8
+    kind = "decode" if workload in ("decode", "sparse_decode") else "scst" if workload == "scst" else "xe"
+    B = 4 if kind == "xe" else 8
     b = synth_batch(B, 36, cfg.att_feat_size, cfg.vocab_size, 5, cfg.max_seq_length, 1, "cpu")
     state = {}
     n, t0 = 0, None
     t_start = time.time()
-    kind = "decode" if workload in ("decode", "sparse_decode") else "scst" if workload == "scst" else "xe"
 
     def update(seqs, weights=None):
         for p in P.values():
@@ -122,41 +124,66 @@ def cpu_baseline(workload, cfg_dict, seconds=9.0):
             break
     dt = (time.time() - t0) / max(n, 1)
     what = {"xe": "5 captions each, fwd+bwd+Adam", "decode": "beam-5 decode", "scst": "greedy + 5 rollouts + update"}[kind]
-    return {"value": round(units / dt, 2), "unit": "captions/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of {B} images ({what}), oracle/ort_oracle.py, torch CPU fp32, {cores} threads"}
+    return {"value": round(units / dt, 2), "unit": "captions/sec", "cores": cores, "host_threads": os.cpu_count() or 1, "kind": "port",
+            "images_per_step": B,
+            "sample": (f"{n} steps of {B} images ({what}{'; BASELINE configs[0] exactly' if kind == 'xe' else ''}), oracle/ort_oracle.py, "
+                       f"torch CPU fp32, {cores} of the host's {os.cpu_count() or 1} threads")}
 
 
-PMC_TAG = "r04"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
+PMC_TAG = "r05"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
+PMC_MANIFEST = f"profiles/{PMC_TAG}_manifest.json"     # {"lib_md5", "git_head", ...}: written by scratch/prof_r05.sh with the passes
+
+# The kernels whose counters `traffic` is read from, by their FULL names (template arguments included) as this build launches them:
+# a profile of another instantiation is not a measurement of this one.
+STACK_DENSE = "ortk::decoder_stack_kernel<false, 32, false>(ortk::StackArgs)"
+STACK_SPARSE = "ortk::decoder_stack_kernel<true, 20, false>(ortk::StackArgs)"
+GEMM_FWD = ("gemm_bf16_dma256_kernel<false, false>(ortk_gemm_args, int, int, int)",
+            "gemm_bf16_glds_kernel<false, false, false, 4>(ortk_gemm_args, int, int, int)",
+            "gemm_bf16_dma64_kernel<3>(ortk_gemm_args, int, int, int)", "gemm_bf16_dma64_kernel<8>(ortk_gemm_args, int, int, int)")
+
+
+def lib_md5():
+    import hashlib
+    from sparse_image_captioning_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.md5(f.read()).hexdigest()
 
 
 def pmc_traffic(kernel, workload, precision, B):
     """HBM bytes per launch of ONE kernel family (`kernel`: "stack" = the decoder stack kernel, "gemm" = the forward-layout
     GEMMs) from the committed PMC passes of THIS command (profiles/README.md): 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction
-    for 16-B/lane streaming reads), launch-weighted over the kernel's instances.  Returns (bytes | None, note): None for
-    kernels / workloads / sizes without a committed PMC profile, and — loudly — when the committed CSVs do not contain the
-    kernels this build launches (a stale profile is not a measurement)."""
+    for 16-B/lane streaming reads), launch-weighted over the kernel's instances.  Returns (bytes | None, note).  None — with the
+    reason in the note, which rides on the line as `traffic_note` — for kernels / workloads / sizes without a committed PMC pass,
+    when the passes were not collected from THIS library (profiles/<tag>_manifest.json records the md5 of the libortk.so that ran
+    them; it must equal the md5 of the library loaded now), and when the CSVs do not hold the kernel under its full name."""
     import csv
     here = os.path.dirname(os.path.abspath(__file__))
     if kernel == "stack" and workload in ("decode", "sparse_decode") and precision == "bf16" and B == 1024:
-        want = ("decoder_stack_kernel<true" if workload == "sparse_decode" else "decoder_stack_kernel<false",)
+        want = (STACK_SPARSE if workload == "sparse_decode" else STACK_DENSE,)
         must = want[0]
         tag = "sparse_decode_stack" if workload == "sparse_decode" else "decode_stack"
         files = [f"{PMC_TAG}_{tag}_pmc_fetch_size.csv", f"{PMC_TAG}_{tag}_pmc_write_size.csv"]
     elif kernel == "gemm" and workload == "xe" and precision == "bf16" and B == 256:
-        want = ("gemm_bf16_glds_kernel<false, false", "gemm_bf16_dma256_kernel<false, false", "gemm_bf16_dma64_kernel")
-        must = "gemm_bf16_dma256_kernel<false, false"
+        want = GEMM_FWD
+        must = GEMM_FWD[0]
         files = [f"{PMC_TAG}_xe_b256_pmc_fetch_size.csv", f"{PMC_TAG}_xe_b256_pmc_write_size.csv"]
     else:
         return None, "no PMC pass committed for this workload / size"
+    try:
+        man = json.load(open(os.path.join(here, PMC_MANIFEST)))
+    except (OSError, ValueError):
+        return None, f"STALE: no {PMC_MANIFEST} (which library the PMC passes ran is unknown)"
+    now = lib_md5()
+    if man.get("lib_md5") != now:
+        return None, f"STALE: PMC passes of libortk.so md5 {str(man.get('lib_md5'))[:8]} (commit {str(man.get('git_head'))[:8]}), loaded md5 {now[:8]}"
     tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     n = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
     seen = set()
     try:
         for cname, fname in zip(("FETCH_SIZE", "WRITE_SIZE"), files):
             for r in csv.DictReader(open(os.path.join(here, "profiles", fname))):
-                hit = [w for w in want if w in r["kernel"]]
-                if hit and r["counter"] == cname:
-                    seen.add(hit[0])
+                if r["kernel"] in want and r["counter"] == cname:
+                    seen.add(r["kernel"])
                     tot[cname] += float(r["total"]); n[cname] += int(r["launches"])
     except (OSError, KeyError, ValueError) as e:
         return None, f"profiles/{files[0]} / {files[1]} unreadable ({type(e).__name__}): no traffic figure"
@@ -164,7 +191,7 @@ def pmc_traffic(kernel, workload, precision, B):
         return None, f"STALE: profiles/{files[0]} / {files[1]} do not contain the dominant kernel of this build ({must})"
     kb = 2.0 * tot["FETCH_SIZE"] / n["FETCH_SIZE"] + tot["WRITE_SIZE"] / n["WRITE_SIZE"]
     return round(kb * 1024), (f"HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE from profiles/{files[0]} / {files[1]} "
-                              "(separate rocprofv3 --pmc passes of this command), launch-weighted over the same kernels")
+                              f"(separate rocprofv3 --pmc passes of this command on libortk.so md5 {now[:8]}), launch-weighted")
 
 
 NOTES = "profiles/bench_notes.json"       # parity evidence per dtype, kernel descriptions, how `traffic` is read: prose, not on the line
@@ -224,6 +251,7 @@ WORKLOADS = {
 # per-image forward work of the dense model (6.354 GFLOP in all): encoder + the packed cross-attention K|V projection do
 # not depend on the caption positions, the decoder stack + generator scale with the decoder rows actually computed
 GFLOP_FWD_ENC, GFLOP_FWD_DEC = 1.680, 4.674
+GFLOP_DECODE_PER_IMAGE = 6.62       # beam-5 decode, dense (encoder 1.46 + 5 rows x 18 steps x 54.28 MFLOP + attention)
 
 
 def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, precision=None):
@@ -343,22 +371,24 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
     n0, ms0, fl0, by0 = per_key[key]
     ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
     ach_iso = iso[key][2] / (iso[key][1] * 1e-3) / 1e12 if iso[key][1] > 0 else 0.0
-    traffic, _ = pmc_traffic("gemm", workload if not variant else "", precision, B)
+    traffic, tnote = pmc_traffic("gemm", workload if not variant else "", precision, B)
     gemm = {"bound": "mfma", "kernel": "forward-layout GEMMs (gemm_bf16_dma256 / glds / dma64)" if precision == "bf16" else "gemm_f32_kernel (forward layout)",
             "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            **({"traffic_note": tnote} if traffic is None and tnote.startswith("STALE") else {}),
             "launches": n0, "avg_us": round(ms0 * 1e3 / max(n0, 1), 1), "isolated_frac": round(ach_iso / peak, 4),
             "alg_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 2), "alg_bytes_per_launch": round(by0 / max(n0, 1))}
     stack = None        # decode: the one-launch-per-position decoder stack (key 16), same HIP-event hook
     if per_key[16][0]:
         sn, sms, sfl, sby = per_key[16]
         gbs_k = sby / (sms * 1e-3) / 1e9
-        st_traffic, _ = pmc_traffic("stack", ("sparse_decode" if sstream else "decode") if decode and "988" not in variant and precision == "bf16" else "", precision, B)
+        st_traffic, st_note = pmc_traffic("stack", ("sparse_decode" if sstream else "decode") if decode and "988" not in variant and precision == "bf16" else "", precision, B)
         stack = {"kernel": ("decoder_stack_kernel<sparse>" if sstream else "decoder_stack_kernel") if decode else "decoder_stack_tp_kernel",
                  "launches": sn, "avg_us": round(sms * 1e3 / sn, 1), "alg_bytes_per_launch": round(sby / sn), "achieved": round(gbs_k, 1),
                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4), "traffic": st_traffic,
                  # (beam search: the cached K / V rows are the UNIQUE rows each pass references — beams share ancestors through the
                  #  ancestry table; the beam step counts them on the device, ortk_prof_collect_bytes adds them in)
-                 "kv_rows_counted": "unique" if decode else "per row"}
+                 "kv_rows_counted": "unique" if decode else "per row",
+                 **({"traffic_note": st_note} if st_traffic is None and st_note.startswith("STALE") else {})}
     chain = None        # rows-stationary chains of the forward pass (key 17): weights streamed out of L2 per workgroup; HBM-side figure
     if per_key[17][0]:
         cn, cms, cfl, cby = per_key[17]
@@ -383,6 +413,13 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         gbs = algo / (ms_per_step * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "whole step", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "alg_bytes_per_step": round(algo)}
+        if decode and precision != "bf16":
+            # fp32 parity mode: 6.62 GFLOP per image against the 157 TF/s fp32 matrix peak is 43 ms per 1 024 images,
+            # ten times the HBM time of its bytes — the decode is MFMA-bound in this mode
+            tf = GFLOP_DECODE_PER_IMAGE * B / 1e3 / (ms_per_step * 1e-3)
+            roofline = {"bound": "mfma", "kernel": "whole step", "achieved": round(tf, 1), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_F32_TFLOPS, 4), "traffic": None, "alg_gflop_per_step": round(GFLOP_DECODE_PER_IMAGE * B, 1),
+                        "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
         if stack is not None:
             roofline["dominant_kernel"] = stack
     else:
@@ -512,7 +549,8 @@ def main():
                 kind = "decode" if "decode" in wl else "scst" if wl == "scst" else "xe"
                 cb = cpu(kind)
                 if cb is not None and kind != "xe":
-                    c["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"]}        # (kind "port": the oracle, bench_notes.json)
+                    c["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"], "host_threads": cb["host_threads"],
+                                         "images_per_step": cb["images_per_step"]}       # (kind "port": the oracle, bench_notes.json)
                 extra[wl + ("_" + var if var else "")] = c
             out["workloads"] = extra
         out["cpu_baseline"] = cpu("decode" if "decode" in args.workload else "scst" if args.workload == "scst" else "xe")

@@ -231,6 +231,10 @@ typedef struct ortk_spmm_args {
     const float* bias; const float* rowscale; const float* resid; int64_t ldr;
     const void* gate; int64_t ldg; int32_t gate_dtype; float gate_scale;
     int32_t relu; float drop_p; uint32_t drop_seed;
+    /* optional (rows ints): output row m takes the dropout draws of row drop_rows[m] — the valid-position decoder layout
+     * (ortk_batch.row_pos) draws what the padded (caption, position) layout draws, so a step is the same function of its seed in
+     * both layouts and an SCST update on the valid positions reproduces the masks of its train-mode rollout. */
+    const int32_t* drop_rows;
 } ortk_spmm_args;
 int ortk_spmm(const ortk_sparse_plan* plan, int32_t block, const ortk_spmm_args* a, ortk_stream stream);
 
@@ -264,6 +268,7 @@ typedef struct ortk_chain_args {
     int32_t n2; const float* bias_s2; void* out2; int64_t ld2;
     float drop_p, eps;
     int32_t* progress;      /* optional: 16 ints of device scratch (zeroed by the call) -> 8 L2 prefetcher workgroups pace the weight stream */
+    const int32_t* drop_rows;   /* optional (M ints): row m draws its dropout (seed_r / seed_h / seed_o) as row drop_rows[m] (see ortk_gemm_args) */
 } ortk_chain_args;
 size_t ortk_chain_packed_bytes(int32_t n_units);
 int ortk_row_chain(const ortk_chain_args* a, ortk_stream stream);
@@ -291,6 +296,7 @@ typedef struct ortk_bchain_args {
     const float *xb, *stb, *gb, *dresb; float *dxb, *dab, *dbb; void* dzb; uint32_t seed_b; int32_t mask_b;
     int32_t n2; void* out2;
     float drop_p, eps;
+    const int32_t* drop_rows;   /* optional (M ints): the masked copies dza / dzb / dz0 draw row m as row drop_rows[m] (see ortk_gemm_args) */
 } ortk_bchain_args;
 int ortk_row_bchain(const ortk_bchain_args* a, ortk_stream stream);
 
@@ -462,6 +468,10 @@ typedef struct ortk_gemm_args {
      * [64 j, 64 j + 64) below stat_ncols of row m of C (bias included; {-inf, 0} for an empty block).  Mixed precision, bf16
      * operands, forward layout, plain bias epilogue, N a multiple of 128, K of 64; ORTK_EINVAL otherwise. */
     float* tile_stats; int32_t stat_ncols;
+    /* optional (M ints): output row m takes the dropout draws of row drop_rows[m] — the valid-position decoder layout
+     * (ortk_batch.row_pos) draws what the padded (caption, position) layout draws, so a step is the same function of its seed in
+     * both layouts and an SCST update on the valid positions reproduces the masks of its train-mode rollout. */
+    const int32_t* drop_rows;   /* applied before drop_row_stride / drop_row_off */
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its
@@ -485,6 +495,11 @@ int ortk_layernorm_bwd(const float* dy, const float* x, const float* a, const fl
 int ortk_layernorm_bwd_drop(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
                             float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
                             float drop_p, uint32_t drop_seed, ortk_stream stream);
+/* Same; drop_rows (optional, `rows` ints): dz[row] takes the draws of row drop_rows[row] (index drop_rows[row]*d + col) — the
+ * valid-position decoder layout keyed like the padded one (see ortk_gemm_args.drop_rows). */
+int ortk_layernorm_bwd_drop_rows(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
+                                 float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
+                                 float drop_p, uint32_t drop_seed, const int32_t* drop_rows, ortk_stream stream);
 
 /* Geometry bias of BoxMultiHeadedAttention (relation_transformer.py:196-256,177-183,286):
  * out[l,b,h,i,j] = log(max(relu(WG[l,h].e_ij + bG[l,h]), 1e-6)).  wg[l]/bg[l] are per-layer device pointers
@@ -547,6 +562,11 @@ typedef struct ortk_attn_args {
      * self-attention: Lq = 1, drop_tf_lk = drop_tf_T; cross-attention: Lq = samples of the image, drop_tf_lk = regions.
      * drop_tf_T = 0: the natural index ((g*H + h) * Lq + i) * Lk + j.  Served by the generic kernel only. */
     int32_t drop_tf_T, drop_tf_t, drop_tf_lk;
+    /* optional, with q_off (ragged query groups), drop_p > 0: query row r (an index into q) draws the probability dropout of
+     * row drop_rows[r] of the UNRAGGED layout — group g's query i becomes i' = drop_rows[q_off[g*q_off_stride] + i] - g*Lq in the
+     * index ((g*H + h) * Lq + i') * Lk + j.  Cross-attention on the valid positions (an image's rows are the valid positions of
+     * its captions) then draws what the padded layout draws; forward and backward alike. */
+    const int32_t* drop_rows;
 } ortk_attn_args;
 int ortk_attention_fwd(const ortk_attn_args* a, ortk_stream stream);
 int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream);
@@ -561,10 +581,13 @@ int ortk_embed_bwd(const int64_t* seq, int64_t seq_stride, const float* dout, fl
 /* In-place log_softmax over the first V columns of (rows, ld) (OutputEmbedding, transformer.py:412-413);
  * logits are first multiplied by `scale` (1/temperature). */
 int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, float scale, ortk_stream stream);
-/* Fused cross-entropy on logits (rows, ld): loss_dev += -sum logp[target]*w/norm; dlogits (rows, ld_dl; fp32 or bf16;
- * may alias logits when fp32 with ld_dl == ld) <- dLoss/dlogits, zero in the pad columns. */
+/* Fused cross-entropy on logits (rows, ld): *loss_dev = -sum logp[target]*w/norm (LanguageModelCriterion / RewardCriterion,
+ * utils/losses.py:15-43); dlogits (rows, ld_dl; fp32 or bf16; may alias logits when fp32 with ld_dl == ld) <- dLoss/dlogits,
+ * zero in the pad columns.  The sum is DETERMINISTIC: every row's term goes to row_loss[row] and one workgroup adds them in a
+ * fixed order (no atomics) — the same bits on every run.  row_loss: ortk_xent_scratch_floats(rows) floats of caller scratch. */
+int64_t ortk_xent_scratch_floats(int64_t rows);
 int ortk_xent_fwd_bwd(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
-                      const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld,
+                      const float* norm_dev, float* loss_dev, float* row_loss, int64_t rows, int32_t V, int64_t ld,
                       void* dlogits, int32_t dl_dtype, int64_t ld_dl, ortk_stream stream);
 /* log_softmax backward: dlogits = dlogp - exp(logp) * sum_v dlogp, written over (rows, ld_out). */
 int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, void* dlogits, int32_t dl_dtype,
@@ -576,12 +599,18 @@ int ortk_colsum(const void* x, int32_t x_dtype, int64_t ld, float* out, int64_t 
 int ortk_gate_apply(const float* x, const float* gate, void* y, int32_t y_dtype, int64_t n, float scale, ortk_stream stream);
 /* y = x * keep(seed,i)/(1-p) — backward of a residual-branch dropout. */
 int ortk_dropout_apply(const float* x, void* y, int32_t y_dtype, int64_t n, float p, uint32_t seed, ortk_stream stream);
+/* Same over (rows, d) with row r keyed as row drop_rows[r] (index drop_rows[r]*d + col); drop_rows = NULL: ortk_dropout_apply. */
+int ortk_dropout_apply_rows(const float* x, void* y, int32_t y_dtype, int64_t rows, int32_t d, float p, uint32_t seed,
+                            const int32_t* drop_rows, ortk_stream stream);
 /* fp32 -> bf16 copy (the working copy of the weight arena in precision 1). */
 int ortk_cast_bf16(const float* x, void* y, int64_t n, ortk_stream stream);
 int ortk_fill(float* x, int64_t n, float value, ortk_stream stream);
 /* y[r, 0..cols) += x[r, 0..cols): x and y are column blocks of (rows, ld) matrices of `dtype` (0 fp32, 1 bf16) */
 int ortk_axpy_cols(const void* x, void* y, int32_t dtype, int64_t ld, int64_t rows, int32_t cols, ortk_stream stream);
-int ortk_sum(const float* x, int64_t n, float* out_dev, ortk_stream stream);  /* *out_dev = sum(x) */
+/* *out_dev = sum(x[0..n)) in a fixed order (no atomics: bit-identical reruns).  n <= 65 536 needs no scratch (NULL); longer
+ * inputs take ortk_sum_scratch_floats(n) floats. */
+int64_t ortk_sum_scratch_floats(int64_t n);
+int ortk_sum(const float* x, int64_t n, float* scratch, float* out_dev, ortk_stream stream);
 
 /* clip_grad_value_ + Adam (utils/optim.py:116-126,187-191; torch.optim.Adam update rule).
  * bc1 = 1-beta1^t, bc2 = 1-beta2^t computed by the host in double precision. */

@@ -326,10 +326,12 @@ def decode_step(st: DecodeState, it: Tensor, drop=None) -> Tensor:
     return generator(P, x[:, -1])
 
 
-def gumbel_from_hash(seed: int, t: int, rows: int, vocab: int) -> Tensor:
+def gumbel_from_hash(seed: int, t: int, rows: int, vocab: int, row_offset: int = 0) -> Tensor:
     """Counter-based uniforms -> Gumbel noise; the SAME integer hash runs inside the HIP sampler
-    (csrc/ortk_common.h: ortk_hash_u32), so multinomial decoding is reproducible token-for-token."""
-    r = torch.arange(rows, dtype=torch.int64)[:, None]
+    (csrc/ortk_common.h: ortk_hash_u32), so multinomial decoding is reproducible token-for-token.  `row_offset`: the draws are
+    keyed by the GLOBAL row (ortk_decode_opts.sample_row_offset: a data-parallel rank samples what one process samples on the
+    whole batch)."""
+    r = torch.arange(row_offset, row_offset + rows, dtype=torch.int64)[:, None]
     v = torch.arange(vocab, dtype=torch.int64)[None, :]
     M = 0xFFFFFFFF
     x = (r * 0x9E3779B1 + v * 0x85EBCA77 + (t + 1) * 0xC2B2AE3D + seed * 0x27D4EB2F) & M
@@ -342,7 +344,7 @@ def gumbel_from_hash(seed: int, t: int, rows: int, vocab: int) -> Tensor:
 
 def sample_greedy_or_multinomial(P, cfg, att_feats, boxes, att_masks, num_random_sample: int = 0,
                                  temperature: float = 1.0, decoding_constraint: int = 0, seed: int = 0, drop=None, drop_step=None,
-                                 scores_out=None):
+                                 scores_out=None, sample_row_offset: int = 0):
     """``_generate_captions`` greedy / multinomial branches (transformer.py:507-561).
 
     Multinomial draws use Gumbel-max over ``gumbel_from_hash`` (an exact sampler of
@@ -365,7 +367,7 @@ def sample_greedy_or_multinomial(P, cfg, att_feats, boxes, att_masks, num_random
         if decoding_constraint and t > 0:
             logp = logp.scatter(1, seq[:, t - 1:t], float("-inf"))
         if num_random_sample > 0:
-            z = logp / temperature + gumbel_from_hash(seed, t, n, logp.size(1))
+            z = logp / temperature + gumbel_from_hash(seed, t, n, logp.size(1), sample_row_offset)
             if scores_out is not None:          # (tests: the perturbed scores of every step, to show that a flipped token is a near-tie)
                 scores_out.append(z.clone())
             it = z.argmax(-1)

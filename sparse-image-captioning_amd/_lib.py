@@ -58,7 +58,7 @@ class SpmmArgs(C.Structure):
                 ("x_dtype", C.c_int32), ("y_dtype", C.c_int32),
                 ("bias", C.c_void_p), ("rowscale", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64),
                 ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_dtype", C.c_int32), ("gate_scale", C.c_float),
-                ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
+                ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_rows", C.c_void_p)]
 
 
 class ChainUnit(C.Structure):
@@ -75,7 +75,7 @@ class ChainArgs(C.Structure):
                 ("seed_h", C.c_uint32), ("seed_o", C.c_uint32),
                 ("g2", C.c_void_p), ("b2", C.c_void_p), ("y2", C.c_void_p), ("st2", C.c_void_p),
                 ("n2", C.c_int32), ("bias_s2", C.c_void_p), ("out2", C.c_void_p), ("ld2", C.c_int64),
-                ("drop_p", C.c_float), ("eps", C.c_float), ("progress", C.c_void_p)]
+                ("drop_p", C.c_float), ("eps", C.c_float), ("progress", C.c_void_p), ("drop_rows", C.c_void_p)]
 
 
 class BChainArgs(C.Structure):
@@ -87,7 +87,7 @@ class BChainArgs(C.Structure):
                 ("NC", C.c_int32), ("hgate", C.c_void_p), ("gh", C.c_void_p), ("gate_scale", C.c_float),
                 ("xb", C.c_void_p), ("stb", C.c_void_p), ("gb", C.c_void_p), ("dresb", C.c_void_p), ("dxb", C.c_void_p), ("dab", C.c_void_p),
                 ("dbb", C.c_void_p), ("dzb", C.c_void_p), ("seed_b", C.c_uint32), ("mask_b", C.c_int32),
-                ("n2", C.c_int32), ("out2", C.c_void_p), ("drop_p", C.c_float), ("eps", C.c_float)]
+                ("n2", C.c_int32), ("out2", C.c_void_p), ("drop_p", C.c_float), ("eps", C.c_float), ("drop_rows", C.c_void_p)]
 
 
 class Tuning(C.Structure):
@@ -118,7 +118,7 @@ class GemmArgs(C.Structure):
                 ("ln_mode", C.c_int32), ("ln_y_dtype", C.c_int32),
                 ("ln_a", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
                 ("ln_x", C.c_void_p), ("ln_dres", C.c_void_p), ("ln_da", C.c_void_p), ("ln_db", C.c_void_p),
-                ("tile_stats", C.c_void_p), ("stat_ncols", C.c_int32)]
+                ("tile_stats", C.c_void_p), ("stat_ncols", C.c_int32), ("drop_rows", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -134,7 +134,7 @@ class AttnArgs(C.Structure):
                 ("k_new", C.c_void_p), ("v_new", C.c_void_p), ("ld_new", C.c_int64), ("bwd_part", C.c_int32),
                 ("precision", C.c_int32), ("qkv_dtype", C.c_int32),
                 ("q_off", C.c_void_p), ("q_off_stride", C.c_int32), ("kv_ragged", C.c_int32),
-                ("drop_tf_T", C.c_int32), ("drop_tf_t", C.c_int32), ("drop_tf_lk", C.c_int32)]
+                ("drop_tf_T", C.c_int32), ("drop_tf_t", C.c_int32), ("drop_tf_lk", C.c_int32), ("drop_rows", C.c_void_p)]
 
 
 _P, _I32, _I64, _F, _U32, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t
@@ -175,6 +175,7 @@ SIGNATURES = {
     "ortk_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd_drop": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _I32, _F, C.c_uint32, _P]),
+    "ortk_layernorm_bwd_drop_rows": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _I32, _F, C.c_uint32, _P, _P]),
     "ortk_box_logbias_fwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, _I32, _I32, _I32, _I32, _P]),
     "ortk_box_logbias_bwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, C.POINTER(_P), C.POINTER(_P),
                                    _I32, _I32, _I32, _I32, _P]),
@@ -184,15 +185,18 @@ SIGNATURES = {
     "ortk_embed_fwd": (_I32, [_P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _F, _U32, _P]),
     "ortk_embed_bwd": (_I32, [_P, _I64, _P, _P, _I64, _I32, _I32, _F, _U32, _P]),
     "ortk_log_softmax": (_I32, [_P, _I64, _I32, _I64, _F, _P]),
-    "ortk_xent_fwd_bwd": (_I32, [_P, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I64, _P, _I32, _I64, _P]),
+    "ortk_xent_scratch_floats": (_I64, [_I64]),
+    "ortk_xent_fwd_bwd": (_I32, [_P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _I32, _I64, _P, _I32, _I64, _P]),
     "ortk_log_softmax_bwd": (_I32, [_P, _P, _I64, _P, _I32, _I64, _I64, _I32, _P]),
     "ortk_colsum": (_I32, [_P, _I32, _I64, _P, _I64, _I32, _P]),
     "ortk_gate_apply": (_I32, [_P, _P, _P, _I32, _I64, _F, _P]),
     "ortk_dropout_apply": (_I32, [_P, _P, _I32, _I64, _F, _U32, _P]),
+    "ortk_dropout_apply_rows": (_I32, [_P, _P, _I32, _I64, _I32, _F, _U32, _P, _P]),
     "ortk_dropout_site_seed": (_U32, [_U64, _I32, _I32, _I32]),
     "ortk_cast_bf16": (_I32, [_P, _P, _I64, _P]),
     "ortk_fill": (_I32, [_P, _I64, _F, _P]),
-    "ortk_sum": (_I32, [_P, _I64, _P, _P]),
+    "ortk_sum_scratch_floats": (_I64, [_I64]),
+    "ortk_sum": (_I32, [_P, _I64, _P, _P, _P]),
     "ortk_adam_clip": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P]),
     "ortk_adam_clip_zero": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P]),
     "ortk_mask_apply": (_I32, [_P, _P, _P, _I64, _I32, _U32, _P]),

@@ -113,6 +113,9 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
     const int i = it * 16 + lr;                     // this lane's query (operand row and output row)
     const bool iv = it < nit && i < Lqg;
     const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
+    // dropout draws of a ragged group keyed like the unragged layout's (ortk_attn_args.drop_rows): query i -> drop_rows[.] - g Lq
+    const int64_t drow = (a.drop_rows && a.q_off && iv && a.drop_p > 0.f)
+                             ? (((int64_t)g * a.H + h) * Lq + ((int64_t)a.drop_rows[qrow0 + i] - (int64_t)g * Lq)) * Lk : prow;
     bf16x8 qf[DK / 32];
 #pragma unroll
     for (int ks = 0; ks < DK / 32; ++ks) qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(ortk_attn_args a) {
             }
             if (a.drop_p > 0.f) {
                 bool kp[4];
-                ortk_keep4(a.drop_seed, (uint64_t)(prow + j0), a.drop_p, kp);
+                ortk_keep4(a.drop_seed, (uint64_t)(drow + j0), a.drop_p, kp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] = kp[r] ? p[r] * inv_keep : 0.f;
             }
@@ -245,6 +248,8 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
     const int i0 = it * 16, i = i0 + lr;
     const bool iv = it < nit && i < Lqg;
     const int64_t prow = (((int64_t)g * a.H + h) * Lq + i) * Lk;
+    const int64_t drow = (a.drop_rows && a.q_off && iv && a.drop_p > 0.f)
+                             ? (((int64_t)g * a.H + h) * Lq + ((int64_t)a.drop_rows[qrow0 + i] - (int64_t)g * Lq)) * Lk : prow;
     float4 praw[NJT];
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kernel(ortk_attn_args a, int L
             const float pv[4] = {praw[jt].x, praw[jt].y, praw[jt].z, praw[jt].w};
             float pd[4];
             bool kp[4] = {true, true, true, true};
-            if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)(prow + j0), a.drop_p, kp);
+            if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)(drow + j0), a.drop_p, kp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool valid = iv && j0 + r < Lk;

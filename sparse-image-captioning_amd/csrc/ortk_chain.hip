@@ -38,6 +38,17 @@ constexpr int CFRAG = 64;          // uint4 per fragment (1 KB)
 constexpr int CKSTEP = 4 * CFRAG;  // uint4 per k-step of one wave (4 column tiles)
 constexpr int CUNIT = 16 * CKSTEP; // uint4 per unit of one wave (64 KB)
 constexpr int CIMG = CRB * CD * 2; // bytes of one bf16 A image
+// Dropout keys of the workgroup's rows, behind everything else in LDS: row r draws as row skey[r] = drop_rows[r0 + r] (the valid-position
+// layout keyed like the padded one, ortk_chain_args.drop_rows) or r0 + r.  A table instead of a load at every site: the kernels sit at
+// 256 VGPRs and a hoisted per-lane copy of the keys spills (28-36 bytes of scratch per lane in the first version).
+constexpr int CKEY_BYTES = 512;
+__device__ __forceinline__ void c_fill_keys(uint32_t* skey, const int32_t* __restrict__ drop_rows, int r0, int nrow, int tid) {
+    if (tid < CKEY_BYTES / 4) {
+        const int g = r0 + (tid < nrow ? tid : 0);
+        skey[tid] = drop_rows ? (uint32_t)drop_rows[g] : (uint32_t)g;
+    }
+    __syncthreads();
+}
 
 // A images: [row][64 chunks of 16 B], physical chunk = chunk ^ (row & 15) (conflict-free MFMA operand reads, as ortk_decstack.hip)
 __device__ __forceinline__ int c_off(int row, int chunk) { return row * 1024 + ((chunk ^ (row & 15)) << 4); }
@@ -102,6 +113,7 @@ struct ChainArgs {
     float drop_p, eps;
     int32_t* progress;             // [8] zeroed before the launch: units begun by the pace-maker workgroup of each XCD (NULL: no prefetchers)
     int32_t npf, slots;            // L2 prefetcher workgroups at the head of the grid (0 | 8); compute workgroups per round
+    const int32_t* drop_rows;      // optional: row g draws its dropout as row drop_rows[g] (ortk_chain_args.drop_rows)
 };
 constexpr int CAHEAD = 3;          // units the L2 prefetcher may run in front of its pace-maker
 
@@ -142,6 +154,8 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
 #define CH_UNIT_BEGIN() do { ++unit_no; if (pace) __hip_atomic_store(a.progress + (blockIdx.x & 7), unit_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
     const int r0 = bid * a.rb;
     const int nrow = min(a.rb, a.M - r0);          // rows of this workgroup that exist
+    uint32_t* skey = reinterpret_cast<uint32_t*>(smem + 3 * CIMG + 2 * CRB * 8 * sizeof(float));
+    c_fill_keys(skey, a.drop_rows, r0, nrow, tid);
     const float ik = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const uint32_t thr = ortk_keep_thr(a.drop_p);
     const bool drop = a.drop_p > 0.f;
@@ -178,7 +192,6 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int mt = 0; mt < CMT; ++mt) {
             const int row = 16 * mt + (lane & 15);
-            const uint32_t g = (uint32_t)(r0 + (row < nrow ? row : 0));
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = 64 * wave + 16 * nt + 4 * (lane >> 4);
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
                 for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[nt][r];
                 if (drop) {
                     bool kp[4];
-                    ortk_keep4_u32(seed, g * (uint32_t)CD + (uint32_t)col, thr, kp);
+                    ortk_keep4_u32(seed, skey[row < nrow ? row : 0] * (uint32_t)CD + (uint32_t)col, thr, kp);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
                 }
@@ -321,7 +334,6 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
 #pragma unroll
             for (int mt = 0; mt < CMT; ++mt) {
                 const int row = 16 * mt + (lane & 15);
-                const uint32_t g = (uint32_t)(r0 + (row < nrow ? row : 0));
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int col = 64 * wave + 16 * nt + 4 * (lane >> 4);
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(512) void row_chain_kernel(ChainArgs a) {
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[mt][nt][r] + bias[nt][r], 0.f);
                     if (drop) {
                         bool kp[4];
-                        ortk_keep4_u32(a.seed_h, g * ffn + (uint32_t)(c * CD + col), thr, kp);
+                        ortk_keep4_u32(a.seed_h, skey[row < nrow ? row : 0] * ffn + (uint32_t)(c * CD + col), thr, kp);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
                     }
@@ -380,7 +392,7 @@ constexpr int WSPD = WSPD_;                 // k-steps of weight fragments in fl
 constexpr int WKSTEP = WNT * CFRAG;         // uint4 per k-step of one wave
 constexpr int WUNIT = 16 * WKSTEP;          // uint4 per unit of one wave (64 KB)
 constexpr int WIMG = WRB * 1024;            // bytes of an image (76 rows); MFMA tiles cover 80: rows 76.. of A0 read H0, of H0 the red arrays
-constexpr size_t WIDE_LDS = (size_t)2 * WIMG + 2 * (16 * WMT) * WNW * sizeof(float);
+constexpr size_t WIDE_LDS = (size_t)2 * WIMG + 2 * (16 * WMT) * WNW * sizeof(float) + CKEY_BYTES;
 static_assert(2 * (16 * WMT) * WNW * sizeof(float) >= 4 * 1024, "the tile rows past the second image stay inside the allocation");
 static_assert(WIDE_LDS <= 160 * 1024, "LDS budget");
 
@@ -470,6 +482,8 @@ __global__ __launch_bounds__(512) void row_chain_wide_kernel(ChainArgs a) {
 #define CH_FRESH_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
     const int r0 = blockIdx.x * a.rb;
     const int nrow = min(a.rb, a.M - r0);
+    uint32_t* skey = reinterpret_cast<uint32_t*>(smem + 2 * WIMG + 2 * (16 * WMT) * WNW * sizeof(float));
+    c_fill_keys(skey, a.drop_rows, r0, nrow, tid);
     const float ik = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const uint32_t thr = ortk_keep_thr(a.drop_p);
     const bool drop = a.drop_p > 0.f;
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(512) void row_chain_wide_kernel(ChainArgs a) {
                 for (int r = 0; r < 4; ++r) v[r] = xa[mt][nt][r] + bias[r];
                 if (drop) {
                     bool kp[4];
-                    ortk_keep4_u32(seed, g * (uint32_t)CD + (uint32_t)col, thr, kp);
+                    ortk_keep4_u32(seed, skey[row < nrow ? row : 0] * (uint32_t)CD + (uint32_t)col, thr, kp);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
                 }
@@ -622,7 +636,6 @@ __global__ __launch_bounds__(512) void row_chain_wide_kernel(ChainArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < WMT; ++mt) {
                     const int row = 16 * mt + (lane & 15);
-                    const uint32_t g = (uint32_t)(r0 + (row < nrow ? row : 0));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int col = WCW * wave + 32 * hf + 16 * j + 4 * (lane >> 4);
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(512) void row_chain_wide_kernel(ChainArgs a) {
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(hacc[mt][j][r] + bias[r], 0.f);
                         if (drop) {
                             bool kp[4];
-                            ortk_keep4_u32(a.seed_h, g * ffn + (uint32_t)(c * CD + col), thr, kp);
+                            ortk_keep4_u32(a.seed_h, skey[row < nrow ? row : 0] * ffn + (uint32_t)(c * CD + col), thr, kp);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ik : 0.f;
                         }
@@ -684,6 +697,7 @@ struct BChainArgs {
     const float *xb, *stb, *gb, *dresb; float *dxb, *dab, *dbb; __bf16* dzb; uint32_t seed_b; int32_t mask_b;
     int32_t n2; __bf16* out2;
     float drop_p, eps;
+    const int32_t* drop_rows;
 };
 
 __global__ __launch_bounds__(512) void row_bchain_kernel(BChainArgs a) {
@@ -698,6 +712,8 @@ __global__ __launch_bounds__(512) void row_bchain_kernel(BChainArgs a) {
 #define CH_FRESH_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
     const int r0 = blockIdx.x * a.rb;
     const int nrow = min(a.rb, a.M - r0);
+    uint32_t* skey = reinterpret_cast<uint32_t*>(smem + 3 * CIMG + 2 * CRB * 8 * sizeof(float));
+    c_fill_keys(skey, a.drop_rows, r0, nrow, tid);
     const float ik = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const uint32_t thr = ortk_keep_thr(a.drop_p);
     const bool drop = a.drop_p > 0.f;
@@ -796,7 +812,7 @@ __global__ __launch_bounds__(512) void row_bchain_kernel(BChainArgs a) {
                     float z[4] = {o[0], o[1], o[2], o[3]};
                     if (drop) {
                         bool kp[4];
-                        ortk_keep4_u32(seed, (uint32_t)g * (uint32_t)CD + (uint32_t)col, thr, kp);
+                        ortk_keep4_u32(seed, skey[row < nrow ? row : 0] * (uint32_t)CD + (uint32_t)col, thr, kp);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) z[e] = kp[e] ? z[e] * ik : 0.f;
                     }
@@ -934,7 +950,7 @@ __global__ __launch_bounds__(256) void chain_pack_all_kernel(const __bf16* __res
     }
 }
 
-constexpr size_t CHAIN_LDS = (size_t)3 * CIMG + 2 * CRB * 8 * sizeof(float);
+constexpr size_t CHAIN_LDS = (size_t)3 * CIMG + 2 * CRB * 8 * sizeof(float) + CKEY_BYTES;
 
 }  // namespace
 
@@ -1019,7 +1035,7 @@ int chain_run(const ortk_chain_args* p, const void* packed, hipStream_t s) {
     a.seed_h = p->seed_h; a.seed_o = p->seed_o;
     a.g2 = p->g2; a.b2 = p->b2; a.y2 = reinterpret_cast<__bf16*>(p->y2); a.st2 = p->st2;
     a.n2 = p->n2; a.bias_s2 = p->bias_s2; a.out2 = reinterpret_cast<__bf16*>(p->out2); a.ld2 = (int)p->ld2;
-    a.drop_p = p->drop_p; a.eps = p->eps;
+    a.drop_p = p->drop_p; a.eps = p->eps; a.drop_rows = p->drop_rows;
     const unsigned grid = (unsigned)(ortk_cdiv(p->M, a.rb) + a.npf);
     ProfMark pm;
     if (ortk_prof_active()) {
@@ -1069,7 +1085,7 @@ int bchain_run(const ortk_bchain_args* p, const void* packed, hipStream_t s) {
     a.xb = p->xb; a.stb = p->stb; a.gb = p->gb; a.dresb = p->dresb; a.dxb = p->dxb; a.dab = p->dab; a.dbb = p->dbb;
     a.dzb = reinterpret_cast<__bf16*>(p->dzb); a.seed_b = p->seed_b; a.mask_b = p->mask_b;
     a.n2 = p->n2; a.out2 = reinterpret_cast<__bf16*>(p->out2);
-    a.drop_p = p->drop_p; a.eps = p->eps;
+    a.drop_p = p->drop_p; a.eps = p->eps; a.drop_rows = p->drop_rows;
     ProfMark pm;
     if (ortk_prof_active()) (void)prof_begin(PROF_KEY_CHAIN, 2.0 * p->M * n_units * CD * CD, (double)n_units * CD * CD * 2, s, pm); else pm.live = false;
     hipLaunchKernelGGL(row_bchain_kernel, dim3((unsigned)ortk_cdiv(p->M, a.rb)), dim3(512), CHAIN_LDS, s, a);

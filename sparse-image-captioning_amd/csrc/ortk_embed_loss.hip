@@ -23,7 +23,7 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const int64_t* __restric
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     // eval_stride K > 0 (train-mode decode with greedy rows): rows with row % K == 0 are eval-mode rows — no dropout — and row
     // q K + k (k >= 1) draws like row q (K - 1) + k - 1
-    int64_t drow = row;
+    int64_t drow = prow;      // (the valid-position layout draws what the padded (caption, position) layout draws)
     bool drop = drop_p > 0.f;
     if (eval_stride > 0) { const int64_t q = row / eval_stride, k = row - q * eval_stride; drop = drop && k != 0; drow = q * (eval_stride - 1) + k - 1; }
     for (int c = threadIdx.x; c < d; c += 128) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(const int64_t* __restric
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     for (int c = threadIdx.x; c < d; c += 128) {
         float g = dout[row * d + c];
-        if (drop_p > 0.f) g = ortk_keep(seed, (uint64_t)row * d + c, drop_p) ? g * inv_keep : 0.f;
+        if (drop_p > 0.f) g = ortk_keep(seed, (uint64_t)prow * d + c, drop_p) ? g * inv_keep : 0.f;
         atomicAdd(&dlut[tok * d + c], g * scale);
     }
 }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x,
 
 __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                    int64_t target_stride, int T, const float* __restrict__ weight,
-                                                   const float* __restrict__ norm_dev, float* __restrict__ loss_dev, int V,
+                                                   const float* __restrict__ norm_dev, float* __restrict__ row_loss, int V,
                                                    int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl, const int32_t* __restrict__ row_pos) {
     __shared__ float sh[4];
     const int64_t r = blockIdx.x;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
     for (int c = threadIdx.x; c < V; c += 256) s += expf(row[c] - mx);
     s = block_sum(s, sh);
     const float lse = logf(s);
-    if (threadIdx.x == 0 && w != 0.f) atomicAdd(loss_dev, -((row[tgt] - mx) - lse) * w);
+    if (threadIdx.x == 0) row_loss[r] = w != 0.f ? -((row[tgt] - mx) - lse) * w : 0.f;      // summed in a fixed order by loss_reduce_kernel
     __syncthreads();
     // dlogits may alias logits (fp32, same ld): every element is read before it is overwritten by the same thread
     for (int c = threadIdx.x; c < (int)ld_dl; c += 256) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
 template <int NPT>
 __global__ __launch_bounds__(256) void xent_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                        int64_t target_stride, int T, const float* __restrict__ weight,
-                                                       const float* __restrict__ norm_dev, float* __restrict__ loss_dev, int V,
+                                                       const float* __restrict__ norm_dev, float* __restrict__ row_loss, int V,
                                                        int64_t ld, void* dlogits, int dl_dt, int64_t ld_dl, const int32_t* __restrict__ row_pos) {
     __shared__ float sh[4];
     const int64_t r = blockIdx.x;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void xent_reg_kernel(const float* __restrict__
     for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) s += expf(z[u] - mx);
     s = block_sum(s, sh);
     const float lse = logf(s);
-    if (tid == 0 && w != 0.f) atomicAdd(loss_dev, -((row[tgt] - mx) - lse) * w);
+    if (tid == 0) row_loss[r] = w != 0.f ? -((row[tgt] - mx) - lse) * w : 0.f;
     __syncthreads();     // dlogits may alias logits (fp32 mode): row[tgt] is read before any element is overwritten
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
@@ -188,6 +188,16 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
     const float inv_keep = 1.f / (1.f - p);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         st_elem(y, i, y_dt, (p > 0.f && !ortk_keep(seed, (uint64_t)i, p)) ? 0.f : x[i] * inv_keep);
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_rows_kernel(const float* __restrict__ x, void* __restrict__ y, int y_dt, int64_t rows, int d,
+                                                                 float p, uint32_t seed, const int32_t* __restrict__ drop_rows) {
+    const float inv_keep = 1.f / (1.f - p);
+    const int64_t n = rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / d; const int c = (int)(i - r * d);
+        st_elem(y, i, y_dt, (p > 0.f && !ortk_keep(seed, (uint64_t)drop_rows[r] * (uint64_t)d + (uint64_t)c, p)) ? 0.f : x[i] * inv_keep);
+    }
 }
 
 __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ x, const float* __restrict__ gate,
@@ -262,12 +272,29 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, int64_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
 }
 
-__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
-    __shared__ float sh[4];
+// Fixed-order sums (no atomics: the same bits on every run, whatever the block scheduling).  Stage 1: block b sums its contiguous
+// SUM_CHUNK-element slice — thread t the elements t, t + 1024, ... in that order, then a tree over the 1 024 partials — into part[b];
+// stage 2 (one block) does the same over the partials.  n <= SUM_CHUNK: one launch.  The scalar every caller reads — the loss of
+// LanguageModelCriterion / RewardCriterion (utils/losses.py:15-43: one torch.sum over the (rows, T) terms) — comes out of here.
+constexpr int SUM_THREADS = 1024;
+constexpr int64_t SUM_CHUNK = 64 * 1024;
+__device__ __forceinline__ float fixed_order_block_sum(const float* __restrict__ x, int64_t n, float* sh) {
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    for (int64_t i = threadIdx.x; i < n; i += SUM_THREADS) s += x[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int k = SUM_THREADS / 2; k >= 1; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    return sh[0];
+}
+__global__ __launch_bounds__(SUM_THREADS) void sum_fixed_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float sh[SUM_THREADS];
+    const int64_t i0 = (int64_t)blockIdx.x * SUM_CHUNK;
+    const float s = fixed_order_block_sum(x + i0, n - i0 < SUM_CHUNK ? n - i0 : SUM_CHUNK, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 inline unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>(ortk_cdiv(n, 256), 2048); }
@@ -320,29 +347,49 @@ extern "C" int ortk_log_softmax(float* x, int64_t rows, int32_t V, int64_t ld, f
 }
 
 namespace ortk {
+// *out_dev = sum(x[0..n)) in a fixed order; `part` (sum_partials(n) floats of scratch) is needed when n > SUM_CHUNK
+int64_t sum_partials(int64_t n) { return n > SUM_CHUNK ? ortk_cdiv(n, SUM_CHUNK) : 0; }
+int sum_fixed(const float* x, int64_t n, float* part, float* out_dev, hipStream_t s) {
+    if (!x || !out_dev || n < 0) return ORTK_EINVAL;
+    if (n == 0) return ortk_fill(out_dev, 1, 0.f, (ortk_stream)s);
+    const int64_t nb = ortk_cdiv(n, SUM_CHUNK);
+    if (nb > 1 && !part) return ORTK_EINVAL;
+    if (nb > SUM_CHUNK) return ORTK_EINVAL;      // (4e9 elements: no caller of this path)
+    hipLaunchKernelGGL(sum_fixed_kernel, dim3((unsigned)nb), dim3(SUM_THREADS), 0, s, x, n, nb > 1 ? part : out_dev);
+    ORTK_CHECK_LAUNCH();
+    if (nb > 1) {
+        hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(SUM_THREADS), 0, s, part, nb, out_dev);
+        ORTK_CHECK_LAUNCH();
+    }
+    return 0;
+}
+// row_loss: xent_scratch_floats(rows) floats of scratch (the per-row terms, then the partials of a two-stage sum); *loss_dev = their
+// fixed-order sum
+int64_t xent_scratch_floats(int64_t rows) { return rows < 0 ? -1 : rows + sum_partials(rows); }
 int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight, const float* norm_dev,
-              float* loss_dev, int64_t rows, const int32_t* row_pos, int32_t V, int64_t ld, void* dlogits, int32_t dl_dtype, int64_t ld_dl,
-              hipStream_t s) {
-    if (!logits || !targets || !weight || !norm_dev || !loss_dev || !dlogits || rows < 0 || V < 1 || ld < V || ld_dl < V || T < 1)
+              float* loss_dev, float* row_loss, int64_t rows, const int32_t* row_pos, int32_t V, int64_t ld, void* dlogits, int32_t dl_dtype,
+              int64_t ld_dl, hipStream_t s) {
+    if (!logits || !targets || !weight || !norm_dev || !loss_dev || !row_loss || !dlogits || rows < 0 || V < 1 || ld < V || ld_dl < V || T < 1)
         return ORTK_EINVAL;
     if (dl_dtype != ORTK_F32 && dl_dtype != ORTK_BF16) return ORTK_EINVAL;
-    if (rows == 0) return 0;
+    if (rows == 0) return ortk_fill(loss_dev, 1, 0.f, (ortk_stream)s);
     if (V <= 256 * 40 && ld_dl <= 256 * 40 && V > 256 * 8)
         hipLaunchKernelGGL(xent_reg_kernel<40>, dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T,
-                           weight, norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
+                           weight, norm_dev, row_loss, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
     else
         hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T, weight,
-                           norm_dev, loss_dev, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
+                           norm_dev, row_loss, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
     ORTK_CHECK_LAUNCH();
-    return 0;
+    return sum_fixed(row_loss, rows, row_loss + rows, loss_dev, s);
 }
 }  // namespace ortk
 
+extern "C" int64_t ortk_xent_scratch_floats(int64_t rows) { return ortk::xent_scratch_floats(rows); }
 extern "C" int ortk_xent_fwd_bwd(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight,
-                                 const float* norm_dev, float* loss_dev, int64_t rows, int32_t V, int64_t ld, void* dlogits,
+                                 const float* norm_dev, float* loss_dev, float* row_loss, int64_t rows, int32_t V, int64_t ld, void* dlogits,
                                  int32_t dl_dtype, int64_t ld_dl, ortk_stream stream) {
-    return ortk::xent_rows(logits, targets, target_stride, T, weight, norm_dev, loss_dev, rows, nullptr, V, ld, dlogits, dl_dtype, ld_dl,
-                           ortk_s(stream));
+    return ortk::xent_rows(logits, targets, target_stride, T, weight, norm_dev, loss_dev, row_loss, rows, nullptr, V, ld, dlogits, dl_dtype,
+                           ld_dl, ortk_s(stream));
 }
 
 extern "C" int ortk_log_softmax_bwd(const float* logp, const float* dlogp, int64_t ld_in, void* dlogits, int32_t dl_dtype,
@@ -369,6 +416,17 @@ extern "C" int ortk_dropout_apply(const float* x, void* y, int32_t y_dtype, int6
     if (!x || !y || n < 0 || p < 0.f || p >= 1.f || (y_dtype != ORTK_F32 && y_dtype != ORTK_BF16)) return ORTK_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, ortk_s(stream), x, y, (int)y_dtype, n, p, seed);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_dropout_apply_rows(const float* x, void* y, int32_t y_dtype, int64_t rows, int32_t d, float p, uint32_t seed,
+                                       const int32_t* drop_rows, ortk_stream stream) {
+    if (rows < 0 || d < 1) return ORTK_EINVAL;
+    if (!drop_rows) return ortk_dropout_apply(x, y, y_dtype, rows * d, p, seed, stream);
+    if (!x || !y || p < 0.f || p >= 1.f || (y_dtype != ORTK_F32 && y_dtype != ORTK_BF16)) return ORTK_EINVAL;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(dropout_apply_rows_kernel, dim3(ew_grid(rows * d)), dim3(256), 0, ortk_s(stream), x, y, (int)y_dtype, rows, (int)d, p, seed, drop_rows);
     ORTK_CHECK_LAUNCH();
     return 0;
 }
@@ -416,12 +474,9 @@ extern "C" int ortk_fill(float* x, int64_t n, float value, ortk_stream stream) {
     return 0;
 }
 
-extern "C" int ortk_sum(const float* x, int64_t n, float* out_dev, ortk_stream stream) {
-    if (!x || !out_dev || n < 0) return ORTK_EINVAL;
-    if (int e = ortk_fill(out_dev, 1, 0.f, stream)) return e;
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(sum_kernel, dim3((unsigned)std::min<int64_t>(ortk_cdiv(n, 256), 256)), dim3(256), 0, ortk_s(stream), x, n,
-                       out_dev);
-    ORTK_CHECK_LAUNCH();
-    return 0;
+// *out_dev = sum(x) in a fixed order.  n <= 65 536 (every caller of the path: the (rows, T) normaliser mask): one launch, no scratch;
+// longer inputs need `scratch` = ortk_sum_scratch_floats(n) floats.
+extern "C" int64_t ortk_sum_scratch_floats(int64_t n) { return n < 0 ? -1 : ortk::sum_partials(n); }
+extern "C" int ortk_sum(const float* x, int64_t n, float* scratch, float* out_dev, ortk_stream stream) {
+    return ortk::sum_fixed(x, n, scratch, out_dev, ortk_s(stream));
 }

@@ -56,6 +56,7 @@ struct Epi {
     int relu; float drop_p; uint32_t drop_seed; int accumulate; bool first_split;
     int M, N;
     int drop_rs, drop_r0;      // dropout draw of element (m, n): index (m * drop_rs + drop_r0) * N + n   (1, 0: the plain m * N + n)
+    const int32_t* drop_rows;  // optional: row m draws as row drop_rows[m] (applied before drop_rs / drop_r0; ortk_gemm_args.drop_rows)
 };
 
 // 4 consecutive elements of a row vector / matrix row, zero beyond N
@@ -94,6 +95,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
         const int m = mrow0 + 16 * i;
         if (m >= EM) continue;
         const float rs = e.rowscale ? e.rowscale[m] : 1.f;
+        const uint64_t dm = (e.drop_p > 0.f && e.drop_rows) ? (uint64_t)e.drop_rows[m] : (uint64_t)m;
         float4 res[NJ], gat[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -118,7 +120,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
             const float gg[4] = {gat[j].x, gat[j].y, gat[j].z, gat[j].w};
             float v[4];
             bool kp[4] = {true, true, true, true};
-            if (e.drop_p > 0.f) ortk_keep4(e.drop_seed, ((uint64_t)m * (uint64_t)e.drop_rs + (uint64_t)e.drop_r0) * (uint64_t)e.N + n0, e.drop_p, kp);
+            if (e.drop_p > 0.f) ortk_keep4(e.drop_seed, (dm * (uint64_t)e.drop_rs + (uint64_t)e.drop_r0) * (uint64_t)e.N + n0, e.drop_p, kp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = acc[i][j][r] + bb[r];
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(ortk_gemm_args p, int til
     }
 
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     epilogue_tile<false>(e, mb + wm * 64 + lr, nb + wn * 64 + 4 * lk, acc);
 }
 
@@ -451,7 +453,7 @@ __device__ __forceinline__ void epilogue_staged(const Epi& e, float* sC, int mb,
             float x = a4[q] + bb[q];
             if (e.relu) x = fmaxf(x, 0.f);
             x *= rs;
-            if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, ((uint64_t)m * (uint64_t)e.drop_rs + (uint64_t)e.drop_r0) * (uint64_t)e.N + (n0 + q), e.drop_p) ? x * inv_keep : 0.f;
+            if (e.drop_p > 0.f) x = ortk_keep(e.drop_seed, (((e.drop_rows ? (uint64_t)e.drop_rows[m] : (uint64_t)m)) * (uint64_t)e.drop_rs + (uint64_t)e.drop_r0) * (uint64_t)e.N + (n0 + q), e.drop_p) ? x * inv_keep : 0.f;
             if (e.gate) x = gg[q] > 0.f ? x * e.gate_scale : 0.f;
             v[q] = x + rr[q];
         }
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(ortk_gemm_args p, int ti
         }
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     if (TA && do_cs) __syncthreads();     // the column-sum scratch shares the LDS with the staged C tile
     static_assert(128 * CP * sizeof(float) <= BF16_LDS_BYTES_C, "staged C tile must fit the staging LDS");
     // plain stores are faster straight from the accumulator layout (64-B segments, no LDS round trip: 491 vs 436 TF
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
         }
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     if (!BIG && p.accumulate) {
         __syncthreads();      // the staged C tile reuses the ring
         epilogue_staged<true>(e, reinterpret_cast<float*>(smem16), mb, nb, wm, wn, lane, wave,
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
         }
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
-          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off};
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     if (mb + 256 <= p.M) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
@@ -1004,6 +1006,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_row512_kernel(ortk_gemm_args
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + 16 * i, rowc = min(row, p.M - 1);
+            const uint64_t drow = (p.drop_p > 0.f && p.drop_rows) ? (uint64_t)p.drop_rows[rowc] : (uint64_t)rowc;
             f32x4 res[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1015,7 +1018,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_row512_kernel(ortk_gemm_args
             for (int j = 0; j < 8; ++j) {
                 bool kp[4] = {true, true, true, true};
                 if (p.drop_p > 0.f)
-                    ortk_keep4(p.drop_seed, ((uint64_t)rowc * (uint64_t)drs + (uint64_t)p.drop_row_off) * (uint64_t)RP_N + (col0 + 16 * j), p.drop_p, kp);
+                    ortk_keep4(p.drop_seed, (drow * (uint64_t)drs + (uint64_t)p.drop_row_off) * (uint64_t)RP_N + (col0 + 16 * j), p.drop_p, kp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[i][j][r] + bias4[j][r];
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_row512_kernel(ortk_gemm_args
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + i0) = o;
                 if (p.ln_y) {
                     bool kp[4] = {true, true, true, true};
-                    if (p.drop_p > 0.f) ortk_keep4(p.drop_seed, (uint64_t)i0, p.drop_p, kp);
+                    if (p.drop_p > 0.f) ortk_keep4(p.drop_seed, p.drop_rows ? (uint64_t)p.drop_rows[row] * RP_N + (uint64_t)(col0 + 16 * j) : (uint64_t)i0, p.drop_p, kp);
                     st_elem4(p.ln_y, i0, p.ln_y_dtype, make_float4(kp[0] ? o[0] * ik : 0.f, kp[1] ? o[1] * ik : 0.f, kp[2] ? o[2] * ik : 0.f, kp[3] ? o[3] * ik : 0.f));
                 }
             }
@@ -1392,8 +1395,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             if (int e = ortk_gemm(&q, stream)) return e;
             float* Cf = reinterpret_cast<float*>(p.C);
             if (p.ln_mode == 1) return ortk_layernorm_fwd(Cf, p.ln_a, p.ln_b, p.ln_y, p.ln_y_dtype, p.ln_stats, p.M, p.N, p.ln_eps, stream);
-            return ortk_layernorm_bwd_drop(Cf, p.ln_x, p.ln_a, p.ln_stats, p.ln_dres, Cf, p.ln_da, p.ln_db, p.M, p.N, p.ln_eps,
-                                           p.ln_y, p.ln_y_dtype, p.drop_p, p.drop_seed, stream);
+            return ortk_layernorm_bwd_drop_rows(Cf, p.ln_x, p.ln_a, p.ln_stats, p.ln_dres, Cf, p.ln_da, p.ln_db, p.M, p.N, p.ln_eps,
+                                                p.ln_y, p.ln_y_dtype, p.drop_p, p.drop_seed, p.drop_rows, stream);
         }
         gemm16_fn g = p.ln_mode == 1 ? gemm_bf16_row512_kernel<1> : gemm_bf16_row512_kernel<2>;
         static bool rp_attr[2] = {false, false};

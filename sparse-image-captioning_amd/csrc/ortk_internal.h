@@ -166,8 +166,11 @@ int embed_fwd_rows(const int64_t* seq, int64_t seq_stride, const float* lut, con
 int embed_bwd_rows(const int64_t* seq, int64_t seq_stride, const float* dout, float* dlut, int64_t nrows, const int32_t* row_pos, int32_t T,
                    int32_t d, float drop_p, uint32_t seed, hipStream_t s);
 int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride, int32_t T, const float* weight, const float* norm_dev,
-              float* loss_dev, int64_t rows, const int32_t* row_pos, int32_t V, int64_t ld, void* dlogits, int32_t dl_dtype, int64_t ld_dl,
-              hipStream_t s);
+              float* loss_dev, float* row_loss, int64_t rows, const int32_t* row_pos, int32_t V, int64_t ld, void* dlogits, int32_t dl_dtype,
+              int64_t ld_dl, hipStream_t s);
+int64_t xent_scratch_floats(int64_t rows);
+int64_t sum_partials(int64_t n);
+int sum_fixed(const float* x, int64_t n, float* part, float* out_dev, hipStream_t s);
 
 // end of a decode on the column-split stack kernel: if *status != 0 (an exchange group never completed) the outputs become
 // all-pad captions with NaN log-probs and scores — a failed decode cannot pass for a result

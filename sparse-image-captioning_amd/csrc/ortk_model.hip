@@ -203,6 +203,10 @@ static void bwd_plan_built_by(const ortk_sparse_plan* plan, const void* ws, uint
     for (int i = 0; i < 8; ++i) { if (g_bwd_owner[i].plan == plan) { slot = i; break; } if (!g_bwd_owner[i].plan) slot = i; }
     g_bwd_owner[slot] = BwdPlanOwner{plan, ws, seed, train};
 }
+static void bwd_plan_forget(const ortk_sparse_plan* plan) {
+    std::lock_guard<std::mutex> g(g_bwd_owner_mu);
+    for (auto& o : g_bwd_owner) if (o.plan == plan) o = BwdPlanOwner{};
+}
 static bool bwd_plan_is_of(const ortk_sparse_plan* plan, const void* ws, uint64_t seed, int train) {
     std::lock_guard<std::mutex> g(g_bwd_owner_mu);
     for (const auto& o : g_bwd_owner) if (o.plan == plan) return o.ws == ws && o.seed == seed && o.train == train;
@@ -325,7 +329,7 @@ struct TrainWS {
     void* w16t;                             // ... and of every weight block TRANSPOSED (operand of the data-gradient GEMMs)
     float *x0, *logbias, *dscore; void* mem /*A*/; float* st_mem;
     EncBuf enc[MAXLAYERS];
-    float *dx0, *keymask; void* ckv /*Q*/; void* dec_out /*A*/; float *st_out, *logits; void* dlogits /*A; aliases logits in fp32*/;
+    float *dx0, *keymask; void* ckv /*Q*/; void* dec_out /*A*/; float *st_out, *logits, *row_loss /*criterion terms, one per decoder row*/; void* dlogits /*A; aliases logits in fp32*/;
     DecBuf dec[MAXLAYERS];
     // backward temporaries
     float *ga, *gb, *gy; void* gdo /*Q: dO of an attention backward*/; void *gt /*A*/, *gt2 /*A*/, *gt3 /*A*/, *gqkv /*A*/, *gh /*A*/, *gkv /*A*/; float* scalar;
@@ -376,6 +380,7 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
     }
     w.dec_out = act(Md * d); w.st_out = b.take<float>(Md * 2);
     w.logits = b.take<float>(Md * w.ldv);
+    w.row_loss = b.take<float>(xent_scratch_floats(Md));
     w.dlogits = c.precision ? act(Md * w.ldv) : (void*)w.logits;
     w.ga = b.take<float>(Mx * d); w.gb = b.take<float>(Mx * d); w.gy = b.take<float>(Mx * d);
     w.gdo = c.precision ? act(Mx * d) : nullptr;
@@ -439,6 +444,8 @@ struct Ctx {
     const ortk_sparse_plan* ell_f = nullptr;        // optional sparse plan over (N,K) weight blocks: forward-layout products
     const ortk_sparse_plan* ell_b = nullptr;        // ... over their transposed copies: data-gradient products (mixed precision)
     const void* W16T = nullptr;                  // transposed bf16 weight blocks (training workspaces, mixed precision)
+    const int32_t* drop_rows = nullptr;          // valid-position decoder rows: row m draws its dropout as row drop_rows[m] of the padded
+                                                 // (caption, position) layout (ortk_batch.row_pos; set around the DECODER's operators only)
     int drop_rs = 0, drop_r0 = 0;                // decode step in train mode: output row m draws like row m * drop_rs + drop_r0 of the
                                                  // teacher-forced pass (ortk_gemm_args.drop_row_stride / _off); 0: the natural index
     bool use_side = false;                       // weight-gradient GEMMs (and other independent work) on `side`
@@ -510,6 +517,7 @@ static int fwd_gemm(const Ctx& c, const void* X, int xdt, int64_t ldx, int64_t w
             ortk_spmm_args sa; std::memset(&sa, 0, sizeof(sa));
             sa.X = X; sa.x_dtype = xdt; sa.ldx = ldx; sa.Y = Y; sa.y_dtype = ydt; sa.ldy = ldy; sa.M = M;
             sa.bias = bias; sa.rowscale = rowscale; sa.resid = resid; sa.ldr = ldr; sa.relu = relu; sa.drop_p = drop; sa.drop_seed = seed;
+            sa.drop_rows = c.drop_rows;
             return ortk_spmm(c.ell_f, blk, &sa, (ortk_stream)c.s);
         }
     }
@@ -517,7 +525,7 @@ static int fwd_gemm(const Ctx& c, const void* X, int xdt, int64_t ldx, int64_t w
     a.A = X; a.a_dtype = xdt; a.lda = ldx; a.B = c.W(woff); a.b_dtype = c.wdt(); a.ldb = K; a.C = Y; a.c_dtype = ydt; a.ldc = ldy;
     a.M = (int)M; a.N = N; a.K = K;
     a.bias = bias; a.relu = relu; a.drop_p = drop; a.drop_seed = seed; a.resid = resid; a.ldr = ldr; a.rowscale = rowscale;
-    a.drop_row_stride = c.drop_rs; a.drop_row_off = c.drop_r0;
+    a.drop_row_stride = c.drop_rs; a.drop_row_off = c.drop_r0; a.drop_rows = c.drop_rows;
     a.precision = c.prec;
     return ortk_gemm(&a, (ortk_stream)c.s);
 }
@@ -604,15 +612,16 @@ static int ln_bwd(const Ctx& c, const float* dy, const float* x, float* G, int64
                   const float* dres, float* dx, int64_t rows, void* dz = nullptr, int next_op = -1) {
     const bool fuse = dz && next_op >= 0 && (c.p_drop() > 0.f || c.adt == ORTK_BF16);
     if (fuse) TRY(c.before_write(dz));
-    return ortk_layernorm_bwd_drop(dy, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, fuse ? dz : nullptr,
-                                   c.adt, c.p_drop(), fuse ? c.sub((uint32_t)next_op) : 0, (ortk_stream)c.s);
+    return ortk_layernorm_bwd_drop_rows(dy, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, fuse ? dz : nullptr,
+                                        c.adt, c.p_drop(), fuse ? c.sub((uint32_t)next_op) : 0, c.drop_rows, (ortk_stream)c.s);
 }
 // gradient through a residual-branch dropout: the buffer (and its dtype) holding dx * keep/(1-p).
 // Mixed precision always goes through `tmp` (it also performs the fp32 -> bf16 conversion of the GEMM operand).
 static int drop_bwd(const Ctx& c, const float* dx, void* tmp, int64_t n, uint32_t op, const void** out, int* out_dt,
                     bool done_by_ln_bwd = false) {
     if (c.p_drop() > 0.f || c.adt == ORTK_BF16) {
-        if (!done_by_ln_bwd) TRY(ortk_dropout_apply(dx, tmp, c.adt, n, c.p_drop(), c.sub(op), (ortk_stream)c.s));
+        const int d_ = c.cfg->d_model;
+        if (!done_by_ln_bwd) TRY(ortk_dropout_apply_rows(dx, tmp, c.adt, n / d_, d_, c.p_drop(), c.sub(op), c.drop_rows, (ortk_stream)c.s));
         *out = tmp; *out_dt = c.adt;
     } else { *out = dx; *out_dt = ORTK_F32; }
     return 0;
@@ -917,8 +926,12 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
             TRY(ortk_sparse_build(cfg->sparse_fwd, src, sdt, stream));
         }
     }
-    if (cs.on && phase != 2) TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.s));
     const int64_t Me = w.Me, Md = compact ? bt->Mc : w.Md;
+    // Phase 1 has no captions, so it packs for the kernel forms of (Me, R * T).  A phase 2 on the valid positions whose row count
+    // picks the OTHER form of the chain kernel (76-row blocks stream the FFN units in another order) packs again, from the same bf16
+    // weight copy, for the layout chain_run() will derive from its own row count (the encoder's units, already consumed, ride along).
+    const bool repack2 = phase == 2 && cs.on && chain_wide(w.Md) != chain_wide(Md);
+    if (cs.on && (phase != 2 || repack2)) TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.s));
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
     const AttMode am = att_mode(cfg->share_att_dec);
     const int64_t cw = o.cw, cv = o.cv;
@@ -950,7 +963,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
             ca.a_in = b.o1; ca.bias_r = P + e.bo; ca.x_mid = b.xm1; ca.seed_r = cx.sub(dop(l, 1));
             ca.g1 = P + e.n1a; ca.b1 = P + e.n1b; ca.y1 = b.y2; ca.st1 = b.st2;
             ca.n1 = 1; ca.bias_s1 = P + e.cqb; ca.out1 = b.qc; ca.ld1 = d;
-            ca.drop_p = cx.p_drop(); ca.eps = 1e-6f;
+            ca.drop_p = cx.p_drop(); ca.eps = 1e-6f; ca.drop_rows = cx.drop_rows;
             return chain_run(&ca, cs.stream_of(w.chain_pk, cs.db[l]), cx.s);
         }
         TRY(fwd_gemm(cx, b.o1, A, d, e.wo, P + e.bo, b.xm1, ORTK_F32, d, Md, d, d, false, cx.p_drop(), cx.sub(dop(l, 1)), x, d));
@@ -968,7 +981,16 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     if (phase != 2)
         TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc,
                             box_early ? &box_done : nullptr, &cs, w.chain_pk));
-    if (phase == 1) return c.join();       // (the transposed weight copy of the side stream included)
+    // From here on every operator with a dropout site runs on DECODER rows: on the valid positions it draws what the padded
+    // (caption, position) layout draws (a step is the same function of its seed in both layouts; an SCST update on the valid
+    // positions reproduces its train-mode rollout's masks).
+    c.drop_rows = compact ? bt->row_pos : nullptr;
+    if (phase == 1) {
+        // (the data-gradient plan is built by phase 2, from this phase's transposed copy: until then no backward may take the
+        //  images a previous step left in the plan for current)
+        if (cfg->sparse_bwd) bwd_plan_forget(cfg->sparse_bwd);
+        return c.join();                   // (the transposed weight copy of the side stream included)
+    }
     TRY(c.wait_ev(fplan_done));
     {
         const Ctx cx = prefix_side ? c.on_side() : c;
@@ -979,7 +1001,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     // the data-gradient plan's images (from this call's transposed weights: this step's mask sample) are built beside the forward
     // — 0.2 ms the backward used to start with — behind everything the forward waits for on the side stream
     hipEvent_t bplan_done = nullptr;
-    if (phase != 2 && cfg->precision && cfg->sparse_bwd && w.w16t) {
+    if (cfg->precision && cfg->sparse_bwd && w.w16t) {          // (phases 0 and 2: EVERY forward that a backward can follow builds and marks)
         if (c.use_side) {
             TRY(ortk_sparse_build(cfg->sparse_bwd, w.w16t, ORTK_BF16, (ortk_stream)c.side->s));
             TRY(c.side_mark(&bplan_done));
@@ -1001,7 +1023,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
         a.ldk = a.ldv = U * cw;
         a.o = b.o2; a.o_dtype = A; a.ldo = d; a.kmask = bt->att_masks; a.p = b.Pc; a.nkv = B; a.H = H; a.Lq = spi * T; a.Lk = S; a.dk = dk;
         a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 2));
-        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; }                       // an image's rows: those of its spi captions
+        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; a.drop_rows = bt->row_pos; }      // an image's rows: those of its spi captions
         TRY(ortk_attention_fwd(&a, stream));
         if (dchains) {                // [Wco + x -> LayerNorm 2 -> FFN + x -> LayerNorm 0 of layer l + 1 (or the stack's) -> next Wqkv]
             ortk_chain_args ca; std::memset(&ca, 0, sizeof(ca));
@@ -1017,7 +1039,7 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
             } else {
                 ca.g2 = P + o.dec_na; ca.b2 = P + o.dec_nb; ca.y2 = w.dec_out; ca.st2 = w.st_out;
             }
-            ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
+            ca.drop_p = c.p_drop(); ca.eps = 1e-6f; ca.drop_rows = c.drop_rows;
             TRY(chain_run(&ca, cs.stream_of(w.chain_pk, cs.dc[l]), c.s));
             x = b.xout;
             continue;
@@ -1048,9 +1070,8 @@ extern "C" int ortk_loss(const ortk_config* cfg, const ortk_batch* bt, void* ws,
     if (!ws || !norm_dev || !loss_dev || !bt->tok_weight) return ORTK_EINVAL;
     TrainWS w; carve_train(*cfg, bt->B, bt->S, bt->R, bt->T, ws, w);
     if (w.bytes > ws_bytes) return ORTK_ENOSPC;
-    TRY(ortk_fill(loss_dev, 1, 0.f, stream));
     const bool compact = batch_compact(bt);
-    return xent_rows(w.logits, bt->seqs + 1, bt->seq_stride, bt->T, bt->tok_weight, norm_dev, loss_dev, compact ? bt->Mc : w.Md,
+    return xent_rows(w.logits, bt->seqs + 1, bt->seq_stride, bt->T, bt->tok_weight, norm_dev, loss_dev, w.row_loss, compact ? bt->Mc : w.Md,
                      compact ? bt->row_pos : nullptr, cfg->vocab, w.ldv, w.dlogits, w.adt, w.ldv, ortk_s(stream));
 }
 
@@ -1149,6 +1170,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         ca.n2 = 1; ca.out2 = dO;
     };
     if (phase != 2) {
+    c.drop_rows = compact ? bt->row_pos : nullptr;      // (decoder rows: the masked copies draw what the forward drew; reset below)
     // ---- decoder half: generator, decoder stack, token embedding, cross-attention K/V projections; leaves the gradient
     // of the encoder memory in w.gy.  Every gradient at arena offsets >= ortk_arena_decoder_offset is final afterwards.
     // generator (over the padded vocabulary: pad columns of dlogits are exact zeros)
@@ -1163,7 +1185,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         void* dtA = gt_cur; void* dtB = gt_new(); void* ghb = gh_new();
         {   // X of the top layer, on the masked gradient the final LayerNorm's backward left
             const DecOff& e = o.dec[L - 1]; const DecBuf& b = w.dec[L - 1];
-            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca)); ca.drop_rows = c.drop_rows;
             ca.n_units = bs.units(bs.bx_top); ca.M = Md; ca.nin = 0; ca.dz0 = dtA;
             x_part(ca, b.h, ghb, b.xm2, b.st3, e.n2a, e.n2b, dx, cur, dtB, c.sub(dop(L - 1, 3)), w.gdo);
             ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
@@ -1186,14 +1208,14 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
             a.d_o = (const float*)w.gdo; a.lddo = d; a.dq = dq; a.lddq = d; a.dqkv_dtype = A;
             a.d_k = off_elems(w.gkv, gslot[l] * cw, A); a.dv = off_elems(w.gkv, gslot[l] * cw + gdv, A);
             a.lddk = a.lddv = ldg;
-            if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; }
+            if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; a.drop_rows = bt->row_pos; }
             TRY(c.before_write(dq));
             TRY(ortk_attention_bwd(&a, stream));
             TRY(wgrad_gemm(c, dq, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
             // Y: [dq . Wcq -> LayerNorm 1' (+ cur) -> masked copy -> . Wo]
             void* dtD = gt_new();
             {
-                ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+                ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca)); ca.drop_rows = c.drop_rows;
                 ca.n_units = bs.units(bs.by[l]); ca.M = Md; ca.nin = 1; ca.ain = dq; ca.ld_ain = d;
                 ca.xa = b.xm1; ca.sta = b.st2; ca.ga = params + e.n1a; ca.dresa = cur; ca.dxa = oth; ca.daa = G + e.n1a; ca.dba = G + e.n1b;
                 ca.dza = dtD; ca.seed_a = c.sub(dop(l, 1)); ca.mask_a = 1;
@@ -1215,7 +1237,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
             TRY(ortk_attention_bwd(&a, stream));
             TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
             // Z (+ X of the layer below): [dQKV . Wqkv -> LayerNorm 0' (+ oth) -> masked copy] [-> FFN' -> LayerNorm 2' -> masked copy -> . Wco]
-            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca)); ca.drop_rows = c.drop_rows;
             ca.M = Md; ca.nin = 3; ca.ain = w.gqkv; ca.ld_ain = 3 * d;
             ca.xa = xin; ca.sta = b.st1; ca.ga = params + e.n0a; ca.dresa = oth; ca.dxa = cur; ca.daa = G + e.n0a; ca.dba = G + e.n0b;
             ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
@@ -1261,7 +1283,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.d_o = (const float*)dO; a.lddo = d; a.dq = gt_new(); a.lddq = d; a.dqkv_dtype = A;
         a.d_k = off_elems(w.gkv, gslot[l] * cw, A); a.dv = off_elems(w.gkv, gslot[l] * cw + gdv, A);
         a.lddk = a.lddv = ldg;
-        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; }
+        if (compact) { a.q_off = bt->cap_off; a.q_off_stride = spi; a.drop_rows = bt->row_pos; }
         TRY(c.before_write(gt_cur));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, gt_cur, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
@@ -1307,6 +1329,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     TRY(wgrad_gemm(c, w.gkv, A, ldg, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, (int)(U * cw), d));
     TRY(dgrad_gemm(c, w.gkv, A, ldg, o.ckv_w, w.gy, ORTK_F32, d, Me, (int)(U * cw), d));
     TRY(c.join());
+    c.drop_rows = nullptr;
     }
     if (phase == 1) return 0;
     // ---- encoder half (reads the memory gradient left in w.gy)
@@ -1336,7 +1359,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         void* dtA = gt_cur; void* dtB = gt_new(); void* ghb = gh_new();
         {
             const EncOff& e = o.enc[L - 1]; const EncBuf& b = w.enc[L - 1];
-            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca)); ca.drop_rows = c.drop_rows;
             ca.n_units = bs.units(bs.ex_top); ca.M = Me; ca.nin = 0; ca.dz0 = dtA;
             x_part(ca, b.h, ghb, b.xm, b.st2, e.n1a, e.n1b, dx, cur, dtB, c.sub(eop(L - 1, 1)), w.gdo);
             ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
@@ -1360,7 +1383,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
             TRY(ortk_attention_bwd(&a, stream));
             if (l == 1 && box_split) TRY(box_grad(1, L - 1));
             TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
-            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca));
+            ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca)); ca.drop_rows = c.drop_rows;
             ca.M = Me; ca.nin = 3; ca.ain = w.gqkv; ca.ld_ain = 3 * d;
             ca.xa = xin; ca.sta = b.st1; ca.ga = params + e.n0a; ca.dresa = cur; ca.dxa = oth; ca.daa = G + e.n0a; ca.dba = G + e.n0b;
             ca.drop_p = c.p_drop(); ca.eps = 1e-6f;

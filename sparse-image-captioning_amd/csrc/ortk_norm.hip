@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ dres, float* __restrict__ dx,
                                                      float* __restrict__ da, float* __restrict__ db, int64_t rows, int d,
                                                      float eps, int rows_per_block, void* __restrict__ dz, int dz_dt,
-                                                     float drop_p, uint32_t drop_seed) {
+                                                     float drop_p, uint32_t drop_seed, const int32_t* __restrict__ drop_rows) {
     using C = Cols<VEC, NREG>;
     extern __shared__ float red[];  // [4 waves][2][d] partial da / db
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const float mg = sg / (float)d;
         const float coef = r * r * sgx / ((float)(d - 1) * sd);
         float* dxr = dx + row * d;
+        // (dz draws the dropout of row drop_rows[row]: the valid-position layout keyed like the padded one)
+        const uint64_t krow = (dz && drop_rows) ? (uint64_t)drop_rows[row] : (uint64_t)row;
 #pragma unroll
         for (int it = 0; it < C::NIT; ++it) {
             const int c = C::col(lane, it);
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                         const float ik = 1.f / (1.f - drop_p);
                         float4 z;
                         bool kp[4] = {true, true, true, true};
-                        if (drop_p > 0.f) ortk_keep4(drop_seed, i0, drop_p, kp);
+                        if (drop_p > 0.f) ortk_keep4(drop_seed, krow * (uint64_t)d + (uint64_t)c, drop_p, kp);
                         z.x = kp[0] ? o.x * ik : 0.f;
                         z.y = kp[1] ? o.y * ik : 0.f;
                         z.z = kp[2] ? o.z * ik : 0.f;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     dxr[c] = o;
                     if (dz) {
                         const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)c;
-                        st_elem(dz, (int64_t)i0, dz_dt, (drop_p > 0.f && !ortk_keep(drop_seed, i0, drop_p)) ? 0.f : o * (1.f / (1.f - drop_p)));
+                        st_elem(dz, (int64_t)i0, dz_dt, (drop_p > 0.f && !ortk_keep(drop_seed, krow * (uint64_t)d + (uint64_t)c, drop_p)) ? 0.f : o * (1.f / (1.f - drop_p)));
                     }
                 }
             }
@@ -208,6 +210,12 @@ extern "C" int ortk_layernorm_fwd(const float* x, const float* a, const float* b
 extern "C" int ortk_layernorm_bwd_drop(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
                                        float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
                                        float drop_p, uint32_t drop_seed, ortk_stream stream) {
+    return ortk_layernorm_bwd_drop_rows(dy, x, a, stats, dres, dx, da, db, rows, d, eps, dz, dz_dtype, drop_p, drop_seed, nullptr, stream);
+}
+
+extern "C" int ortk_layernorm_bwd_drop_rows(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
+                                            float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
+                                            float drop_p, uint32_t drop_seed, const int32_t* drop_rows, ortk_stream stream) {
     if (!dy || !x || !a || !stats || !dx || !da || !db || d < 2 || d > 2048 || rows < 0) return ORTK_EINVAL;
     if (dz && ((dz_dtype != ORTK_F32 && dz_dtype != ORTK_BF16) || drop_p < 0.f || drop_p >= 1.f)) return ORTK_EINVAL;
     if (rows == 0) return 0;
@@ -217,7 +225,7 @@ extern "C" int ortk_layernorm_bwd_drop(const float* dy, const float* x, const fl
     dim3 grid((unsigned)ortk_cdiv(rows, rpb)), block(256);
     const size_t shm = 8 * (size_t)d * sizeof(float);
     const bool vec = d % 4 == 0 && al16(dy) && al16(x) && al16(a) && al16(dres) && al16(dx) && (dz == nullptr || (reinterpret_cast<uintptr_t>(dz) & 15) == 0);
-#define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps, rpb, dz, (int)dz_dtype, drop_p, drop_seed)
+#define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps, rpb, dz, (int)dz_dtype, drop_p, drop_seed, drop_rows)
     if (d <= 512) { if (vec) LN_B(true, 8); else LN_B(false, 8); }
     else          { if (vec) LN_B(true, 32); else LN_B(false, 32); }
 #undef LN_B

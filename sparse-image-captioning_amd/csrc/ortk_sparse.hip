@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT) void spmm_ell_kernel(SpmmP p, int rpw, int ngro
                 }
                 const float rs = a.rowscale ? a.rowscale[m] : 1.f;
                 bool kp[4] = {true, true, true, true};
-                if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)m * (uint64_t)p.N + n0, a.drop_p, kp);
+                if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)(a.drop_rows ? (int64_t)a.drop_rows[m] : (int64_t)m) * (uint64_t)p.N + n0, a.drop_p, kp);
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -578,7 +578,7 @@ __device__ __forceinline__ void gu_store4(const ortk_spmm_args& a, int N, int64_
     }
     const float rs = a.rowscale ? a.rowscale[m] : 1.f;
     bool kp[4] = {true, true, true, true};
-    if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)m * (uint64_t)N + n0, a.drop_p, kp);
+    if (a.drop_p > 0.f) ortk_keep4(a.drop_seed, (uint64_t)(a.drop_rows ? (int64_t)a.drop_rows[m] : (int64_t)m) * (uint64_t)N + n0, a.drop_p, kp);
     float v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -564,7 +564,7 @@ class RelationTransformerModel(CaptionModelBase):
         """Whether ``mode="sample"`` serves this option combination for B images of S regions (e.g. train-mode rollouts with the
         greedy baseline as eval-mode rows of the same launches: the column-split stack kernel only).  No device work."""
         o, _, ex = self._decode_opts(dict(opt, seed=opt.get("seed", 0)))      # (a probe draws no seed)
-        if getattr(self, "_plans", None) is not None and self._plans[0] is not None and not ex.startswith("sparse_"):
+        if getattr(self, "_plans", None) is not None and self._plans[0] is not None and not ex.startswith("sparse_") and not o.train:
             o.sparse = self._plans[0].ref()
         if att_max_len is not None:
             S = min(int(S), int(att_max_len))
@@ -582,7 +582,10 @@ class RelationTransformerModel(CaptionModelBase):
         pptr = self._eff_params_ptr(False, 0)
         fresh_plan = getattr(self, "_plans", None) is None
         plan = self._sparse_plans()[0]
-        if plan is not None and not ex.startswith("sparse_"):
+        # (train-mode rollouts — the default SCST step of a pruned model with enable_sparse_kernels() — have no sparse form: every
+        #  dropout site is an epilogue of the dense kernels; they run the dense products on the zero-filled effective weights, which
+        #  is what the reference's MaskedLinear computes, pruning/masked_layer.py:134-135)
+        if plan is not None and not ex.startswith("sparse_") and not o.train:
             o.sparse = plan.ref()
         else:
             plan = None
@@ -648,10 +651,18 @@ class RelationTransformerModel(CaptionModelBase):
         # it is read on the first decodes of a model, then every 64th, and whenever opt["check_status"] asks.
         if (o.exec_flags & (L.DEC_SPLIT_SMALL | L.DEC_STACK_SPLIT)) and ex != "unfused":
             self._decode_calls = getattr(self, "_decode_calls", 0) + 1
+            self._status_ws = (getattr(self, "_status_ws", []) + used_ws)[-4:]       # unchecked decodes (the most recent few)
             if opt.get("check_status", self._decode_calls <= 2 or self._decode_calls % 64 == 0):
-                for ws in used_ws:
-                    L.check(lib.ortk_decode_status(L.ptr(ws), L.stream_ptr()), "ortk_decode (status)")
+                self.check_decode_status()
         return seq, lp, score
+
+    def check_decode_status(self):
+        """Raise if one of the not yet checked decodes of this model (the most recent four at most) ran the column-split stack kernel
+        and one of its exchange groups never met (its outputs are then poisoned: all-pad captions, NaN log-probs).  A host synchronisation — free for a caller that has already
+        waited for the decode's output (``NativeTrainer.scst_step`` with a host-side reward)."""
+        pending, self._status_ws = getattr(self, "_status_ws", []), []
+        for ws in pending:
+            L.check(L.lib().ortk_decode_status(L.ptr(ws), L.stream_ptr()), "ortk_decode (status)")
 
     def _sample(self, att_feats, boxes, att_masks=None, opt=None, **kwargs):
         """``_sample`` (relation_transformer.py:390-396) + ``_generate_captions`` (transformer.py:471-561).

@@ -26,6 +26,14 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def sample_row_offset(images_per_rank, rows_per_image, r=None):
+    """First GLOBAL decode row of rank r's shard (``ortk_decode_opts.sample_row_offset``): the multinomial draws of an SCST rollout
+    are keyed by (seed, position, global row), so N ranks on their image shards sample exactly what one process samples on the
+    whole batch (rows_per_image = num_samples, + 1 when the greedy baseline rides in the same decode)."""
+    r = rank() if r is None else r
+    return int(r) * int(images_per_rank) * int(rows_per_image)
+
+
 def shard_batch(data, r=None, n=None):
     """Rank r's slice of a collated batch: images [r*B/n, (r+1)*B/n) and their caption rows (rows of `seqs` /
     `masks` are grouped by image: row = image*seq_per_img + k, data/collate.py:133-150)."""

@@ -41,6 +41,7 @@ class NativeTrainer:
         self.step_count = 0
         self.loss_dev = torch.zeros(1, device=self.dev)
         self.norm_dev = torch.zeros(1, device=self.dev)
+        self._sum_scratch = None
         self.masked = getattr(model, "MASKED", False)
         if self.masked:
             self.train_masks = model._supermask
@@ -91,6 +92,7 @@ class NativeTrainer:
         # block denser than its reserved capacity would silently lose weights, so the sticky device flag is read (host sync)
         # after the first step and then every `overflow_check_every` steps, and a hit raises
         self.overflow_check_every = 50
+        self.check_rollout_status = False       # scst_step: read the rollout decode's status word even with a device-side reward (host sync)
 
     # ------------------------------------------------------------------ pieces
     def _batch(self, data, tok_weight):
@@ -179,7 +181,7 @@ class NativeTrainer:
         return self._step(data, tok_w, tok_w, train)
 
     def scst_step(self, data, reward_fn, num_samples=5, baseline="greedy", train=True, sample="random", update_dropout=False,
-                  sample_dropout=None):
+                  sample_dropout=None, rollout_opt=None):
         """SCST step (utils/training.py:202-255): greedy baseline + `num_samples` rollouts (no graph, cached attention), rewards
         from ``reward_fn(sample_seq (N,ns,L), greedy_seq (N,1,L) | None) -> (N*ns,)``, then ONE teacher-forced pass over
         [BOS, sample] with per-token weight mask*reward (RewardCriterion).
@@ -203,8 +205,12 @@ class NativeTrainer:
         ``sample_dropout=False`` is the dropout-free variant: eval-mode rollouts (greedy + samples in one decode pass) and, with
         ``update_dropout=False``, an eval-mode update — sampling policy = differentiated policy = the eval-mode model (teacher-forced
         and incremental log-probs agree to 3e-6).  NOT the reference's estimator: no dropout anywhere in the step.
-        ``update_dropout=True`` recomputes under a fresh dropout pattern (rounds 1-2)."""
+        ``update_dropout=True`` recomputes under a fresh dropout pattern (rounds 1-2).
+
+        ``rollout_opt``: extra entries for the ``opt`` dict of the rollout decodes (``temperature``, ``executor``, ...; the reference
+        passes ``temperature = config.scst_sample_temperature`` there, utils/training.py:226-237)."""
         m = self.model
+        extra = dict(rollout_opt or {})
         was_training = m.training
         greedy = None
         B = data["att_feats"].size(0)
@@ -215,11 +221,12 @@ class NativeTrainer:
         drop_seed = None
         sparse_stream = getattr(m, "_sparse_stream", False)
         share_encoder = False
+        m._status_ws = []
         with torch.no_grad():
             if sample_dropout and train:
                 assert sample == "random", "train-mode sampling: multinomial rollouts"
                 drop_seed = m._next_seed()
-                opt = {"num_random_sample": num_samples, "beam_size": 0, "train_mode": True, "drop_seed": drop_seed}
+                opt = dict(extra, num_random_sample=num_samples, beam_size=0, train_mode=True, drop_seed=drop_seed)
                 # Dense model: the update's encoder half runs first, in TRAIN mode under drop_seed, into the training workspace; the
                 # rollout's train-mode rows decode on that memory.  (Masked models draw a Bernoulli weight mask per training
                 # forward while the rollout runs on the eval-mode masks: their passes share nothing.)
@@ -227,15 +234,15 @@ class NativeTrainer:
                 if share_encoder:
                     m.train()
                     opt["memory"] = self.encode_for_update(data, B * num_samples, train=True, seed=drop_seed)
-                fused = dict(opt, with_greedy=True, sample_row_offset=parallel.rank() * B * (num_samples + 1))
+                fused = dict(opt, with_greedy=True, sample_row_offset=parallel.sample_row_offset(B, num_samples + 1))
                 if baseline == "greedy" and share_encoder and m.decode_supported(B, data["att_feats"].size(1), fused, data.get("att_max_len")):
                     seq, _ = m(**kw, opt=fused)
                     greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
                 else:
                     if baseline == "greedy":
                         m.eval()
-                        greedy, _ = m(**kw, opt={"beam_size": 1})
-                    seq, _ = m(**kw, opt=dict(opt, sample_row_offset=parallel.rank() * B * num_samples))
+                        greedy, _ = m(**kw, opt=dict(extra, beam_size=1))
+                    seq, _ = m(**kw, opt=dict(opt, sample_row_offset=parallel.sample_row_offset(B, num_samples)))
             else:
                 # One encoder pass per step: the update pass recomputes the rollout's log-probs in the SAME mode as the rollout
                 # (eval-mode model) unless a dropout variant was asked for, so its encoder half runs first, into the training
@@ -248,33 +255,40 @@ class NativeTrainer:
                 if sample == "beam_search":
                     assert num_samples > 1, "beam search needs more than one beam"
                     if baseline == "greedy":
-                        greedy, _ = m(**kw, opt=dict({"beam_size": 1}, **mem_opt))
-                    seq, _ = m(**kw, opt=dict({"beam_size": num_samples}, **mem_opt))
+                        greedy, _ = m(**kw, opt=dict(extra, beam_size=1, **mem_opt))
+                    seq, _ = m(**kw, opt=dict(extra, beam_size=num_samples, **mem_opt))
                 else:
                     assert sample == "random", sample
                     # ONE decode pass for the greedy baseline and the samples (row 0 of each image is the arg-max decode):
                     # token for token what the two calls of utils/training.py:220-237 return, at half the launches
-                    seq, _ = m(**kw, opt={"num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
+                    seq, _ = m(**kw, opt={**extra, "num_random_sample": num_samples, "beam_size": 0, "with_greedy": baseline == "greedy",
                                           # the draws are keyed by the GLOBAL row of the batch: N ranks on their shards sample what
                                           # one process samples on the whole batch
-                                          "sample_row_offset": parallel.rank() * B * (num_samples + (baseline == "greedy")), **mem_opt})
+                                          "sample_row_offset": parallel.sample_row_offset(B, num_samples + (baseline == "greedy")), **mem_opt})
                     if baseline == "greedy":
                         greedy, seq = seq[:, :1].contiguous(), seq[:, 1:].contiguous()
         m.train(was_training)
         reward = reward_fn(seq, greedy)
         host_reward = not reward.is_cuda
+        if host_reward or self.check_rollout_status:
+            # A rollout on the column-split kernel whose exchange timed out returns all-pad captions and NaN log-probs: the update
+            # would divide by a zero mask sum and Adam would write NaN into every weight.  A host-side reward has already waited for
+            # the rollout, so reading its status word costs nothing there; a device-side reward_fn keeps the step free of host
+            # synchronisation and relies on the decode's periodic check (first two calls, then every 64th) unless
+            # `check_rollout_status` is set.
+            m.check_decode_status()             # (the greedy baseline's decode, when it was a call of its own, and the rollout's)
         reward = reward.to(self.dev).float().reshape(-1)
         rows = seq.reshape(-1, seq.size(-1))
         mask = (rows != m.pad_idx).float()
         tf = dict(data)
         tf.pop("cap_len", None); tf.pop("_valid_rows", None)      # (those of the ground-truth captions)
-        if host_reward and self.valid_positions and drop_seed is None:
+        if host_reward and self.valid_positions:
             # The lengths of the SAMPLED captions live on the device.  A reward computed on the host (the CIDEr-D scorer of
             # scst/scorers.py) has already waited for the rollout, so reading them back costs one small copy and the update
             # pass then runs its decoder on the valid positions only (a sampled caption is tokens, EOS, then pads: its
             # weights lie in a prefix).  A device-side reward_fn keeps the whole step free of host synchronisation: padded layout.
-            # (Not with train-mode rollouts: the valid-position layout keys its dropout draws by the COMPACT row, the rollout by
-            # (row, position) of the padded layout — the update must reproduce the rollout's masks, so it stays padded.)
+            # (Train-mode rollouts included: every dropout site of the valid-position layout is keyed by the row's (caption,
+            # position) index in the padded layout — ortk_batch.row_pos — so the update reproduces the rollout's masks there too.)
             pos = torch.arange(1, mask.size(1) + 1, device=mask.device, dtype=mask.dtype)
             tf["cap_len"] = (mask * pos).amax(1).clamp_(min=1).to(torch.int64).cpu()       # 1 + index of the last weighted position
         tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
@@ -302,7 +316,12 @@ class NativeTrainer:
         if not self._grads_clean:
             self.grads.zero_()
         self._grads_clean = False
-        L.check(L.lib().ortk_sum(L.ptr(norm_mask.contiguous()), norm_mask.numel(), L.ptr(self.norm_dev), L.stream_ptr()), "ortk_sum")
+        n_norm = norm_mask.numel()
+        ns = L.lib().ortk_sum_scratch_floats(n_norm)       # (0 up to 65 536 mask entries: one fixed-order launch)
+        if ns > 0 and (self._sum_scratch is None or self._sum_scratch.numel() < ns):
+            self._sum_scratch = torch.empty(ns, device=self.dev)
+        L.check(L.lib().ortk_sum(L.ptr(norm_mask.contiguous()), n_norm, L.ptr(self._sum_scratch) if ns > 0 else None,
+                                 L.ptr(self.norm_dev), L.stream_ptr()), "ortk_sum")
         parallel.reduce_scalar_sum(self.norm_dev)   # LanguageModelCriterion semantics over the GLOBAL batch
         batch = self._batch(data, tok_weight)
         lr = self.rate()

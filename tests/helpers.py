@@ -107,3 +107,16 @@ def shared_layer_state(cfg, param_names, seed, gen_scale=1.0, eos_bias=0.0, requ
 def plain_shapes(g10) -> dict:
     """Parameter name -> shape of the reference's plain `transformer` model, as recorded in golden G10."""
     return {str(n): tuple(int(x) for x in str(sh).split(",")) for n, sh in zip(g10["param_names"], g10["param_shapes"])}
+
+
+FP32_EPS = 2.0 ** -24
+
+
+def atomics_bar(n_addends, scale):
+    """How far two runs of ONE fp32 sum of `n_addends` terms may lie apart when only the ORDER of its atomic adds differs
+    (split-K weight gradients, bias / LayerNorm-parameter column sums, embedding rows): every add rounds by at most eps times a
+    partial sum, and a partial sum of terms bounded by `scale / n` each stays below `scale`, so each run is within n * eps * scale
+    of the exact sum and two runs within twice that.  `scale`: the magnitude of the largest gradient element; `n_addends`: an upper
+    bound on the atomic contributions to one element (rows of the reduction).  A bar DERIVED from the addend count, not tuned to a
+    box: a wrong mask, a lost tile or a stale operand moves gradients by O(scale), orders of magnitude above it."""
+    return 2.0 * float(n_addends) * FP32_EPS * float(scale)

@@ -73,6 +73,85 @@ def test_two_rank_data_parallel_equals_full_batch(tmp_path):
     np.testing.assert_allclose(got["arena_bf16"], ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())       # bf16 addends
 
 
+def _scst_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import common as C
+    import helpers as H
+    from oracle import ort_oracle as O
+    from sparse_image_captioning_amd import parallel
+    cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
+    P = H.g1_state(requires_grad=True)
+    Pd = {k: v.detach() for k, v in P.items()}
+    full = H.torch_batch(C.make_inputs(seed=5, n_img=4, n_reg=12, feat=C.TINY_CFG["att_feat_size"], vocab=C.TINY_CFG["vocab_size"], spi=1))
+    full = {k: v for k, v in full.items() if k not in ("seqs", "masks")}
+    mine = parallel.shard_batch(full)
+    B, ns, seed = mine["att_feats"].size(0), 3, 77
+    assert B == 2
+    # NativeTrainer.scst_step: the rollout's draws are keyed by the GLOBAL row (parallel.sample_row_offset -> opt["sample_row_offset"])
+    off = parallel.sample_row_offset(B, ns)
+    assert off == rank * B * ns
+    with torch.no_grad():
+        seq, _ = O.sample_greedy_or_multinomial(Pd, cfg, mine["att_feats"], mine["boxes"], mine["att_masks"], num_random_sample=ns,
+                                                seed=seed, sample_row_offset=off)
+    rows = seq.reshape(-1, seq.size(-1))
+    mask = (rows != 0).float()
+    reward = torch.linspace(-1.0, 1.0, 4 * ns)[off:off + B * ns]             # the global reward vector's slice of this shard
+    norm = mask.sum().reshape(1).clone()
+    parallel.reduce_scalar_sum(norm)                                        # RewardCriterion over the GLOBAL batch
+    tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
+    logp = O.forward_logp(P, cfg, mine["att_feats"].repeat_interleave(ns, 0), mine["boxes"].repeat_interleave(ns, 0), tf_in,
+                          mine["att_masks"].repeat_interleave(ns, 0))
+    tok = logp.gather(2, rows.unsqueeze(2)).squeeze(2)
+    loss = -(tok * mask * reward[:, None]).sum() / norm[0]
+    loss.backward()
+    arena = torch.cat([P[n].grad.reshape(-1) for n in sorted(P)])
+    loss_t = loss.detach().reshape(1).clone()
+    parallel.allreduce_arena(arena, loss_t)
+    gathered = [torch.zeros_like(rows) for _ in range(world)]
+    dist.all_gather(gathered, rows)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "scst.npz"), arena=arena.numpy(), loss=loss_t.numpy(), rows=torch.cat(gathered).numpy(), norm=norm.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_scst_sharding_samples_and_updates_like_one_process(tmp_path):
+    """SCST shards by image too: each rank rolls out ITS images with the multinomial draws keyed by the
+    global decode row (`parallel.sample_row_offset`, what `NativeTrainer.scst_step` puts into `opt["sample_row_offset"]`), divides
+    by the GLOBAL mask sum and adds its gradient arena into the all-reduce.  Two gloo ranks (the oracle stands in for the GPU path)
+    sample token for token what ONE process samples on the whole batch, and the summed loss / gradient arena equal the
+    full-batch RewardCriterion's (utils/losses.py:15-29, utils/training.py:239-255)."""
+    port = 29500 + ((os.getpid() + 777) % 2000)
+    mp.spawn(_scst_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    import common as C
+    import helpers as H
+    from oracle import ort_oracle as O
+    got = np.load(os.path.join(str(tmp_path), "scst.npz"))
+    cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
+    P = H.g1_state(requires_grad=True)
+    Pd = {k: v.detach() for k, v in P.items()}
+    full = H.torch_batch(C.make_inputs(seed=5, n_img=4, n_reg=12, feat=C.TINY_CFG["att_feat_size"], vocab=C.TINY_CFG["vocab_size"], spi=1))
+    ns = 3
+    with torch.no_grad():
+        seq, _ = O.sample_greedy_or_multinomial(Pd, cfg, full["att_feats"], full["boxes"], full["att_masks"], num_random_sample=ns, seed=77)
+    rows = seq.reshape(-1, seq.size(-1))
+    np.testing.assert_array_equal(got["rows"], rows.numpy())
+    assert len({tuple(r) for r in rows.tolist()}) > 4                       # (the rollouts really differ from row to row)
+    tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
+    logp = O.forward_logp(P, cfg, full["att_feats"].repeat_interleave(ns, 0), full["boxes"].repeat_interleave(ns, 0), tf_in,
+                          full["att_masks"].repeat_interleave(ns, 0))
+    loss = O.reward_loss(logp.gather(2, rows.unsqueeze(2)).squeeze(2), rows, torch.linspace(-1.0, 1.0, 4 * ns))
+    loss.backward()
+    ref = torch.cat([P[n].grad.reshape(-1) for n in sorted(P)]).numpy()
+    assert abs(float(got["norm"][0]) - float((rows != 0).sum())) < 1e-6
+    assert abs(float(got["loss"][0]) - loss.item()) < 1e-5
+    np.testing.assert_allclose(got["arena"], ref, rtol=1e-4, atol=2e-6)
+
+
 def test_shard_batch_single_process():
     from sparse_image_captioning_amd import parallel
     data = dict(att_feats=torch.zeros(6, 3, 4), boxes=torch.zeros(6, 3, 4), att_masks=torch.ones(6, 3),

@@ -142,6 +142,74 @@ def test_layernorm_bwd_with_fused_dropout_output(L, rows, d, p, dt):
         assert abs(frac - p) < 0.03
 
 
+def test_dropout_draws_keyed_by_a_row_map(L):
+    """`drop_rows` (ortk_gemm_args / ortk_spmm_args / ortk_layernorm_bwd_drop_rows / ortk_dropout_apply_rows): output row m takes
+    the draws of row drop_rows[m] — how the valid-position decoder layout (ortk_batch.row_pos) draws what the padded (caption,
+    position) layout draws.  Property, per operator: on a subset `sel` of the rows with drop_rows = sel, the operator returns
+    exactly the rows `sel` of its result on all rows (bit for bit: same products, same draws)."""
+    from sparse_image_captioning_amd.sparse import SparsePlan, capacity_for
+    g = torch.Generator().manual_seed(5)
+    Mfull = 1536
+    sel = torch.randperm(Mfull, generator=g)[:1000].sort().values
+    seld, selc = dev(sel.to(torch.int32)), sel.cuda()
+    M = sel.numel()
+    # GEMM epilogues: fp32 kernel (guarded), bf16 register-staged kernel (ragged N), bf16 LDS-DMA kernels (full tiles)
+    for prec, N, K, bf in [(0, 130, 70, False), (1, 130, 72, True), (1, 512, 512, True), (1, 2048, 512, True)]:
+        A, B, bias, res = rnd(Mfull, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(Mfull, N, seed=4)
+        Ad, Bd = dev(A.bfloat16() if bf else A), dev(B.bfloat16() if bf else B)
+        dt = dict(a_dtype=1, b_dtype=1) if bf else {}
+        full = gemm(L, Ad, Bd, Mfull, N, K, 0, 0, prec, bias=dev(bias), resid=dev(res), drop_p=0.3, drop_seed=77, **dt)
+        As, Rs = Ad[selc].contiguous(), dev(res)[selc].contiguous()
+        part = gemm(L, As, Bd, M, N, K, 0, 0, prec, bias=dev(bias), resid=Rs, drop_p=0.3, drop_seed=77, drop_rows=seld, **dt)
+        assert torch.equal(part, full[selc]), (prec, N, K)
+        plain = gemm(L, As, Bd, M, N, K, 0, 0, prec, bias=dev(bias), resid=Rs, drop_p=0.3, drop_seed=77, **dt)
+        assert not torch.equal(plain, part)                      # (without the map the subset draws as rows 0 .. M - 1)
+    # residual-branch dropout of a gradient, alone and fused into the LayerNorm backward
+    d = 512
+    x, dy, a_, b_ = rnd(Mfull, d, seed=6), rnd(Mfull, d, seed=7), 1 + 0.1 * rnd(d, seed=8), rnd(d, seed=9)
+    xd, dyd, ad, bd = dev(x), dev(dy), dev(a_), dev(b_)
+    zf = torch.empty(Mfull, d, device="cuda", dtype=torch.bfloat16)
+    L.check(L.lib().ortk_dropout_apply(L.ptr(dyd), L.ptr(zf), 1, Mfull * d, 0.2, 31, L.stream_ptr()), "drop")
+    zp = torch.empty(M, d, device="cuda", dtype=torch.bfloat16)
+    L.check(L.lib().ortk_dropout_apply_rows(L.ptr(dyd[selc].contiguous()), L.ptr(zp), 1, M, d, 0.2, 31, L.ptr(seld), L.stream_ptr()), "drop_rows")
+    assert torch.equal(zp, zf[selc])
+    y = torch.empty(Mfull, d, device="cuda"); st = torch.empty(Mfull, 2, device="cuda")
+    L.check(L.lib().ortk_layernorm_fwd(L.ptr(xd), L.ptr(ad), L.ptr(bd), L.ptr(y), 0, L.ptr(st), Mfull, d, 1e-6, L.stream_ptr()), "ln")
+
+    def ln_bwd(xx, dd, ss, rows, key):
+        dx = torch.empty(rows, d, device="cuda"); z = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16)
+        da, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+        L.check(L.lib().ortk_layernorm_bwd_drop_rows(L.ptr(dd), L.ptr(xx), L.ptr(ad), L.ptr(ss), None, L.ptr(dx), L.ptr(da), L.ptr(db), rows, d,
+                                                     1e-6, L.ptr(z), 1, 0.2, 32, L.ptr(key) if key is not None else None, L.stream_ptr()), "ln_bwd_drop_rows")
+        return dx, z
+
+    dxf, zf2 = ln_bwd(xd, dyd, st, Mfull, None)
+    dxp, zp2 = ln_bwd(xd[selc].contiguous(), dyd[selc].contiguous(), st[selc].contiguous(), M, seld)
+    assert torch.equal(dxp, dxf[selc]) and torch.equal(zp2, zf2[selc])
+    # sparse products (the masked linears as ELL / GU images): the GEMM's epilogue, the GEMM's keys
+    N, K = 512, 512
+    W = rnd(N, K, seed=11, scale=0.2) * (torch.rand(N, K, generator=g) >= 0.9).float()
+    X = dev(rnd(Mfull, K, seed=12).bfloat16())
+    for fmt in (L.SP_ELL16, L.SP_GU16):
+        plan = SparsePlan([dict(offset=0, N=N, K=K, ld=K, capacity=capacity_for(N, K, 0.2))], fmt, "cuda")
+        plan.build(dev(W.bfloat16())); plan.check_overflow()
+
+        def run(Xr, rows, key):
+            Y = torch.empty(rows, N, device="cuda")
+            a = L.SpmmArgs()
+            a.X, a.Y, a.ldx, a.ldy, a.M, a.x_dtype, a.y_dtype = Xr.data_ptr(), Y.data_ptr(), K, N, rows, 1, 0
+            a.drop_p, a.drop_seed = 0.3, 55
+            if key is not None:
+                a.drop_rows = key.data_ptr()
+            plan.spmm(0, a)
+            torch.cuda.synchronize()
+            return Y
+
+        yf = run(X, Mfull, None)
+        yp = run(X[selc].contiguous(), M, seld)
+        assert torch.equal(yp, yf[selc]), fmt
+
+
 def _boxes(B, S, seed):
     import common as Cm
     return torch.from_numpy(Cm.make_inputs(seed, B, S, 4, 10, 1)["boxes"])
@@ -448,10 +516,26 @@ def test_embed_xent_softmax_colsum(L):
     ref_loss.backward()
     nd = torch.tensor([norm.item()], device="cuda"); wd = dev(w)
     seqd = dev(seq)  # keep alive
-    loss = torch.zeros(1, device="cuda"); ld_dev = dev(logits)
+    loss = torch.full((1,), 7.0, device="cuda"); ld_dev = dev(logits)          # (*loss_dev is overwritten, not accumulated into)
+    row_loss = torch.empty(L.lib().ortk_xent_scratch_floats(R * T), device="cuda")
     L.check(L.lib().ortk_xent_fwd_bwd(L.ptr(ld_dev), C.c_void_p(seqd.data_ptr() + 8), T + 1, T, L.ptr(wd), L.ptr(nd), L.ptr(loss),
-                                      R * T, V, ld, L.ptr(ld_dev), 0, ld, L.stream_ptr()), "xent")
+                                      L.ptr(row_loss), R * T, V, ld, L.ptr(ld_dev), 0, ld, L.stream_ptr()), "xent")
     assert abs(loss.item() - ref_loss.item()) < 1e-5 * max(1, abs(ref_loss.item()))
+    # the per-row terms, and the scalar = their sum in the documented fixed order (thread t adds rows t, t + 1024, ...; then a tree):
+    # the same bits on every run
+    ref_rows = -(lp.detach().gather(1, seq[:, 1:].reshape(-1, 1)).squeeze(1) * w.reshape(-1)) / norm
+    torch.testing.assert_close(row_loss[:R * T].cpu(), ref_rows, rtol=1e-5, atol=1e-7)
+    part = torch.zeros(1024); rl = row_loss[:R * T].cpu()
+    for t in range(min(1024, R * T)):
+        acc = torch.zeros((), dtype=torch.float32)
+        for v in rl[t::1024]:
+            acc = acc + v
+        part[t] = acc
+    k = 512
+    while k >= 1:
+        part[:k] = part[:k] + part[k:2 * k]
+        k //= 2
+    assert loss.item() == part[0].item(), (loss.item(), part[0].item())
     torch.testing.assert_close(ld_dev.cpu()[:, :V], lg.grad, rtol=1e-4, atol=1e-7)
     assert float(ld_dev[:, V:].abs().max()) == 0.0
     # log_softmax (+ temperature) and its backward
@@ -468,6 +552,20 @@ def test_embed_xent_softmax_colsum(L):
     X = rnd(1000, 77, seed=6); acc = dev(torch.ones(77))
     L.check(L.lib().ortk_colsum(L.ptr(dev(X)), 0, 77, L.ptr(acc), 1000, 77, L.stream_ptr()), "colsum")
     torch.testing.assert_close(acc.cpu(), 1 + X.sum(0), rtol=1e-4, atol=1e-4)
+    # fixed-order scalar sum (the criterion's normaliser; the loss itself goes through the same reduction): one launch up to 65 536
+    # elements, two stages beyond; bit-identical reruns, empty input = 0
+    for n in (0, 1, 1023, 23040, 65536, 65537, 300001):
+        xs = rnd(max(n, 1), seed=7 + n % 5)[:n].contiguous()
+        ns = L.lib().ortk_sum_scratch_floats(n)
+        assert ns == (0 if n <= 65536 else -(-n // 65536))
+        scratch = torch.empty(max(ns, 1), device="cuda")
+        outs = []
+        for _ in range(3):
+            o = torch.full((1,), 3.0, device="cuda")
+            L.check(L.lib().ortk_sum(L.ptr(dev(xs)) if n else L.ptr(scratch), n, L.ptr(scratch) if ns else None, L.ptr(o), L.stream_ptr()), "sum")
+            outs.append(o.item())
+        assert outs[0] == outs[1] == outs[2]
+        assert abs(outs[0] - xs.double().sum().item()) <= 1e-6 * max(1.0, xs.double().abs().sum().item())
 
 
 def test_adam_clip_and_masks(L):
@@ -891,12 +989,14 @@ def _ln_ref(x, g, b, eps=1e-6):
     return g * (x - mean) / (sd + eps) + b, mean.squeeze(-1), sd.squeeze(-1)
 
 
-@pytest.mark.parametrize("M,p,parts,pf", [(1000, 0.1, "R1SFL2S", 1), (16640, 0.1, "R1SFL2S", 1), (9216, 0.0, "R1SFL2S", 1), (777, 0.1, "1S", 1),
-                                          (2000, 0.1, "R1S", 0), (5120, 0.0, "R1F2", 1),
-                                          # the 76-row (four-wave) form of the kernel: chosen where it saves a round of workgroups
-                                          (16640, 0.1, "R1SFL2S", 0), (12300, 0.1, "R1SFL2S", 0), (19456, 0.0, "R1F2", 0), (13000, 0.1, "R1S", 0),
-                                          (36864, 0.1, "1S", 0)])
-def test_row_chain_vs_separate_ops(L, M, p, parts, pf):
+@pytest.mark.parametrize("M,p,parts,pf,keyed", [(1000, 0.1, "R1SFL2S", 1, 0), (16640, 0.1, "R1SFL2S", 1, 0), (9216, 0.0, "R1SFL2S", 1, 0), (777, 0.1, "1S", 1, 0),
+                                                (2000, 0.1, "R1S", 0, 0), (5120, 0.0, "R1F2", 1, 0),
+                                                # the 76-row (four-wave) form of the kernel: chosen where it saves a round of workgroups
+                                                (16640, 0.1, "R1SFL2S", 0, 0), (12300, 0.1, "R1SFL2S", 0, 0), (19456, 0.0, "R1F2", 0, 0), (13000, 0.1, "R1S", 0, 0),
+                                                (36864, 0.1, "1S", 0, 0),
+                                                # ortk_chain_args.drop_rows: row m draws the dropout of row drop_rows[m] (both kernel forms)
+                                                (1000, 0.1, "R1SFL2S", 1, 1), (14000, 0.1, "R1SFL2S", 0, 1)])
+def test_row_chain_vs_separate_ops(L, M, p, parts, pf, keyed):
     """ortk_row_chain (csrc/ortk_chain.hip: the row-wise operators between two attention calls in ONE rows-stationary launch) against
     the same chain in torch fp32 on the bf16-rounded operands, with the kernels' own dropout masks: residual streams within 2e-3
     (fp32 accumulation order), bf16 outputs within one bf16 step, LayerNorm statistics within 1e-4.  Chains: the decoder's
@@ -960,6 +1060,13 @@ def test_row_chain_vs_separate_ops(L, M, p, parts, pf):
     if n2:
         a.bias_s2, a.out2, a.ld2 = bs2.data_ptr(), out2.data_ptr(), out2.stride(0)
     a.drop_p, a.eps = p, 1e-6
+    # keyed: rows draw as OTHER rows of a taller (Mk, .) tensor — what the valid-position decoder layout does with ortk_batch.row_pos
+    Mk = M + 500 if keyed else M
+    key_rows = torch.randperm(Mk, generator=g)[:M].sort().values if keyed else torch.arange(M)
+    key_dev = dev(key_rows.to(torch.int32))
+    if keyed:
+        a.drop_rows = key_dev.data_ptr()
+    key_idx = key_rows.cuda()
     prog = torch.zeros(16, dtype=torch.int32, device="cuda")
     if pf:                               # with the L2 prefetcher workgroups (always the 48-row form)
         a.progress = prog.data_ptr()
@@ -973,7 +1080,7 @@ def test_row_chain_vs_separate_ops(L, M, p, parts, pf):
     one_bf16 = lambda ref: 2.0 ** -7 * ref.abs().clamp(min=1.0)          # one step of an 8-bit mantissa (+ slack for a rounding boundary)
     if hasR:
         t = a_in.float() @ f(W["r"]).t() + br
-        if p > 0: t = t * _keep_mask(L, sr, M * d, p).view(M, d)
+        if p > 0: t = t * _keep_mask(L, sr, Mk * d, p).view(Mk, d)[key_idx]
         xr = xr + t
         assert (x_mid - xr).abs().max().item() < 2e-3
     yr, mean, sd = _ln_ref(xr, g1, b1)
@@ -985,10 +1092,10 @@ def test_row_chain_vs_separate_ops(L, M, p, parts, pf):
         assert ((out1.float() - ref).abs() <= one_bf16(ref) + 2e-3).all()
     if hasF:
         hr = torch.relu(yb @ f(W["w1"]).t() + bh)
-        if p > 0: hr = hr * _keep_mask(L, sh, M * ff, p).view(M, ff)
+        if p > 0: hr = hr * _keep_mask(L, sh, Mk * ff, p).view(Mk, ff)[key_idx]
         assert ((h.float() - hr).abs() <= one_bf16(hr) + 2e-3).all()
         t = h.float() @ f(W["w2"]).t() + bo
-        if p > 0: t = t * _keep_mask(L, so, M * d, p).view(M, d)
+        if p > 0: t = t * _keep_mask(L, so, Mk * d, p).view(Mk, d)[key_idx]
         xr = xr + t
         assert (x_out - xr).abs().max().item() < 4e-3
     if has2:
