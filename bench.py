@@ -239,6 +239,9 @@ WORKLOADS = {
     "scst": ("configs[3]: ORT dense SCST, the reference's estimator: eval-mode greedy baseline + 5 multinomial rollouts drawn in TRAIN mode "
              "(dropout on) + teacher-forced update under the same dropout masks"),
     "scst_nodrop": "configs[3] without dropout: eval-mode greedy + 5 rollouts in one decode pass, eval-mode update (NOT the reference's estimator)",
+    "scst_hostreward": ("configs[3] as the reference runs it end to end: the reward arrives from the HOST (the CIDEr-D scorer's flow: one "
+                        "synchronisation per step) and the sampled captions END (generator scaled x3 with an EOS bias, so that sampled lengths "
+                        "look like real captions instead of a random-init model's 18 tokens): the update runs on the valid positions only"),
     "decode": "ORT dense, cached-KV beam-5 decode, 1024 images (mixed precision)",
     "decode_fp32": "ORT dense, cached-KV beam-5 decode, 1024 images, fp32 parity mode (token-exact vs the reference)",
     "sparse_decode": "configs[4]: ORT 95% sparse, cached-KV beam-5 decode, 1024 images, decoder stack kernel on the sparse weight stream",
@@ -285,6 +288,14 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
                 for n_, p in model.named_parameters():
                     if p.dim() >= 2:
                         p.mul_((torch.rand_like(p) < keep).float())
+    if workload == "scst" and variant == "hostreward":
+        # captions that end: the knobs of golden G1 (tests/golden/common.py: generator x 3, EOS bias 3.2) on the random-init model
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if n_.endswith("generator.proj.weight"):
+                    p.mul_(3.0)
+                if n_.endswith("generator.proj.bias"):
+                    p[config.eos_token_id] += 3.2
     model = model.to(dev)
     if use_csr:                              # sparse products (ortk_spmm) for the weight blocks where they pay
         model.enable_sparse_kernels("auto" if "988" in variant else 0.9, train=True)
@@ -307,10 +318,15 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         model.train()
         tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000)
         rw = torch.randn(B * 5, device=dev)
+        if variant == "hostreward":
+            rw = rw.cpu()          # (scst_step reads the sampled lengths back and runs the update on the valid positions)
         sample_dropout = variant != "nodrop"
+        lens = []
 
         def step():
-            tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy", sample_dropout=sample_dropout)
+            _, _, seq_, _ = tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy", sample_dropout=sample_dropout)
+            if variant == "hostreward" and len(lens) < 4:
+                lens.append(float((seq_ != 0).sum(-1).float().mean()))
         units_per_step = B * 5
     else:
         model.train()
@@ -438,6 +454,8 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
                                   "frac": round(exe / (ms_per_step * 1e-3) / peak, 4),
                                   "padded_equivalent_tflop": round(GFLOP_FWD_PER_IMAGE * 3 * B / 1e3, 3)}
     wname = workload + ("_" + variant if variant else "")
+    if workload == "scst" and variant == "hostreward" and lens:
+        roofline["mean_sampled_length"] = round(sum(lens) / len(lens), 2)
     out = {"metric": "captions/sec", "value": round(value, 1), "unit": "captions/sec", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
@@ -462,6 +480,8 @@ def compact(r):
         out["chains"] = {x: rf["chain_kernel"][x] for x in ("launches", "avg_us")}
     if "whole_step" in rf:
         out["whole_step_frac"] = rf["whole_step"]["frac"]
+    if "mean_sampled_length" in rf:
+        out["mean_sampled_length"] = rf["mean_sampled_length"]
     return out
 
 
@@ -472,7 +492,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="xe", choices=("xe", "sparse_xe", "scst", "decode", "sparse_decode"))
     ap.add_argument("--variant", default="", help="workload variant: kernels | 988 | 988_kernels (sparse_xe), dense_kernels | 988 | "
-                    "988_dense_kernels (sparse_decode), nodrop (scst), fp32 (decode) — see WORKLOADS")
+                    "988_dense_kernels (sparse_decode), nodrop | hostreward (scst), fp32 (decode) — see WORKLOADS")
     ap.add_argument("--allreduce-dtype", default="fp32", choices=("fp32", "bf16"),
                     help="N > 1: gradient arenas cross xGMI in fp32 (default: the sum is exact up to order) or rounded to bf16 (half the bytes)")
     ap.add_argument("--overlap-allreduce", default="auto", choices=("auto", "on", "off"),
@@ -541,7 +561,7 @@ def main():
         if args.workload == "xe" and not variant and world == 1 and not args.no_extra_workloads and not args.batch:
             extra = {}
             for wl, var, st, wu in (("sparse_xe", "", 20, 3), ("sparse_xe", "kernels", 12, 3), ("sparse_xe", "988", 12, 3),
-                                    ("sparse_xe", "988_kernels", 12, 3), ("scst", "", 12, 3), ("scst", "nodrop", 12, 3),
+                                    ("sparse_xe", "988_kernels", 12, 3), ("scst", "", 12, 3), ("scst", "nodrop", 12, 3), ("scst", "hostreward", 12, 3),
                                     ("decode", "", 10, 3), ("decode", "fp32", 3, 1), ("sparse_decode", "", 10, 3),
                                     ("sparse_decode", "dense_kernels", 10, 3), ("sparse_decode", "988", 10, 3),
                                     ("sparse_decode", "988_scatter", 10, 3), ("sparse_decode", "988_dense_kernels", 10, 3)):

@@ -114,10 +114,16 @@ typedef struct ortk_batch {
      * rows [cap_off[r], cap_off[r+1]) of a compact row space of Mc rows (cap_off: device, R+1 entries, cap_off[0] = 0,
      * 1 <= length <= T; the captions of an image stay adjacent), row_pos[i] = r*T + t of compact row i (device, Mc entries).
      * The caller guarantees tok_weight[r][t] == 0 for every position outside the prefix.  Same loss and gradients as the
-     * padded layout (dropout draws are keyed by the compact row). */
+     * padded layout, in train mode too: every dropout site of compact row i draws as row row_pos[i] of the padded layout. */
     const int32_t* cap_off;
     const int32_t* row_pos;
     int32_t        Mc;
+    /* 1 = the captions are ROLLOUTS (the update pass of an SCST step): the decoder's self-attention masks nothing but the
+     * future.  The reference differentiates its sampled captions through the cached incremental passes that drew them, and a
+     * cached step attends to EVERY earlier position (transformer.py:265-269: mask = None once a cache exists) — also to one
+     * whose sampled token happens to carry the PAD id, which the teacher-forced key mask (seq != pad,
+     * relation_transformer.py:356-358) would hide.  0 = that key mask (ground-truth captions: PAD only pads). */
+    int32_t        no_pad_keys;
 } ortk_batch;
 
 size_t ortk_train_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T);

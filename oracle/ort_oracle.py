@@ -208,14 +208,18 @@ def embed_tokens(P, cfg, tok: Tensor, pos0: int = 0) -> Tensor:
     return e + pe[pos0:pos0 + tok.size(1)]
 
 
-def decode_tf(P, cfg, memory: Tensor, att_masks: Tensor, seq_in: Tensor, drop=None) -> Tensor:
+def decode_tf(P, cfg, memory: Tensor, att_masks: Tensor, seq_in: Tensor, drop=None, rollouts: bool = False) -> Tensor:
     """Teacher-forced decoder (transformer.py:187-210); memory/att_masks already repeated per caption row.  Dropout sites as
-    in `encode`, plus the PositionalEncoding's (transformer.py:398-401)."""
+    in `encode`, plus the PositionalEncoding's (transformer.py:398-401).  `rollouts`: the rows are SAMPLED captions whose
+    log-probs the reference takes from its cached incremental passes (utils/training.py:224-237): those attend to every earlier
+    position (transformer.py:265-269: mask = None once a cache exists), so the self-attention mask is the causal one alone —
+    it differs from (seq != pad) & causal only behind a sampled token that carries the PAD id."""
     h = cfg.num_heads
     T = seq_in.size(1)
     x = _drop(drop, "emb", embed_tokens(P, cfg, seq_in))
     causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
-    self_mask = ((seq_in != cfg.pad_token_id)[:, None, :] & causal[None])[:, None]  # (R,1,T,T)
+    keys = torch.ones_like(seq_in, dtype=torch.bool) if rollouts else (seq_in != cfg.pad_token_id)
+    self_mask = (keys[:, None, :] & causal[None])[:, None]  # (R,1,T,T)
     src_mask = (att_masks != 0)[:, None, None, :]
     sa = getattr(cfg, "share_att_decoder", None)
     for l in range(cfg.num_layers):
@@ -237,8 +241,9 @@ def generator(P, x: Tensor) -> Tensor:
     return F.log_softmax(_linear(P, "model.generator.proj", x), dim=-1)
 
 
-def forward_logp(P, cfg, att_feats, boxes, seqs, att_masks, drop=None) -> Tensor:
-    """``_forward`` (relation_transformer.py:368-372): (R, T, V) log-probs, T = seqs.size(1)-1.  `drop`: see `_drop`."""
+def forward_logp(P, cfg, att_feats, boxes, seqs, att_masks, drop=None, rollouts: bool = False) -> Tensor:
+    """``_forward`` (relation_transformer.py:368-372): (R, T, V) log-probs, T = seqs.size(1)-1.  `drop`: see `_drop`; `rollouts`: see
+    `decode_tf`."""
     mem = encode(P, cfg, att_feats, boxes, att_masks, drop)
     R, B = seqs.size(0), att_feats.size(0)
     if R != B:
@@ -246,7 +251,7 @@ def forward_logp(P, cfg, att_feats, boxes, seqs, att_masks, drop=None) -> Tensor
         spi = R // B
         mem = mem.repeat_interleave(spi, 0)
         att_masks = att_masks.repeat_interleave(spi, 0)
-    return generator(P, decode_tf(P, cfg, mem, att_masks, seqs[:, :-1], drop))
+    return generator(P, decode_tf(P, cfg, mem, att_masks, seqs[:, :-1], drop, rollouts))
 
 
 def xe_loss(logp: Tensor, target: Tensor, mask: Tensor) -> Tensor:

@@ -36,7 +36,7 @@ class Batch(C.Structure):
     _fields_ = [("att_feats", C.c_void_p), ("boxes", C.c_void_p), ("att_masks", C.c_void_p), ("seqs", C.c_void_p),
                 ("seq_stride", C.c_int64), ("tok_weight", C.c_void_p),
                 ("B", C.c_int32), ("S", C.c_int32), ("R", C.c_int32), ("T", C.c_int32),
-                ("cap_off", C.c_void_p), ("row_pos", C.c_void_p), ("Mc", C.c_int32)]
+                ("cap_off", C.c_void_p), ("row_pos", C.c_void_p), ("Mc", C.c_int32), ("no_pad_keys", C.c_int32)]
 
 
 SP_ELL32, SP_ELL16, SP_GU16 = 0, 1, 2     # ortk_sparse_plan.format

@@ -722,11 +722,23 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
+#ifndef STATS_NOEXP
                     if (c0 + 16 * j + r < p.stat_ncols) sm += __expf((acc[i][j][r] + bias4[j][r]) - mx);
+#else
+                    if (c0 + 16 * j + r < p.stat_ncols) sm += (acc[i][j][r] + bias4[j][r]) - mx;
+#endif
             sm += __shfl_xor(sm, 16, 64);
             sm += __shfl_xor(sm, 32, 64);
+#ifdef STATS_NOSTORE
+            if (lg == 0 && m < p.M && sm == 1234.5f) {
+#else
             if (lg == 0 && m < p.M) {
+#endif
+#ifdef STATS_TRANSPOSED
+                float* q = p.tile_stats + ((int64_t)blk * p.M + m) * 2;
+#else
                 float* q = p.tile_stats + ((int64_t)m * nblk + blk) * 2;
+#endif
                 q[0] = mx; q[1] = sm;
             }
         }

@@ -994,8 +994,9 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     TRY(c.wait_ev(fplan_done));
     {
         const Ctx cx = prefix_side ? c.on_side() : c;
+        // (no_pad_keys: rollout captions — the key mask hides nothing, as in the cached passes that drew them; ortk_batch)
         TRY(embed_fwd_rows(bt->seqs, bt->seq_stride, P + o.lut, P + o.pe, w.dx0, w.keymask, Md, compact ? bt->row_pos : nullptr, T, 0, d,
-                           cfg->pad_id, c.p_drop(), c.sub(OP_EMB), cx.s));
+                           bt->no_pad_keys ? -1 : cfg->pad_id, c.p_drop(), c.sub(OP_EMB), cx.s));
         if (prefix_side) { TRY(self_part(cx, 0, w.dx0)); TRY(c.side_mark(&prefix_done)); }
     }
     // the data-gradient plan's images (from this call's transposed weights: this step's mask sample) are built beside the forward

@@ -435,8 +435,9 @@ class RelationTransformerModel(CaptionModelBase):
             data["_valid_rows"] = self._valid_rows(data["cap_len"], R, T, seqs.device) if ok else None
         return data["_valid_rows"]
 
-    def _make_batch(self, att_feats, boxes, att_masks, seqs=None, tok_weight=None, valid_rows=None):
+    def _make_batch(self, att_feats, boxes, att_masks, seqs=None, tok_weight=None, valid_rows=None, rollouts=False):
         b = L.Batch()
+        b.no_pad_keys = 1 if rollouts else 0      # (sampled captions: causal mask only, as the cached passes that drew them; ortk.h)
         keep = [att_feats, boxes, att_masks]
         b.att_feats, b.boxes, b.att_masks = att_feats.data_ptr(), boxes.data_ptr(), att_masks.data_ptr()
         b.B, b.S = att_feats.shape[0], att_feats.shape[1]
@@ -499,7 +500,8 @@ class RelationTransformerModel(CaptionModelBase):
     def _forward(self, att_feats, boxes, seqs, att_masks=None, **kwargs):
         """``_forward`` (relation_transformer.py:368-372): log-probs (R, T, V), T = seqs.size(1) - 1."""
         att_feats, boxes, att_masks = self._prepare(att_feats, boxes, att_masks, kwargs.get("att_max_len"))
-        batch = self._make_batch(att_feats, boxes, att_masks, seqs)
+        # (rollouts=True — `_sample` under autograd: the rows are sampled captions, causal mask only; see ortk_batch.no_pad_keys)
+        batch = self._make_batch(att_feats, boxes, att_masks, seqs, rollouts=bool(kwargs.get("rollouts", False)))
         train = bool(self.training)
         seed = self._next_seed() if train else 0
         params = self._param_list()
@@ -682,7 +684,7 @@ class RelationTransformerModel(CaptionModelBase):
         if ns > 0 and torch.is_grad_enabled() and any(p.requires_grad for p in params):
             rows = seq.view(-1, self.seq_length)
             tf_in = torch.cat([rows.new_full((rows.size(0), 1), self.bos_idx), rows], 1)
-            logp = self._forward(feats, bxs, tf_in, masks)                     # (N*ns, L, V), differentiable
+            logp = self._forward(feats, bxs, tf_in, masks, rollouts=True)      # (N*ns, L, V), differentiable
             tok_lp = logp.gather(2, rows.unsqueeze(2)).squeeze(2).view_as(lp)
             lp = torch.where(seq != self.pad_idx, tok_lp, lp)
         return seq, lp

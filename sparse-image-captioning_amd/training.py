@@ -95,22 +95,24 @@ class NativeTrainer:
         self.check_rollout_status = False       # scst_step: read the rollout decode's status word even with a device-side reward (host sync)
 
     # ------------------------------------------------------------------ pieces
-    def _batch(self, data, tok_weight):
+    def _batch(self, data, tok_weight, rollouts=False):
         m = self.model
         feats, boxes, masks = m._prepare(data["att_feats"], data.get("boxes"), data.get("att_masks"), data.get("att_max_len"))
         # `cap_len` (host-side list / CPU tensor, one entry per caption row: decoder positions that carry a target) switches the
         # decoder to the valid positions only (ortk_batch.cap_off / row_pos); the collate function provides it
-        return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight, m.valid_position_tables(data) if self.valid_positions else None)
+        return m._make_batch(feats, boxes, masks, data["seqs"], tok_weight, m.valid_position_tables(data) if self.valid_positions else None,
+                             rollouts=rollouts)
 
-    def encode_for_update(self, data, rows, train=False, seed=0):
+    def encode_for_update(self, data, rows, train=False, seed=0, positions=None):
         """Phase 1 of the update pass of an SCST step, BEFORE the rollout: bf16 weight copies + encoder on `data`'s images into the
-        training workspace of (B, S, rows, seq_length) — the shapes the update over `rows` sampled captions will use.  Returns the
+        training workspace of (B, S, rows, positions) — the shapes the update over `rows` captions of `positions` decoder positions
+        (default seq_length: sampled captions) will use; `_step(..., encoded=True)` refuses any other geometry.  Returns the
         device address of the encoder memory ((B*S, d_model), the precision's activation type) for `opt["memory"]` of the rollout
         decode; the update then runs `_step(..., encoded=True)`: decoder + criterion + backward on that encoder state."""
         m, lib = self.model, L.lib()
         feats, boxes, masks = m._prepare(data["att_feats"], data.get("boxes"), data.get("att_masks"), data.get("att_max_len"))
         b = m._make_batch(feats, boxes, masks, None, None, None)
-        b.R, b.T = int(rows), int(m.seq_length)
+        b.R, b.T = int(rows), int(m.seq_length if positions is None else positions)
         m._sparse_plans()
         nbytes = lib.ortk_train_workspace_bytes(C.byref(m._ccfg), b.B, b.S, b.R, b.T)
         ws = m._workspace(("train", b.B, b.S, b.R, b.T), nbytes, True)
@@ -122,6 +124,7 @@ class NativeTrainer:
         if not mem:
             raise L.OrtkError("ortk_train_workspace_memory")
         self._enc_keep = (feats, boxes, masks, ws)
+        self._enc_geom = (b.B, b.S, b.R, b.T, bool(train), int(seed))
         return int(mem)
 
     def _fwd_bwd(self, batch, norm, train=True, seed=None, after_decoder_half=None, encoded=False):
@@ -131,6 +134,13 @@ class NativeTrainer:
         if seed is None:
             seed = m._next_seed() if train else 0
         m._sparse_plans()          # sparse training plans (enable_sparse_kernels(train=True)) ride on the config
+        if encoded:
+            # phase 2 runs on the workspace phase 1 carved: the same geometry (T = seq_length: sampled captions), mode and seed
+            geom = (batch.B, batch.S, batch.R, batch.T, bool(train), int(seed))
+            if getattr(self, "_enc_geom", None) != geom:
+                raise ValueError(f"encoded=True: encode_for_update() prepared {getattr(self, '_enc_geom', None)}, the update asks for "
+                                 f"{geom} (images, regions, caption rows, positions, train, seed)")
+            self._enc_geom = None
         nbytes = lib.ortk_train_workspace_bytes(C.byref(m._ccfg), batch.B, batch.S, batch.R, batch.T)
         ws = m._workspace(("train", batch.B, batch.S, batch.R, batch.T), nbytes, True)
         pptr = m._eff_params_ptr(train, seed)
@@ -292,10 +302,12 @@ class NativeTrainer:
             pos = torch.arange(1, mask.size(1) + 1, device=mask.device, dtype=mask.dtype)
             tf["cap_len"] = (mask * pos).amax(1).clamp_(min=1).to(torch.int64).cpu()       # 1 + index of the last weighted position
         tf["seqs"] = torch.cat([rows.new_full((rows.size(0), 1), m.bos_idx), rows], 1)
+        # rollouts=True: the teacher-forced pass masks nothing but the future — what the cached passes that drew the captions saw
+        # (a sampled token may carry the PAD id; utils/training.py:252-254 drops it from the loss, later positions still attend to it)
         if drop_seed is not None:
-            loss = self._step(tf, mask * reward[:, None], mask, True, seed=drop_seed, encoded=share_encoder)
+            loss = self._step(tf, mask * reward[:, None], mask, True, seed=drop_seed, encoded=share_encoder, rollouts=True)
         else:
-            loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout, encoded=share_encoder)
+            loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout, encoded=share_encoder, rollouts=True)
         return loss, reward, seq, greedy
 
     @staticmethod
@@ -310,7 +322,7 @@ class NativeTrainer:
             return torch.from_numpy(sc_sample - sc_baseline).float()
         return fn
 
-    def _step(self, data, tok_weight, norm_mask, train, seed=None, encoded=False):
+    def _step(self, data, tok_weight, norm_mask, train, seed=None, encoded=False, rollouts=False):
         m = self.model
         self.step_count += 1
         if not self._grads_clean:
@@ -323,7 +335,7 @@ class NativeTrainer:
         L.check(L.lib().ortk_sum(L.ptr(norm_mask.contiguous()), n_norm, L.ptr(self._sum_scratch) if ns > 0 else None,
                                  L.ptr(self.norm_dev), L.stream_ptr()), "ortk_sum")
         parallel.reduce_scalar_sum(self.norm_dev)   # LanguageModelCriterion semantics over the GLOBAL batch
-        batch = self._batch(data, tok_weight)
+        batch = self._batch(data, tok_weight, rollouts)
         lr = self.rate()
         early = None
         if self.early_adam:

@@ -535,7 +535,7 @@ def test_native_scst_step_vs_oracle(P, g1):
     # ---- loss and gradients: oracle teacher-forced log-probs of the SAME tokens, RewardCriterion, autograd
     rows = seq.cpu().view(-1, seq.size(-1))
     tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
-    logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"])
+    logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"], rollouts=True)
     tok_lp = logp.gather(2, rows.unsqueeze(2)).squeeze(2)
     ref_loss = O.reward_loss(tok_lp, rows, reward.cpu())
     assert abs(loss.item() - ref_loss.item()) < 1e-4, (loss.item(), ref_loss.item())
@@ -1541,7 +1541,7 @@ def test_scst_beam_search_sample_mode_vs_oracle(P, g1):
         assert torch.equal(seq.cpu(), oseq) and torch.equal(greedy.cpu(), ogreedy)
         rows = oseq.view(-1, oseq.size(-1))
         tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
-        logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"])
+        logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"], rollouts=True)
         ref_loss = O.reward_loss(logp.gather(2, rows.unsqueeze(2)).squeeze(2), rows, rw)
     assert abs(loss.item() - ref_loss.item()) < 1e-4, (loss.item(), ref_loss.item())
 
@@ -1615,7 +1615,7 @@ def test_train_mode_sampling_vs_oracle(P, g1):
     # the teacher-forced pass of the same seed reproduces the rollout's log-probs (the pass scst_step differentiates)
     rows = seq.view(-1, seq.size(-1))
     tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
-    batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in)
+    batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in, rollouts=True)
     logp, _ = m._run_forward(batch, True, drop_seed, want_logp=True, cache_ws=False)
     tok_lp = logp[..., :m.vocab_size].gather(2, rows.unsqueeze(2)).squeeze(2)
     v2 = rows != 0
@@ -1628,7 +1628,7 @@ def test_train_mode_sampling_vs_oracle(P, g1):
     loss, _, sseq, sgreedy = tr.scst_step(b, lambda s_, g_: rw, num_samples=ns, baseline="greedy", sample_dropout=True)
     seed_used = (torch.initial_seed() * 1000003 + 301) & 0xFFFFFFFFFFFFFFFF or 1          # the first seed scst_step drew
     srows = sseq.view(-1, sseq.size(-1))
-    sbatch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), torch.cat([srows.new_full((R, 1), C.BOS), srows], 1))
+    sbatch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), torch.cat([srows.new_full((R, 1), C.BOS), srows], 1), rollouts=True)
     # (the step has updated the weights: recompute on the restored ones)
     m.load_state_dict(H.g1_state(), strict=False)
     slogp, _ = m._run_forward(sbatch, True, seed_used, want_logp=True, cache_ws=False)
@@ -1652,7 +1652,7 @@ def test_forward_in_two_phases_and_decode_on_its_memory(P, full_state, precision
     tok_w = b["masks"][:, 1:].contiguous().float()
     l0 = tr._step(b, tok_w, tok_w, False).item()
     g0 = tr.grads.clone()
-    mem = tr.encode_for_update(b, b["seqs"].size(0))
+    mem = tr.encode_for_update(b, b["seqs"].size(0), positions=b["seqs"].size(1) - 1)
     l1 = tr._step(b, tok_w, tok_w, False, encoded=True).item()
     # same kernels on the same operands in both schedules, and the criterion adds its row terms in a fixed order: the same bits
     assert l0 == l1, (l0, l1)
@@ -1684,7 +1684,7 @@ def _tf_logp_oracle(Pm, cfg, cb, rows, drop=None):
     """Oracle teacher-forced log-probs (fp32 CPU) of caption rows (R, L) for the images of batch `cb` (R / N rows per image)."""
     tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
     with torch.no_grad():
-        logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"], **({"drop": drop} if drop else {}))
+        logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"], rollouts=True, **({"drop": drop} if drop else {}))
     return logp
 
 
@@ -1823,7 +1823,7 @@ def test_train_mode_sampling_on_the_split_kernel_vs_oracle(P, margin_state):
 
     def tf_lp(rows_, seed_):
         tf_in = torch.cat([rows_.new_full((rows_.size(0), 1), C.BOS), rows_], 1)
-        batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in)
+        batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in, rollouts=True)
         logp, _ = m._run_forward(batch, True, seed_, want_logp=True, cache_ws=False)
         return logp[..., :m.vocab_size].gather(2, rows_.unsqueeze(2)).squeeze(2)
 
@@ -1981,15 +1981,15 @@ def test_split_forward_on_valid_positions_packs_the_chains_for_its_own_kernel_fo
     b = _cuda(H.torch_batch(C.make_inputs(seed=91, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
     g = torch.Generator().manual_seed(3)
     rows = torch.zeros(B * ns, T, dtype=torch.long)
-    rows[:, :10] = torch.randint(4, 10001, (B * ns, 10), generator=g)
-    rows[:, 10] = C.EOS
+    rows[:, :11] = torch.randint(4, 10001, (B * ns, 11), generator=g)
+    rows[:, 11] = C.EOS
     rows = rows.cuda()
     mask = (rows != 0).float()
     reward = torch.randn(B * ns, generator=g).cuda()
     tf = dict(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"],
               seqs=torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1))
-    cap_len = torch.full((B * ns,), 11, dtype=torch.int64)
-    Mc = 11 * B * ns + (-11 * B * ns) % 256
+    cap_len = torch.full((B * ns,), 12, dtype=torch.int64)          # BOS + 11 tokens: 12 positions carry a target (the last one: EOS)
+    Mc = 12 * B * ns + (-12 * B * ns) % 256
     assert not _chain_wide(B * ns * T) and _chain_wide(Mc), (B * ns * T, Mc)
     tr = NativeTrainer(m, noamopt_factor=0.0, noamopt_warmup=10, keep_grads=True)          # lr 0: the weights stay
     m.eval()
@@ -2017,24 +2017,30 @@ def test_split_forward_on_valid_positions_packs_the_chains_for_its_own_kernel_fo
 
 def test_split_forward_rebuilds_the_data_gradient_plan_from_its_own_weights(P):
     """A split forward (phase 1 = encoder, phase 2 = decoder; the update of an SCST step) of a model with sparse TRAINING kernels
-    must build the data-gradient plan's images from ITS weights: two eval-mode updates (seed 0 both times, same cached workspace)
-    with an optimizer step in between — the second step's gradients equal those of a fresh trainer that starts from the weights
-    the first step left (before the fix the second backward found the first step's images 'current' and skipped the rebuild)."""
+    must build the data-gradient plan's images from ITS weights: two updates under the SAME seed on the same cached workspace (an
+    SCST step whose seed a caller fixes; eval-mode updates always have seed 0) with an optimizer step in between — the second step's
+    gradients equal those of a fresh trainer that starts from the weights the first step left (before the fix the second backward
+    found the first step's images 'current' — the key was (plan, workspace, seed, mode) — and skipped the rebuild)."""
     from sparse_image_captioning_amd.training import NativeTrainer
     b = _cuda(H.g1_batch())
     R = b["seqs"].size(0)
+    # (the split forward is the SCST update's: caption rows of max_seq_length positions behind BOS — one PAD column more than G1's)
+    b["seqs"] = torch.cat([b["seqs"], b["seqs"].new_zeros(R, 1)], 1)
+    b["masks"] = torch.cat([b["masks"], b["masks"].new_zeros(R, 1)], 1)
+    assert b["seqs"].size(1) - 1 == C.TINY_CFG["max_seq_length"]
     tok_w = b["masks"][:, 1:].contiguous().float()
 
     def trainer():
         m = _model(P, "relation_transformer_prune", C.TINY_CFG, _prune_state(), precision=1)
         m.enable_sparse_kernels(min_sparsity=0.5, train=True)
         assert m._sparse_plans()[1] is not None
-        m.eval()
-        return m, NativeTrainer(m, noamopt_factor=0.4, noamopt_warmup=1, keep_grads=True)      # lr 0.05 per Adam step: the weights really move
+        m.train()
+        # lr 0.05 per Adam step: the weights really move; the mask logits stay (their group's rate is its own: 0 here)
+        return m, NativeTrainer(m, noamopt_factor=0.4, noamopt_warmup=1, keep_grads=True, prune_supermask_lr=0.0)
 
     def split_step(tr):
-        tr.encode_for_update(b, R)
-        loss = tr._step(b, tok_w, tok_w, False, encoded=True).item()
+        tr.encode_for_update(b, R, train=True, seed=5)
+        loss = tr._step(b, tok_w, tok_w, True, seed=5, encoded=True).item()
         return loss, tr.grads.clone()
 
     ma, ta = trainer()
@@ -2050,6 +2056,11 @@ def test_split_forward_rebuilds_the_data_gradient_plan_from_its_own_weights(P):
     assert l2 == lref, (l2, lref)
     assert ((g2 - gref).norm() / gref.norm()).item() < 1e-3, ((g2 - gref).norm() / gref.norm()).item()
     ma.check_sparse_overflow(); mb.check_sparse_overflow()
+    # a phase 2 whose geometry is not phase 1's is refused (it would read another carve of the workspace)
+    ta.encode_for_update(b, R, train=True, seed=5)
+    short = dict(b, seqs=b["seqs"][:, :-1].contiguous())
+    with pytest.raises(ValueError, match="encode_for_update"):
+        ta._step(short, tok_w[:, :-1].contiguous(), tok_w[:, :-1].contiguous(), True, seed=5, encoded=True)
 
 
 def test_default_scst_step_runs_with_sparse_kernels_enabled(P):
@@ -2147,7 +2158,7 @@ def test_scst_default_step_at_bench_size_properties(P, margin_state):
     rows = s1.reshape(-1, s1.size(-1))
     tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
     drop_seed = (torch.initial_seed() * 1000003 + 41) & 0xFFFFFFFFFFFFFFFF or 1       # the first seed drawn after counter = 40
-    batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in)
+    batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in, rollouts=True)
     with torch.no_grad():
         logp, _ = m._run_forward(batch, True, drop_seed, want_logp=True, cache_ws=False)
         tf = logp[..., :m.vocab_size].gather(2, rows.unsqueeze(2)).squeeze(2)
@@ -2155,6 +2166,9 @@ def test_scst_default_step_at_bench_size_properties(P, margin_state):
         ev = m(att_feats=b["att_feats"], boxes=b["boxes"], seqs=tf_in, att_masks=b["att_masks"]).gather(2, rows.unsqueeze(2)).squeeze(2)
     roll = rlp1[:, 1:].reshape(-1, rlp1.size(-1))
     err = (tf - roll)[rows != 0].abs()
+    # (measured: 0.016 max / 0.003 mean over ~20 000 token positions.  Before the update pass took the causal mask alone for rollouts
+    #  — ortk_batch.no_pad_keys — the one row in 1 280 that had sampled a token with the PAD id was off by 0.15-0.28 at every later
+    #  position: this bar is what found it)
     assert err.max().item() < 0.05 and err.mean().item() < 0.005, (err.max().item(), err.mean().item())
     assert (ev - roll)[rows != 0].abs().mean().item() > 0.02               # (the masks matter: eval-mode log-probs are another policy's)
     # host-side reward: the update on the valid positions, under the same masks
@@ -2163,3 +2177,43 @@ def test_scst_default_step_at_bench_size_properties(P, margin_state):
     assert torch.equal(s3, s1) and torch.equal(gr3, gr1)
     assert abs(l3 - l1) < 2e-5 * max(1.0, abs(l1)), (l3, l1)
     assert ((g3_ - g1_).norm() / g1_.norm()).item() < 2e-3, ((g3_ - g1_).norm() / g1_.norm()).item()
+
+
+def test_rollout_update_uses_the_causal_mask_only_vs_oracle_incremental(P, g1):
+    """The SCST update recomputes the log-probs of SAMPLED captions by one teacher-forced pass; the reference differentiates the
+    cached incremental passes that drew them, and a cached step attends to every earlier position (transformer.py:265-269: no mask
+    once a cache exists) — also to a sampled token that carries the PAD id, which the teacher-forced key mask (seq != pad,
+    relation_transformer.py:356-358) would hide from later positions.  With `ortk_batch.no_pad_keys` (NativeTrainer sets it for
+    rollouts) the teacher-forced log-probs equal the ORACLE's incremental ones at every position, PAD ids in mid-caption included;
+    without it they differ behind such a token (and only there)."""
+    m = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state())
+    cb = H.g1_batch()
+    b = _cuda(cb)
+    cfg = _oracle_cfg(C.TINY_CFG)
+    B, ns, T, V = cb["att_feats"].size(0), 3, C.TINY_CFG["max_seq_length"], C.TINY_CFG["vocab_size"]
+    g = torch.Generator().manual_seed(12)
+    rows = torch.zeros(B * ns, T, dtype=torch.long)
+    rows[:, :9] = torch.randint(4, V, (B * ns, 9), generator=g)
+    rows[:, 9] = C.EOS
+    with_pad = torch.arange(B * ns) % 2 == 0
+    rows[with_pad, 3] = C.PAD                                   # a sampled token with the PAD id, mid-caption
+    tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
+    # oracle: the cached incremental passes (what the reference's SCST graph is made of), teacher-forced on the same tokens
+    state = H.g1_state()
+    with torch.no_grad():
+        mem = O.encode(state, cfg, cb["att_feats"], cb["boxes"], cb["att_masks"])
+        st = O.DecodeState(state, cfg, mem.repeat_interleave(ns, 0), cb["att_masks"].repeat_interleave(ns, 0))
+        inc = torch.stack([O.decode_step(st, tf_in[:, t]) for t in range(T)], 1)          # (rows, T, V)
+    out = {}
+    for rollouts in (True, False):
+        batch = m._make_batch(*m._prepare(b["att_feats"], b["boxes"], b["att_masks"]), tf_in.cuda(), rollouts=rollouts)
+        with torch.no_grad():
+            logp, _ = m._run_forward(batch, False, 0, want_logp=True, cache_ws=False)
+        out[rollouts] = logp[..., :V].cpu()
+    upto = 10                                                   # positions 0..9 predict the 9 tokens and EOS
+    err = (out[True][:, :upto] - inc[:, :upto]).abs()
+    assert err.max().item() < 1e-4, err.max().item()
+    d = (out[False][:, :upto] - inc[:, :upto]).abs().amax(-1)    # (rows, positions): the masked variant
+    assert d[~with_pad].max().item() < 1e-4                      # captions without such a token: the same either way
+    assert d[with_pad][:, :4].max().item() < 1e-4                # ... and up to the position that FEEDS the PAD-id token
+    assert d[with_pad][:, 4:].min().item() > 1e-4                # behind it the key mask changes every position
