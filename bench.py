@@ -241,7 +241,7 @@ WORKLOADS = {
     "scst_nodrop": "configs[3] without dropout: eval-mode greedy + 5 rollouts in one decode pass, eval-mode update (NOT the reference's estimator)",
     "scst_hostreward": ("configs[3] as the reference runs it end to end: the reward arrives from the HOST (the CIDEr-D scorer's flow: one "
                         "synchronisation per step) and the sampled captions END (generator scaled x3 with an EOS bias, so that sampled lengths "
-                        "look like real captions instead of a random-init model's 18 tokens): the update runs on the valid positions only"),
+                        "look like real captions instead of a random-init model's 18 tokens; mean length on the line): the update runs on the valid positions only"),
     "decode": "ORT dense, cached-KV beam-5 decode, 1024 images (mixed precision)",
     "decode_fp32": "ORT dense, cached-KV beam-5 decode, 1024 images, fp32 parity mode (token-exact vs the reference)",
     "sparse_decode": "configs[4]: ORT 95% sparse, cached-KV beam-5 decode, 1024 images, decoder stack kernel on the sparse weight stream",
@@ -289,13 +289,13 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
                     if p.dim() >= 2:
                         p.mul_((torch.rand_like(p) < keep).float())
     if workload == "scst" and variant == "hostreward":
-        # captions that end: the knobs of golden G1 (tests/golden/common.py: generator x 3, EOS bias 3.2) on the random-init model
+        # captions that end: the knobs of golden G1 (tests/golden/common.py: generator x 3 + an EOS bias) on the random-init model
         with torch.no_grad():
             for n_, p in model.named_parameters():
                 if n_.endswith("generator.proj.weight"):
                     p.mul_(3.0)
                 if n_.endswith("generator.proj.bias"):
-                    p[config.eos_token_id] += 3.2
+                    p[config.eos_token_id] += args.scst_eos_bias
     model = model.to(dev)
     if use_csr:                              # sparse products (ortk_spmm) for the weight blocks where they pay
         model.enable_sparse_kernels("auto" if "988" in variant else 0.9, train=True)
@@ -510,6 +510,9 @@ def main():
                     help="teacher forcing over all 17 positions of every caption as the reference does (default: the decoder runs on "
                          "the valid positions only; same loss and gradients)")
     ap.add_argument("--scst-train-sampling", action="store_true", help="(kept for old command lines: the scst workload now IS train-mode sampling)")
+    ap.add_argument("--scst-eos-bias", type=float, default=4.6,
+                    help="scst --variant hostreward: EOS logit bias on the x3-scaled random-init generator (4.6: sampled captions of ~12 of 18 "
+                         "positions, the length of the XE workload's synthetic captions; the line reports the mean sampled length)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="default run on one GPU: do not add the `workloads` object (BASELINE configs[2], [3], [4] timed in this process)")

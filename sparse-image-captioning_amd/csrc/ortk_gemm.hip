@@ -706,39 +706,47 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
         f32x4 bias4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (a block that lies below stat_ncols as a whole — every block but the vocabulary's last — takes the form without the
+        //  per-element bounds tests: the epilogue is vector-ALU time the CU's other workgroup cannot use for its MFMAs)
+        const bool whole = nb + wn * 64 + 64 <= p.stat_ncols;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = mb + wm * (16 * MI) + 16 * i + lr;
-            float mx = -INFINITY;
+            float v[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + 16 * j + r < p.stat_ncols) mx = fmaxf(mx, acc[i][j][r] + bias4[j][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sm = 0.f;
+                for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] + bias4[j][r];
+            float mx = -INFINITY, sm = 0.f;
+            if (whole) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#ifndef STATS_NOEXP
-                    if (c0 + 16 * j + r < p.stat_ncols) sm += __expf((acc[i][j][r] + bias4[j][r]) - mx);
-#else
-                    if (c0 + 16 * j + r < p.stat_ncols) sm += (acc[i][j][r] + bias4[j][r]) - mx;
-#endif
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, v[j][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sm += __expf(v[j][r] - mx);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + 16 * j + r < p.stat_ncols) mx = fmaxf(mx, v[j][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + 16 * j + r < p.stat_ncols) sm += __expf(v[j][r] - mx);
+            }
             sm += __shfl_xor(sm, 16, 64);
             sm += __shfl_xor(sm, 32, 64);
-#ifdef STATS_NOSTORE
-            if (lg == 0 && m < p.M && sm == 1234.5f) {
-#else
             if (lg == 0 && m < p.M) {
-#endif
-#ifdef STATS_TRANSPOSED
-                float* q = p.tile_stats + ((int64_t)blk * p.M + m) * 2;
-#else
                 float* q = p.tile_stats + ((int64_t)m * nblk + blk) * 2;
-#endif
                 q[0] = mx; q[1] = sm;
             }
         }
