@@ -16,7 +16,7 @@ L = pkg._lib
 L.require_gpu()
 lib = L.lib()
 N, K, V = 10112, 512, 10001
-for M in (5120, 1536):
+for M in (5120, 1536, 16640):      # decode (1 024 images x 5 beams), SCST rollout (256 x 6), the XE step's valid positions
     A = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
     B = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
     bias = torch.randn(N, device="cuda")

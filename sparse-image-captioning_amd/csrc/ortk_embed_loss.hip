@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
 
 // Register-resident form (V <= 256 * NPT): each thread keeps its strided slice of the row, so the 870 MB logits tensor
 // is read ONCE instead of three times; max, sum and gradient run in the element order of xent_kernel (bit-identical).
-template <int NPT>
+// FAST (mixed precision: the gradient leaves as bf16): ONE v_exp_f32 per element — e = exp(z - max) stays in the register that held
+// z, the gradient is e / sum — instead of two evaluations of libm's expf (~20 vector instructions each: the kernel was bound by them,
+// not by its one read of the logits).  The fp32 parity mode keeps the exact form (bit-identical to xent_kernel).
+template <int NPT, bool FAST>
 __global__ __launch_bounds__(256) void xent_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                        int64_t target_stride, int T, const float* __restrict__ weight,
                                                        const float* __restrict__ norm_dev, float* __restrict__ row_loss, int V,
@@ -137,18 +140,25 @@ __global__ __launch_bounds__(256) void xent_reg_kernel(const float* __restrict__
     for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) mx = fmaxf(mx, z[u]);
     mx = block_max(mx, sh);
     float s = 0.f;
+    if (FAST) {
 #pragma unroll
-    for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) s += expf(z[u] - mx);
+        for (int u = 0; u < NPT; ++u) { z[u] = tid + 256 * u < V ? __expf(z[u] - mx) : 0.f; s += z[u]; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) if (tid + 256 * u < V) s += expf(z[u] - mx);
+    }
     s = block_sum(s, sh);
     const float lse = logf(s);
     if (tid == 0) row_loss[r] = w != 0.f ? -((row[tgt] - mx) - lse) * w : 0.f;
     __syncthreads();     // dlogits may alias logits (fp32 mode): row[tgt] is read before any element is overwritten
+    const float ws_ = FAST ? w / s : 0.f;
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
         const int c = tid + 256 * u;
         if (c < (int)ld_dl) {
             float g = 0.f;
-            if (c < V && w != 0.f) g = (expf((z[u] - mx) - lse) - (c == tgt ? 1.f : 0.f)) * w;
+            if (FAST) { if (c < V && w != 0.f) g = z[u] * ws_ - (c == tgt ? w : 0.f); }
+            else if (c < V && w != 0.f) g = (expf((z[u] - mx) - lse) - (c == tgt ? 1.f : 0.f)) * w;
             st_elem(dlogits, r * ld_dl + c, dl_dt, g);
         }
     }
@@ -373,8 +383,11 @@ int xent_rows(const float* logits, const int64_t* targets, int64_t target_stride
         return ORTK_EINVAL;
     if (dl_dtype != ORTK_F32 && dl_dtype != ORTK_BF16) return ORTK_EINVAL;
     if (rows == 0) return ortk_fill(loss_dev, 1, 0.f, (ortk_stream)s);
-    if (V <= 256 * 40 && ld_dl <= 256 * 40 && V > 256 * 8)
-        hipLaunchKernelGGL(xent_reg_kernel<40>, dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T,
+    if (V <= 256 * 40 && ld_dl <= 256 * 40 && V > 256 * 8 && dl_dtype == ORTK_BF16)
+        hipLaunchKernelGGL((xent_reg_kernel<40, true>), dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T,
+                           weight, norm_dev, row_loss, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
+    else if (V <= 256 * 40 && ld_dl <= 256 * 40 && V > 256 * 8)
+        hipLaunchKernelGGL((xent_reg_kernel<40, false>), dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T,
                            weight, norm_dev, row_loss, V, ld, dlogits, (int)dl_dtype, ld_dl, row_pos);
     else
         hipLaunchKernelGGL(xent_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, targets, target_stride, T, weight,
