@@ -510,8 +510,8 @@ def main():
                     help="teacher forcing over all 17 positions of every caption as the reference does (default: the decoder runs on "
                          "the valid positions only; same loss and gradients)")
     ap.add_argument("--scst-train-sampling", action="store_true", help="(kept for old command lines: the scst workload now IS train-mode sampling)")
-    ap.add_argument("--scst-eos-bias", type=float, default=4.6,
-                    help="scst --variant hostreward: EOS logit bias on the x3-scaled random-init generator (4.6: sampled captions of ~12 of 18 "
+    ap.add_argument("--scst-eos-bias", type=float, default=5.4,
+                    help="scst --variant hostreward: EOS logit bias on the x3-scaled random-init generator (5.4: sampled captions of ~13 of 18 "
                          "positions, the length of the XE workload's synthetic captions; the line reports the mean sampled length)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
