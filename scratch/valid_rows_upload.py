@@ -1,0 +1,68 @@
+"""The XE step with its valid-position tables REBUILT every step (what an SCST update on the valid positions does), synced per step:
+which way of getting the tables onto the device stalls the host?  a = pinned staging + cudaMemcpyAsync (the code path), b = blocking
+copy from pageable memory, c = lengths uploaded (blocking, 10 KB), tables computed by device kernels, d = no rebuild (cached tables)."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+import sparse_image_captioning_amd as pkg
+from sparse_image_captioning_amd.utils.config import ort_config
+from sparse_image_captioning_amd.training import NativeTrainer
+dev = torch.device("cuda", 0)
+config = ort_config(drop_prob_src=0.5, prune_type="supermask", max_seq_length=18)
+torch.manual_seed(8888)
+model = pkg.get_model("relation_transformer")(config, precision="bf16").to(dev).train()
+batch = bench.synth_batch(256, 36, 2048, 10001, 5, 18, 1000, dev)
+tx = NativeTrainer(model, noamopt_factor=0.0, noamopt_warmup=20000)
+orig = model._valid_rows
+
+def lengths(cap_len, R, T):
+    n = torch.as_tensor(cap_len, dtype=torch.int64, device="cpu").clamp(1, T).clone()
+    extra = int((-int(n.sum())) % 256)
+    if extra:
+        room = (T - n).clamp(min=0)
+        take = torch.minimum(room, (extra - (torch.cumsum(room, 0) - room)).clamp(min=0))
+        n += take
+    return n
+
+def variant_b(cap_len, R, T, dev_):
+    n = lengths(cap_len, R, T)
+    off = torch.zeros(R + 1, dtype=torch.int64); off[1:] = torch.cumsum(n, 0)
+    Mc = int(off[-1])
+    rows = torch.repeat_interleave(torch.arange(R, dtype=torch.int64) * T - off[:-1], n) + torch.arange(Mc, dtype=torch.int64)
+    return off.to(torch.int32).to(dev_), rows.to(torch.int32).to(dev_), Mc
+
+def variant_c(cap_len, R, T, dev_):
+    n = lengths(cap_len, R, T)
+    Mc = int(n.sum())
+    nd = n.to(dev_)
+    off = torch.zeros(R + 1, dtype=torch.int64, device=dev_); off[1:] = torch.cumsum(nd, 0)
+    rows = torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=dev_) * T - off[:-1], nd, output_size=Mc) + torch.arange(Mc, dtype=torch.int64, device=dev_)
+    return off.to(torch.int32), rows.to(torch.int32), Mc
+
+ring = {"i": 0, "slots": []}
+def variant_e(cap_len, R, T, dev_):          # lengths through a persistent pinned ring + async copy, tables by device kernels
+    n = lengths(cap_len, R, T)
+    Mc = int(n.sum())
+    if len(ring["slots"]) < 4:
+        ring["slots"].append([torch.empty(R, dtype=torch.int64).pin_memory(), None]); slot = ring["slots"][-1]
+    else:
+        slot = ring["slots"][ring["i"] % 4]
+        slot[1].synchronize()
+    ring["i"] += 1
+    slot[0].copy_(n)
+    nd = slot[0].to(dev_, non_blocking=True)
+    slot[1] = torch.cuda.Event(); slot[1].record()
+    off = torch.zeros(R + 1, dtype=torch.int64, device=dev_); off[1:] = torch.cumsum(nd, 0)
+    rows = torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=dev_) * T - off[:-1], nd, output_size=Mc) + torch.arange(Mc, dtype=torch.int64, device=dev_)
+    return off.to(torch.int32), rows.to(torch.int32), Mc
+
+for name, fn, rebuild in (("e pinned lengths + device-built", variant_e, True), ("a pinned + async copy", orig, True), ("b blocking copy", variant_b, True), ("c device-built", variant_c, True), ("d cached", orig, False), ("a again", orig, True)):
+    model._valid_rows = fn
+    out = []
+    bb = dict(batch)
+    for it in range(16):
+        if rebuild: bb = {k: v for k, v in batch.items() if k != "_valid_rows"}
+        t0 = time.perf_counter(); tx.xe_step(bb); torch.cuda.current_stream().synchronize(); out.append(round(1e3 * (time.perf_counter() - t0), 1))
+    print(name, out[2:])

@@ -160,6 +160,7 @@ class RelationTransformerModel(CaptionModelBase):
         self._bind()
         self.reset_parameters()
         self._ws_cache = {}
+        self._vr_stage = {}                # pinned staging rings of the valid-position tables, per (caption rows, positions)
         self._seed_counter = 0
         self.done_beams = None
 
@@ -224,6 +225,7 @@ class RelationTransformerModel(CaptionModelBase):
             setattr(self, attr, t)
         self._bind()
         self._ws_cache = {}
+        self._vr_stage = {}
         self._plans = None                 # sparse plans live on the old device
         self._ccfg.sparse_fwd = None
         self._ccfg.sparse_bwd = None
@@ -399,8 +401,8 @@ class RelationTransformerModel(CaptionModelBase):
     def _valid_rows(self, cap_len, R, T, dev):
         """Device tables of the valid-position decoder layout (``ortk_batch.cap_off / row_pos``) from the HOST-side caption
         lengths: ``cap_len[r]`` = decoder positions of caption r that carry a target (1 + index of its last non-zero target
-        weight: ``len(tokens) + 1`` for BOS, tokens, EOS).  Everything is computed on the host (the collate function knows
-        the lengths): no device read-back, two small asynchronous uploads."""
+        weight: ``len(tokens) + 1`` for BOS, tokens, EOS).  The lengths (and the row count, which sizes every launch) are the
+        host's (the collate function knows them): no device read-back; one small asynchronous upload, the tables by device kernels."""
         n = torch.as_tensor(cap_len, dtype=torch.int64, device="cpu").clamp(1, T).clone()
         assert n.numel() == R, "cap_len needs one entry per caption row"
         # Row counts that are not a multiple of the GEMM tiles (256 rows) send the weight-gradient products (their reduction
@@ -413,13 +415,29 @@ class RelationTransformerModel(CaptionModelBase):
             if int(take.sum()) < extra:
                 return None          # (nearly no padding in this batch: nothing to gain)
             n += take
-        off = torch.zeros(R + 1, dtype=torch.int64)
-        off[1:] = torch.cumsum(n, 0)
-        Mc = int(off[-1])
-        rows = torch.repeat_interleave(torch.arange(R, dtype=torch.int64) * T - off[:-1], n) + torch.arange(Mc, dtype=torch.int64)
-        # (pinned staging: an upload from pageable memory makes the host wait for the stream — a full synchronisation per step)
-        up = lambda t: t.to(torch.int32).pin_memory().to(dev, non_blocking=True)
-        return up(off), up(rows), Mc
+        Mc = int(n.sum())
+        # The tables are built ON THE DEVICE from the lengths: only `n` (8 bytes per caption) crosses PCIe, through a persistent ring of
+        # four pinned staging buffers per (R, T) and an asynchronous copy.  Measured (scratch/valid_rows_upload.py, XE step with the
+        # tables rebuilt every step, host synchronised per step): uploading the finished tables (65 KB of row indices; pinned +
+        # cudaMemcpyAsync, or a blocking copy from pageable memory) makes every second or third step stall for 60-90 ms somewhere
+        # later in the step (the host blocks inside HIP with the GPU idle); 10 KB of lengths + device kernels: 11.8 ms per step,
+        # every step (11.5 with cached tables).  A training loop has a new batch every step, an SCST update new lengths every step.
+        ring = self._vr_stage.setdefault((R, T), {"i": 0, "slots": []})
+        if len(ring["slots"]) < 4:
+            ring["slots"].append([torch.empty(R, dtype=torch.int64).pin_memory(), None])
+            slot = ring["slots"][-1]
+        else:
+            slot = ring["slots"][ring["i"] % 4]
+            slot[1].synchronize()             # (the upload that last used this slot: four batches ago)
+        ring["i"] += 1
+        slot[0].copy_(n)
+        nd = slot[0].to(dev, non_blocking=True)
+        slot[1] = torch.cuda.Event(); slot[1].record()
+        off = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.cumsum(nd, 0)
+        rows = torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=dev) * T - off[:-1], nd, output_size=Mc)
+        rows += torch.arange(Mc, dtype=torch.int64, device=dev)
+        return off.to(torch.int32), rows.to(torch.int32), Mc
 
     def valid_position_tables(self, data):
         """The device tables of the valid-position decoder layout for a batch dict that carries ``cap_len`` (see

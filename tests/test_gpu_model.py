@@ -2217,3 +2217,55 @@ def test_rollout_update_uses_the_causal_mask_only_vs_oracle_incremental(P, g1):
     assert d[~with_pad].max().item() < 1e-4                      # captions without such a token: the same either way
     assert d[with_pad][:, :4].max().item() < 1e-4                # ... and up to the position that FEEDS the PAD-id token
     assert d[with_pad][:, 4:].min().item() > 1e-4                # behind it the key mask changes every position
+
+
+@pytest.mark.parametrize("n_img,n_reg,spi,seq_len,precision", [(1, 1, 1, 2, 0), (2, 128, 3, 64, 0), (1, 128, 64, 64, 0), (3, 128, 2, 64, 1)])
+def test_geometry_limits_vs_oracle(P, n_img, n_reg, spi, seq_len, precision):
+    """The extremes `check_batch` accepts, against the oracle on a tiny model: ONE image with ONE region and ONE decoder position;
+    128 regions (the most an image may carry) with 64-position captions (the most `ortk_config.seq_len` allows); 64 captions x 64
+    positions per image = 4 096 rows in one cross-attention group (the bound on captions-per-image x T); ragged regions.  fp32: loss
+    1e-4, every gradient 2e-4 x scale, greedy tokens exact; mixed precision: the bf16 tolerances of the suite."""
+    from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
+    cfgd = dict(C.TINY_CFG, max_seq_length=seq_len)
+    cfg = _oracle_cfg(cfgd)
+    state = H.torch_state(H.dense_param_shapes(cfgd), 4321, C.G1_GEN_SCALE, C.G1_EOS_BIAS)
+    cb = H.torch_batch(C.make_inputs(seed=5 + n_reg, n_img=n_img, n_reg=n_reg, feat=cfgd["att_feat_size"], vocab=cfgd["vocab_size"], spi=spi,
+                                     ragged=n_img > 1, seq_len=max(seq_len, 6)))
+    if seq_len < 6:          # the shortest caption there is: [BOS, EOS] — one decoder position
+        cb["seqs"] = torch.tensor([[C.BOS, C.EOS]] * (n_img * spi)); cb["masks"] = torch.ones(n_img * spi, 2)
+    assert cb["seqs"].shape == (n_img * spi, seq_len)
+    b = _cuda(cb)
+    m = _model(P, "relation_transformer", cfgd, state, precision=precision)
+    Pm = {k: v.clone().requires_grad_() for k, v in state.items()}
+    ref_logp = O.forward_logp(Pm, cfg, cb["att_feats"], cb["boxes"], cb["seqs"], cb["att_masks"])
+    ref_loss = O.xe_loss(ref_logp, cb["seqs"][:, 1:], cb["masks"][:, 1:])
+    ref_loss.backward()
+    logp = m(att_feats=b["att_feats"], boxes=b["boxes"], seqs=b["seqs"], att_masks=b["att_masks"])
+    assert logp.shape == ref_logp.shape
+    loss = LanguageModelCriterion()(logp, b["seqs"][:, 1:], b["masks"][:, 1:])
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < (1e-4 if precision == 0 else 2e-2) * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    num = den = 0.0
+    for n, p in m.named_parameters():
+        ref = Pm[n].grad
+        if n.endswith("attn.linears.1.bias") or ref is None:       # (key-projection biases: analytically zero gradient)
+            continue
+        if precision == 0:
+            assert (p.grad.cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, float(ref.abs().max())), n
+        num += float((p.grad.cpu() - ref).pow(2).sum()); den += float(ref.pow(2).sum())
+    assert (num / den) ** 0.5 < (1e-4 if precision == 0 else 5e-2), (num / den) ** 0.5      # (bf16 operands: all gradients together, in L2)
+    with torch.no_grad():
+        oseq, olp = O.sample_greedy_or_multinomial(state, cfg, cb["att_feats"], cb["boxes"], cb["att_masks"])
+        seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 1}, mode="sample")
+    assert seq.shape == (n_img, 1, seq_len)
+    if precision == 0:
+        np.testing.assert_array_equal(seq.cpu().numpy(), oseq.numpy())
+        close(lp.cpu()[oseq != 0], olp[oseq != 0].numpy(), 2e-4)
+    else:
+        # bf16 operands may flip an arg-max among near-tied logits of a tiny random model and the caption goes another way from there on:
+        # instead of token equality, the log-probs the decode reports for ITS tokens are the oracle's teacher-forced log-probs of them
+        rows = seq[:, 0].cpu()
+        tf_in = torch.cat([rows.new_full((rows.size(0), 1), C.BOS), rows], 1)
+        with torch.no_grad():
+            want = O.forward_logp(state, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"], rollouts=True).gather(2, rows.unsqueeze(2)).squeeze(2)
+        assert (lp[:, 0].cpu() - want)[rows != 0].abs().max().item() < 0.1
