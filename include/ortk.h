@@ -126,6 +126,10 @@ typedef struct ortk_batch {
     int32_t        no_pad_keys;
 } ortk_batch;
 
+/* The two tables of the valid-position layout from the per-caption position counts (device, int64, 1 <= counts[r] <= T; R <=
+ * 65 536): cap_off (R + 1 ints; cap_off[R] = Mc = sum of the counts, which the HOST must know too — it sizes every launch) and
+ * row_pos (Mc ints): row_pos[cap_off[r] + t] = r * T + t.  Two small launches; nothing but the counts has to cross PCIe. */
+int ortk_valid_position_tables(const int64_t* counts, int32_t R, int32_t T, int32_t* cap_off, int32_t* row_pos, ortk_stream stream);
 size_t ortk_train_workspace_bytes(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T);
 /* 1 if a batch of this geometry may carry the valid-position layout (cap_off / row_pos / Mc), else 0. */
 int ortk_valid_positions_ok(const ortk_config* cfg, int32_t B, int32_t S, int32_t R, int32_t T);

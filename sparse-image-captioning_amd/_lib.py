@@ -182,6 +182,7 @@ SIGNATURES = {
     "ortk_box_embedding": (_I32, [_P, C.POINTER(_F), _P, _I32, _I32, _P]),
     "ortk_attention_fwd": (_I32, [C.POINTER(AttnArgs), _P]),
     "ortk_attention_bwd": (_I32, [C.POINTER(AttnArgs), _P]),
+    "ortk_valid_position_tables": (_I32, [_P, _I32, _I32, _P, _P, _P]),
     "ortk_embed_fwd": (_I32, [_P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _F, _U32, _P]),
     "ortk_embed_bwd": (_I32, [_P, _I64, _P, _P, _I64, _I32, _I32, _F, _U32, _P]),
     "ortk_log_softmax": (_I32, [_P, _I64, _I32, _I64, _F, _P]),

@@ -307,6 +307,34 @@ __global__ __launch_bounds__(SUM_THREADS) void sum_fixed_kernel(const float* __r
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
+// Tables of the valid-position decoder layout (ortk_batch.cap_off / row_pos) from the per-caption position counts: one workgroup
+// scans the counts (R <= 1024 * 64: every thread a contiguous run of captions, a tree over the thread totals), then every caption
+// writes the padded (caption, position) index of each of its compact rows.
+__global__ __launch_bounds__(1024) void valid_rows_scan_kernel(const int64_t* __restrict__ n, int R, int32_t* __restrict__ cap_off) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (R + 1023) / 1024, r0 = tid * per, r1 = min(R, r0 + per);
+    int s = 0;
+    for (int r = r0; r < r1; ++r) s += (int)n[r];
+    part[tid] = s;
+    __syncthreads();
+    for (int k = 1; k < 1024; k <<= 1) {          // inclusive scan of the thread totals
+        const int v = tid >= k ? part[tid - k] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int acc = tid ? part[tid - 1] : 0;
+    if (tid == 0) cap_off[0] = 0;
+    for (int r = r0; r < r1; ++r) { acc += (int)n[r]; cap_off[r + 1] = acc; }
+}
+__global__ __launch_bounds__(256) void valid_rows_fill_kernel(const int32_t* __restrict__ cap_off, int R, int T, int32_t* __restrict__ row_pos) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const int o = cap_off[r], cnt = cap_off[r + 1] - o;
+    for (int t = lane; t < cnt; t += 64) row_pos[o + t] = r * T + t;
+}
+
 inline unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>(ortk_cdiv(n, 256), 2048); }
 
 }  // namespace
@@ -475,6 +503,15 @@ extern "C" int ortk_axpy_cols(const void* x, void* y, int32_t dtype, int64_t ld,
     if (!x || !y || rows < 0 || cols < 0 || ld < cols || (dtype != ORTK_F32 && dtype != ORTK_BF16)) return ORTK_EINVAL;
     if (rows == 0 || cols == 0) return 0;
     hipLaunchKernelGGL(add_cols_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, ortk_s(stream), x, y, (int)dtype, ld, rows, cols);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ortk_valid_position_tables(const int64_t* counts, int32_t R, int32_t T, int32_t* cap_off, int32_t* row_pos, ortk_stream stream) {
+    if (!counts || !cap_off || !row_pos || R < 1 || R > 1024 * 64 || T < 1) return ORTK_EINVAL;
+    hipLaunchKernelGGL(valid_rows_scan_kernel, dim3(1), dim3(1024), 0, ortk_s(stream), counts, (int)R, cap_off);
+    ORTK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(valid_rows_fill_kernel, dim3((unsigned)ortk_cdiv(R, 4)), dim3(256), 0, ortk_s(stream), cap_off, (int)R, (int)T, row_pos);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -420,8 +420,8 @@ class RelationTransformerModel(CaptionModelBase):
         # four pinned staging buffers per (R, T) and an asynchronous copy.  Measured (scratch/valid_rows_upload.py, XE step with the
         # tables rebuilt every step, host synchronised per step): uploading the finished tables (65 KB of row indices; pinned +
         # cudaMemcpyAsync, or a blocking copy from pageable memory) makes every second or third step stall for 60-90 ms somewhere
-        # later in the step (the host blocks inside HIP with the GPU idle); 10 KB of lengths + device kernels: 11.8 ms per step,
-        # every step (11.5 with cached tables).  A training loop has a new batch every step, an SCST update new lengths every step.
+        # later in the step (the host blocks inside HIP with the GPU idle); 10 KB of lengths + two device launches
+        # (ortk_valid_position_tables): 11.6-11.8 ms per step, every step (11.5 with cached tables).  A training loop has a new batch every step, an SCST update new lengths every step.
         ring = self._vr_stage.setdefault((R, T), {"i": 0, "slots": []})
         if len(ring["slots"]) < 4:
             ring["slots"].append([torch.empty(R, dtype=torch.int64).pin_memory(), None])
@@ -433,11 +433,10 @@ class RelationTransformerModel(CaptionModelBase):
         slot[0].copy_(n)
         nd = slot[0].to(dev, non_blocking=True)
         slot[1] = torch.cuda.Event(); slot[1].record()
-        off = torch.zeros(R + 1, dtype=torch.int64, device=dev)
-        off[1:] = torch.cumsum(nd, 0)
-        rows = torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=dev) * T - off[:-1], nd, output_size=Mc)
-        rows += torch.arange(Mc, dtype=torch.int64, device=dev)
-        return off.to(torch.int32), rows.to(torch.int32), Mc
+        off = torch.empty(R + 1, dtype=torch.int32, device=dev)
+        rows = torch.empty(Mc, dtype=torch.int32, device=dev)
+        L.check(L.lib().ortk_valid_position_tables(L.ptr(nd), R, T, L.ptr(off), L.ptr(rows), L.stream_ptr()), "ortk_valid_position_tables")
+        return off, rows, Mc
 
     def valid_position_tables(self, data):
         """The device tables of the valid-position decoder layout for a batch dict that carries ``cap_len`` (see

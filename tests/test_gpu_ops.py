@@ -142,6 +142,21 @@ def test_layernorm_bwd_with_fused_dropout_output(L, rows, d, p, dt):
         assert abs(frac - p) < 0.03
 
 
+@pytest.mark.parametrize("R,T", [(1, 1), (5, 17), (1280, 18), (5000, 64), (65536, 3)])
+def test_valid_position_tables(L, R, T):
+    """ortk_valid_position_tables: cap_off = exclusive prefix sums of the per-caption position counts, row_pos[cap_off[r] + t] =
+    r * T + t — the tables of the valid-position decoder layout (ortk_batch.cap_off / row_pos), built on the device."""
+    g = torch.Generator().manual_seed(R + T)
+    n = torch.randint(1, T + 1, (R,), generator=g)
+    Mc = int(n.sum())
+    off = torch.full((R + 1,), -1, dtype=torch.int32, device="cuda")
+    rows = torch.full((Mc,), -1, dtype=torch.int32, device="cuda")
+    L.check(L.lib().ortk_valid_position_tables(L.ptr(dev(n)), R, T, L.ptr(off), L.ptr(rows), L.stream_ptr()), "tables")
+    ref_off = torch.zeros(R + 1, dtype=torch.int64); ref_off[1:] = torch.cumsum(n, 0)
+    ref_rows = torch.repeat_interleave(torch.arange(R) * T - ref_off[:-1], n) + torch.arange(Mc)
+    assert torch.equal(off.cpu().long(), ref_off) and torch.equal(rows.cpu().long(), ref_rows)
+
+
 def test_dropout_draws_keyed_by_a_row_map(L):
     """`drop_rows` (ortk_gemm_args / ortk_spmm_args / ortk_layernorm_bwd_drop_rows / ortk_dropout_apply_rows): output row m takes
     the draws of row drop_rows[m] — how the valid-position decoder layout (ortk_batch.row_pos) draws what the padded (caption,
