@@ -368,11 +368,19 @@ class RelationTransformerModel(CaptionModelBase):
         return (torch.initial_seed() * 1000003 + self._seed_counter) & 0xFFFFFFFFFFFFFFFF or 1
 
     def _workspace(self, key, nbytes, cache):
-        if cache and key in self._ws_cache and self._ws_cache[key].numel() >= nbytes:
-            return self._ws_cache[key]
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._flat.device)
-        if cache:
-            self._ws_cache[key] = ws
+        # ONE cached buffer per kind of call ("train", "decode" + chunk of a multi-stream decode, "step"), grown to the largest
+        # request seen: the geometry in `key` varies from batch to batch in a real loop (the collate pads to the batch's longest
+        # region list, 10-100; the last batch of an epoch is short) and a buffer per distinct geometry — 5-7 GB each at 256 images
+        # — would pile up without bound.  Every executor call carves what it needs from the front of the buffer it is handed.
+        if not cache:
+            return torch.empty(int(nbytes), dtype=torch.uint8, device=self._flat.device)
+        slot = (key[0], key[5] if key[0] == "decode" and len(key) > 5 else 0)
+        ws = self._ws_cache.get(slot)
+        if ws is None or ws.numel() < nbytes:
+            ws = None
+            self._ws_cache.pop(slot, None)          # (release the smaller buffer before asking for the larger one)
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._flat.device)
+            self._ws_cache[slot] = ws
         return ws
 
     @staticmethod

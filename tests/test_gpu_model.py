@@ -2269,3 +2269,33 @@ def test_geometry_limits_vs_oracle(P, n_img, n_reg, spi, seq_len, precision):
         with torch.no_grad():
             want = O.forward_logp(state, cfg, cb["att_feats"], cb["boxes"], tf_in, cb["att_masks"], rollouts=True).gather(2, rows.unsqueeze(2)).squeeze(2)
         assert (lp[:, 0].cpu() - want)[rows != 0].abs().max().item() < 0.1
+
+
+def test_one_cached_workspace_per_call_kind_across_batch_geometries(P):
+    """A real loop sees a new geometry nearly every batch (the collate pads to the batch's longest region list; the last batch of an
+    epoch is short).  The model keeps ONE cached workspace per kind of call, grown to the largest request — not one per geometry
+    (5-7 GB each at 256 images) — and every call carves what it needs from the front: a step on a buffer that an earlier, larger
+    or differently shaped batch used gives bit for bit the loss (and the decode the tokens) of a fresh model on that batch."""
+    from sparse_image_captioning_amd.training import NativeTrainer
+
+    def batch(seed, n_img, n_reg, spi):
+        return _cuda(H.torch_batch(C.make_inputs(seed=seed, n_img=n_img, n_reg=n_reg, feat=C.TINY_CFG["att_feat_size"], vocab=C.TINY_CFG["vocab_size"], spi=spi)))
+
+    geoms = [(31, 4, 12, 2), (32, 6, 36, 3), (33, 2, 7, 5), (34, 6, 36, 3), (35, 3, 20, 1)]
+
+    def run(m, b):
+        tr = NativeTrainer(m, noamopt_factor=0.0, noamopt_warmup=10)
+        loss = tr.xe_step(b, train=False).item()
+        with torch.no_grad():
+            seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 3}, mode="sample")
+        return loss, seq.clone(), lp.clone()
+
+    for precision in (0, 1):
+        shared = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state(), precision=precision)
+        for g in geoms:
+            b = batch(*g)
+            got = run(shared, b)
+            fresh = run(_model(P, "relation_transformer", C.TINY_CFG, H.g1_state(), precision=precision), b)
+            assert got[0] == fresh[0], (g, got[0], fresh[0])
+            assert torch.equal(got[1], fresh[1]) and torch.equal(got[2], fresh[2]), g
+        assert len(shared._ws_cache) <= 2, list(shared._ws_cache)          # "train" and "decode"
