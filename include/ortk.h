@@ -640,6 +640,23 @@ int ortk_adam_clip_zero(float* p, float* g, float* m, float* v, int64_t n, float
 int ortk_mask_apply(const float* w, const float* m, float* w_eff, int64_t n, int32_t mode, uint32_t seed, ortk_stream stream);
 int ortk_mask_bwd(const float* dw_eff, const float* w, const float* m, float* dw, float* dm, int64_t n, int32_t mode,
                   uint32_t seed, const float* extra_coef_dev, ortk_stream stream);
+/* The element-wise tail of a masked (supermask / binary-mask) training step over a RANGE of the arena in ONE pass
+ * (scripts/train_n_prune_transformer.py:132-168 after loss.backward(); pruning/sampler.py:10-66; utils/optim.py:116-126,187-191):
+ *   s = sample(ml) as the forward drew it (mode, seed, draws: see ortk_mask_apply); dW = g * s;
+ *   ds = (g * w + extra_coef[0]) * sigmoid'(ml) [mode != 2] * active;           (straight-through + sparsity-loss term; frozen scopes)
+ *   clip + Adam(lr_w, eps_w) on w with dW;  clip + Adam(lr_m, eps_m) on ml with ds (mm / mv NULL: the masks are not trained);  g = 0.
+ * Every pointer addresses element index0 of its arena (index0 a multiple of 4); bc1 / bc2 = 1 - beta^t as in ortk_adam_clip.
+ * 14-15 array passes instead of the 22 of ortk_mask_bwd + a cleared dm + two ortk_adam_clip launches. */
+typedef struct ortk_masked_adam_args {
+    float *w, *g, *mw, *vw;               /* weights, their gradient (dLoss/d(s*w) in, zeros out), Adam moments */
+    float *ml, *mm, *mv;                  /* mask logits (or binary masks, mode 2) and their Adam moments (NULL, NULL: read only) */
+    const float* draws;                   /* optional explicit uniforms (mode 1), element i of the range */
+    const float* active;                  /* optional 0 / 1 per element: mask logits outside it keep a zero gradient */
+    const float* extra_coef;              /* optional device scalar: d(sparsity loss)/d(sample) */
+    int64_t n, index0; int32_t mode; uint32_t seed;
+    float lr_w, eps_w, lr_m, eps_m, beta1, beta2, clip, bc1, bc2;
+} ortk_masked_adam_args;
+int ortk_masked_adam_step(const ortk_masked_adam_args* a, ortk_stream stream);
 /* Mode 1 with EXPLICIT uniforms draws[i] in [0,1) in place of the counter hash: s = draws[i] < sigmoid(m[i]), torch.bernoulli's
  * definition for a given uniform (pruning/sampler.py:10-17) — lets a caller (and the parity tests, with the reference's own
  * draws) reproduce a given Bernoulli mask sample in the forward and in the straight-through backward. */

@@ -90,6 +90,15 @@ class BChainArgs(C.Structure):
                 ("n2", C.c_int32), ("out2", C.c_void_p), ("drop_p", C.c_float), ("eps", C.c_float), ("drop_rows", C.c_void_p)]
 
 
+class MaskedAdamArgs(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("g", C.c_void_p), ("mw", C.c_void_p), ("vw", C.c_void_p),
+                ("ml", C.c_void_p), ("mm", C.c_void_p), ("mv", C.c_void_p),
+                ("draws", C.c_void_p), ("active", C.c_void_p), ("extra_coef", C.c_void_p),
+                ("n", C.c_int64), ("index0", C.c_int64), ("mode", C.c_int32), ("seed", C.c_uint32),
+                ("lr_w", C.c_float), ("eps_w", C.c_float), ("lr_m", C.c_float), ("eps_m", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("clip", C.c_float), ("bc1", C.c_float), ("bc2", C.c_float)]
+
+
 class Tuning(C.Structure):
     _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
                 ("side_stream", C.c_int32), ("row_chain", C.c_int32), ("chain_wide", C.c_int32), ("spmm_alias", C.c_int32)]
@@ -202,6 +211,7 @@ SIGNATURES = {
     "ortk_adam_clip_zero": (_I32, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P]),
     "ortk_mask_apply": (_I32, [_P, _P, _P, _I64, _I32, _U32, _P]),
     "ortk_mask_bwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _U32, _P, _P]),
+    "ortk_masked_adam_step": (_I32, [C.POINTER(MaskedAdamArgs), _P]),
     "ortk_mask_count": (_I32, [_P, _I64, _I32, _P, _P]),
     "ortk_mask_apply_draws": (_I32, [_P, _P, _P, _P, _I64, _P]),
     "ortk_mask_bwd_draws": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _P, _P]),

@@ -83,6 +83,11 @@ class NativeTrainer:
         # element-wise, so the split is exact); the gradient arena is cleared by the update itself (ortk_adam_clip_zero).
         self.early_adam = (self.world == 1 and not self.masked and not self.overlap and self._dec_off % 4 == 0
                            and 0 < self._dec_off < self.grads.numel())      # (never beside an exchange of that half)
+        # Masked models, one process: the element-wise tail of a step — straight-through mask backward, clip + Adam on the weights, clip +
+        # Adam on the mask logits — as ONE pass over the arena (ortk_masked_adam_step) unless keep_grads asks for dW / dm or an all-reduce
+        # has to come between the backward and Adam: configs[2] 12.33 -> 11.92 ms (scratch/masked_tail_ab.py; the same tail split over two
+        # streams beside the encoder half of the backward gained nothing on top: the backward is bandwidth-bound itself).
+        self.fused_masked_tail = True
         self._opt_stream = None
         self._grads_clean = False
         # keep_grads: `self.grads` still holds the step's gradient after the step (tests, diagnostics); default: the update
@@ -310,6 +315,30 @@ class NativeTrainer:
             loss = self._step(tf, mask * reward[:, None], mask, train and update_dropout, encoded=share_encoder, rollouts=True)
         return loss, reward, seq, greedy
 
+    def _masked_tail(self, a, b, train, seed, coef, lr):
+        """The element-wise tail of a masked step over arena range [a, b) in one pass (ortk_masked_adam_step): dW_eff -> (dW, dm)
+        (straight-through, pruning/sampler.py), frozen scopes, clip + Adam on the weights (clearing the gradient), clip + Adam on the
+        mask logits (their own group: train_n_prune_transformer.py:67-82)."""
+        m, lib = self.model, L.lib()
+        draws = m._draws(train)
+        k = L.MaskedAdamArgs()
+        k.w, k.g, k.mw, k.vw = m._flat[a:b].data_ptr(), self.grads[a:b].data_ptr(), self.m[a:b].data_ptr(), self.v[a:b].data_ptr()
+        k.ml = m._mask_flat[a:b].data_ptr()
+        if self.train_masks:
+            k.mm, k.mv = self.mm[a:b].data_ptr(), self.mv[a:b].data_ptr()
+            if self.mask_active is not None:
+                k.active = self.mask_active[a:b].data_ptr()
+        if draws is not None:
+            k.draws = draws[a:b].data_ptr()
+        if coef is not None:
+            k.extra_coef = coef.data_ptr()
+        k.n, k.index0, k.mode, k.seed = b - a, a, (1 if draws is not None else m._mode(train)), m._mask_seed(seed)
+        t, (b1, b2) = self.step_count, self.betas
+        k.lr_w, k.eps_w = lr, self.eps
+        k.lr_m, k.eps_m = (self.mask_lr, self.mask_eps) if self.train_masks else (0.0, 1.0)
+        k.beta1, k.beta2, k.clip, k.bc1, k.bc2 = b1, b2, self.clip, 1.0 - b1 ** t, 1.0 - b2 ** t
+        L.check(lib.ortk_masked_adam_step(C.byref(k), L.stream_ptr()), "ortk_masked_adam_step")
+
     @staticmethod
     def scorer_reward_fn(scorer, refs, eos_idx=3, pad_idx=0, decode=None):
         """``reward_fn`` for :meth:`scst_step` from a :class:`..scst.CaptionScorer` and the images' reference captions:
@@ -366,8 +395,10 @@ class NativeTrainer:
             m.check_sparse_overflow()
         if self.masked:
             coef = None
+            one_pass = self.world == 1 and self.fused_masked_tail and not self.keep_grads      # (no exchange between the backward and Adam)
             if self.train_masks:
-                self.dm.zero_()
+                if not one_pass:
+                    self.dm.zero_()
                 if self.sparsity_target is not None:
                     sl = m.compute_sparsity_loss(self.sparsity_target, self.sparsity_weight, self.step_count - 1,
                                                  self.max_train_step)
@@ -375,6 +406,10 @@ class NativeTrainer:
                     coef, m._sparsity_coef = m._sparsity_coef, None
                     if self.world > 1:
                         coef = coef / self.world     # identical on every rank; the all-reduce below sums it back
+            if one_pass:
+                self._masked_tail(0, m._n_train, train, seed, coef, lr)
+                self._grads_clean = True
+                return loss
             draws = m._draws(train)
             if draws is not None:
                 L.check(L.lib().ortk_mask_bwd_draws(L.ptr(self.grads), L.ptr(m._flat), L.ptr(m._mask_flat), L.ptr(draws), L.ptr(self.grads),

@@ -620,6 +620,68 @@ def test_adam_clip_and_masks(L):
     assert torch.equal(dw, we)
 
 
+@pytest.mark.parametrize("mode,train_masks,with_draws,with_active", [(1, True, False, True), (1, True, True, False), (0, True, False, False), (2, False, False, False)])
+def test_masked_adam_step_equals_the_separate_launches(L, mode, train_masks, with_draws, with_active):
+    """ortk_masked_adam_step (the element-wise tail of a masked training step in one pass over a RANGE of the arena) against the
+    launches it replaces — ortk_mask_bwd[_draws] into a cleared dm, the frozen-scope multiply, ortk_adam_clip_zero on the weights,
+    ortk_adam_clip on the mask logits — on the same inputs: weights, mask logits, all four moment arrays and the cleared gradient."""
+    n, i0 = 100003, 4096          # a range that starts inside the arena: the hash draws are keyed by the arena position
+    g = torch.Generator().manual_seed(mode + 10 * with_draws)
+    mk = lambda scale=1.0: (torch.randn(i0 + n, generator=g) * scale)
+    W, G, ML = mk(0.3), mk(0.05), (mk(2.0) if mode != 2 else (torch.rand(i0 + n, generator=g) < 0.3).float())
+    MW, VW, MM, MV = mk(0.01), mk(0.01).abs(), mk(0.01), mk(0.01).abs()
+    draws = torch.rand(i0 + n, generator=g) if with_draws else None
+    active = (torch.rand(i0 + n, generator=g) < 0.7).float() if with_active else None
+    coef = torch.tensor([0.37])
+    hyper = dict(lr_w=3e-3, eps_w=1e-9, lr_m=100.0, eps_m=1e-2, b1=0.9, b2=0.98, clip=0.1, t=3)
+    bc1, bc2 = 1 - hyper["b1"] ** hyper["t"], 1 - hyper["b2"] ** hyper["t"]
+    seed = 0xABCDEF
+    # reference: the separate launches over the WHOLE arena prefix [0, i0 + n) (the hash index is the arena position), range compared
+    w1, g1, ml1, mw1, vw1, mm1, mv1 = (dev(t.clone()) for t in (W, G, ML, MW, VW, MM, MV))
+    dm = torch.zeros(i0 + n, device="cuda")
+    N = i0 + n
+    if with_draws:
+        L.check(L.lib().ortk_mask_bwd_draws(L.ptr(g1), L.ptr(w1), L.ptr(ml1), L.ptr(dev(draws)), L.ptr(g1), L.ptr(dm), N, L.ptr(dev(coef)), L.stream_ptr()), "bwd")
+    else:
+        L.check(L.lib().ortk_mask_bwd(L.ptr(g1), L.ptr(w1), L.ptr(ml1), L.ptr(g1), L.ptr(dm) if train_masks else None, N, mode, seed,
+                                      L.ptr(dev(coef)), L.stream_ptr()), "bwd")
+    if with_active:
+        dm.mul_(dev(active))
+    L.check(L.lib().ortk_adam_clip_zero(L.ptr(w1), L.ptr(g1), L.ptr(mw1), L.ptr(vw1), N, hyper["lr_w"], hyper["b1"], hyper["b2"], hyper["eps_w"],
+                                        hyper["clip"], bc1, bc2, L.stream_ptr()), "adam w")
+    if train_masks:
+        L.check(L.lib().ortk_adam_clip(L.ptr(ml1), L.ptr(dm), L.ptr(mm1), L.ptr(mv1), N, hyper["lr_m"], hyper["b1"], hyper["b2"], hyper["eps_m"],
+                                       hyper["clip"], bc1, bc2, L.stream_ptr()), "adam m")
+    # one pass over the range [i0, i0 + n)
+    w2, g2, ml2, mw2, vw2, mm2, mv2 = (dev(t.clone()) for t in (W, G, ML, MW, VW, MM, MV))
+    keep = [dev(draws) if with_draws else None, dev(active) if with_active else None, dev(coef)]
+    k = L.MaskedAdamArgs()
+    sl = lambda t: t[i0:].data_ptr()
+    k.w, k.g, k.mw, k.vw, k.ml = sl(w2), sl(g2), sl(mw2), sl(vw2), sl(ml2)
+    if train_masks:
+        k.mm, k.mv = sl(mm2), sl(mv2)
+    if with_draws:
+        k.draws = sl(keep[0])
+    if with_active:
+        k.active = sl(keep[1])
+    k.extra_coef = keep[2].data_ptr()
+    k.n, k.index0, k.mode, k.seed = n, i0, mode, seed
+    k.lr_w, k.eps_w, k.lr_m, k.eps_m = hyper["lr_w"], hyper["eps_w"], hyper["lr_m"], hyper["eps_m"]
+    k.beta1, k.beta2, k.clip, k.bc1, k.bc2 = hyper["b1"], hyper["b2"], hyper["clip"], bc1, bc2
+    L.check(L.lib().ortk_masked_adam_step(C.byref(k), L.stream_ptr()), "ortk_masked_adam_step")
+    torch.cuda.synchronize()
+    for name, a_, b_ in (("w", w1, w2), ("mw", mw1, mw2), ("vw", vw1, vw2), ("ml", ml1, ml2), ("mm", mm1, mm2), ("mv", mv1, mv2)):
+        orig = dev({"w": W, "mw": MW, "vw": VW, "ml": ML, "mm": MM, "mv": MV}[name])[i0:]
+        d_ = (b_[i0:] - a_[i0:]).abs()
+        # (the two kernels may contract a multiply-add differently: an ulp of the UPDATE — lr 100 on the mask logits — not of the result)
+        tol = 2e-6 * (a_[i0:].abs() + (a_[i0:] - orig).abs()) + 1e-9
+        assert bool((d_ <= tol).all()), (name, float(d_.max()), int((d_ > tol).sum()))
+        assert torch.equal(b_[:i0], dev({"w": W, "mw": MW, "vw": VW, "ml": ML, "mm": MM, "mv": MV}[name])[:i0]), name      # nothing outside the range
+    assert float(g2[i0:].abs().max()) == 0.0 and torch.equal(g2[:i0], dev(G)[:i0])
+    if mode == 1 and not with_draws:
+        assert float((w2[i0:] != dev(W)[i0:]).float().mean()) > 0.2          # (the sampled masks let a good part of the weights move)
+
+
 def test_bf16_storage_paths(L):
     """Mixed-precision storage: bf16 A / B operands, bf16 C, bf16 LN / attention / dropout outputs vs fp32 math."""
     M, N, K = 300, 200, 192
