@@ -73,7 +73,8 @@ __device__ __forceinline__ float4 ldrow4(const float* __restrict__ p, int n0, in
 // Epilogue of one wave's 64x64 sub-tile: acc[i][j] holds C[m = mrow0 + 16 i][n = ncol0 + 16 j + 0..3].
 // Bias is loaded once per j; residual / gate rows are fetched as float4 for all four j of a row BEFORE any of that
 // row's stores (independent loads in flight together instead of 16 load->store chains per thread).
-template <bool FAST, int MI = 4, int NJ = 4>
+// (MS / NS: row / column distance between neighbouring accumulators: 16 / 16 for the 16x16 MFMA grid, 32 / 8 for the 32x32 one)
+template <bool FAST, int MI = 4, int NJ = 4, int MS = 16, int NS = 16>
 __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0, f32x4 (&acc)[MI][NJ]) {
     const bool first = e.first_split;
     // FAST: the launcher has verified full tiles and vector alignment of every pointer -> no bounds / alignment tests
@@ -87,19 +88,19 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
     float4 bias4[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int n0 = ncol0 + 16 * j;
+        const int n0 = ncol0 + NS * j;
         bias4[j] = (e.bias && first && n0 < EN) ? ldrow4(e.bias + n0, n0, EN, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = mrow0 + 16 * i;
+        const int m = mrow0 + MS * i;
         if (m >= EM) continue;
         const float rs = e.rowscale ? e.rowscale[m] : 1.f;
         const uint64_t dm = (e.drop_p > 0.f && e.drop_rows) ? (uint64_t)e.drop_rows[m] : (uint64_t)m;
         float4 res[NJ], gat[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n0 = ncol0 + 16 * j;
+            const int n0 = ncol0 + NS * j;
             res[j] = (e.resid && first && n0 < EN) ? ldrow4(e.resid + (int64_t)m * e.ldr + n0, n0, EN, vec_r) : make_float4(0.f, 0.f, 0.f, 0.f);
             gat[j] = make_float4(1.f, 1.f, 1.f, 1.f);
             if (e.gate && n0 < EN) {
@@ -113,7 +114,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n0 = ncol0 + 16 * j;
+            const int n0 = ncol0 + NS * j;
             if (n0 >= EN) continue;
             const float bb[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
             const float rr[4] = {res[j].x, res[j].y, res[j].z, res[j].w};
@@ -1299,6 +1300,156 @@ template <bool TA, bool TB> gemm16_fn pick16(int adt, int bdt, bool fast) {
     return fast ? pick16t<TA, TB, true>(adt, bdt) : pick16t<TA, TB, false>(adt, bdt);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix cores (forward layout, fp32 operands and results: the fp32 parity mode).
+//
+// `v_mfma_f32_16x16x4_f32` runs at 1/16 of the bf16 MFMA rate (157 TF/s on the chip; gemm_f32_kernel reached 58).  Every fp32 value is
+// instead split, while its tile is staged, into THREE bf16 values that add up to it exactly:
+//     x1 = bf16(x),  x2 = bf16(x - x1),  x3 = bf16(x - x1 - x2)          (round to nearest; the differences are exact in fp32;
+//     |x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|, x - x1 - x2 - x3 = 0 for every normal fp32 x whose third part is not subnormal)
+// and a product a b is accumulated as the SIX partial products of at least 2^-16 relative size,
+//     a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
+// each exact in fp32 (8 x 8 significant bits) and summed in the MFMA's fp32 accumulators.  What is dropped (a2 b3 + a3 b2 + a3 b3) is
+// at most 2^-23 |a b| per term, the size of ONE fp32 rounding of the product; the accumulation error over K terms is that of any fp32
+// dot product.  Six bf16 MFMAs replace eight fp32 MFMAs of the same 32-deep k-slice at 1/16 of the cycles each: 2.67 x the fp32 matrix
+// peak (418 TF/s of fp32-equivalent work on the chip).
+// (tests/test_gpu_ops.py: test_gemm_f32_split_vs_float64 holds it to the native fp32 kernel's error against a float64 product.)
+//
+// Workgroup tile (64 WM) x (64 WN), 4 waves as 2 x 2, each wave WM x WN accumulators of `v_mfma_f32_32x32x16_bf16` (32 cycles, of
+// which 24 are free for the vector ALU: the split costs 5.5 vector instructions per element).  K is consumed 32 at a time: the fp32
+// tile travels global -> registers -> (split) -> three [m][k] bf16 images per operand in LDS (64-byte rows, the XOR swizzle of the
+// LDS-DMA kernels; conflict-free for the 32-row ds_read_b128 fragments as well), single-buffered: 24 KB (64 x 64) .. 48 KB (128 x 128)
+// per workgroup, three workgroups per compute unit — one splits while another multiplies.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ __forceinline__ unsigned int pk_bf16(float x, float y) {
+    const bf16x2 v = __builtin_convertvector((f32x2){x, y}, bf16x2);     // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned int, v);
+}
+// two fp32 values -> three packed bf16 pairs
+__device__ __forceinline__ void split3(float x, float y, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
+    p1 = pk_bf16(x, y);
+    x -= __uint_as_float(p1 << 16); y -= __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = pk_bf16(x, y);
+    x -= __uint_as_float(p2 << 16); y -= __uint_as_float(p2 & 0xFFFF0000u);
+    p3 = pk_bf16(x, y);
+}
+
+template <int WM, int WN, int GM, int GN, int MINB>
+__global__ __launch_bounds__(64 * GM * GN, MINB) void gemm_f32x3_kernel(ortk_gemm_args p, int tilesM, int tilesN, int) {
+    constexpr int RA = 32 * WM * GM, RB = 32 * WN * GN, BK = 32, NT = 64 * GM * GN;
+    constexpr int CA = RA * 4 / NT, CB = RB * 4 / NT;            // 8-column chunks per thread and k-step
+    static_assert(CA * NT == RA * 4 && CB * NT == RB * 4, "tile rows must divide over the threads");
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3][RA * BK];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3][RB * BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / GN, wn = wave % GN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, mt = bid / tilesN;
+    const int mb = mt * RA, nb = nt * RB;
+    const float* Af = reinterpret_cast<const float*>(p.A);
+    const float* Bf = reinterpret_cast<const float*>(p.B);
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: thread -> (row f >> 2, 8-column chunk f & 3) of the tile, f = tid + 256 u; rows past the matrix re-read its last row
+    // (their results are dropped by the epilogue)
+    const float* ga[CA]; const float* gb[CB];
+    int oa[CA], ob[CB];
+#pragma unroll
+    for (int u = 0; u < CA; ++u) {
+        const int f = tid + NT * u, r = f >> 2, c = f & 3;
+        ga[u] = Af + (int64_t)min(mb + r, p.M - 1) * p.lda + 8 * c;
+        oa[u] = r * BK + ((c ^ swz_mk(r)) << 3);
+    }
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+        const int f = tid + NT * u, r = f >> 2, c = f & 3;
+        gb[u] = Bf + (int64_t)min(nb + r, p.N - 1) * p.ldb + 8 * c;
+        ob[u] = r * BK + ((c ^ swz_mk(r)) << 3);
+    }
+    f32x4 ra[CA][2], rb[CB][2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < CA; ++u) {
+            ra[u][0] = *reinterpret_cast<const f32x4*>(ga[u] + k0);
+            ra[u][1] = *reinterpret_cast<const f32x4*>(ga[u] + k0 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            rb[u][0] = *reinterpret_cast<const f32x4*>(gb[u] + k0);
+            rb[u][1] = *reinterpret_cast<const f32x4*>(gb[u] + k0 + 4);
+        }
+    };
+    auto put = [&](__bf16* i0, __bf16* i1, __bf16* i2, int off, const f32x4 (&v)[2]) {
+        unsigned int q[3][4];
+        split3(v[0][0], v[0][1], q[0][0], q[1][0], q[2][0]);
+        split3(v[0][2], v[0][3], q[0][1], q[1][1], q[2][1]);
+        split3(v[1][0], v[1][1], q[0][2], q[1][2], q[2][2]);
+        split3(v[1][2], v[1][3], q[0][3], q[1][3], q[2][3]);
+        *reinterpret_cast<u32x4*>(i0 + off) = (u32x4){q[0][0], q[0][1], q[0][2], q[0][3]};
+        *reinterpret_cast<u32x4*>(i1 + off) = (u32x4){q[1][0], q[1][1], q[1][2], q[1][3]};
+        *reinterpret_cast<u32x4*>(i2 + off) = (u32x4){q[2][0], q[2][1], q[2][2], q[2][3]};
+    };
+
+    const int l32 = lane & 31, lh = lane >> 5, sw = swz_mk(l32);
+    const int fa0 = (wm * 32 * WM + l32) * BK, fb0 = (wn * 32 * WN + l32) * BK;
+    if (p.K > 0) gload(0);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+#pragma unroll
+        for (int u = 0; u < CA; ++u) put(sA[0], sA[1], sA[2], oa[u], ra[u]);
+#pragma unroll
+        for (int u = 0; u < CB; ++u) put(sB[0], sB[1], sB[2], ob[u], rb[u]);
+        __syncthreads();
+        if (k0 + BK < p.K) gload(k0 + BK);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int co = ((2 * s + lh) ^ sw) << 3;
+            bf16x8 a[3][WM], b[3][WN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sA[pl] + fa0 + i * 32 * BK + co);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[pl][j] = *reinterpret_cast<const bf16x8*>(sB[pl] + fb0 + j * 32 * BK + co);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    // smallest partial products first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2][j], a[0][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1][j], a[1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[2][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1][j], a[0][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[0][i], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // 32 x 32 accumulator (operands swapped: rows = n): lane holds m = lane & 31 and n = 8 g + 4 (lane >> 5) + 0..3 for g = 0..3
+    f32x4 acc4[WM][4 * WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc4[i][4 * j + g] = (f32x4){acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+    Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
+          p.relu, p.drop_p, p.drop_seed, 0, true, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
+    epilogue_tile<false, WM, 4 * WN, 32, 8>(e, mb + wm * 32 * WM + l32, nb + wn * 32 * WN + 4 * lh, acc4);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ profiling hook
@@ -1462,6 +1613,32 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     }
     if (!p.precision) {
         if (p.tile_stats) return ORTK_EINVAL;
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        if (key == 0 && ortk::tuning().f32_split && !p.accumulate && p.K > 0 && p.K % 32 == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
+            al16(p.A) && al16(p.B)) {
+            // three-way bf16 split on the bf16 matrix cores (gemm_f32x3_kernel); tile size by how many workgroups it gives the chip
+            const int64_t t128 = (int64_t)tilesM * tilesN;
+            const int force = ortk::tuning().f32_split;     // 1 automatic | 2.. a fixed kernel instance (scratch/f32x3_bench.py)
+            // measured on the shapes of the fp32 parity decode (scratch/f32x3_bench.py, profiles/r05_f32_split_gemm.txt): short grids
+            // want many small workgroups, long ones the tile that re-reads least
+            const int shape = force > 1 ? force : t128 < 320 ? 3 : t128 < 1536 ? 7 : 6;
+#define ORTK_X3(WM_, WN_, GM_, GN_, MB_) do { const int tm = (int)ortk_cdiv(p.M, 32 * WM_ * GM_), tn = (int)ortk_cdiv(p.N, 32 * WN_ * GN_); \
+            hipLaunchKernelGGL((gemm_f32x3_kernel<WM_, WN_, GM_, GN_, MB_>), dim3((unsigned)(tm * tn)), dim3(64 * GM_ * GN_), 0, s, p, tm, tn, 0); } while (0)
+            switch (shape) {
+                case 2:  ORTK_X3(2, 2, 2, 2, 2); break;      // 128 x 128
+                case 4:  ORTK_X3(2, 1, 2, 2, 2); break;      // 128 x 64
+                case 5:  ORTK_X3(1, 2, 2, 2, 2); break;      // 64 x 128
+                case 6:  ORTK_X3(2, 2, 2, 2, 3); break;      // 128 x 128, three workgroups per CU
+                case 7:  ORTK_X3(2, 1, 2, 2, 3); break;      // 128 x 64, three
+                case 8:  ORTK_X3(2, 2, 4, 2, 2); break;      // 256 x 128, 8 waves
+                case 9:  ORTK_X3(2, 2, 2, 4, 2); break;      // 128 x 256, 8 waves
+                default: ORTK_X3(1, 1, 2, 2, 2); break;      // 64 x 64
+            }
+#undef ORTK_X3
+            if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
+            ORTK_CHECK_LAUNCH();
+            return 0;
+        }
         switch (key) {
             case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;

@@ -76,6 +76,46 @@ def test_gemm_layouts(L, prec, tol, M, N, K):
     assert (out.cpu() - ref).abs().max().item() <= tol * scale
 
 
+@pytest.mark.parametrize("M,N,K", [(640, 384, 512), (5120, 512, 2048), (257, 1000, 544), (1, 5, 32), (5000, 10112, 512)])
+def test_gemm_f32_split_vs_float64(L, M, N, K):
+    """fp32 products of the forward layout run on the bf16 matrix cores: every operand split into three bf16 parts, six partial
+    products kept (ortk_gemm.hip: gemm_f32x3_kernel; ortk_tuning.f32_split).  Held to the error of the fp32 MFMA kernel it replaces,
+    both against a float64 product of the same fp32 operands: the split form's rms error may not exceed 1.25 x the native
+    kernel's, its max error 2 x, and both stay inside 4 sqrt(K) 2^-24 of the result's scale.  Operands with a wide dynamic range
+    (magnitudes over 2^+-20) and exact zeros included; every tile shape gives the same bits (same k order); epilogue as the
+    native kernel's."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-20, 21, (M, K), generator=g).float())
+    B = torch.randn(N, K, generator=g) * 0.05
+    A[torch.rand(M, K, generator=g) < 0.1] = 0.0
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    Ad, Bd, bd, rd = dev(A), dev(B), dev(bias), dev(res)
+    ref = A.double() @ B.double().t()
+    scale = ref.abs().max().item()
+    outs = {}
+    prev = L.set_tuning(f32_split=0)
+    try:
+        for v in (0, 1, 2, 3, 4, 5):
+            L.set_tuning(f32_split=v)
+            outs[v] = gemm(L, Ad, Bd, M, N, K).cpu()
+        L.set_tuning(f32_split=1)
+        full = gemm(L, Ad, Bd, M, N, K, bias=bd, relu=1, resid=rd).cpu()
+        L.set_tuning(f32_split=0)
+        full0 = gemm(L, Ad, Bd, M, N, K, bias=bd, relu=1, resid=rd).cpu()
+    finally:
+        L.set_tuning(**prev)
+    for v in (1, 3, 4, 5):
+        assert torch.equal(outs[2], outs[v])
+    e0, e1 = (outs[0].double() - ref), (outs[2].double() - ref)
+    bar = 4 * math.sqrt(K) * 2.0 ** -24 * scale
+    assert e0.abs().max().item() <= bar and e1.abs().max().item() <= bar
+    if M * N >= 10000:      # (the comparison of two error samples needs a sample)
+        assert e1.abs().max().item() <= 2.0 * e0.abs().max().item()
+        assert e1.pow(2).mean().sqrt().item() <= 1.25 * e0.pow(2).mean().sqrt().item()
+    torch.testing.assert_close(full, full0, rtol=0, atol=2 * bar)
+    torch.testing.assert_close(full, (torch.relu(ref + bias.double()) + res.double()).float(), rtol=0, atol=2 * bar)
+
+
 def test_gemm_epilogues_and_splitk(L):
     M, N, K = 200, 72, 160
     A, B, bias, res, rs = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6), (rnd(M, seed=7) > 0).float()
