@@ -243,7 +243,7 @@ WORKLOADS = {
                         "synchronisation per step) and the sampled captions END (generator scaled x3 with an EOS bias, so that sampled lengths "
                         "look like real captions instead of a random-init model's 18 tokens; mean length on the line): the update runs on the valid positions only"),
     "decode": "ORT dense, cached-KV beam-5 decode, 1024 images (mixed precision)",
-    "decode_fp32": "ORT dense, cached-KV beam-5 decode, 1024 images, fp32 parity mode (token-exact vs the reference)",
+    "decode_fp32": "ORT dense, cached-KV beam-5 decode, 1024 images, fp32 parity mode (token-exact vs the reference; fp32 storage and accumulation, products split over the bf16 matrix cores)",
     "sparse_decode": "configs[4]: ORT 95% sparse, cached-KV beam-5 decode, 1024 images, decoder stack kernel on the sparse weight stream",
     "sparse_decode_dense_kernels": "configs[4]: the same decode as dense kernels on zero-filled weights (the reference's flow)",
     "sparse_decode_988": "configs[4] at 98.8%: sparse weight stream, gather form (per-column lists; auto from 98.5% zeros on)",
@@ -430,12 +430,17 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         roofline = {"bound": "hbm", "kernel": "whole step", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "alg_bytes_per_step": round(algo)}
         if decode and precision != "bf16":
-            # fp32 parity mode: 6.62 GFLOP per image against the 157 TF/s fp32 matrix peak is 43 ms per 1 024 images,
-            # ten times the HBM time of its bytes — the decode is MFMA-bound in this mode
+            # fp32 parity mode: 6.62 GFLOP per image — ten times the HBM time of its bytes: MFMA-bound.  Its projections run
+            # on the bf16 matrix cores as six bf16 partial products per fp32 product (ortk_gemm.hip: gemm_f32x3_kernel; ortk_tuning.f32_split),
+            # so the peak that bounds it is the bf16 MFMA peak / 6 = 416.7 TF/s of fp32-equivalent work (the fp32 MFMA peak, 157.3 TF/s =
+            # 43 ms per 1 024 images, bounded the kernel this replaced: `vs_fp32_mfma_peak`)
             tf = GFLOP_DECODE_PER_IMAGE * B / 1e3 / (ms_per_step * 1e-3)
-            roofline = {"bound": "mfma", "kernel": "whole step", "achieved": round(tf, 1), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / PEAK_F32_TFLOPS, 4), "traffic": None, "alg_gflop_per_step": round(GFLOP_DECODE_PER_IMAGE * B, 1),
-                        "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
+            split = L.set_tuning()["f32_split"] != 0
+            pk = PEAK_BF16_TFLOPS / 6.0 if split else PEAK_F32_TFLOPS
+            roofline = {"bound": "mfma", "kernel": "whole step", "achieved": round(tf, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
+                        "frac": round(tf / pk, 4), "traffic": None, "alg_gflop_per_step": round(GFLOP_DECODE_PER_IMAGE * B, 1),
+                        "hbm_frac": round(gbs / PEAK_HBM_GBS, 4), "vs_fp32_mfma_peak": round(tf / PEAK_F32_TFLOPS, 4),
+                        "products": "6 bf16 MFMA partial products per fp32 product (three-way operand split)" if split else "fp32 MFMA"}
         if stack is not None:
             roofline["dominant_kernel"] = stack
     else:

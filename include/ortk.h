@@ -327,7 +327,8 @@ typedef struct ortk_tuning {
                                 tile over the staged X planes (two workgroups per compute unit instead of one) | 0 */
     int32_t f32_split;       /* fp32 products of the forward layout (precision 0: the fp32 parity mode): 1 (default) on the bf16 matrix cores, every
                                 operand split into three bf16 parts and six partial products kept (fp32-level error, ortk_gemm.hip:
-                                gemm_f32x3_kernel) | 0 the fp32 MFMA kernel | 2..5 as 1 with a fixed tile (128x128, 64x64, 128x64, 64x128) */
+                                gemm_f32x3_kernel / gemm_f32x3p_kernel) | 0 the fp32 MFMA kernel | 2..7 as 1 with a fixed kernel instance
+                                (single-buffered 64x64, 128x64, 128x128; pipelined 64x64, 128x64, 256x128) */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

@@ -22,6 +22,15 @@ stats decode_stack_b1024_beam5 "--workload decode"
 stats sparse_decode_stack_b1024_beam5 "--workload sparse_decode"
 stats scst_b256_ns5 "--workload scst"
 stats sparse_xe_kernels "--workload sparse_xe --variant kernels"
+stats decode_fp32_b1024_beam5 "--workload decode --variant fp32"
+# the split fp32 GEMM: per-shape times / errors, and the counters of its instances
+python3 scratch/f32x3_bench.py > $O/r05_f32_split_gemm.txt 2>&1
+: > $O/r05_f32_split_pmc.txt
+for ctr in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/raw_x3 -o t -- python3 scratch/f32x3_one.py > $O/x3pmc.log 2>&1
+  python3 scratch/pmc_kernels.py $O/raw_x3/t_counter_collection.csv gemm_f32 >> $O/r05_f32_split_pmc.txt 2>&1
+  rm -rf $O/raw_x3
+done
 pmc xe_b256_pmc_fetch_size FETCH_SIZE --
 pmc xe_b256_pmc_write_size WRITE_SIZE --
 pmc decode_stack_pmc_fetch_size FETCH_SIZE -- --workload decode

@@ -1319,7 +1319,8 @@ template <bool TA, bool TB> gemm16_fn pick16(int adt, int bdt, bool fast) {
 // which 24 are free for the vector ALU: the split costs 5.5 vector instructions per element).  K is consumed 32 at a time: the fp32
 // tile travels global -> registers -> (split) -> three [m][k] bf16 images per operand in LDS (64-byte rows, the XOR swizzle of the
 // LDS-DMA kernels; conflict-free for the 32-row ds_read_b128 fragments as well), single-buffered: 24 KB (64 x 64) .. 48 KB (128 x 128)
-// per workgroup, three workgroups per compute unit — one splits while another multiplies.
+// per workgroup, three workgroups per compute unit — one splits while another multiplies.  (gemm_f32x3p_kernel below is the
+// software-pipelined form; this one serves the grids that want many mid-sized workgroups.)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -1448,6 +1449,161 @@ __global__ __launch_bounds__(64 * GM * GN, MINB) void gemm_f32x3_kernel(ortk_gem
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, 0, true, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     epilogue_tile<false, WM, 4 * WN, 32, 8>(e, mb + wm * 32 * WM + l32, nb + wn * 32 * WN + 4 * lh, acc4);
+}
+
+// The same product, software-pipelined inside the wave: the three-plane images are DOUBLE-buffered (one barrier per k-step) and the
+// split of tile t + 1 (vector ALU, no memory operand until its stores) is written between the fragment reads and the MFMAs of tile t,
+// so that it issues in the 24 cycles per `v_mfma_f32_32x32x16_bf16` the matrix pipe leaves free; the raw fp32 tiles are fetched TWO
+// k-steps ahead into two register sets (a whole k-step of latency budget instead of one MFMA phase).  Loads past the last tile are
+// clamped to it (branch-free steps); what they deliver is split into a buffer nobody reads again.
+template <int WM, int WN, int GM, int GN, int MINB>
+__global__ __launch_bounds__(64 * GM * GN, MINB) void gemm_f32x3p_kernel(ortk_gemm_args p, int tilesM, int tilesN, int) {
+    constexpr int RA = 32 * WM * GM, RB = 32 * WN * GN, BK = 32, NT = 64 * GM * GN;
+    constexpr int CA = RA * 4 / NT, CB = RB * 4 / NT, NC = CA + CB;
+    static_assert(CA * NT == RA * 4 && CB * NT == RB * 4, "tile rows must divide over the threads");
+    constexpr int IA = RA * BK, IB = RB * BK, BUF = 3 * (IA + IB);       // bf16 elements: one plane of A / of B, one buffer
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / GN, wn = wave % GN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, mt = bid / tilesN;
+    const int mb = mt * RA, nb = nt * RB;
+    const float* Af = reinterpret_cast<const float*>(p.A);
+    const float* Bf = reinterpret_cast<const float*>(p.B);
+    const int T = p.K / BK;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* gc[NC];
+    int oc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const bool isA = c < CA;
+        const int f = tid + NT * (isA ? c : c - CA), r = f >> 2, ch = f & 3;
+        gc[c] = isA ? Af + (int64_t)min(mb + r, p.M - 1) * p.lda + 8 * ch : Bf + (int64_t)min(nb + r, p.N - 1) * p.ldb + 8 * ch;
+        oc[c] = (isA ? 0 : 3 * IA) + r * BK + ((ch ^ swz_mk(r)) << 3);
+    }
+    f32x4 r0[NC][2], r1[NC][2];
+    auto gload = [&](f32x4 (&x)[NC][2], int kt) {
+        const int k0 = min(kt, T - 1) * BK;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            x[c][0] = *reinterpret_cast<const f32x4*>(gc[c] + k0);
+            x[c][1] = *reinterpret_cast<const f32x4*>(gc[c] + k0 + 4);
+        }
+    };
+    const int l32 = lane & 31, lh = lane >> 5, sw = swz_mk(l32);
+    const int fa0 = (wm * 32 * WM + l32) * BK, fb0 = 3 * IA + (wn * 32 * WN + l32) * BK;
+    // one k-step: multiply the tile in `rbuf`; split the raw tile `x` into `wbuf` on the way (SPLIT = false: the last tile)
+    auto step = [&](const __bf16* rbuf, __bf16* wbuf, const f32x4 (&x)[NC][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int co = ((2 * s + lh) ^ sw) << 3;
+            bf16x8 a[3][WM], b[3][WN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(rbuf + pl * IA + fa0 + i * 32 * BK + co);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[pl][j] = *reinterpret_cast<const bf16x8*>(rbuf + pl * IB + fb0 + j * 32 * BK + co);
+            }
+            unsigned int q[(NC + 1) / 2][3][4];
+#pragma unroll
+            for (int c = s; c < NC; c += 2) {
+                split3(x[c][0][0], x[c][0][1], q[c >> 1][0][0], q[c >> 1][1][0], q[c >> 1][2][0]);
+                split3(x[c][0][2], x[c][0][3], q[c >> 1][0][1], q[c >> 1][1][1], q[c >> 1][2][1]);
+                split3(x[c][1][0], x[c][1][1], q[c >> 1][0][2], q[c >> 1][1][2], q[c >> 1][2][2]);
+                split3(x[c][1][2], x[c][1][3], q[c >> 1][0][3], q[c >> 1][1][3], q[c >> 1][2][3]);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2][j], a[0][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1][j], a[1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[2][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1][j], a[0][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[0][i], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int c = s; c < NC; c += 2) {
+                const int ps = c < CA ? IA : IB;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<u32x4*>(wbuf + oc[c] + pl * ps) = (u32x4){q[c >> 1][pl][0], q[c >> 1][pl][1], q[c >> 1][pl][2], q[c >> 1][pl][3]};
+            }
+            {
+                // pin the interleave: behind every MFMA the share of this half's split instructions that fits its shadow (the
+                // compiler's own order left runs of back-to-back MFMAs next to runs of vector instructions: 2-4 % slower)
+                constexpr int NMF = WM * WN * 6, NCH = (NC + 1) / 2, VPM = (NCH * 46 + NMF - 1) / NMF;
+#pragma unroll
+                for (int m = 0; m < NMF; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+            }
+        }
+    };
+
+    __bf16* buf0 = smem16;
+    __bf16* buf1 = smem16 + BUF;
+    if (T > 0) {
+        gload(r0, 0);
+        gload(r1, 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            unsigned int q[3][4];
+            split3(r0[c][0][0], r0[c][0][1], q[0][0], q[1][0], q[2][0]);
+            split3(r0[c][0][2], r0[c][0][3], q[0][1], q[1][1], q[2][1]);
+            split3(r0[c][1][0], r0[c][1][1], q[0][2], q[1][2], q[2][2]);
+            split3(r0[c][1][2], r0[c][1][3], q[0][3], q[1][3], q[2][3]);
+            const int ps = c < CA ? IA : IB;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(buf0 + oc[c] + pl * ps) = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+        }
+        gload(r0, 2);
+        __syncthreads();
+        int t = 0;
+        for (; t + 1 < T; t += 2) {
+            step(buf0, buf1, r1);       // tile t; tile t + 1 -> buffer 1
+            gload(r1, t + 3);
+            __syncthreads();
+            step(buf1, buf0, r0);       // tile t + 1; tile t + 2 (or a copy of the last tile) -> buffer 0
+            gload(r0, t + 4);
+            __syncthreads();
+        }
+        if (t < T) step(buf0, buf1, r1);   // odd tile count: the last tile (what is split on the way is not read)
+    }
+
+    f32x4 acc4[WM][4 * WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc4[i][4 * j + g] = (f32x4){acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+    Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
+          p.relu, p.drop_p, p.drop_seed, 0, true, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
+    epilogue_tile<false, WM, 4 * WN, 32, 8>(e, mb + wm * 32 * WM + l32, nb + wn * 32 * WN + 4 * lh, acc4);
+}
+template <int WM, int WN, int GM, int GN, int MINB>
+int launch_f32x3p(const ortk_gemm_args& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 3 * (32 * WM * GM + 32 * WN * GN) * 32 * sizeof(__bf16);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32x3p_kernel<WM, WN, GM, GN, MINB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int tm = (int)ortk_cdiv(p.M, 32 * WM * GM), tn = (int)ortk_cdiv(p.N, 32 * WN * GN);
+    hipLaunchKernelGGL((gemm_f32x3p_kernel<WM, WN, GM, GN, MINB>), dim3((unsigned)(tm * tn)), dim3(64 * GM * GN), lds, s, p, tm, tn, 0);
+    return 0;
 }
 
 }  // namespace
@@ -1617,22 +1773,22 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         if (key == 0 && ortk::tuning().f32_split && !p.accumulate && p.K > 0 && p.K % 32 == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
             al16(p.A) && al16(p.B)) {
             // three-way bf16 split on the bf16 matrix cores (gemm_f32x3_kernel); tile size by how many workgroups it gives the chip
-            const int64_t t128 = (int64_t)tilesM * tilesN;
-            const int force = ortk::tuning().f32_split;     // 1 automatic | 2.. a fixed kernel instance (scratch/f32x3_bench.py)
-            // measured on the shapes of the fp32 parity decode (scratch/f32x3_bench.py, profiles/r05_f32_split_gemm.txt): short grids
-            // want many small workgroups, long ones the tile that re-reads least
-            const int shape = force > 1 ? force : t128 < 320 ? 3 : t128 < 1536 ? 7 : 6;
+            // Instance by how the grid fills the 256 compute units (measured on the shapes of the fp32 parity decode:
+            // scratch/f32x3_bench.py, profiles/r05_f32_split_gemm.txt): the 256 x 128 pipelined tile wherever its grid fills at least
+            // 3/4 of its last round of workgroups; short grids (at most 1.25 workgroups of 128 x 128 per unit) the 64 x 64 pipelined
+            // tile; in between 128 x 64, three workgroups per unit.
+            const int64_t t128 = (int64_t)tilesM * tilesN, big = ortk_cdiv(p.M, 256) * (int64_t)tilesN;
+            const int force = ortk::tuning().f32_split;     // 1 automatic | 2..7 a fixed kernel instance
+            const int shape = force > 1 ? force : big * 4 >= ortk_cdiv(big, 256) * 256 * 3 ? 7 : t128 < 320 ? 5 : 3;
 #define ORTK_X3(WM_, WN_, GM_, GN_, MB_) do { const int tm = (int)ortk_cdiv(p.M, 32 * WM_ * GM_), tn = (int)ortk_cdiv(p.N, 32 * WN_ * GN_); \
             hipLaunchKernelGGL((gemm_f32x3_kernel<WM_, WN_, GM_, GN_, MB_>), dim3((unsigned)(tm * tn)), dim3(64 * GM_ * GN_), 0, s, p, tm, tn, 0); } while (0)
             switch (shape) {
-                case 2:  ORTK_X3(2, 2, 2, 2, 2); break;      // 128 x 128
-                case 4:  ORTK_X3(2, 1, 2, 2, 2); break;      // 128 x 64
-                case 5:  ORTK_X3(1, 2, 2, 2, 2); break;      // 64 x 128
-                case 6:  ORTK_X3(2, 2, 2, 2, 3); break;      // 128 x 128, three workgroups per CU
-                case 7:  ORTK_X3(2, 1, 2, 2, 3); break;      // 128 x 64, three
-                case 8:  ORTK_X3(2, 2, 4, 2, 2); break;      // 256 x 128, 8 waves
-                case 9:  ORTK_X3(2, 2, 2, 4, 2); break;      // 128 x 256, 8 waves
-                default: ORTK_X3(1, 1, 2, 2, 2); break;      // 64 x 64
+                case 2:  ORTK_X3(1, 1, 2, 2, 2); break;               // single-buffered: 64 x 64 (24 KB)
+                case 3:  ORTK_X3(2, 1, 2, 2, 3); break;               //                  128 x 64 (36 KB), three workgroups per unit
+                case 4:  ORTK_X3(2, 2, 2, 2, 3); break;               //                  128 x 128 (48 KB), three
+                case 5:  launch_f32x3p<1, 1, 2, 2, 3>(p, s); break;   // pipelined:       64 x 64 (48 KB)
+                case 6:  launch_f32x3p<2, 1, 2, 2, 2>(p, s); break;   //                  128 x 64 (72 KB)
+                default: launch_f32x3p<2, 2, 4, 2, 1>(p, s); break;   //                  256 x 128, 8 waves (144 KB)
             }
 #undef ORTK_X3
             if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }

@@ -780,7 +780,7 @@ const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
 extern "C" int ortk_set_tuning(const ortk_tuning* t) {
-    if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1 || t->f32_split < 0 || t->f32_split > 9) return ORTK_EINVAL;
+    if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1 || t->f32_split < 0 || t->f32_split > 7) return ORTK_EINVAL;
     ortk::g_tuning = *t;
     return 0;
 }

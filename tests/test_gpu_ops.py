@@ -95,7 +95,7 @@ def test_gemm_f32_split_vs_float64(L, M, N, K):
     outs = {}
     prev = L.set_tuning(f32_split=0)
     try:
-        for v in (0, 1, 2, 3, 4, 5):
+        for v in (0, 1, 2, 3, 4, 5, 6, 7):
             L.set_tuning(f32_split=v)
             outs[v] = gemm(L, Ad, Bd, M, N, K).cpu()
         L.set_tuning(f32_split=1)
@@ -104,7 +104,7 @@ def test_gemm_f32_split_vs_float64(L, M, N, K):
         full0 = gemm(L, Ad, Bd, M, N, K, bias=bd, relu=1, resid=rd).cpu()
     finally:
         L.set_tuning(**prev)
-    for v in (1, 3, 4, 5):
+    for v in (1, 3, 4, 5, 6, 7):
         assert torch.equal(outs[2], outs[v])
     e0, e1 = (outs[0].double() - ref), (outs[2].double() - ref)
     bar = 4 * math.sqrt(K) * 2.0 ** -24 * scale
