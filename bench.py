@@ -232,6 +232,8 @@ def selftest(rank, world, args):
 # baseline, rollouts drawn and differentiated with every dropout on); `scst_nodrop` the dropout-free variant of rounds 1-3.
 WORKLOADS = {
     "xe": "configs[1]: ORT dense, 256 images x 5 captions, teacher-forcing XE fwd+bwd+clip+Adam",
+    "xe_fp32": ("configs[1] in the fp32 parity mode (the mode the 'fp32 XE loss within 1e-4' bar is held in): fp32 storage and accumulation, every "
+                "product as six bf16 MFMA partial products of three-way split operands, all three GEMM layouts"),
     "sparse_xe": "configs[2]: ORT 95% supermask-sparse XE step, masked dense GEMMs (the reference's flow)",
     "sparse_xe_kernels": "configs[2]: the same step, forward + data-gradient products as sparse kernels (ortk_spmm), weight gradients dense",
     "sparse_xe_988": "configs[2] at 98.8%: the reference's NNZ 0.7M model, masked dense GEMMs",
@@ -383,12 +385,14 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
     if rank != 0:
         return None
     per_key, iso = collected[2], collected[1]
-    peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
+    # fp32 parity mode: its products run as six bf16 MFMA partial products of three-way split operands unless ortk_tuning.f32_split = 0
+    f32_split = precision != "bf16" and L.set_tuning()["f32_split"] != 0
+    peak = PEAK_BF16_TFLOPS if precision == "bf16" else round(PEAK_BF16_TFLOPS / 6.0, 1) if f32_split else PEAK_F32_TFLOPS
     n0, ms0, fl0, by0 = per_key[key]
     ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
     ach_iso = iso[key][2] / (iso[key][1] * 1e-3) / 1e12 if iso[key][1] > 0 else 0.0
     traffic, tnote = pmc_traffic("gemm", workload if not variant else "", precision, B)
-    gemm = {"bound": "mfma", "kernel": "forward-layout GEMMs (gemm_bf16_dma256 / glds / dma64)" if precision == "bf16" else "gemm_f32_kernel (forward layout)",
+    gemm = {"bound": "mfma", "kernel": "forward-layout GEMMs (gemm_bf16_dma256 / glds / dma64)" if precision == "bf16" else ("forward-layout fp32 GEMMs as split bf16 products (gemm_f32x3_kernel / gemm_f32x3p_kernel)" if f32_split else "gemm_f32_kernel (forward layout)"),
             "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             **({"traffic_note": tnote} if traffic is None and tnote.startswith("STALE") else {}),
             "launches": n0, "avg_us": round(ms0 * 1e3 / max(n0, 1), 1), "isolated_frac": round(ach_iso / peak, 4),
@@ -568,7 +572,7 @@ def main():
         # stays within a couple of minutes).  One GPU only: the driver's scaling runs measure the headline.
         if args.workload == "xe" and not variant and world == 1 and not args.no_extra_workloads and not args.batch:
             extra = {}
-            for wl, var, st, wu in (("sparse_xe", "", 20, 3), ("sparse_xe", "kernels", 12, 3), ("sparse_xe", "988", 12, 3),
+            for wl, var, st, wu in (("xe", "fp32", 8, 2), ("sparse_xe", "", 20, 3), ("sparse_xe", "kernels", 12, 3), ("sparse_xe", "988", 12, 3),
                                     ("sparse_xe", "988_kernels", 12, 3), ("scst", "", 12, 3), ("scst", "nodrop", 12, 3), ("scst", "hostreward", 12, 3),
                                     ("decode", "", 10, 3), ("decode", "fp32", 3, 1), ("sparse_decode", "", 10, 3),
                                     ("sparse_decode", "dense_kernels", 10, 3), ("sparse_decode", "988", 10, 3),

@@ -402,6 +402,8 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* img, int m0, int ks, int la
 // 48 K-splits took 554 us, of which ~400 us were atomics.
 constexpr int CP = 128 + 4;   // fp32 row pitch of the staged C tile (528 B: 16-B aligned)
 template <bool FAST>
+__device__ __forceinline__ void epilogue_from_lds(const Epi& e, float* sC, int mb, int nb, int lane, int wave);
+template <bool FAST>
 __device__ __forceinline__ void epilogue_staged(const Epi& e, float* sC, int mb, int nb, int wm, int wn, int lane, int wave,
                                                 f32x4 (&acc)[4][4]) {
     {   // registers -> LDS (lane holds 4 consecutive n of row m)
@@ -413,6 +415,11 @@ __device__ __forceinline__ void epilogue_staged(const Epi& e, float* sC, int mb,
                 *reinterpret_cast<f32x4*>(sC + (mr + 16 * i) * CP + nc + 16 * j) = acc[i][j];
     }
     __syncthreads();
+    epilogue_from_lds<FAST>(e, sC, mb, nb, lane, wave);
+}
+// the 128 x 128 fp32 tile staged row-major (pitch CP) in sC -> memory (4 waves)
+template <bool FAST>
+__device__ __forceinline__ void epilogue_from_lds(const Epi& e, float* sC, int mb, int nb, int lane, int wave) {
     const int EN = FAST ? 0x7FFFFFFF : e.N, EM = FAST ? 0x7FFFFFFF : e.M;
     const bool first = e.first_split;
     if (e.accumulate) {
@@ -1606,6 +1613,158 @@ int launch_f32x3p(const ortk_gemm_args& p, hipStream_t s) {
     return 0;
 }
 
+// The transposed-operand layouts of the same split product (fp32 parity mode: data gradients dX = dY W with W stored (K, N), weight
+// gradients dW = dY^T X with both operands stored k-major and K = the batch's rows split over workgroups that accumulate with
+// atomics).  A k-major operand is staged as float4s ALONG its contiguous dimension (4 m of one k-row), split, and written as 8-byte
+// pieces into three [k][m] images (256-byte rows, chunk' = chunk ^ 4 (k & 3)); the 32-row fragments come out of
+// `ds_read_b64_tr_b16` pairs (conflict-free with that swizzle: the 4 k-rows x 4 chunks of a 32-lane half are 16 distinct chunks).
+// 128 x 128 tile, 4 waves of 64 x 64, single-buffered images; k-rows past the end of the reduction are staged as zeros, columns past
+// the matrix re-read its last four (dropped by the epilogue).
+__device__ __forceinline__ bf16x8 x3_frag_km(const __bf16* img, int m0, int s, int lane) {
+    const int g = lane >> 4, j = lane & 15;
+    const int k = 16 * s + 8 * (g >> 1) + (j >> 2), m = m0 + 16 * (g & 1) + 4 * (j & 3);
+    const __bf16* a = img + k * 128 + ((((m >> 3) ^ (4 * (k & 3)))) << 3) + (m & 4);
+    const bf16x4 lo = tr_read(a), hi = tr_read(a + 4 * 128);
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+template <bool TA, bool ACC>
+__global__ __launch_bounds__(256, ACC ? 2 : 3) void gemm_f32x3t_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    constexpr int BK = 32, IMG = 128 * BK;
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];      // 6 images (48 KB); ACC: the staged C tile (66 KB) over them
+    __bf16* sA = smem16;
+    __bf16* sB = smem16 + 3 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks = rest / tilesM;
+    const int mb = mt * 128, nb = nt * 128;
+    const int k_begin = ks * kchunk, k_end = min(p.K, k_begin + kchunk);
+    const float* Af = reinterpret_cast<const float*>(p.A);
+    const float* Bf = reinterpret_cast<const float*>(p.B);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // k-major operand: float4 number f = tid + 256 u (u < 4) of the 32 x 128 tile: k-row f >> 5, columns 4 (f & 31) ..+3
+    // row-major A (dgrad): 8-column chunk f = tid + 256 u (u < 2): row f >> 2, chunk f & 3  (as gemm_f32x3_kernel)
+    const int kr = tid >> 5, c4 = (tid & 31) * 4;
+    const float* gbk = Bf + (int64_t)kr * p.ldb + min(nb + c4, p.N - 4);
+    const float* gak = TA ? Af + (int64_t)kr * p.lda + min(mb + c4, p.M - 4) : nullptr;
+    const int okm = kr * 128 + ((((c4 >> 3) ^ (4 * (kr & 3)))) << 3) + (c4 & 4);      // (+ 8 u rows: same swizzle, 8 * 128 elements further)
+    const float* gar[2]; int oar[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int f = tid + 256 * u, r = f >> 2, c = f & 3;
+        gar[u] = TA ? nullptr : Af + (int64_t)min(mb + r, p.M - 1) * p.lda + 8 * c;
+        oar[u] = r * BK + ((c ^ swz_mk(r)) << 3);
+    }
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = k0 + kr + 8 * u < k_end;
+            rb[u] = in ? *reinterpret_cast<const f32x4*>(gbk + (int64_t)(k0 + 8 * u) * p.ldb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (TA) ra[u] = in ? *reinterpret_cast<const f32x4*>(gak + (int64_t)(k0 + 8 * u) * p.lda) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (!TA) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ra[2 * u] = *reinterpret_cast<const f32x4*>(gar[u] + k0);
+                ra[2 * u + 1] = *reinterpret_cast<const f32x4*>(gar[u] + k0 + 4);
+            }
+        }
+    };
+    auto put_km = [&](__bf16* img, int off, f32x4 v) {
+        unsigned int q[3][2];
+        split3(v[0], v[1], q[0][0], q[1][0], q[2][0]);
+        split3(v[2], v[3], q[0][1], q[1][1], q[2][1]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(img + pl * IMG + off) = make_uint2(q[pl][0], q[pl][1]);
+    };
+    auto put_mk = [&](__bf16* img, int off, f32x4 v0, f32x4 v1) {
+        unsigned int q[3][4];
+        split3(v0[0], v0[1], q[0][0], q[1][0], q[2][0]);
+        split3(v0[2], v0[3], q[0][1], q[1][1], q[2][1]);
+        split3(v1[0], v1[1], q[0][2], q[1][2], q[2][2]);
+        split3(v1[2], v1[3], q[0][3], q[1][3], q[2][3]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(img + pl * IMG + off) = (u32x4){q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+    };
+
+    const int l32 = lane & 31, lh = lane >> 5, sw = swz_mk(l32);
+    if (k_begin < k_end) gload(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            put_km(sB, okm + 8 * u * 128, rb[u]);
+            if (TA) put_km(sA, okm + 8 * u * 128, ra[u]);
+        }
+        if (!TA) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) put_mk(sA, oar[u], ra[2 * u], ra[2 * u + 1]);
+        }
+        __syncthreads();
+        if (k0 + BK < k_end) gload(k0 + BK);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[3][2], b[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[pl][i] = TA ? x3_frag_km(sA + pl * IMG, wm * 64 + 32 * i, s, lane)
+                                  : *reinterpret_cast<const bf16x8*>(sA + pl * IMG + (wm * 64 + 32 * i + l32) * BK + (((2 * s + lh) ^ sw) << 3));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[pl][j] = x3_frag_km(sB + pl * IMG, wn * 64 + 32 * j, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2][j], a[0][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1][j], a[1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[2][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1][j], a[0][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][j], a[0][i], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
+          p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
+    if (ACC) {
+        // split-K accumulation: the tile goes through LDS so that every atomic instruction adds 256 contiguous bytes
+        float* sC = reinterpret_cast<float*>(smem16);
+        const int mr = wm * 64 + l32, nc = wn * 64 + 4 * lh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(sC + (mr + 32 * i) * CP + nc + 32 * j + 8 * g) =
+                        (f32x4){acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        __syncthreads();
+        epilogue_from_lds<false>(e, sC, mb, nb, lane, wave);
+        return;
+    }
+    f32x4 acc4[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc4[i][4 * j + g] = (f32x4){acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+    epilogue_tile<false, 2, 8, 32, 8>(e, mb + wm * 64 + l32, nb + wn * 64 + 4 * lh, acc4);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ profiling hook
@@ -1745,7 +1904,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         return 0;
     }
     const int tilesM = (int)ortk_cdiv(p.M, BM), tilesN = (int)ortk_cdiv(p.N, BN);
-    const int bk = p.precision ? BK16 : 16;
+    // (fp32 transposed layouts on the split kernels consume K 32 at a time: K-split chunks are made multiples of 32 for them)
+    const int bk = p.precision ? BK16 : (ortk::tuning().f32_split && (p.transA || p.transB)) ? 32 : 16;
     int splitk = p.accumulate ? (p.splitk > 0 ? p.splitk : 1) : 1;
     int kchunk = bk;
     if (p.K <= 0) {
@@ -1791,6 +1951,23 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
                 default: launch_f32x3p<2, 2, 4, 2, 1>(p, s); break;   //                  256 x 128, 8 waves (144 KB)
             }
 #undef ORTK_X3
+            if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
+            ORTK_CHECK_LAUNCH();
+            return 0;
+        }
+        // transposed-operand layouts of the split product (gemm_f32x3t_kernel): dgrad without accumulation, wgrad with or without
+        if (key != 0 && ortk::tuning().f32_split && p.K > 0 && (p.ldb & 3) == 0 && al16(p.B) && (p.N & 3) == 0 && p.N >= 4 && kchunk % 32 == 0 &&
+            (key == 1 ? !p.accumulate && p.K % 32 == 0 && (p.lda & 3) == 0 && al16(p.A)
+                      : (p.lda & 3) == 0 && al16(p.A) && (p.M & 3) == 0 && p.M >= 4)) {
+            typedef void (*x3t_fn)(ortk_gemm_args, int, int, int);
+            const x3t_fn fn = key == 1 ? gemm_f32x3t_kernel<false, false> : p.accumulate ? gemm_f32x3t_kernel<true, true> : gemm_f32x3t_kernel<true, false>;
+            const size_t lds = p.accumulate ? BF16_LDS_BYTES_C : (size_t)6 * 128 * 32 * sizeof(__bf16);
+            static bool x3t_attr = false;
+            if (!x3t_attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32x3t_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES_C);
+                x3t_attr = true;
+            }
+            hipLaunchKernelGGL(fn, grid, block, lds, s, p, tilesM, tilesN, kchunk);
             if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
             ORTK_CHECK_LAUNCH();
             return 0;

@@ -116,6 +116,49 @@ def test_gemm_f32_split_vs_float64(L, M, N, K):
     torch.testing.assert_close(full, (torch.relu(ref + bias.double()) + res.double()).float(), rtol=0, atol=2 * bar)
 
 
+@pytest.mark.parametrize("M,N,K", [(640, 384, 512), (2048, 512, 5000), (260, 1000, 96), (4, 8, 33)])
+def test_gemm_f32_split_transposed_layouts_vs_float64(L, M, N, K):
+    """The data-gradient (B stored (K, N)) and weight-gradient (both operands stored k-major; split-K accumulation with atomics)
+    layouts of the fp32 split product (ortk_gemm.hip: gemm_f32x3t_kernel) against a float64 product, next to the fp32 MFMA kernel
+    they replace (f32_split = 0): same bars as the forward layout's test.  K that is no multiple of 32 (zero-filled k-rows), tiles
+    that overhang M and N, bias + ReLU + residual epilogue, accumulation on top of existing content."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-12, 13, (M, K), generator=g).float())
+    B = torch.randn(N, K, generator=g) * 0.05
+    ref = A.double() @ B.double().t()
+    scale = ref.abs().max().item()
+    bar = 4 * math.sqrt(K) * 2.0 ** -24 * scale
+    Ad, Bd = dev(A), dev(B)
+    Atd, Btd = dev(A.t().contiguous()), dev(B.t().contiguous())
+    C0 = rnd(M, N, seed=11)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    out = {}
+    prev = L.set_tuning(f32_split=0)
+    try:
+        for v in (0, 1):
+            L.set_tuning(f32_split=v)
+            o = {}
+            if K % 32 == 0:
+                o["dgrad"] = gemm(L, Ad, Btd, M, N, K, 0, 1).cpu()
+                o["dgrad_epi"] = gemm(L, Ad, Btd, M, N, K, 0, 1, bias=dev(bias), relu=1, resid=dev(res)).cpu()
+            o["wgrad"] = gemm(L, Atd, Btd, M, N, K, 1, 1).cpu()
+            for sk in (1, 3, 8):
+                o["wgrad_acc%d" % sk] = gemm(L, Atd, Btd, M, N, K, 1, 1, C=dev(C0.clone()), accumulate=1, splitk=sk).cpu()
+            out[v] = o
+    finally:
+        L.set_tuning(**prev)
+    for name in out[1]:
+        want = ref
+        if name == "dgrad_epi":
+            want = torch.relu(ref + bias.double()) + res.double()
+        elif name.startswith("wgrad_acc"):
+            want = ref + C0.double()
+        e0, e1 = out[0][name].double() - want, out[1][name].double() - want
+        assert e1.abs().max().item() <= 2 * bar, name
+        if M * N >= 10000:
+            assert e1.pow(2).mean().sqrt().item() <= 1.25 * e0.pow(2).mean().sqrt().item() + 2.0 ** -24 * scale, name
+
+
 def test_gemm_epilogues_and_splitk(L):
     M, N, K = 200, 72, 160
     A, B, bias, res, rs = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6), (rnd(M, seed=7) > 0).float()
