@@ -232,7 +232,7 @@ def selftest(rank, world, args):
 # baseline, rollouts drawn and differentiated with every dropout on); `scst_nodrop` the dropout-free variant of rounds 1-3.
 WORKLOADS = {
     "xe": "configs[1]: ORT dense, 256 images x 5 captions, teacher-forcing XE fwd+bwd+clip+Adam",
-    "xe_fp32": ("configs[1] in the fp32 parity mode (the mode the 'fp32 XE loss within 1e-4' bar is held in): fp32 storage and accumulation, every "
+    "xe_fp32": ("configs[1], fp32 parity mode: the mode the 'fp32 XE loss within 1e-4' bar is held in; fp32 storage and accumulation, every "
                 "product as six bf16 MFMA partial products of three-way split operands, all three GEMM layouts"),
     "sparse_xe": "configs[2]: ORT 95% supermask-sparse XE step, masked dense GEMMs (the reference's flow)",
     "sparse_xe_kernels": "configs[2]: the same step, forward + data-gradient products as sparse kernels (ortk_spmm), weight gradients dense",
@@ -245,7 +245,7 @@ WORKLOADS = {
                         "synchronisation per step) and the sampled captions END (generator scaled x3 with an EOS bias, so that sampled lengths "
                         "look like real captions instead of a random-init model's 18 tokens; mean length on the line): the update runs on the valid positions only"),
     "decode": "ORT dense, cached-KV beam-5 decode, 1024 images (mixed precision)",
-    "decode_fp32": "ORT dense, cached-KV beam-5 decode, 1024 images, fp32 parity mode (token-exact vs the reference; fp32 storage and accumulation, products split over the bf16 matrix cores)",
+    "decode_fp32": "beam-5 decode, 1024 images, fp32 parity mode: ORT dense, cached KV, token-exact vs the reference (fp32 storage and accumulation, products split over the bf16 matrix cores)",
     "sparse_decode": "configs[4]: ORT 95% sparse, cached-KV beam-5 decode, 1024 images, decoder stack kernel on the sparse weight stream",
     "sparse_decode_dense_kernels": "configs[4]: the same decode as dense kernels on zero-filled weights (the reference's flow)",
     "sparse_decode_988": "configs[4] at 98.8%: sparse weight stream, gather form (per-column lists; auto from 98.5% zeros on)",
@@ -571,20 +571,24 @@ def main():
         # The other BASELINE configs, timed in this same process with the same contract (fewer steps: the whole default run
         # stays within a couple of minutes).  One GPU only: the driver's scaling runs measure the headline.
         if args.workload == "xe" and not variant and world == 1 and not args.no_extra_workloads and not args.batch:
-            extra = {}
+            extra, cpu_kinds = {}, {}
             for wl, var, st, wu in (("xe", "fp32", 8, 2), ("sparse_xe", "", 20, 3), ("sparse_xe", "kernels", 12, 3), ("sparse_xe", "988", 12, 3),
                                     ("sparse_xe", "988_kernels", 12, 3), ("scst", "", 12, 3), ("scst", "nodrop", 12, 3), ("scst", "hostreward", 12, 3),
                                     ("decode", "", 10, 3), ("decode", "fp32", 3, 1), ("sparse_decode", "", 10, 3),
                                     ("sparse_decode", "dense_kernels", 10, 3), ("sparse_decode", "988", 10, 3),
-                                    ("sparse_decode", "988_scatter", 10, 3), ("sparse_decode", "988_dense_kernels", 10, 3)):
+                                    ("sparse_decode", "988_scatter", 10, 3)):      # (988_dense_kernels: by --variant; it measures what
+                                                                                    #  sparse_decode_dense_kernels measures, zeros are zeros)
                 c = compact(run_workload(args, wl, var, st, wu, rank, world, dev, pkg))
                 kind = "decode" if "decode" in wl else "scst" if wl == "scst" else "xe"
                 cb = cpu(kind)
                 if cb is not None and kind != "xe":
-                    c["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"], "host_threads": cb["host_threads"],
-                                         "images_per_step": cb["images_per_step"]}       # (kind "port": the oracle, bench_notes.json)
+                    c["cpu_baseline"] = kind                   # -> out["cpu_baselines"][kind]
+                    cpu_kinds[kind] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "host_threads": cb["host_threads"],
+                                       "images_per_step": cb["images_per_step"], "kind": cb["kind"]}       # ("port": the oracle, bench_notes.json)
                 extra[wl + ("_" + var if var else "")] = c
             out["workloads"] = extra
+            if cpu_kinds:
+                out["cpu_baselines"] = cpu_kinds       # the oracle on the host cores for the decode / scst workloads (the xe figure: `cpu_baseline`)
         out["cpu_baseline"] = cpu("decode" if "decode" in args.workload else "scst" if args.workload == "scst" else "xe")
         print(json.dumps(out, separators=(",", ":")), flush=True)
     if dist.is_initialized():
