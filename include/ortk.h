@@ -463,7 +463,7 @@ typedef struct ortk_gemm_args {
     int32_t relu; float drop_p; uint32_t drop_seed;
     int32_t accumulate, splitk, precision;
     int32_t a_dtype, b_dtype, c_dtype, gate_dtype;   /* storage type of A / B / C / gate: 0 = fp32, 1 = bf16 (precision 1 only) */
-    float* colsum;   /* optional, transA && precision 1: colsum[m] += sum_k A[k,m] (bias gradient fused into the wgrad GEMM) */
+    float* colsum;   /* optional, transA: colsum[m] += sum_k A[k,m] (bias gradient fused into the wgrad GEMM; precision 0 outside the split kernels' shapes: its own launch) */
     /* dropout draw of output element (m, n): index (m * drop_row_stride + drop_row_off) * N + n; 0 / 0 = the plain m * N + n.
      * A decode step at position t reproduces the draws of the teacher-forced (rows x T positions, N) output with (T, t). */
     int32_t drop_row_stride, drop_row_off;

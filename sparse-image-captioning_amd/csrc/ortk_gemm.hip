@@ -1664,6 +1664,10 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void gemm_f32x3t_kernel(ortk_gemm
         oar[u] = r * BK + ((c ^ swz_mk(r)) << 3);
     }
     f32x4 ra[4], rb[4];
+    // fused bias gradient (weight-gradient layout): column sums of the A tile over this workgroup's k-range, by the first column tile's
+    // workgroups; a thread's four float4s of a k-step cover the SAME four columns (c4 ..+3) of four k-rows
+    const bool do_cs = TA && p.colsum != nullptr && nt == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1703,6 +1707,7 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void gemm_f32x3t_kernel(ortk_gemm
         for (int u = 0; u < 4; ++u) {
             put_km(sB, okm + 8 * u * 128, rb[u]);
             if (TA) put_km(sA, okm + 8 * u * 128, ra[u]);
+            if (TA && do_cs) cs += ra[u];
         }
         if (!TA) {
 #pragma unroll
@@ -1737,6 +1742,22 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void gemm_f32x3t_kernel(ortk_gemm
         __syncthreads();
     }
 
+    if (TA && do_cs) {
+        // the 8 threads that own the same four columns (tid & 31 equal) -> one atomic per column (the images are free: the K loop
+        // ended with a barrier); columns past M were clamped copies: not added
+        f32x4* red = reinterpret_cast<f32x4*>(smem16);
+        red[tid] = cs;
+        __syncthreads();
+        if (tid < 32) {
+            f32x4 t = red[tid];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) t += red[tid + 32 * r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (mb + c4 + q < p.M) atomicAdd(p.colsum + mb + c4 + q, t[q]);
+        }
+        __syncthreads();
+    }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     if (ACC) {
@@ -1862,7 +1883,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
     if (!p.precision && (p.a_dtype || p.b_dtype)) return ORTK_EINVAL;   // fp32 MFMA path takes fp32 operands only
     if (p.accumulate && p.c_dtype) return ORTK_EINVAL;                   // accumulation targets the fp32 gradient arena
     if (p.transA && !p.transB) return ORTK_EINVAL;                       // layout not needed by the path
-    if (p.colsum && !(p.precision && p.transA)) return ORTK_EINVAL;      // fused column sums: bf16-MFMA wgrad layout only
+    if (p.colsum && !p.transA) return ORTK_EINVAL;                       // fused column sums: the weight-gradient layout only
     if (p.ln_mode) {
         // LayerNorm fused into the epilogue (forward: of the result; backward: the product is the LayerNorm's output gradient)
         if (p.ln_mode < 1 || p.ln_mode > 2 || p.c_dtype != ORTK_F32 || p.ldc != p.N || p.accumulate || p.transA || p.gate || p.rowscale ||
@@ -1972,6 +1993,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             ORTK_CHECK_LAUNCH();
             return 0;
         }
+        // (the fp32 MFMA kernel has no fused column sums: the same sums from their own launch)
+        if (p.colsum) { if (int e = ortk_colsum(p.A, ORTK_F32, p.lda, p.colsum, p.K, p.M, stream)) return e; }
         switch (key) {
             case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p, tilesM, tilesN, kchunk); break;

@@ -589,18 +589,16 @@ static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, cons
     int64_t sk = tiles >= 256 ? (M >= 16384 ? 3 : 1) : (384 + tiles / 2) / tiles;
     const int64_t max_sk = std::max<int64_t>(1, M / 512);
     a.splitk = (int)std::max<int64_t>(1, std::min(sk, max_sk));
-    if (c.prec) a.colsum = db;             // bias gradient fused into the wgrad kernel (bf16-MFMA path)
+    a.colsum = db;                         // bias gradient fused into the wgrad kernel (both precisions; ortk_gemm falls back to ortk_colsum)
     if (c.use_side) {
         hipEvent_t ready = c.side->take(), done = c.side->take();
         if (hipEventRecord(ready, c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, ready, 0) != hipSuccess) return ORTK_EINVAL;
         TRY(ortk_gemm(&a, (ortk_stream)c.side->s));
-        if (db && !c.prec) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)c.side->s));
         if (hipEventRecord(done, c.side->s) != hipSuccess) return ORTK_EINVAL;
         c.reads(dY, done);
         return 0;
     }
     TRY(ortk_gemm(&a, (ortk_stream)c.s));
-    if (db && !c.prec) TRY(ortk_colsum(dY, dydt, lddy, db, M, Nout, (ortk_stream)c.s));
     return 0;
 }
 static int ln_fwd(const Ctx& c, const float* x, int64_t a, int64_t b, void* y, int ydt, float* st, int64_t rows) {

@@ -141,12 +141,17 @@ def test_gemm_f32_split_transposed_layouts_vs_float64(L, M, N, K):
             if K % 32 == 0:
                 o["dgrad"] = gemm(L, Ad, Btd, M, N, K, 0, 1).cpu()
                 o["dgrad_epi"] = gemm(L, Ad, Btd, M, N, K, 0, 1, bias=dev(bias), relu=1, resid=dev(res)).cpu()
-            o["wgrad"] = gemm(L, Atd, Btd, M, N, K, 1, 1).cpu()
+            csum = torch.zeros(M, device="cuda")
+            o["wgrad"] = gemm(L, Atd, Btd, M, N, K, 1, 1, colsum=csum).cpu()      # + fused column sums of A (the bias gradient)
+            o["colsum"] = csum.cpu()
             for sk in (1, 3, 8):
                 o["wgrad_acc%d" % sk] = gemm(L, Atd, Btd, M, N, K, 1, 1, C=dev(C0.clone()), accumulate=1, splitk=sk).cpu()
             out[v] = o
     finally:
         L.set_tuning(**prev)
+    for v in (0, 1):
+        cs = out[v].pop("colsum")
+        torch.testing.assert_close(cs.double(), A.double().sum(1), rtol=0, atol=4 * math.sqrt(K) * 2.0 ** -24 * A.abs().sum(1).max().item())
     for name in out[1]:
         want = ref
         if name == "dgrad_epi":
