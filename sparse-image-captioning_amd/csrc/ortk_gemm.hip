@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(64 * GM * GN, MINB) void gemm_f32x3p_kernel(ortk_ge
     };
     const int l32 = lane & 31, lh = lane >> 5, sw = swz_mk(l32);
     const int fa0 = (wm * 32 * WM + l32) * BK, fb0 = 3 * IA + (wn * 32 * WN + l32) * BK;
-    // one k-step: multiply the tile in `rbuf`; split the raw tile `x` into `wbuf` on the way (SPLIT = false: the last tile)
+    // one k-step: multiply the tile in `rbuf`; split the raw tile `x` into `wbuf` on the way
     auto step = [&](const __bf16* rbuf, __bf16* wbuf, const f32x4 (&x)[NC][2]) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
