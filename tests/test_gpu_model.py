@@ -1204,6 +1204,35 @@ def test_decode_at_bench_size_properties(P, full_state):
         assert (l4 - l1[:64])[same].abs().mean().item() < 0.01
 
 
+def test_fp32_parity_decode_at_bench_size_split_products_vs_fp32_mfma(P, full_state):
+    """The token-exact (fp32 parity) decode at BASELINE's decode size — 1 024 images, beam 5, 36 regions, full-size random-init
+    weights: flat logits, the hardest case for token agreement — with its projections as six bf16 MFMA partial products of
+    three-way split operands (ortk_tuning.f32_split = 1, the default; ortk_gemm.hip: gemm_f32x3_kernel / gemm_f32x3p_kernel)
+    against the same decode on the fp32 MFMA kernels (f32_split = 0).  Both are fp32 computations in different summation orders,
+    so the bar allows near-ties: at most 0.5 % of the images may decode to another best caption, and only where the two best
+    captions' scores are within 1e-4 of each other; on identical captions the token log-probs agree to 2e-5.  (Observed: 0 of
+    1 024 captions differ, log-probs within 4e-6.)  Deterministic: the split decode twice gives the same bits."""
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=0)
+    B = 1024
+    b = _cuda(H.torch_batch(C.make_inputs(seed=61, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True)))
+    kw = dict(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 5}, mode="sample")
+    prev = P._lib.set_tuning(f32_split=0)
+    try:
+        with torch.no_grad():
+            s0, l0 = m(**kw)
+            P._lib.set_tuning(f32_split=1)
+            s1, l1 = m(**kw)
+            s2, l2 = m(**kw)
+    finally:
+        P._lib.set_tuning(**prev)
+    assert torch.equal(s1, s2) and torch.equal(l1, l2)
+    differ = (s0 != s1).any(-1)
+    assert differ.float().mean().item() <= 0.005, int(differ.sum())
+    if differ.any():
+        assert (l0.sum(-1) - l1.sum(-1))[differ].abs().max().item() < 1e-4
+    assert (l0 - l1)[~differ].abs().max().item() < 2e-5
+
+
 def test_decode_executor_is_chosen_by_size(P, full_state):
     """Default dispatch (no `executor` option): decodes of at most 4 096 rows run the column-split stack kernel when the model has the
     GPU to itself (`exclusive_gpu`, the default) and the unfused executor when it has not (below 1 600 rows); larger ones the plain
