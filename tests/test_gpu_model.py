@@ -1204,6 +1204,37 @@ def test_decode_at_bench_size_properties(P, full_state):
         assert (l4 - l1[:64])[same].abs().mean().item() < 0.01
 
 
+def test_fp32_parity_xe_step_at_bench_size_split_products_vs_fp32_mfma(P, full_state):
+    """The fp32 parity XE step at BASELINE configs[1]'s size (256 images x 5 captions x 36 regions, full-size weights) with every
+    GEMM layout as split bf16 products (f32_split = 1: gemm_f32x3_kernel / gemm_f32x3p_kernel forward, gemm_f32x3t_kernel for the
+    data and weight gradients, fused bias-gradient column sums) against the same step on the fp32 MFMA kernels (f32_split = 0):
+    both in eval mode (no dropout draws), same weights.  The north star's bar for the loss is 1e-4 against the reference; the two
+    fp32 evaluations have to agree far inside it: loss within 2e-6 relative, the whole gradient arena within 3e-4 of its norm
+    (observed 1.2e-4: three times the bar the fp32 step holds against itself under a permutation of the images) and 2e-3 of its
+    largest entry element-wise (fp32 atomics in both)."""
+    from sparse_image_captioning_amd.training import NativeTrainer
+    m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=0)
+    b = _cuda(H.torch_batch(C.make_inputs(seed=11, n_img=256, n_reg=36, feat=2048, vocab=10001, spi=5, ragged=True)))
+    tr = NativeTrainer(m, noamopt_factor=1.0, noamopt_warmup=20000, keep_grads=True)
+    flat0 = m._flat.clone()
+    out = {}
+    prev = P._lib.set_tuning(f32_split=0)
+    try:
+        for v in (0, 1):
+            P._lib.set_tuning(f32_split=v)
+            with torch.no_grad():
+                m._flat.copy_(flat0)
+            tr.m.zero_(); tr.v.zero_(); tr.step_count = 0
+            m.eval()
+            out[v] = (tr.xe_step(b, train=False).item(), tr.grads.clone())
+    finally:
+        P._lib.set_tuning(**prev)
+    (l0, g0), (l1, g1_) = out[0], out[1]
+    assert np.isfinite(l1) and abs(l1 - l0) <= 2e-6 * abs(l0), (l0, l1)
+    rel, mx = (g1_ - g0).norm().item() / g0.norm().item(), (g1_ - g0).abs().max().item() / g0.abs().max().item()
+    assert rel <= 3e-4 and mx <= 2e-3, (rel, mx)
+
+
 def test_fp32_parity_decode_at_bench_size_split_products_vs_fp32_mfma(P, full_state):
     """The token-exact (fp32 parity) decode at BASELINE's decode size — 1 024 images, beam 5, 36 regions, full-size random-init
     weights: flat logits, the hardest case for token agreement — with its projections as six bf16 MFMA partial products of
