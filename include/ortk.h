@@ -329,6 +329,8 @@ typedef struct ortk_tuning {
                                 operand split into three bf16 parts and six partial products kept (fp32-level error, ortk_gemm.hip:
                                 gemm_f32x3_kernel / gemm_f32x3p_kernel) | 0 the fp32 MFMA kernel | 2..7 as 1 with a fixed kernel instance
                                 (single-buffered 64x64, 128x64, 128x128; pipelined 64x64, 128x64, 256x128) */
+    int32_t wgrad_wgs;       /* workgroups a weight-gradient GEMM with fewer than 256 output tiles is split into along K (384: tuned with the kernel alone
+                                on the chip; fewer = fewer split-K atomics, which run at 1.3 TB/s at the memory side) */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

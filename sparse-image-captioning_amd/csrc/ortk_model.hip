@@ -586,7 +586,8 @@ static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, cons
     // path's shapes (scratch/wgrad_bench.py): ~384 workgroups (1.5 per CU) for the small outputs, 3 splits for the
     // 10112x512 generator (632 tiles alone leave a 23 % tail), never fewer than 8 K-steps per workgroup.
     const int64_t tiles = ortk_cdiv(Nout, 128) * ortk_cdiv(Kin, 128);
-    int64_t sk = tiles >= 256 ? (M >= 16384 ? 3 : 1) : (384 + tiles / 2) / tiles;
+    const int64_t wgs = ortk::tuning().wgrad_wgs;
+    int64_t sk = tiles >= 256 ? (M >= 16384 ? 3 : 1) : (wgs + tiles / 2) / tiles;
     const int64_t max_sk = std::max<int64_t>(1, M / 512);
     a.splitk = (int)std::max<int64_t>(1, std::min(sk, max_sk));
     a.colsum = db;                         // bias gradient fused into the wgrad kernel (both precisions; ortk_gemm falls back to ortk_colsum)
@@ -773,12 +774,12 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
 extern "C" int ortk_set_tuning(const ortk_tuning* t) {
-    if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1 || t->f32_split < 0 || t->f32_split > 7) return ORTK_EINVAL;
+    if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1 || t->f32_split < 0 || t->f32_split > 7 || t->wgrad_wgs < 1) return ORTK_EINVAL;
     ortk::g_tuning = *t;
     return 0;
 }
