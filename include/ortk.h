@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ORTK_VERSION 1
+#define ORTK_VERSION 2      /* bumped whenever a struct or a signature of this header changes: a binding must refuse another version */
 #define ORTK_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ORTK_ENOSPC (-2)   /* workspace too small */
 #define ORTK_ENOSYS (-3)   /* option not implemented (e.g. ACORT weight sharing) */
@@ -331,6 +331,13 @@ typedef struct ortk_tuning {
                                 (single-buffered 64x64, 128x64, 128x128; pipelined 64x64, 128x64, 256x128) */
     int32_t wgrad_wgs;       /* workgroups a weight-gradient GEMM with fewer than 256 output tiles is split into along K (384: tuned with the kernel alone
                                 on the chip; fewer = fewer split-K atomics, which run at 1.3 TB/s at the memory side) */
+    int32_t wgrad_group;     /* grouped weight gradients (ortk_wgrad_group: the weight gradients of a layer in one launch on the side stream), bit mask:
+                                1 the encoder / decoder layers | 2 the generator | 4 the memory's K|V projection | 8 the row ranges of a tile meet in
+                                memory (workspace) instead of adding with atomics.  0 = one launch per projection (ortk_gemm).  Mixed precision only */
+    int32_t wgrad_group_splitk;   /* row ranges of every grouped launch of the executor: 0 automatic (the two fields below) | 1..8 */
+    int32_t wgrad_group_wgs;      /* workgroups a grouped launch of the executor is given (row ranges = this / its 256 x 256 tiles, rounded; 80: the
+                                     launch shares the chip with the caller's stream instead of filling it, scratch/wgrad_group_ab.py) */
+    int32_t wgrad_group_tail;     /* 1 (default): the last group before the caller's stream waits for the side stream gets a full round of workgroups | 0 */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);
@@ -490,6 +497,33 @@ typedef struct ortk_gemm_args {
     const int32_t* drop_rows;   /* applied before drop_row_stride / drop_row_off */
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
+/* The weight (and bias) gradients of up to ORTK_WGRAD_MAX projections over the SAME `rows` batch rows in one launch (mixed precision):
+ *   dW_i (Nout_i x Kin_i, fp32, ld lddw) += dY_i^T X_i,   db_i (Nout_i, optional) += column sums of dY_i,
+ * dY_i (rows x Nout_i) and X_i (rows x Kin_i) bf16 row-major, 16-byte aligned, leading dimensions and widths multiples of 8.
+ * Replaces the per-Linear weight / bias autograd of the reference's step (scripts/train_transformer.py:65-81 over the nn.Linear
+ * modules of models/transformer.py:214-358): a layer's gradients share one grid of 256 x 256 tiles x `splitk` row ranges
+ * (0 = automatic: one round of workgroups) that add into the arena with 256-byte atomic rows; any row count.  ORTK_EINVAL for
+ * anything else (the caller then runs the same products through ortk_gemm, transA = transB = 1, accumulate). */
+#define ORTK_WGRAD_MAX 8
+typedef struct ortk_wgrad_item {
+    const void* dY; int64_t lddy;
+    const void* X; int64_t ldx;
+    float* dW; int64_t lddw;
+    float* db;
+    int32_t Nout, Kin;
+} ortk_wgrad_item;
+typedef struct ortk_wgrad_group_args {
+    ortk_wgrad_item item[ORTK_WGRAD_MAX];
+    int32_t n, splitk;
+    int64_t rows;
+    int32_t flags;      /* 0; measurement only: 1 = both waves of a SIMD in lock step (one barrier per stage) instead of the ping-pong schedule,
+                           2 / 4 = (with 1) no products / no operand fetch, 8 = atomics although a workspace is given */
+    void* ws; size_t ws_bytes;   /* optional, 256-byte aligned, ortk_wgrad_group_workspace_bytes(a): the row ranges of a tile then meet in memory
+                                    (partial tiles + a ticket per tile; the last range to arrive adds them up with plain loads / stores) instead
+                                    of adding to the arena with atomics.  The workspace must not be shared by launches on different streams. */
+} ortk_wgrad_group_args;
+int ortk_wgrad_group(const ortk_wgrad_group_args* a, ortk_stream stream);
+size_t ortk_wgrad_group_workspace_bytes(const ortk_wgrad_group_args* a);
 /* Measurement hook (off by default, never on inside a timed region): HIP events around every ortk_gemm launch on its
  * launch stream, summed per kernel instance key = precision*4 + transA*2 + transB.  collect() synchronises.
  * on = 1: the executor also keeps every launch on the caller's stream (kernels timed one at a time); on = 2: the schedule of

@@ -101,7 +101,8 @@ class MaskedAdamArgs(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
-                ("side_stream", C.c_int32), ("row_chain", C.c_int32), ("chain_wide", C.c_int32), ("spmm_alias", C.c_int32), ("f32_split", C.c_int32), ("wgrad_wgs", C.c_int32)]
+                ("side_stream", C.c_int32), ("row_chain", C.c_int32), ("chain_wide", C.c_int32), ("spmm_alias", C.c_int32), ("f32_split", C.c_int32), ("wgrad_wgs", C.c_int32),
+                ("wgrad_group", C.c_int32), ("wgrad_group_splitk", C.c_int32), ("wgrad_group_wgs", C.c_int32), ("wgrad_group_tail", C.c_int32)]
 
 
 DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL, DEC_SPARSE_GATHER = 1, 2, 4, 8, 16, 32, 64      # ortk_decode_opts.exec_flags
@@ -128,6 +129,19 @@ class GemmArgs(C.Structure):
                 ("ln_a", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
                 ("ln_x", C.c_void_p), ("ln_dres", C.c_void_p), ("ln_da", C.c_void_p), ("ln_db", C.c_void_p),
                 ("tile_stats", C.c_void_p), ("stat_ncols", C.c_int32), ("drop_rows", C.c_void_p)]
+
+
+class WgradItem(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("lddy", C.c_int64), ("X", C.c_void_p), ("ldx", C.c_int64),
+                ("dW", C.c_void_p), ("lddw", C.c_int64), ("db", C.c_void_p), ("Nout", C.c_int32), ("Kin", C.c_int32)]
+
+
+WGRAD_MAX = 8
+
+
+class WgradGroupArgs(C.Structure):
+    _fields_ = [("item", WgradItem * WGRAD_MAX), ("n", C.c_int32), ("splitk", C.c_int32), ("rows", C.c_int64), ("flags", C.c_int32),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
 class AttnArgs(C.Structure):
@@ -178,6 +192,8 @@ SIGNATURES = {
     "ortk_get_tuning": (None, [C.POINTER(Tuning)]),
     "ortk_set_tuning": (_I32, [C.POINTER(Tuning)]),
     "ortk_gemm": (_I32, [C.POINTER(GemmArgs), _P]),
+    "ortk_wgrad_group": (_I32, [C.POINTER(WgradGroupArgs), _P]),
+    "ortk_wgrad_group_workspace_bytes": (_SZ, [C.POINTER(WgradGroupArgs)]),
     "ortk_prof_enable": (_I32, [_I32]),
     "ortk_prof_collect": (_I32, [_I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ortk_prof_collect_bytes": (_I32, [_I32, C.POINTER(C.c_double)]),
@@ -225,6 +241,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2      # include/ortk.h: ORTK_VERSION
 
 
 def lib():
@@ -236,6 +253,11 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C sparse-image-captioning_amd/csrc`).  There is no CPU / PyTorch fallback.")
         h = C.CDLL(LIB_PATH)
+        h.ortk_version.restype = C.c_int32
+        if h.ortk_version() != ABI_VERSION:
+            raise OrtkUnavailable(
+                f"{LIB_PATH} is ABI version {h.ortk_version()}, these bindings were written for version {ABI_VERSION} (include/ortk.h: "
+                "ORTK_VERSION): a stale build.  Rebuild it with `make -C sparse-image-captioning_amd/csrc`.")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype = res

@@ -16,6 +16,7 @@ bool ortk_prof_serial();
 // the same measurement hook around a launch that is not an ortk_gemm; ortk_prof_collect(key) then reports it
 constexpr int PROF_KEY_DECSTACK = 16;
 constexpr int PROF_KEY_CHAIN = 17;        // row_chain_kernel launches (ortk_chain.hip)
+constexpr int PROF_KEY_WGRAD_GROUP = 18;  // wgrad_group_kernel launches (ortk_wgrad.hip)
 struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; int slot = -1; double per_count = 0.0; };
 bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m);
 void prof_end(const ProfMark& m, hipStream_t s);

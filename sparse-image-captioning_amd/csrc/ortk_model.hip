@@ -336,6 +336,12 @@ struct TrainWS {
     void* chain_pk = nullptr;               // weight units of the rows-stationary chains in streaming order (chain_layout; mixed precision)
     void* chain_pk_b = nullptr;             // ... of the backward chains (bchain_layout, from the transposed copy)
     void* gh2 = nullptr;                    // second FFN hidden-gradient buffer: the backward chains alternate (a weight gradient still reads the other)
+    // grouped weight gradients (ortk_wgrad_group, mixed precision): a layer's dY operands stay alive until the layer's ONE launch on the
+    // side stream has read them, while the next layer's are already being written
+    static constexpr int NGT = 10;          // (rows, d) gradient temporaries in rotation: 4 per decoder layer, two layers alive + slack
+    void* gtp[NGT] = {};
+    void* gqkv2 = nullptr;                  // layers alternate between gqkv / gqkv2 and gh / gh2
+    void* wg_ws = nullptr; size_t wg_ws_bytes = 0;      // partial tiles + tickets of one grouped launch (launches are ordered by their stream)
     size_t bytes;
 };
 
@@ -391,6 +397,19 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
         if (cs.bytes) w.chain_pk = b.take_bytes(cs.bytes);
         ChainSet bs; bchain_layout(c, o, bs, true);
         if (bs.bytes) { w.chain_pk_b = b.take_bytes(bs.bytes); w.gh2 = act(Mx * ff); }
+    }
+    if (c.precision) {
+        w.gtp[0] = w.gt; w.gtp[1] = w.gt2; w.gtp[2] = w.gt3;
+        for (int i = 3; i < TrainWS::NGT; ++i) w.gtp[i] = act(Mx * d);
+        w.gqkv2 = act(Mx * 3 * d);
+        if (!w.gh2) w.gh2 = act(Mx * ff);
+        // the largest group: a decoder layer (6 projections), an encoder layer, the generator, the memory's K|V projection
+        const int64_t lay_tiles = 2 * ortk_cdiv(d, 256) * ortk_cdiv(ff, 256) + 4 * ortk_cdiv(d, 256) * ortk_cdiv(d, 256) + ortk_cdiv(3 * d, 256) * ortk_cdiv(d, 256);
+        const int64_t gen_tiles = ortk_cdiv(w.ldv, 256) * ortk_cdiv(d, 256), kv_tiles = ortk_cdiv(L * 2 * d, 256) * ortk_cdiv(d, 256);
+        const int64_t tiles = std::max(lay_tiles, std::max(gen_tiles, kv_tiles));
+        // (at most max(256, tiles) partial tiles per launch: the K ranges are chosen for one round of workgroups; a forced split of 8 at most)
+        w.wg_ws_bytes = (size_t)(((tiles * 4 + 255) & ~(int64_t)255) + std::max<int64_t>(256 + tiles, tiles * 8) * 256 * 256 * 4);
+        w.wg_ws = b.take_bytes(w.wg_ws_bytes);
     }
     w.bytes = (b.off + 255) & ~(size_t)255;
 }
@@ -451,7 +470,11 @@ struct Ctx {
     bool use_side = false;                       // weight-gradient GEMMs (and other independent work) on `side`
     SideStream* side = nullptr;                  // the side stream of this call's (device, caller stream)
     struct Pend { const void* buf; hipEvent_t done; };
-    mutable Pend pend[8] = {};                   // buffers a forked, not yet joined wgrad reads
+    mutable Pend pend[32] = {};                  // buffers a forked, not yet joined wgrad reads
+    // weight gradients collected for ONE grouped launch (ortk_wgrad_group): wgrad_gemm appends while `grp_on`, flush_wgrads launches
+    mutable ortk_wgrad_group_args grp = {};
+    bool grp_on = false;
+    void* wg_ws = nullptr; size_t wg_ws_bytes = 0;
     mutable hipEvent_t last_done = nullptr;
     void reads(const void* buf, hipEvent_t done) const {
         for (auto& p : pend) if (p.buf == buf || p.buf == nullptr) { p.buf = buf; p.done = done; last_done = done; return; }
@@ -576,9 +599,49 @@ static int dgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, int6
     TRY(c.before_write(dX));
     return ortk_gemm(&a, (ortk_stream)c.s);
 }
+// the collected weight gradients of a layer in ONE launch (ortk_wgrad.hip), on the side stream when there is one: the launch waits for
+// everything queued on the caller's stream so far (the last dY), and every dY it reads is marked pending until it is done
+// Row ranges: a launch that fills the chip keeps the caller's stream waiting (its workgroups hold a compute unit's LDS each: 11.4 ms per XE
+// step against 11.3 ungrouped), so a group gets about ortk_tuning.wgrad_group_wgs workgroups — with the ~130-workgroup data-gradient
+// launches of the caller's stream the two queues then share the 256 units side by side (10.7 ms).  `urgent`: the caller's stream is about
+// to wait for this launch (the last group before a join): one full round of workgroups.
+static int flush_wgrads(const Ctx& c, bool urgent = false) {
+    if (c.grp.n == 0) return 0;
+    int64_t tiles = 0;
+    for (int i = 0; i < c.grp.n; ++i) tiles += ortk_cdiv(c.grp.item[i].Nout, 256) * ortk_cdiv(c.grp.item[i].Kin, 256);
+    const int forced = tuning().wgrad_group_splitk, target = tuning().wgrad_group_wgs;
+    c.grp.splitk = forced > 0 ? forced : (urgent && tuning().wgrad_group_tail) ? 0 : (int)std::max<int64_t>(1, (target + tiles / 2) / tiles);
+    c.grp.flags = 0;
+    c.grp.ws = nullptr; c.grp.ws_bytes = 0;
+    if (tuning().wgrad_group & 8) {
+        const size_t need = ortk_wgrad_group_workspace_bytes(&c.grp);
+        if (need && need <= c.wg_ws_bytes) { c.grp.ws = c.wg_ws; c.grp.ws_bytes = c.wg_ws_bytes; }
+    }
+    int e = 0;
+    if (c.use_side) {
+        hipEvent_t ready = c.side->take(), done = c.side->take();
+        if (hipEventRecord(ready, c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, ready, 0) != hipSuccess) return ORTK_EINVAL;
+        e = ortk_wgrad_group(&c.grp, (ortk_stream)c.side->s);
+        if (!e && hipEventRecord(done, c.side->s) != hipSuccess) e = ORTK_EINVAL;
+        if (!e) for (int i = 0; i < c.grp.n; ++i) c.reads(c.grp.item[i].dY, done);
+    } else {
+        e = ortk_wgrad_group(&c.grp, (ortk_stream)c.s);
+    }
+    c.grp.n = 0;
+    return e;
+}
 // dW += dY^T X ; db += colsum(dY)
 static int wgrad_gemm(const Ctx& c, const void* dY, int dydt, int64_t lddy, const void* X, int xdt, int64_t ldx, float* dW, float* db,
                       int64_t M, int Nout, int Kin) {
+    if (c.grp_on && dydt == ORTK_BF16 && xdt == ORTK_BF16 && !(Nout & 7) && !(Kin & 7) && Nout >= 8 && Kin >= 8 && !(lddy & 7) && !(ldx & 7) &&
+        !(reinterpret_cast<uintptr_t>(dY) & 15) && !(reinterpret_cast<uintptr_t>(X) & 15) && (c.grp.n == 0 || c.grp.rows == M)) {
+        if (c.grp.n == ORTK_WGRAD_MAX) TRY(flush_wgrads(c));
+        ortk_wgrad_item& it = c.grp.item[c.grp.n++];
+        it.dY = dY; it.lddy = lddy; it.X = X; it.ldx = ldx; it.dW = dW; it.lddw = Kin; it.db = db; it.Nout = Nout; it.Kin = Kin;
+        c.grp.rows = M;
+        return 0;
+    }
+    TRY(flush_wgrads(c));      // (keeps the order of the additions into a shared weight block)
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
     a.A = dY; a.a_dtype = dydt; a.lda = lddy; a.transA = 1; a.B = X; a.b_dtype = xdt; a.ldb = ldx; a.transB = 1; a.C = dW; a.ldc = Kin;
     a.M = Nout; a.N = Kin; a.K = (int)M; a.accumulate = 1; a.precision = c.prec;
@@ -774,12 +837,13 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384, 3, 0, 80, 1};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
 extern "C" int ortk_set_tuning(const ortk_tuning* t) {
-    if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1 || t->f32_split < 0 || t->f32_split > 7 || t->wgrad_wgs < 1) return ORTK_EINVAL;
+    if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1 || t->f32_split < 0 || t->f32_split > 7 || t->wgrad_wgs < 1 ||
+        t->wgrad_group < 0 || t->wgrad_group > 15 || t->wgrad_group_splitk < 0 || t->wgrad_group_splitk > 8 || t->wgrad_group_wgs < 1 || t->wgrad_group_tail < 0 || t->wgrad_group_tail > 1) return ORTK_EINVAL;
     ortk::g_tuning = *t;
     return 0;
 }
@@ -1138,18 +1202,24 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     // first, all dV slices behind them (column L*d on), folded by one add over L*d columns.
     const AttMode ame = att_mode(cfg->share_att_enc), amd = att_mode(cfg->share_att_dec);
     const int64_t cw = o.cw, cv = o.cv, ldg = (int64_t)L * 2 * d, gdv = cfg->share_att_dec == 1 ? (int64_t)L * d : d;
-    auto fold = [&](const AttMode& m, int64_t rows) -> int {
+    auto fold = [&](const AttMode& m, int64_t rows, void* gq) -> int {
         if (m.gsrc < 0) return 0;
-        return ortk_axpy_cols(off_elems(w.gqkv, (int64_t)m.gsrc * d, A), off_elems(w.gqkv, (int64_t)m.gdst * d, A), A, 3 * d, rows, d, stream);
+        return ortk_axpy_cols(off_elems(gq, (int64_t)m.gsrc * d, A), off_elems(gq, (int64_t)m.gdst * d, A), A, 3 * d, rows, d, stream);
     };
 
     float* dx = w.ga; float* dx2 = w.gb;
     // the (rows, d) bf16 gradient temporary rotates over three buffers: its producers (ln_bwd's masked copy, the cross-
     // attention dQ, the att_embed gate) never have to wait for the side-stream wgrad that still reads the previous one
-    void* gt_pool[3] = {w.gt, w.gt2, w.gt3};
+    // (grouped weight gradients: ten, so that the four of a layer stay untouched until the layer's launch has read them)
+    const int wgm = tuning().wgrad_group;
+    const bool grouped = A == ORTK_BF16 && (wgm & 7) != 0 && w.gtp[TrainWS::NGT - 1] != nullptr;
+    const int n_gt = grouped ? TrainWS::NGT : 3;
+    void* gt_pool[TrainWS::NGT] = {w.gt, w.gt2, w.gt3};
+    for (int i = 3; i < n_gt; ++i) gt_pool[i] = w.gtp[i];
     int gt_i = 0;
     void* gt_cur = w.gt;
-    auto gt_new = [&]() { gt_i = (gt_i + 1) % 3; gt_cur = gt_pool[gt_i]; return gt_cur; };
+    auto gt_new = [&]() { gt_i = (gt_i + 1) % n_gt; gt_cur = gt_pool[gt_i]; return gt_cur; };
+    c.wg_ws = w.wg_ws; c.wg_ws_bytes = w.wg_ws_bytes;
     // Backward chains (ortk_chain.hip): everything between two attention-backward calls except the weight gradients in one
     // rows-stationary launch each.  Mixed precision, bf16 Q / K / V / dO in all three attention stacks, dense products.
     ChainSet bs; bchain_layout(*cfg, o, bs);
@@ -1158,6 +1228,9 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     // ortk_tuning.row_chain: 1 = forward chains only, 2 = + the encoder's backward (one round of workgroups at 9 216 rows), 3 = + the decoder's
     const bool bch_enc = bch_any && tuning().row_chain >= 2, bch = bch_any && tuning().row_chain >= 3;
     if (bch_enc && phase != 2) TRY(chain_pack_all(w.w16t, w.chain_pk_b, bs.t, c.s));
+    const bool grp_layers = grouped && (wgm & 1), grp_gen = grouped && (wgm & 2), grp_kv = grouped && (wgm & 4);
+    auto gq_of = [&](int l) { return (grp_layers && (l & 1)) ? w.gqkv2 : w.gqkv; };
+    auto gh_of = [&](int l) { return (grp_layers && (l & 1)) ? w.gh2 : w.gh; };
     const int NCc = ff / 512;
     int gh_i = 0;
     auto gh_new = [&]() { gh_i ^= 1; return gh_i ? w.gh2 : w.gh; };
@@ -1175,7 +1248,10 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     // of the encoder memory in w.gy.  Every gradient at arena offsets >= ortk_arena_decoder_offset is final afterwards.
     // generator (over the padded vocabulary: pad columns of dlogits are exact zeros)
     const int Vp = (int)w.ldv;
+    c.grp_on = grp_gen;
     TRY(wgrad_gemm(c, w.dlogits, A, w.ldv, w.dec_out, A, d, G + o.gen_w, G + o.gen_b, Md, Vp, d));
+    TRY(flush_wgrads(c));
+    c.grp_on = false;
     TRY(dgrad_gemm(c, w.dlogits, A, w.ldv, o.gen_w, w.gy, ORTK_F32, d, Md, Vp, d));
     TRY(ln_bwd(c, w.gy, w.dec[L - 1].xout, G, o.dec_na, o.dec_nb, w.st_out, nullptr, dx, Md, gt_new(), dop(L - 1, 5)));
     if (bch) {
@@ -1195,6 +1271,8 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         for (int l = L - 1; l >= 0; --l) {
             const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
             const float* xin = l == 0 ? w.dx0 : w.dec[l - 1].xout;
+            void* const gql = gq_of(l);
+            c.grp_on = grp_layers;
             TRY(wgrad_gemm(c, dtA, A, d, b.h, A, ff, G + e.w2, G + e.b2, Md, d, ff));
             TRY(wgrad_gemm(c, ghb, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
             TRY(wgrad_gemm(c, dtB, A, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
@@ -1231,14 +1309,16 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
             a.v = (const float*)off_elems(b.qkv, amd.v * d, w.qdt_self); a.ldq = a.ldk = a.ldv = 3 * d;
             a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
             a.d_o = (const float*)w.gdo; a.lddo = d; a.dqkv_dtype = A;
-            a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, amd.gk * d, A); a.dv = off_elems(w.gqkv, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+            a.dq = gql; a.d_k = off_elems(gql, amd.gk * d, A); a.dv = off_elems(gql, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
             if (compact) { a.q_off = bt->cap_off; a.q_off_stride = 1; a.kv_ragged = 1; }
-            TRY(c.before_write(w.gqkv));
+            TRY(c.before_write(gql));
             TRY(ortk_attention_bwd(&a, stream));
-            TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
+            TRY(wgrad_gemm(c, gql, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, 3 * d, d));
+            TRY(flush_wgrads(c, l == 0));
+            c.grp_on = false;
             // Z (+ X of the layer below): [dQKV . Wqkv -> LayerNorm 0' (+ oth) -> masked copy] [-> FFN' -> LayerNorm 2' -> masked copy -> . Wco]
             ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca)); ca.drop_rows = c.drop_rows;
-            ca.M = Md; ca.nin = 3; ca.ain = w.gqkv; ca.ld_ain = 3 * d;
+            ca.M = Md; ca.nin = 3; ca.ain = gql; ca.ld_ain = 3 * d;
             ca.xa = xin; ca.sta = b.st1; ca.ga = params + e.n0a; ca.dresa = oth; ca.dxa = cur; ca.daa = G + e.n0a; ca.dba = G + e.n0b;
             ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
             if (l > 0) {
@@ -1262,12 +1342,14 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         const DecOff& e = o.dec[l]; const DecBuf& b = w.dec[l];
         const float* xin = l == 0 ? w.dx0 : w.dec[l - 1].xout;
         const void* dt; int dtt;
+        void* const ghl = gh_of(l); void* const gql = gq_of(l);
+        c.grp_on = grp_layers;
         // feed-forward sublayer
         TRY(drop_bwd(c, dx, gt_cur, Md * d, dop(l, 5), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Md, d, ff));
-        TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Md, d, ff, b.h, A, ff, inv_keep));
-        TRY(wgrad_gemm(c, w.gh, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
-        TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Md, ff, d));
+        TRY(dgrad_gemm(c, dt, dtt, d, e.w2, ghl, A, ff, Md, d, ff, b.h, A, ff, inv_keep));
+        TRY(wgrad_gemm(c, ghl, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
+        TRY(dgrad_gemm(c, ghl, A, ff, e.w1, w.gy, ORTK_F32, d, Md, ff, d));
         TRY(ln_bwd(c, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, Md, gt_new(), dop(l, 3)));
         // cross-attention sublayer
         TRY(drop_bwd(c, dx2, gt_cur, Md * d, dop(l, 3), &dt, &dtt, true));
@@ -1299,13 +1381,15 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.v = (const float*)off_elems(b.qkv, amd.v * d, w.qdt_self); a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.Ps; a.nkv = R; a.H = H; a.Lq = T; a.Lk = T; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(dop(l, 0));
         a.d_o = (const float*)dO; a.lddo = d; a.dqkv_dtype = A;
-        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, amd.gk * d, A); a.dv = off_elems(w.gqkv, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+        a.dq = gql; a.d_k = off_elems(gql, amd.gk * d, A); a.dv = off_elems(gql, amd.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         if (compact) { a.q_off = bt->cap_off; a.q_off_stride = 1; a.kv_ragged = 1; }
-        TRY(c.before_write(w.gqkv));
+        TRY(c.before_write(gql));
         TRY(ortk_attention_bwd(&a, stream));
-        TRY(fold(amd, Md));
-        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, amd.n * d, d));
-        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, amd.n * d, d));
+        TRY(fold(amd, Md, gql));
+        TRY(wgrad_gemm(c, gql, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, amd.n * d, d));
+        TRY(flush_wgrads(c, l == 0));        // the layer's six weight gradients: one launch
+        c.grp_on = false;
+        TRY(dgrad_gemm(c, gql, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, amd.n * d, d));
         TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md, gt_new(), l > 0 ? (int)dop(l - 1, 5) : -1));
         std::swap(dx, dx2);
     }
@@ -1326,7 +1410,10 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     for (int l = 0; l < L; ++l)
         if (cfg->share_dec[l] > 0)
             TRY(ortk_axpy_cols(off_elems(w.gkv, gslot[l] * cw, A), off_elems(w.gkv, o.ckv_slot[l] * cw, A), A, ldg, Me, cw, stream));
+    c.grp_on = grp_kv;
     TRY(wgrad_gemm(c, w.gkv, A, ldg, w.mem, A, d, G + o.ckv_w, G + o.ckv_b, Me, (int)(U * cw), d));
+    TRY(flush_wgrads(c, true));
+    c.grp_on = false;
     TRY(dgrad_gemm(c, w.gkv, A, ldg, o.ckv_w, w.gy, ORTK_F32, d, Me, (int)(U * cw), d));
     TRY(c.join());
     c.drop_rows = nullptr;
@@ -1369,6 +1456,8 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         for (int l = L - 1; l >= 0; --l) {
             const EncOff& e = o.enc[l]; const EncBuf& b = w.enc[l];
             const float* xin = l == 0 ? w.x0 : w.enc[l - 1].xout;
+            void* const gql = gq_of(l);
+            c.grp_on = grp_layers;
             TRY(wgrad_gemm(c, dtA, A, d, b.h, A, ff, G + e.w2, G + e.b2, Me, d, ff));
             TRY(wgrad_gemm(c, ghb, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
             TRY(wgrad_gemm(c, dtB, A, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
@@ -1377,14 +1466,16 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
             a.v = (const float*)off_elems(b.qkv, ame.v * d, w.qdt_enc); a.ldq = a.ldk = a.ldv = 3 * d;
             a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
             a.d_o = (const float*)w.gdo; a.lddo = d; a.dqkv_dtype = A;
-            a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, ame.gk * d, A); a.dv = off_elems(w.gqkv, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+            a.dq = gql; a.d_k = off_elems(gql, ame.gk * d, A); a.dv = off_elems(gql, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
             a.dscore = cfg->no_box ? nullptr : w.dscore + (int64_t)l * B * H * S * S;
-            TRY(c.before_write(w.gqkv));
+            TRY(c.before_write(gql));
             TRY(ortk_attention_bwd(&a, stream));
             if (l == 1 && box_split) TRY(box_grad(1, L - 1));
-            TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
+            TRY(wgrad_gemm(c, gql, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, 3 * d, d));
+            TRY(flush_wgrads(c, l == 0));
+            c.grp_on = false;
             ortk_bchain_args ca; std::memset(&ca, 0, sizeof(ca)); ca.drop_rows = c.drop_rows;
-            ca.M = Me; ca.nin = 3; ca.ain = w.gqkv; ca.ld_ain = 3 * d;
+            ca.M = Me; ca.nin = 3; ca.ain = gql; ca.ld_ain = 3 * d;
             ca.xa = xin; ca.sta = b.st1; ca.ga = params + e.n0a; ca.dresa = cur; ca.dxa = oth; ca.daa = G + e.n0a; ca.dba = G + e.n0b;
             ca.drop_p = c.p_drop(); ca.eps = 1e-6f;
             if (l > 0) {
@@ -1407,11 +1498,13 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         const EncOff& e = o.enc[l]; const EncBuf& b = w.enc[l];
         const float* xin = l == 0 ? w.x0 : w.enc[l - 1].xout;
         const void* dt; int dtt;
+        void* const ghl = gh_of(l); void* const gql = gq_of(l);
+        c.grp_on = grp_layers;
         TRY(drop_bwd(c, dx, gt_cur, Me * d, eop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Me, d, ff));
-        TRY(dgrad_gemm(c, dt, dtt, d, e.w2, w.gh, A, ff, Me, d, ff, b.h, A, ff, inv_keep));
-        TRY(wgrad_gemm(c, w.gh, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
-        TRY(dgrad_gemm(c, w.gh, A, ff, e.w1, w.gy, ORTK_F32, d, Me, ff, d));
+        TRY(dgrad_gemm(c, dt, dtt, d, e.w2, ghl, A, ff, Me, d, ff, b.h, A, ff, inv_keep));
+        TRY(wgrad_gemm(c, ghl, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
+        TRY(dgrad_gemm(c, ghl, A, ff, e.w1, w.gy, ORTK_F32, d, Me, ff, d));
         TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me, gt_new(), eop(l, 1)));
         TRY(drop_bwd(c, dx2, gt_cur, Me * d, eop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
@@ -1422,14 +1515,16 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         a.v = (const float*)off_elems(b.qkv, ame.v * d, w.qdt_enc); a.ldq = a.ldk = a.ldv = 3 * d;
         a.p = b.P; a.nkv = B; a.H = H; a.Lq = S; a.Lk = S; a.dk = dk; a.drop_p = c.p_drop(); a.drop_seed = c.sub(eop(l, 0));
         a.d_o = (const float*)dOe; a.lddo = d; a.dqkv_dtype = A;
-        a.dq = w.gqkv; a.d_k = off_elems(w.gqkv, ame.gk * d, A); a.dv = off_elems(w.gqkv, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
+        a.dq = gql; a.d_k = off_elems(gql, ame.gk * d, A); a.dv = off_elems(gql, ame.gv * d, A); a.lddq = a.lddk = a.lddv = 3 * d;
         a.dscore = cfg->no_box ? nullptr : w.dscore + (int64_t)l * B * H * S * S;
-        TRY(c.before_write(w.gqkv));
+        TRY(c.before_write(gql));
         TRY(ortk_attention_bwd(&a, stream));
         if (l == 1 && box_split) TRY(box_grad(1, L - 1));     // layers 1 .. L-1: beside the last two encoder layers
-        TRY(fold(ame, Me));
-        TRY(wgrad_gemm(c, w.gqkv, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, ame.n * d, d));
-        TRY(dgrad_gemm(c, w.gqkv, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, ame.n * d, d));
+        TRY(fold(ame, Me, gql));
+        TRY(wgrad_gemm(c, gql, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, ame.n * d, d));
+        TRY(flush_wgrads(c, l == 0));        // the layer's four weight gradients: one launch
+        c.grp_on = false;
+        TRY(dgrad_gemm(c, gql, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, ame.n * d, d));
         TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, gt_new(), l > 0 ? (int)eop(l - 1, 3) : -1));
     }
     // geometry bias weights: layer 0 (with the side stream; else all layers), beside the att_embed gradient

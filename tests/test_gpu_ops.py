@@ -189,6 +189,50 @@ def test_gemm_epilogues_and_splitk(L):
     assert torch.equal(out, out2)                                            # counter-based: reproducible
 
 
+@pytest.mark.parametrize("mode", ["atomics", "workspace"])
+@pytest.mark.parametrize("rows,shapes,splitk,ldpad", [
+    (1017, [(512, 512), (1536, 512), (512, 2048), (2048, 512)], 0, 0),        # a layer's projections, ragged row count
+    (333, [(264, 520), (8, 8), (128, 1000)], 0, 8),                            # partial tiles, padded leading dimensions
+    (4097, [(10112, 512)], 3, 0),                                              # the generator's padded vocabulary, three row ranges
+    (31, [(512, 256)], 0, 0), (32, [(512, 256)], 0, 0), (69, [(256, 256)], 0, 0),   # fewer rows than a stage; exactly one; one + a tail
+    (16640, [(512, 512), (1536, 512)], 4, 0),                                  # the XE step's valid decoder rows, four row ranges
+    (2048, [(512, 512)] * 8, 2, 0)])                                           # ORTK_WGRAD_MAX projections
+def test_wgrad_group_vs_torch(L, mode, rows, shapes, splitk, ldpad):
+    """ortk_wgrad_group: dW_i += dY_i^T X_i and db_i += colsum(dY_i) of every projection of the group in one launch, against torch
+    fp32 products of the same bf16 operands (the per-Linear weight / bias autograd of the reference's step,
+    scripts/train_transformer.py:65-81).  fp32 accumulation of exact bf16 products: the bar is the order of the additions
+    (1e-5 of the largest entry), in both reduction forms (atomic rows / partial tiles + last arriver) and on a reused workspace."""
+    lib = L.lib()
+    a = L.WgradGroupArgs(); a.n = len(shapes); a.rows = rows; a.splitk = splitk
+    items = []
+    for i, (n, k) in enumerate(shapes):
+        dY = dev((rnd(rows, n + ldpad, seed=3 * i) * 0.5).bfloat16()); X = dev(rnd(rows, k + ldpad, seed=3 * i + 1).bfloat16())
+        dW = dev(rnd(n, k, seed=3 * i + 2)); db = dev(rnd(n, seed=3 * i + 5))
+        it = a.item[i]
+        it.dY, it.lddy, it.X, it.ldx, it.dW, it.lddw, it.db, it.Nout, it.Kin = dY.data_ptr(), n + ldpad, X.data_ptr(), k + ldpad, dW.data_ptr(), k, db.data_ptr(), n, k
+        items.append((dY, X, dW, db, n, k, dW.clone(), db.clone()))
+    need = lib.ortk_wgrad_group_workspace_bytes(C.byref(a))
+    if mode == "workspace":
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device="cuda"); _KEEP.append(ws)
+        a.ws, a.ws_bytes = ws.data_ptr(), need
+    for rep in range(2):          # the second launch adds on top of the first (and reuses the workspace)
+        L.check(lib.ortk_wgrad_group(C.byref(a), L.stream_ptr()), "ortk_wgrad_group")
+    torch.cuda.synchronize()
+    for dY, X, dW, db, n, k, dW0, db0 in items:
+        ref = dW0.double() + 2 * (dY[:, :n].double().t() @ X[:, :k].double())
+        refb = db0.double() + 2 * dY[:, :n].double().sum(0)
+        assert (dW.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        assert (db.double() - refb).abs().max().item() <= 1e-5 * refb.abs().max().item()
+    # what the launcher refuses: odd widths, misaligned operands, a workspace that is too small
+    bad = L.WgradGroupArgs.from_buffer_copy(a); bad.item[0].Nout = shapes[0][0] - 1
+    assert lib.ortk_wgrad_group(C.byref(bad), L.stream_ptr()) == -1
+    bad = L.WgradGroupArgs.from_buffer_copy(a); bad.item[0].dY = a.item[0].dY + 2
+    assert lib.ortk_wgrad_group(C.byref(bad), L.stream_ptr()) == -1
+    if mode == "workspace" and need:
+        bad = L.WgradGroupArgs.from_buffer_copy(a); bad.ws_bytes = need - 1
+        assert lib.ortk_wgrad_group(C.byref(bad), L.stream_ptr()) == -2
+
+
 @pytest.mark.parametrize("rows,d", [(7, 64), (300, 512), (33, 100), (5, 2048)])
 def test_layernorm_fwd_bwd(L, rows, d):
     x, a, b, dy, dres = rnd(rows, d, seed=1, scale=2.0), 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3), rnd(rows, d, seed=4), rnd(rows, d, seed=5)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/ortk.h but not exported by libortk.so"
     # the ctypes signature table covers the header one-to-one
     assert sorted(P._lib.SIGNATURES) == names
-    assert lib.ortk_version() == 1
+    assert lib.ortk_version() == P._lib.ABI_VERSION == int(re.search(r"#define ORTK_VERSION (\d+)", open(os.path.join(ROOT, "include", "ortk.h")).read()).group(1))
 
 
 def test_every_header_under_include_is_fully_exported():
