@@ -328,7 +328,11 @@ typedef struct ortk_tuning {
     int32_t f32_split;       /* fp32 products of the forward layout (precision 0: the fp32 parity mode): 1 (default) on the bf16 matrix cores, every
                                 operand split into three bf16 parts and six partial products kept (fp32-level error, ortk_gemm.hip:
                                 gemm_f32x3_kernel / gemm_f32x3p_kernel) | 0 the fp32 MFMA kernel | 2..7 as 1 with a fixed kernel instance
-                                (single-buffered 64x64, 128x64, 128x128; pipelined 64x64, 128x64, 256x128) */
+                                (single-buffered 64x64, 128x64, 128x128; pipelined 64x64, 128x64, 256x128).
+                                PRECONDITION of the split forms: finite operands with |x| < 3.39e38 (bf16(x) must not round to infinity).  An
+                                infinite or FLT_MAX-class operand makes the second and third parts NaN (x - inf), where the fp32 MFMA kernel
+                                (f32_split = 0) propagates the infinity; the path's operands (activations, weights, gradients under
+                                clip_grad_value_) are far inside the range, and a guard costs two vector instructions per staged element */
     int32_t wgrad_wgs;       /* workgroups a weight-gradient GEMM with fewer than 256 output tiles is split into along K (384: tuned with the kernel alone
                                 on the chip; fewer = fewer split-K atomics, which run at 1.3 TB/s at the memory side) */
     int32_t wgrad_group;     /* grouped weight gradients (ortk_wgrad_group: the weight gradients of a layer in one launch on the side stream), bit mask:
@@ -517,7 +521,7 @@ typedef struct ortk_wgrad_group_args {
     int32_t n, splitk;
     int64_t rows;
     int32_t flags;      /* 0; measurement only: 1 = both waves of a SIMD in lock step (one barrier per stage) instead of the ping-pong schedule,
-                           2 / 4 = (with 1) no products / no operand fetch, 8 = atomics although a workspace is given */
+                           8 = atomics although a workspace is given */
     void* ws; size_t ws_bytes;   /* optional, 256-byte aligned, ortk_wgrad_group_workspace_bytes(a): the row ranges of a tile then meet in memory
                                     (partial tiles + a ticket per tile; the last range to arrive adds them up with plain loads / stores) instead
                                     of adding to the arena with atomics.  The workspace must not be shared by launches on different streams. */

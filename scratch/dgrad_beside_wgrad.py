@@ -1,6 +1,6 @@
 """What slows a data-gradient GEMM of the XE step down beside a grouped weight-gradient launch on another stream?
 dgrad: (16640 x 512) x (512 x 512)^T on the 256 x 256 LDS-DMA tiles (130 workgroups), repeated back to back on stream 1 while
-stream 2 runs decoder-layer weight-gradient groups of a given shape (workgroups = 56 x splitk; ablations: no products / no fetch)."""
+stream 2 runs decoder-layer weight-gradient groups of a given shape (workgroups = 56 x splitk)."""
 import sys, ctypes as C, time
 sys.path[:0] = ["/root/repo", "/root/repo/scratch"]
 import torch
@@ -30,7 +30,7 @@ for (N, K, f32) in ((512, 512, True), (2048, 512, False), (512, 2048, True)):
     run(dg, None, 5)
     base = run(dg, None)
     line = f"dgrad {M}x{N}x{K}: alone {base:6.1f} us"
-    for sk, fl, name in ((1, 0, "56 wgs"), (2, 0, "112 wgs"), (4, 0, "224 wgs"), (1, 1 | 2, "56 wgs no-mfma"), (1, 1 | 4, "56 wgs no-dma"), (2, 1 | 2, "112 no-mfma"), (2, 1 | 4, "112 no-dma")):
+    for sk, fl, name in ((1, 0, "56 wgs"), (2, 0, "112 wgs"), (4, 0, "224 wgs")):
         wg, keep2 = group(M, shapes, sk); wg.flags = fl
         lib.ortk_wgrad_group(C.byref(wg), s2.cuda_stream); torch.cuda.synchronize()
         # enough wgrad launches to cover the dgrads

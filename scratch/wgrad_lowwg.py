@@ -12,7 +12,7 @@ for name, rows, shapes, sk in (("decoder layer", 16640, [(d, ff), (ff, d), (d, d
                                ("generator", 16640, [(10112, d)], 1)):
     a, keep = group(rows, shapes, sk)
     tiles = sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in shapes)
-    for fl, nm in ((0, "pingpong (2 phases)"), (32, "pingpong (4 phases)")):
+    for fl, nm in ((0, "ping-pong"), (1, "lock step")):
         a.flags = fl
         t = timeit(lambda: lib.ortk_wgrad_group(C.byref(a), s))
         st = rows / sk / 32

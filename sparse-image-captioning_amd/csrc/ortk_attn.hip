@@ -1156,21 +1156,10 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a_in, ortk_stream stream
     }
     if ((attn_impl() == 0 || a->qkv_dtype) && ortk::attn16_ok(a, false)) return ortk::attn16_fwd(a, ortk_s(stream));   // mixed precision
     if (a->qkv_dtype || a->q_off) return ORTK_EINVAL;   // bf16 Q / K / V and ragged groups are only understood by the bf16-operand kernels
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)fwd_lds_bytes(MAXK));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * 4 * (2 * 64 * KP + 128)));
-        attr_set = true;
-    }
+    ortk::lds_attr(reinterpret_cast<const void*>(attn_fwd_kernel), fwd_lds_bytes(MAXK));
+    ortk::lds_attr(reinterpret_cast<const void*>(attn_fwd_wave_kernel), sizeof(float) * 4 * (2 * 64 * KP + 128));
     if (a->drop_tf_T > 0) {      // teacher-forced dropout geometry (train-mode decode step): the generic kernel
         if (a->kv_dtype || a->qkv_dtype || a->Lk > MAXK || a->dk > MAXD) return ORTK_EINVAL;
-        static bool attr_tf = false;
-        if (!attr_tf) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes(MAXK));
-            attr_tf = true;
-        }
         hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(a->nkv * a->H)), dim3(256), fwd_lds_bytes(a->Lk), ortk_s(stream), *a);
         ORTK_CHECK_LAUNCH();
         return 0;
@@ -1217,12 +1206,8 @@ extern "C" int ortk_attention_fwd(const ortk_attn_args* a_in, ortk_stream stream
         const int Lkp = (int)ortk_align(a->Lk, 16), DKP = (int)ortk_align(a->dk, 16);
         const int nw = (int)std::min<int64_t>(8, ortk_cdiv(a->Lq, 16));
         const size_t lds = sizeof(float) * ((size_t)Lkp * (PK_ + PN_) + 64 + (size_t)nw * 16 * PK_ * 2);
-        static bool mf_attr = false;
-        if (!mf_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            mf_attr = true;
-        }
+        ortk::lds_attr(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<0, 0>), 160 * 1024);
+        ortk::lds_attr(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<64, 64>), 160 * 1024);
         const dim3 mgrid((unsigned)(a->nkv * a->H)), mblock(64 * nw);
         if (DKP == 64 && Lkp == 48)      hipLaunchKernelGGL((attn_fwd_mfma_kernel<48, 64>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP);
         else if (DKP == 64 && Lkp == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, 64>), mgrid, mblock, lds, ortk_s(stream), *a, Lkp, DKP);
@@ -1247,16 +1232,9 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
     if ((attn_impl() == 0 || a->qkv_dtype) && ortk::attn16_ok(a, true))     // mixed precision: one kernel does both parts
         return a->bwd_part == 2 ? 0 : ortk::attn16_bwd(a, ortk_s(stream));
     if (a->qkv_dtype || a->q_off) return ORTK_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)bwd_lds_bytes(MAXK));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wave_kernel<64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * (2 * 64 * KP + 192)));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wave_kernel<48>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * (2 * 48 * KP + 192)));
-        attr_set = true;
-    }
+    ortk::lds_attr(reinterpret_cast<const void*>(attn_bwd_kernel), bwd_lds_bytes(MAXK));
+    ortk::lds_attr(reinterpret_cast<const void*>(attn_bwd_wave_kernel<64>), sizeof(float) * 4 * (2 * 64 * KP + 192));
+    ortk::lds_attr(reinterpret_cast<const void*>(attn_bwd_wave_kernel<48>), sizeof(float) * 4 * (2 * 48 * KP + 192));
     const int pairs = a->nkv * a->H;
     if (small_ok(a) && attn_impl() == 0 && a->ldv % 4 == 0 && a->lddo % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(a->v) | reinterpret_cast<uintptr_t>(a->d_o)) & 15) == 0) {
@@ -1290,13 +1268,7 @@ extern "C" int ortk_attention_bwd(const ortk_attn_args* a, ortk_stream stream) {
             else if (DKP == 64 && Lkp == 48 && Lqp == 96)                     fn = attn_bwd_mfma_kernel<48, 64, 96, 0>;
             else if (DKP == 64 && Lkp == 32 && Lqp == 32)                     fn = attn_bwd_mfma_kernel<32, 64, 32, 0>;
             else                                                              fn = attn_bwd_mfma_kernel<0, 0, 0, 0>;
-            static bwd_fn seen[16]; static int nseen = 0;
-            bool known = false;
-            for (int i = 0; i < nseen; ++i) known |= seen[i] == fn;
-            if (!known) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (nseen < 16) seen[nseen++] = fn;
-            }
+            ortk::lds_attr(reinterpret_cast<const void*>(fn), 160 * 1024);
             hipLaunchKernelGGL(fn, mgrid, mblock, bytes, ortk_s(stream), *a, Lkp, DKP, Lqp);
             ORTK_CHECK_LAUNCH();
             return 0;

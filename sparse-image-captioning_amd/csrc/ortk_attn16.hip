@@ -396,12 +396,7 @@ int attn16_fwd(const ortk_attn_args* a, hipStream_t s) {
     const fwd16_fn fn = a->dk == 64 ? (a->qkv_dtype ? pick_fwd<__bf16, 64>(njt) : pick_fwd<float, 64>(njt))
                                     : (a->qkv_dtype ? pick_fwd<__bf16, 32>(njt) : pick_fwd<float, 32>(njt));
     const size_t lds = fwd16_lds(njt, nw, a->dk);
-    static bool attr[32] = {};
-    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0) + (a->dk == 64 ? 0 : 16);
-    if (lds > 64 * 1024 && !attr[ai]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr[ai] = true;
-    }
+    if (lds > 64 * 1024) ortk::lds_attr(reinterpret_cast<const void*>(fn), 160 * 1024);
     hipLaunchKernelGGL(fn, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, s, *a);
     ORTK_CHECK_LAUNCH();
     return 0;
@@ -413,12 +408,7 @@ int attn16_bwd(const ortk_attn_args* a, hipStream_t s) {
                                     : (a->qkv_dtype ? pick_bwd<__bf16, 32>(njt) : pick_bwd<float, 32>(njt));
     const size_t lds = bwd16_lds(njt, Lqp, a->dk);
     if (lds > 160 * 1024) return ORTK_EINVAL;
-    static bool attr[32] = {};
-    const int ai = njt - 1 + (a->qkv_dtype ? 8 : 0) + (a->dk == 64 ? 0 : 16);
-    if (lds > 64 * 1024 && !attr[ai]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr[ai] = true;
-    }
+    if (lds > 64 * 1024) ortk::lds_attr(reinterpret_cast<const void*>(fn), 160 * 1024);
     hipLaunchKernelGGL(fn, dim3((unsigned)(a->nkv * a->H)), dim3(64 * nw), lds, s, *a, Lqp);
     ORTK_CHECK_LAUNCH();
     return 0;

@@ -1603,11 +1603,7 @@ __global__ __launch_bounds__(64 * GM * GN, MINB) void gemm_f32x3p_kernel(ortk_ge
 template <int WM, int WN, int GM, int GN, int MINB>
 int launch_f32x3p(const ortk_gemm_args& p, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 3 * (32 * WM * GM + 32 * WN * GN) * 32 * sizeof(__bf16);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32x3p_kernel<WM, WN, GM, GN, MINB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    ortk::lds_attr(reinterpret_cast<const void*>(gemm_f32x3p_kernel<WM, WN, GM, GN, MINB>), lds);
     const int tm = (int)ortk_cdiv(p.M, 32 * WM * GM), tn = (int)ortk_cdiv(p.N, 32 * WN * GN);
     hipLaunchKernelGGL((gemm_f32x3p_kernel<WM, WN, GM, GN, MINB>), dim3((unsigned)(tm * tn)), dim3(64 * GM * GN), lds, s, p, tm, tn, 0);
     return 0;
@@ -1804,6 +1800,20 @@ std::vector<ProfRec>* g_prof = nullptr;
 }  // namespace
 
 namespace ortk {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, function): set once per pair, from any host thread
+// (a process-wide `static bool` per call site left the second device of a process without it, and raced)
+int lds_attr(const void* fn, size_t bytes) {
+    struct Key { int dev; const void* fn; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Key>* seen = new std::vector<Key>();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ORTK_EINVAL;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Key& k : *seen) if (k.dev == dev && k.fn == fn && k.bytes >= bytes) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return ORTK_EINVAL;
+    seen->push_back(Key{dev, fn, bytes});
+    return 0;
+}
 bool ortk_prof_active() { return g_prof_on; }
 bool ortk_prof_serial() { return g_prof_serial; }
 // the same hook for launches that are not ortk_gemm (key >= 16): begin records the first event, end the second
@@ -1906,11 +1916,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
                                                 p.ln_y, p.ln_y_dtype, p.drop_p, p.drop_seed, p.drop_rows, stream);
         }
         gemm16_fn g = p.ln_mode == 1 ? gemm_bf16_row512_kernel<1> : gemm_bf16_row512_kernel<2>;
-        static bool rp_attr[2] = {false, false};
-        if (!rp_attr[p.ln_mode - 1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RP_LDS_BYTES);
-            rp_attr[p.ln_mode - 1] = true;
-        }
+        ortk::lds_attr(reinterpret_cast<const void*>(g), RP_LDS_BYTES);
         hipStream_t s = ortk_s(stream);
         ProfRec rec{};
         if (g_prof_on) {
@@ -1983,11 +1989,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             typedef void (*x3t_fn)(ortk_gemm_args, int, int, int);
             const x3t_fn fn = key == 1 ? gemm_f32x3t_kernel<false, false> : p.accumulate ? gemm_f32x3t_kernel<true, true> : gemm_f32x3t_kernel<true, false>;
             const size_t lds = p.accumulate ? BF16_LDS_BYTES_C : (size_t)6 * 128 * 32 * sizeof(__bf16);
-            static bool x3t_attr = false;
-            if (!x3t_attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32x3t_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES_C);
-                x3t_attr = true;
-            }
+            ortk::lds_attr(reinterpret_cast<const void*>(gemm_f32x3t_kernel<true, true>), BF16_LDS_BYTES_C);
             hipLaunchKernelGGL(fn, grid, block, lds, s, p, tilesM, tilesN, kchunk);
             if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
             ORTK_CHECK_LAUNCH();
@@ -2038,11 +2040,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             const bool one = (int64_t)tm * tn <= 256 + 64;          // one workgroup per CU: the whole K = 512 panel in flight
             gemm16_fn g = one ? gemm_bf16_dma64_kernel<8> : gemm_bf16_dma64_kernel<3>;    // else three per CU
             const size_t lds = (one ? 8 : 3) * DMA64_STAGE_BYTES;
-            static bool attr64[2] = {false, false};
-            if (!attr64[one]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr64[one] = true;
-            }
+            ortk::lds_attr(reinterpret_cast<const void*>(g), lds);
             hipLaunchKernelGGL(g, dim3((unsigned)(tm * tn)), dim3(256), lds, s, p, tm, tn, kchunk);
             if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
             ORTK_CHECK_LAUNCH();
@@ -2068,23 +2066,13 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             if (big)       gf = key == 4 ? gemm_bf16_glds_kernel<false, false, true, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, true, 4> : gemm_bf16_glds_kernel<true, true, true, 4>;
             else if (deep) gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 8> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 8> : gemm_bf16_glds_kernel<true, true, false, 8>;
             else           gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 4> : gemm_bf16_glds_kernel<true, true, false, 4>;
-            static bool gl_attr[9] = {false, false, false, false, false, false, false, false, false};
-            const int gi = (key == 4 ? 0 : key == 5 ? 1 : 2) + (big ? 3 : deep ? 6 : 0);
             const size_t lds = big ? GLDS_LDS_BYTES_BIG : deep ? 2 * GLDS_RING_BYTES : GLDS_LDS_BYTES;
-            if (!gl_attr[gi]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                gl_attr[gi] = true;
-            }
+            ortk::lds_attr(reinterpret_cast<const void*>(gf), lds);
             if (big && impl != 6 && p.K % HBK == 0) {
                 // 64-column stages (full cache lines); impl 6 = the 32-column 4-stage ring for comparison
                 gemm16_fn g2 = key == 4 ? gemm_bf16_dma256_kernel<false, false> : key == 5 ? gemm_bf16_dma256_kernel<false, true>
                                                                                               : gemm_bf16_dma256_kernel<true, true>;
-                static bool a2[3] = {false, false, false};
-                const int g2i = key == 4 ? 0 : key == 5 ? 1 : 2;
-                if (!a2[g2i]) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA256_LDS_BYTES);
-                    a2[g2i] = true;
-                }
+                ortk::lds_attr(reinterpret_cast<const void*>(g2), DMA256_LDS_BYTES);
                 hipLaunchKernelGGL(g2, dim3((unsigned)big_blocks), dim3(512), DMA256_LDS_BYTES, s, p, (int)ortk_cdiv(p.M, 256), p.N / 256, kchunk);
             }
             else if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, (int)ortk_cdiv(p.M, 256), p.N / 256, kchunk);
@@ -2096,14 +2084,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         gemm16_fn fn = key == 4 ? pick16<false, false>(p.a_dtype, p.b_dtype, fast)
                      : key == 5 ? pick16<false, true>(p.a_dtype, p.b_dtype, fast)
                                 : pick16<true, true>(p.a_dtype, p.b_dtype, fast);
-        // > 64 KB of dynamic LDS needs the attribute once per kernel instance
-        static gemm16_fn seen[32]; static int nseen = 0;
-        bool known = false;
-        for (int i = 0; i < nseen; ++i) known |= seen[i] == fn;
-        if (!known) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF16_LDS_BYTES);
-            if (nseen < 32) seen[nseen++] = fn;
-        }
+        // > 64 KB of dynamic LDS needs the attribute once per kernel instance and device
+        ortk::lds_attr(reinterpret_cast<const void*>(fn), BF16_LDS_BYTES);
         hipLaunchKernelGGL(fn, grid, block, BF16_LDS_BYTES, s, p, tilesM, tilesN, kchunk);
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }

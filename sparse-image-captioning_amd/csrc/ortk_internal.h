@@ -7,6 +7,8 @@ namespace ortk {
 // process-wide A/B switches (ortk.h: ortk_tuning; defaults = the product path).  Set explicitly through ortk_set_tuning — nothing in
 // the library reads the environment.
 const ortk_tuning& tuning();
+// hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for `fn` on the current device: set once per (device, function), thread-safe
+int lds_attr(const void* fn, size_t bytes);
 
 // true while bench.py's per-launch GEMM timing is on (the executor then keeps every GEMM on the caller's stream)
 bool ortk_prof_active();

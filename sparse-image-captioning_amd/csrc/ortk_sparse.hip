@@ -771,11 +771,7 @@ int launch_gu(const GuP& p, hipStream_t s) {
     constexpr int ROWS = 16 * MT;
     constexpr int PITCH = MT == 1 ? 32 : ROWS * 2 + 32;
     const size_t lds = (size_t)GKC * PITCH;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_gu_kernel<MT, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    ortk::lds_attr(reinterpret_cast<const void*>(spmm_gu_kernel<MT, MULTI>), lds);
     const int64_t tiles = ortk_cdiv(p.a.M, ROWS);
     const int ngs = (int)ortk_cdiv(p.G, p.gsplit);
     hipLaunchKernelGGL((spmm_gu_kernel<MT, MULTI>), dim3((unsigned)(tiles * ngs)), dim3(GNT), lds, s, p);
@@ -796,14 +792,10 @@ int launch_spmm(const SpmmP& p, hipStream_t s) {
     const size_t tile_b = (size_t)RB * OP * sizeof(float);
     const size_t lds = (size_t)2 * KT * 16 + tile_b + MAXRPW * sizeof(int);
     const size_t lds_alias = std::max((size_t)2 * KT * 16, tile_b) + MAXRPW * sizeof(int);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alias);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alias);
-        attr = true;
-    }
+    ortk::lds_attr(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256, false>), lds);
+    ortk::lds_attr(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512, false>), lds);
+    ortk::lds_attr(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 256, true>), lds_alias);
+    ortk::lds_attr(reinterpret_cast<const void*>(spmm_ell_kernel<XT, KT, 512, true>), lds_alias);
     const int64_t tiles = ortk_cdiv(p.a.M, RB);
     // long grids: a workgroup walks up to 4 ranges (X staged once); short grids: one range per workgroup and 8 waves
     const int rpw = tiles * p.nranges > 2048 ? std::min(4, p.nranges) : 1;

@@ -141,19 +141,19 @@ __device__ __forceinline__ void multiply_stage(uint32_t st, const uint32_t (&off
 }
 
 // ---- the main loop as a PING-PONG of the two waves of every SIMD (waves w and w + 4: the two row halves of the tile)
-// A 512-thread workgroup puts two waves on each SIMD.  Run in lock step (one barrier per stage: the first version of this kernel)
-// both read their fragments at the same time — the matrix pipe idles — and then both want the pipe: 38 % of the MFMA cycles busy
-// (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r06_wgrad_group.txt).  Here waves 4-7 run ONE BARRIER BEHIND waves 0-3, and every wave
-// alternates [read the fragments of half a stage] barrier [16 MFMAs] barrier: between two barriers one wave of a SIMD multiplies
-// while its partner reads (cdna_hip_programming.md, "The 256^2 8-phase template": the same staggering).  Per stage of 32 rows a
-// wave's halves are its row fragments 0-3 and 4-7 against the stage's four column fragments (read with the first half, kept).
+// A 512-thread workgroup puts two waves on each SIMD.  Run in lock step (one barrier per stage, ortk_wgrad_group_args.flags & 1) both
+// read their fragments at the same time — the matrix pipe idles — and then both want the pipe.  Here waves 4-7 run ONE BARRIER
+// BEHIND waves 0-3 and every wave alternates [read a stage's fragments] barrier [32 MFMAs] barrier: between two barriers one wave
+// of a SIMD multiplies while its partner reads (cdna_hip_programming.md, "The 256^2 8-phase template": the same staggering).
+// Measured alone on the chip (scratch/wgrad_lowwg.py, 56 workgroups of 520 stages): 920 ns per stage against 986 with half stages as
+// phases (four barriers per stage) — 46 % of the nominal MFMA peak of the units the launch holds.
 //
 // Barrier j (counted over the kernel; j = 0 publishes stage 0) and what runs behind it, stage t:
-//     waves 0-3:  j = 4t: read h0 | 4t+1: MFMA h0 | 4t+2: DMA t+3, read h1 | 4t+3: MFMA h1, wait(t+1) | 4t+4 ...
-//     waves 4-7:  j = 4t+1: read h0 | 4t+2: MFMA h0 | 4t+3: DMA t+3, read h1, wait(t+1) | 4t+4: MFMA h1 | 4t+5 ...
-// Stage t + 1 is read from barrier 4t + 4 on: every wave has waited for its own share of it before arriving there.  Slot
-// (t + 3) & 3 held stage t - 1, whose last reads (waves 4-7, h1) are complete before those waves' MFMAs behind barrier 4t: a DMA
-// issued behind barrier 4t + 2 or later is safe.
+//     waves 0-3:  j = 2t: read stage t | 2t+1: DMA t+3, MFMA t, wait(t+1) | 2t+2 ...
+//     waves 4-7:  j = 2t+1: DMA t+3, read stage t, wait(t+1) | 2t+2: MFMA t | 2t+3 ...
+// Stage t + 1 is read from barrier 2t + 2 on: every wave has waited for its own share of it before arriving there.  Slot
+// (t + 3) & 3 held stage t - 1, whose last reads (waves 4-7, behind barrier 2t - 1) are complete before those waves' MFMAs behind
+// barrier 2t: a DMA issued behind barrier 2t + 1 is safe.
 struct Dma { const __bf16* A; const __bf16* B; int lda, ldb, k_begin; uint32_t offA[2], offB[2]; };
 constexpr uint32_t STAGE_BYTES = 2 * W_IMG * 2;
 __device__ __forceinline__ void issue_stage(const Dma& d, int t, __bf16* ring, int wave, int lane) {
@@ -176,53 +176,6 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int H>
-__device__ __forceinline__ void mfma_half(u32x2 (&blo)[4], u32x2 (&bhi)[4], u32x2 (&alo)[4], u32x2 (&ahi)[4], int cs_i, const bf16x8& ones,
-                                          f32x4 (&acc)[8][4], f32x4 (&acc_cs)[2]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ORTK_LGKM_WAIT(0, blo[j]); ORTK_LGKM_WAIT(0, bhi[j]); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { ORTK_LGKM_WAIT(0, alo[i]); ORTK_LGKM_WAIT(0, ahi[i]); }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bf16x8 a = as_frag(alo[i], ahi[i]);
-        if (cs_i == i) acc_cs[H] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, acc_cs[H], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[4 * H + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(blo[j], bhi[j]), a, acc[4 * H + i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-}
-template <int G>       // G = 0: waves 0-3, G = 1: waves 4-7 (one barrier behind)
-__device__ __forceinline__ void pingpong(const Dma& d, int T, __bf16* ring, uint32_t lds0, const uint32_t (&offA)[8], const uint32_t (&offB)[4],
-                                         int cs_i, const bf16x8& ones, f32x4 (&acc)[8][4], f32x4 (&acc_cs)[2], int wave, int lane) {
-    u32x2 blo[4], bhi[4], alo[4], ahi[4];
-    if (G == 1) wg_barrier();
-    for (int t = 0; t < T; ++t) {
-        const uint32_t st = lds0 + (uint32_t)(t & (WNS - 1)) * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tr_pair(blo[j], bhi[j], st + (uint32_t)(W_IMG * 2) + offB[j]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tr_pair(alo[i], ahi[i], st + offA[i]);
-        wg_barrier();
-        mfma_half<0>(blo, bhi, alo, ahi, cs_i, ones, acc, acc_cs);
-        wg_barrier();
-        if (t + WNS - 1 < T) issue_stage(d, t + WNS - 1, ring, wave, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tr_pair(alo[i], ahi[i], st + offA[4 + i]);
-        if (G == 1) wait_stage(t + 1, T);
-        wg_barrier();
-        mfma_half<1>(blo, bhi, alo, ahi, cs_i, ones, acc, acc_cs);
-        if (G == 0) wait_stage(t + 1, T);
-        wg_barrier();
-    }
-    if (G == 0) wg_barrier();
-}
-
-// The same stagger with WHOLE stages as phases (two barriers per stage instead of four: 32 MFMAs between barriers):
-//     waves 0-3:  barrier 2t: read stage t | 2t+1: DMA t+3, MFMA t, wait(t+1) | 2t+2 ...
-//     waves 4-7:  barrier 2t+1: DMA t+3, read stage t, wait(t+1) | 2t+2: MFMA t | 2t+3 ...
 template <int G>
 __device__ __forceinline__ void pingpong2(const Dma& d, int T, __bf16* ring, uint32_t lds0, const uint32_t (&offA)[8], const uint32_t (&offB)[4],
                                           int cs_i, const bf16x8& ones, f32x4 (&acc)[8][4], f32x4 (&acc_cs)[2], int wave, int lane) {
@@ -299,20 +252,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_group_kernel(WgArgs p) {
             wait_stage(t, T);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (t + WNS - 1 < T && !(p.lockstep & 4)) issue_stage(dma, t + WNS - 1, smem16, wave, lane);      // every wave is past its reads of stage t - 1
-            if (!(p.lockstep & 2)) multiply_stage(lds0 + (uint32_t)(t & (WNS - 1)) * STAGE_BYTES, offA, offB, cs_i, ones, acc, acc_cs);
+            if (t + WNS - 1 < T) issue_stage(dma, t + WNS - 1, smem16, wave, lane);      // every wave is past its reads of stage t - 1
+            multiply_stage(lds0 + (uint32_t)(t & (WNS - 1)) * STAGE_BYTES, offA, offB, cs_i, ones, acc, acc_cs);
         }
     } else if (T > 0) {
         for (int t = 0; t < WNS - 1 && t < T; ++t) issue_stage(dma, t, smem16, wave, lane);
         wait_stage(0, T);
         wg_barrier();                                                       // barrier 0: stage 0 is published
-        if (p.lockstep & 32) {       // measurement: half stages as phases (four barriers per stage)
-            if (wm == 0) pingpong<0>(dma, T, smem16, lds0, offA, offB, cs_i, ones, acc, acc_cs, wave, lane);
-            else         pingpong<1>(dma, T, smem16, lds0, offA, offB, cs_i, ones, acc, acc_cs, wave, lane);
-        } else {
-            if (wm == 0) pingpong2<0>(dma, T, smem16, lds0, offA, offB, cs_i, ones, acc, acc_cs, wave, lane);
-            else         pingpong2<1>(dma, T, smem16, lds0, offA, offB, cs_i, ones, acc, acc_cs, wave, lane);
-        }
+        if (wm == 0) pingpong2<0>(dma, T, smem16, lds0, offA, offB, cs_i, ones, acc, acc_cs, wave, lane);
+        else         pingpong2<1>(dma, T, smem16, lds0, offA, offB, cs_i, ones, acc, acc_cs, wave, lane);
     }
     if (rem > 0) {
         // slot T & 3 held stage T - 4 (read before the barrier of step T - 3): free for every wave
@@ -331,7 +279,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_group_kernel(WgArgs p) {
     }
     float* Cp = it.C;
     const int ldc = it.ldc;
-    if (p.lockstep & 16) { if (acc[0][0][0] == 123.456f) Cp[0] = 1.f; return; }     // measurement only: no epilogue
     if (p.slabs != nullptr || p.sk == 1) {
         // ---- epilogue without atomics: the K ranges of a tile meet in memory, the LAST one to arrive adds them up.
         // Every workgroup stores its 256 x 256 fp32 partial tile as a slab in register order (one contiguous KB per wave-instruction),
@@ -421,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_group_kernel(WgArgs p) {
 }  // namespace
 
 extern "C" int ortk_wgrad_group(const ortk_wgrad_group_args* a, ortk_stream stream) {
-    if (!a || a->n < 1 || a->n > ORTK_WGRAD_MAX || a->rows < 0 || a->rows > 0x7FFFFFFF || a->splitk < 0 || (a->flags & ~63)) return ORTK_EINVAL;
+    if (!a || a->n < 1 || a->n > ORTK_WGRAD_MAX || a->rows < 0 || a->rows > 0x7FFFFFFF || a->splitk < 0 || (a->flags & ~9)) return ORTK_EINVAL;
     if (a->rows == 0) return 0;
     WgArgs p; std::memset(&p, 0, sizeof(p));
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -440,7 +387,7 @@ extern "C" int ortk_wgrad_group(const ortk_wgrad_group_args* a, ortk_stream stre
         flops += 2.0 * (double)a->rows * s.Nout * s.Kin;
         bytes += (double)a->rows * (s.Nout + s.Kin) * 2 + (double)s.Nout * s.Kin * 4;
     }
-    p.n = a->n; p.K = (int)a->rows; p.tiles = tiles; p.lockstep = a->flags & (7 | 16 | 32);
+    p.n = a->n; p.K = (int)a->rows; p.tiles = tiles; p.lockstep = a->flags & 1;
     // K ranges: one round of workgroups (256 compute units) when the tiles allow it, never fewer than 8 stages per workgroup
     const int ksteps = (int)ortk_cdiv(a->rows, WBK);
     int sk = a->splitk > 0 ? a->splitk : (tiles >= 256 ? 1 : 256 / tiles);
@@ -458,17 +405,7 @@ extern "C" int ortk_wgrad_group(const ortk_wgrad_group_args* a, ortk_stream stre
         p.slabs = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a->ws) + tk);
         if (hipMemsetAsync(p.tickets, 0, (size_t)tiles * sizeof(int), s) != hipSuccess) return ORTK_EINVAL;
     }
-    {   // > 64 KB of dynamic LDS: the attribute is per device
-        static std::mutex mu; static bool done[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return ORTK_EINVAL;
-        std::lock_guard<std::mutex> lk(mu);
-        if (dev < 0 || dev >= 64 || !done[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_LDS_BYTES) != hipSuccess)
-                return ORTK_EINVAL;
-            if (dev >= 0 && dev < 64) done[dev] = true;
-        }
-    }
+    if (ortk::lds_attr(reinterpret_cast<const void*>(wgrad_group_kernel), W_LDS_BYTES)) return ORTK_EINVAL;
     ortk::ProfMark pm;
     ortk::prof_begin(ortk::PROF_KEY_WGRAD_GROUP, flops, bytes, s, pm);
     hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)(tiles * sk)), dim3(512), W_LDS_BYTES, s, p);

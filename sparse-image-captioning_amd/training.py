@@ -222,8 +222,9 @@ class NativeTrainer:
         and incremental log-probs agree to 3e-6).  NOT the reference's estimator: no dropout anywhere in the step.
         ``update_dropout=True`` recomputes under a fresh dropout pattern (rounds 1-2).
 
-        ``rollout_opt``: extra entries for the ``opt`` dict of the rollout decodes (``temperature``, ``executor``, ...; the reference
-        passes ``temperature = config.scst_sample_temperature`` there, utils/training.py:226-237)."""
+        ``rollout_opt``: extra entries for the ``opt`` dict of the ROLLOUT decodes (``temperature``, ``executor``, ...).  An extension:
+        the reference's SCST path passes only ``num_random_sample`` / ``beam_size`` there (utils/training.py:226-237; it has no
+        temperature option).  A greedy baseline that is a decode of its own does not take them."""
         m = self.model
         extra = dict(rollout_opt or {})
         was_training = m.training
@@ -236,7 +237,7 @@ class NativeTrainer:
         drop_seed = None
         sparse_stream = getattr(m, "_sparse_stream", False)
         share_encoder = False
-        m._status_ws = []
+        # (decodes of earlier steps that are still unchecked stay on the model's list: check_decode_status() below reads them too)
         with torch.no_grad():
             if sample_dropout and train:
                 assert sample == "random", "train-mode sampling: multinomial rollouts"
@@ -256,7 +257,9 @@ class NativeTrainer:
                 else:
                     if baseline == "greedy":
                         m.eval()
-                        greedy, _ = m(**kw, opt=dict(extra, beam_size=1))
+                        # its status word is read NOW: the model keeps one decode workspace, and the rollout's launch below resets the
+                        # word this decode would have raised (a no-op unless this decode ran the column-split kernel)
+                        greedy, _ = m(**kw, opt=dict(beam_size=1, check_status=True))
                     seq, _ = m(**kw, opt=dict(opt, sample_row_offset=parallel.sample_row_offset(B, num_samples)))
             else:
                 # One encoder pass per step: the update pass recomputes the rollout's log-probs in the SAME mode as the rollout
@@ -270,7 +273,7 @@ class NativeTrainer:
                 if sample == "beam_search":
                     assert num_samples > 1, "beam search needs more than one beam"
                     if baseline == "greedy":
-                        greedy, _ = m(**kw, opt=dict(extra, beam_size=1, **mem_opt))
+                        greedy, _ = m(**kw, opt=dict(beam_size=1, check_status=True, **mem_opt))      # (status: as above)
                     seq, _ = m(**kw, opt=dict(extra, beam_size=num_samples, **mem_opt))
                 else:
                     assert sample == "random", sample
@@ -291,7 +294,7 @@ class NativeTrainer:
             # the rollout, so reading its status word costs nothing there; a device-side reward_fn keeps the step free of host
             # synchronisation and relies on the decode's periodic check (first two calls, then every 64th) unless
             # `check_rollout_status` is set.
-            m.check_decode_status()             # (the greedy baseline's decode, when it was a call of its own, and the rollout's)
+            m.check_decode_status()             # (the rollout's decode; a greedy baseline that was a call of its own has been checked)
         reward = reward.to(self.dev).float().reshape(-1)
         rows = seq.reshape(-1, seq.size(-1))
         mask = (rows != m.pad_idx).float()

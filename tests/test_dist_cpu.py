@@ -13,11 +13,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, n_img=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         sys.path.insert(0, p)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import common as C
     import helpers as H
@@ -25,10 +25,14 @@ def _worker(rank, world, port, out_dir):
     from sparse_image_captioning_amd import parallel
     cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
     P = H.g1_state(requires_grad=True)
-    full = H.torch_batch(C.make_inputs(seed=5, n_img=4, n_reg=12, feat=C.TINY_CFG["att_feat_size"], vocab=C.TINY_CFG["vocab_size"], spi=2))
+    full = H.torch_batch(C.make_inputs(seed=5, n_img=n_img, n_reg=12, feat=C.TINY_CFG["att_feat_size"], vocab=C.TINY_CFG["vocab_size"], spi=2))
     mine = parallel.shard_batch(full)
-    assert mine["att_feats"].shape[0] == 2 and mine["seqs"].shape[0] == 4
-    assert torch.equal(mine["seqs"], full["seqs"][rank * 4:(rank + 1) * 4])
+    per = n_img // world
+    assert mine["att_feats"].shape[0] == per and mine["seqs"].shape[0] == 2 * per
+    assert torch.equal(mine["seqs"], full["seqs"][rank * 2 * per:(rank + 1) * 2 * per])
+    assert torch.equal(mine["att_feats"], full["att_feats"][rank * per:(rank + 1) * per])
+    # the rollout rows of this shard inside the global decode (NativeTrainer.scst_step: opt["sample_row_offset"])
+    assert parallel.sample_row_offset(per, 5) == rank * per * 5 and parallel.sample_row_offset(per, 5 + 1) == rank * per * 6
     norm = mine["masks"][:, 1:].sum().reshape(1).clone()
     parallel.reduce_scalar_sum(norm)
     assert abs(norm.item() - full["masks"][:, 1:].sum().item()) < 1e-6
@@ -71,6 +75,28 @@ def test_two_rank_data_parallel_equals_full_batch(tmp_path):
     assert abs(float(got["loss"][0]) - loss.item()) < 1e-5
     np.testing.assert_allclose(got["arena"], ref, rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(got["arena_bf16"], ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())       # bf16 addends
+
+
+def test_eight_rank_shard_arithmetic_equals_full_batch(tmp_path):
+    """The node's real rank count (BASELINE configs[3]: 8 GPUs): 8 gloo ranks x 2 images.  Each rank takes its images and captions,
+    the global normaliser is the all-reduced mask sum, `sample_row_offset` places its rollout rows in the global decode, and the summed
+    loss / gradient arena (split asynchronous all-reduce, as the trainer's overlapped exchange issues it) equal the full-batch step's."""
+    port = 29500 + ((os.getpid() + 1234) % 2000)
+    mp.spawn(_worker, args=(8, port, str(tmp_path), 16), nprocs=8, join=True)
+    import common as C
+    import helpers as H
+    from oracle import ort_oracle as O
+    got = np.load(os.path.join(str(tmp_path), "dp.npz"))
+    cfg = O.OCfg(**{k: v for k, v in C.TINY_CFG.items() if not k.startswith("prune")})
+    P = H.g1_state(requires_grad=True)
+    full = H.torch_batch(C.make_inputs(seed=5, n_img=16, n_reg=12, feat=C.TINY_CFG["att_feat_size"], vocab=C.TINY_CFG["vocab_size"], spi=2))
+    logp = O.forward_logp(P, cfg, full["att_feats"], full["boxes"], full["seqs"], full["att_masks"])
+    loss = O.xe_loss(logp, full["seqs"][:, 1:], full["masks"][:, 1:])
+    loss.backward()
+    ref = torch.cat([P[n].grad.reshape(-1) for n in sorted(P)]).numpy()
+    assert abs(float(got["loss"][0]) - loss.item()) < 1e-5
+    np.testing.assert_allclose(got["arena"], ref, rtol=1e-4, atol=4e-6)
+    np.testing.assert_allclose(got["arena_bf16"], ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
 
 
 def _scst_worker(rank, world, port, out_dir):

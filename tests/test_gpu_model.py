@@ -2359,3 +2359,60 @@ def test_one_cached_workspace_per_call_kind_across_batch_geometries(P):
             assert got[0] == fresh[0], (g, got[0], fresh[0])
             assert torch.equal(got[1], fresh[1]) and torch.equal(got[2], fresh[2]), g
         assert len(shared._ws_cache) <= 2, list(shared._ws_cache)          # "train" and "decode"
+
+
+# ------------------------------------------------------------------------------------------ round 6: the oracle at the benchmark's own sizes
+def test_xe_loss_at_bench_size_vs_oracle(P, full_state):
+    """BASELINE configs[1] at its full size against the ORACLE directly (not a property): 256 images x 5 captions x 36 ragged
+    regions, the teacher-forced XE loss of `O.forward_logp` + `O.xe_loss` (utils/losses.py:32-43 on the log-probs of
+    models/transformer.py:329-358) evaluated on the host in chunks of 32 images.  fp32 parity mode: |loss - oracle| <= 1e-4
+    (north_star's bar); the timed mixed-precision mode against the SAME value: <= 5e-3 (bf16 operands, fp32 accumulation: the
+    per-token log-prob error averages out over 16 640 positions; golden G2's bar for this mode is 2e-2)."""
+    from sparse_image_captioning_amd.utils.losses import LanguageModelCriterion
+    B = 256
+    cb = H.torch_batch(C.make_inputs(seed=11, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=5, ragged=True))
+    cfg = _oracle_cfg(C.FULL_CFG)
+    num = den = 0.0
+    with torch.no_grad():
+        for i0 in range(0, B, 32):
+            sl, rs = slice(i0, i0 + 32), slice(5 * i0, 5 * (i0 + 32))
+            logp = O.forward_logp(full_state, cfg, cb["att_feats"][sl], cb["boxes"][sl], cb["seqs"][rs], cb["att_masks"][sl])
+            tgt, msk = cb["seqs"][rs, 1:], cb["masks"][rs, 1:]
+            num += -(logp.gather(2, tgt.unsqueeze(2)).squeeze(2).double() * msk.double()).sum().item()
+            den += msk.double().sum().item()
+    ref = num / den
+    b = _cuda(cb)
+    got = {}
+    for precision in (0, 1):
+        m = _model(P, "relation_transformer", C.FULL_CFG, full_state, precision=precision)
+        with torch.no_grad():
+            logp = m(att_feats=b["att_feats"], boxes=b["boxes"], seqs=b["seqs"], att_masks=b["att_masks"])
+            got[precision] = LanguageModelCriterion()(logp, b["seqs"][:, 1:], b["masks"][:, 1:]).item()
+        del m, logp
+    print(f"[bench-size XE] oracle {ref:.6f}  fp32 mode {got[0]:.6f}  mixed precision {got[1]:.6f}")
+    assert abs(got[0] - ref) <= 1e-4, (got[0], ref)
+    assert abs(got[1] - ref) <= 5e-3, (got[1], ref)
+
+
+def test_sparse_decode_bench_batch_slice_vs_oracle(P, margin_state):
+    """BASELINE configs[4] at its full size against the ORACLE directly: the 1 024-image batch decoded in ONE call (95 %-pruned ORT,
+    beam 5, fp32 parity mode, the sparse product kernels), and 32 of its images — every 32nd — compared token for token with
+    `O.beam_search` (caption_model.py:56-226 over transformer.py:471-561) on the zero-filled dense weights, the reference's eval flow
+    for pruned checkpoints (scripts/eval_model.py:64-88).  All five beams of an image, in order; log-probs within 2e-4."""
+    m = _model(P, "relation_transformer_prune", C.FULL_CFG, margin_state, precision=0, prune_type="mag_uniform")
+    m.update_masks_once(0.95)
+    m.enable_sparse_kernels(0.9)
+    B = 1024
+    cb = H.torch_batch(C.make_inputs(seed=4100, n_img=B, n_reg=36, feat=2048, vocab=10001, spi=1, ragged=True))
+    b = _cuda({k: cb[k] for k in ("att_feats", "boxes", "att_masks")})
+    with torch.no_grad():
+        seq, lp = m(att_feats=b["att_feats"], boxes=b["boxes"], att_masks=b["att_masks"], opt={"beam_size": 5}, mode="sample")
+    m.check_sparse_overflow()
+    idx = torch.arange(0, B, 32)
+    dense_sd = {k: v.float().cpu() for k, v in m.state_dict_dense(discard_pruning_mask=True).items()}
+    with torch.no_grad():
+        oseq, olp, _ = O.beam_search(dense_sd, _oracle_cfg(C.FULL_CFG), cb["att_feats"][idx], cb["boxes"][idx], cb["att_masks"][idx], 5)
+    got, glp = seq.cpu()[idx], lp.cpu()[idx]
+    assert (oseq != 0).sum(-1).float().mean().item() < 17.0          # (captions end: the margins are real)
+    assert torch.equal(got, oseq), f"{(got != oseq).any(-1).sum().item()} of {oseq.size(0) * oseq.size(1)} beams differ from the oracle"
+    assert (glp - olp)[oseq != 0].abs().max().item() < 2e-4
