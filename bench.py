@@ -64,6 +64,9 @@ def synth_batch(B, S, F, V, spi, seq_len, seed, device):
                 att_max_len=S, cap_len=cap_len)
 
 
+CPU_THREADS = 32        # main() --cpu-threads; profiles/r06_cpu_thread_sweep.txt is the sweep behind the default
+
+
 def cpu_baseline(workload, cfg_dict, seconds=9.0):
     """The oracle (parity-pinned CPU restatement of the reference path, torch CPU fp32) timed on this host's cores on a bounded
     sample of the same workload.  xe: BASELINE configs[0] EXACTLY — 4 images x 5 captions per step, fwd + bwd + clip + Adam (the
@@ -74,9 +77,9 @@ def cpu_baseline(workload, cfg_dict, seconds=9.0):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import helpers as H
     from oracle import ort_oracle as O
-    # torch's intra-op pool degrades badly past ~1 thread per physical core group on the 256-thread GPU host
-    # (measured: 256 threads -> 0.2 captions/s); 32 threads is the fastest setting found, and is what `cores` reports.
-    cores = min(os.cpu_count() or 1, 32)
+    # torch's intra-op pool degrades past a few dozen threads on the 256-thread GPU host at these operator sizes (4 images per step):
+    # profiles/r06_cpu_thread_sweep.txt (scratch/cpu_thread_sweep.py: 16 / 32 / 64 / 128 / 256 threads); `cores` reports what was used.
+    cores = min(os.cpu_count() or 1, CPU_THREADS)
     torch.set_num_threads(cores)
     cfg = O.OCfg(**{k: v for k, v in cfg_dict.items() if not k.startswith("prune")})
     P = H.torch_state(H.dense_param_shapes(cfg_dict), 8888, requires_grad=True)
@@ -130,13 +133,16 @@ def cpu_baseline(workload, cfg_dict, seconds=9.0):
                        f"torch CPU fp32, {cores} of the host's {os.cpu_count() or 1} threads")}
 
 
-PMC_TAG = "r05"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
-PMC_MANIFEST = f"profiles/{PMC_TAG}_manifest.json"     # {"lib_md5", "git_head", ...}: written by scratch/prof_r05.sh with the passes
+PMC_TAG = "r06"      # profiles/<tag>_*_pmc_{fetch,write}_size.csv: the PMC passes of the CURRENT kernels
+PMC_MANIFEST = f"profiles/{PMC_TAG}_manifest.json"     # {"lib_md5", "git_head", ...}: written by scratch/prof_r06.sh with the passes
 
 # The kernels whose counters `traffic` is read from, by their FULL names (template arguments included) as this build launches them:
 # a profile of another instantiation is not a measurement of this one.
 STACK_DENSE = "ortk::decoder_stack_kernel<false, 32, false>(ortk::StackArgs)"
 STACK_SPARSE = "ortk::decoder_stack_kernel<true, 20, false>(ortk::StackArgs)"
+STACK_GATHER = "ortk::decoder_stack_kernel<true, 20, true>(ortk::StackArgs)"
+ROLLOUT = "ortk::decoder_stack_tp_kernel<8, true>(ortk::StackArgs)"
+WGRAD = "wgrad_group_kernel(WgArgs)"
 GEMM_FWD = ("gemm_bf16_dma256_kernel<false, false>(ortk_gemm_args, int, int, int)",
             "gemm_bf16_glds_kernel<false, false, false, 4>(ortk_gemm_args, int, int, int)",
             "gemm_bf16_dma64_kernel<3>(ortk_gemm_args, int, int, int)", "gemm_bf16_dma64_kernel<8>(ortk_gemm_args, int, int, int)")
@@ -158,17 +164,19 @@ def pmc_traffic(kernel, workload, precision, B):
     them; it must equal the md5 of the library loaded now), and when the CSVs do not hold the kernel under its full name."""
     import csv
     here = os.path.dirname(os.path.abspath(__file__))
-    if kernel == "stack" and workload in ("decode", "sparse_decode") and precision == "bf16" and B == 1024:
-        want = (STACK_SPARSE if workload == "sparse_decode" else STACK_DENSE,)
-        must = want[0]
-        tag = "sparse_decode_stack" if workload == "sparse_decode" else "decode_stack"
-        files = [f"{PMC_TAG}_{tag}_pmc_fetch_size.csv", f"{PMC_TAG}_{tag}_pmc_write_size.csv"]
-    elif kernel == "gemm" and workload == "xe" and precision == "bf16" and B == 256:
-        want = GEMM_FWD
-        must = GEMM_FWD[0]
-        files = [f"{PMC_TAG}_xe_b256_pmc_fetch_size.csv", f"{PMC_TAG}_xe_b256_pmc_write_size.csv"]
-    else:
+    # (kernel kind, workload[_variant]) -> (kernels by full name, file tag).  "step": every kernel of the step (whole-step bound)
+    table = {("stack", "decode"): ((STACK_DENSE,), "decode_stack"), ("stack", "sparse_decode"): ((STACK_SPARSE,), "sparse_decode_stack"),
+             ("stack", "sparse_decode_988"): ((STACK_GATHER,), "sparse_decode_988_stack"),
+             ("gemm", "xe"): (GEMM_FWD, "xe_b256"), ("wgrad", "xe"): ((WGRAD,), "xe_b256"),
+             ("gemm", "sparse_xe"): (GEMM_FWD, "sparse_xe_b256"), ("wgrad", "sparse_xe"): ((WGRAD,), "sparse_xe_b256"),
+             ("step", "sparse_xe_kernels"): (None, "sparse_xe_kernels_b256"),
+             ("gemm", "scst"): (GEMM_FWD, "scst_b256"), ("wgrad", "scst"): ((WGRAD,), "scst_b256"), ("rollout", "scst"): ((ROLLOUT,), "scst_b256")}
+    sized = precision == "bf16" and B == (1024 if "decode" in workload else 256)
+    if not sized or (kernel, workload) not in table:
         return None, "no PMC pass committed for this workload / size"
+    want, tag = table[(kernel, workload)]
+    must = want[0] if want else None
+    files = [f"{PMC_TAG}_{tag}_pmc_fetch_size.csv", f"{PMC_TAG}_{tag}_pmc_write_size.csv"]
     try:
         man = json.load(open(os.path.join(here, PMC_MANIFEST)))
     except (OSError, ValueError):
@@ -178,15 +186,27 @@ def pmc_traffic(kernel, workload, precision, B):
         return None, f"STALE: PMC passes of libortk.so md5 {str(man.get('lib_md5'))[:8]} (commit {str(man.get('git_head'))[:8]}), loaded md5 {now[:8]}"
     tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     n = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+    steps_seen = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
     seen = set()
     try:
         for cname, fname in zip(("FETCH_SIZE", "WRITE_SIZE"), files):
             for r in csv.DictReader(open(os.path.join(here, "profiles", fname))):
-                if r["kernel"] in want and r["counter"] == cname:
+                if r["counter"] != cname:
+                    continue
+                if want is None:                      # the whole step: every kernel, per launch of the once-per-step criterion kernel
+                    tot[cname] += float(r["total"])
+                    if r["kernel"].startswith("xent_reg_kernel"):
+                        steps_seen[cname] += int(r["launches"])
+                elif r["kernel"] in want:
                     seen.add(r["kernel"])
                     tot[cname] += float(r["total"]); n[cname] += int(r["launches"])
     except (OSError, KeyError, ValueError) as e:
         return None, f"profiles/{files[0]} / {files[1]} unreadable ({type(e).__name__}): no traffic figure"
+    if want is None:
+        if not steps_seen["FETCH_SIZE"] or not steps_seen["WRITE_SIZE"]:
+            return None, f"STALE: profiles/{files[0]} / {files[1]} do not hold a once-per-step kernel to count the steps by"
+        kb = 2.0 * tot["FETCH_SIZE"] / steps_seen["FETCH_SIZE"] + tot["WRITE_SIZE"] / steps_seen["WRITE_SIZE"]
+        return round(kb * 1024), f"HBM bytes per STEP, all kernels, 2*FETCH_SIZE + WRITE_SIZE from profiles/{files[0]} / {files[1]} (libortk.so md5 {now[:8]})"
     if not n["FETCH_SIZE"] or not n["WRITE_SIZE"] or must not in seen:
         return None, f"STALE: profiles/{files[0]} / {files[1]} do not contain the dominant kernel of this build ({must})"
     kb = 2.0 * tot["FETCH_SIZE"] / n["FETCH_SIZE"] + tot["WRITE_SIZE"] / n["WRITE_SIZE"]
@@ -376,7 +396,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         if rank == 0:
             n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             rec = {}
-            for k in (key, key + 1, key + 3, 16, 17):
+            for k in (key, key + 1, key + 3, 16, 17, 18):
                 lib.ortk_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl))
                 lib.ortk_prof_collect_bytes(k, C.byref(by))
                 rec[k] = (n.value, ms.value, fl.value, by.value)
@@ -391,7 +411,8 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
     n0, ms0, fl0, by0 = per_key[key]
     ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
     ach_iso = iso[key][2] / (iso[key][1] * 1e-3) / 1e12 if iso[key][1] > 0 else 0.0
-    traffic, tnote = pmc_traffic("gemm", workload if not variant else "", precision, B)
+    wtag = workload + ("_" + variant if variant else "")
+    traffic, tnote = pmc_traffic("gemm", wtag, precision, B)
     gemm = {"bound": "mfma", "kernel": "forward-layout GEMMs (gemm_bf16_dma256 / glds / dma64)" if precision == "bf16" else ("forward-layout fp32 GEMMs as split bf16 products (gemm_f32x3_kernel / gemm_f32x3p_kernel)" if f32_split else "gemm_f32_kernel (forward layout)"),
             "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             **({"traffic_note": tnote} if traffic is None and tnote.startswith("STALE") else {}),
@@ -401,7 +422,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
     if per_key[16][0]:
         sn, sms, sfl, sby = per_key[16]
         gbs_k = sby / (sms * 1e-3) / 1e9
-        st_traffic, st_note = pmc_traffic("stack", ("sparse_decode" if sstream else "decode") if decode and "988" not in variant and precision == "bf16" else "", precision, B)
+        st_traffic, st_note = pmc_traffic("stack" if decode else "rollout", wtag, precision, B)
         stack = {"kernel": ("decoder_stack_kernel<sparse>" if sstream else "decoder_stack_kernel") if decode else "decoder_stack_tp_kernel",
                  "launches": sn, "avg_us": round(sms * 1e3 / sn, 1), "alg_bytes_per_launch": round(sby / sn), "achieved": round(gbs_k, 1),
                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_k / PEAK_HBM_GBS, 4), "traffic": st_traffic,
@@ -415,6 +436,17 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
         chain = {"kernel": "row_chain_kernel / row_chain_wide_kernel", "launches": cn, "avg_us": round(cms * 1e3 / cn, 1), "alg_bytes_per_launch": round(cby / cn),
                  "achieved": round(cby / (cms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(cby / (cms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                  "mfma_tflops": round(cfl / (cms * 1e-3) / 1e12, 1)}
+    wgrad = None        # grouped weight gradients (key 18): one launch per layer on the side stream, the largest kernel of a training step by time
+    if per_key[18][0]:
+        gn, gms, gfl, gby = per_key[18]
+        g_ach = gfl / (gms * 1e-3) / 1e12
+        g_iso = iso[18][2] / (iso[18][1] * 1e-3) / 1e12 if iso[18][1] > 0 else 0.0
+        g_traffic, g_note = pmc_traffic("wgrad", wtag, precision, B)
+        wgrad = {"kernel": "wgrad_group_kernel (a layer's weight + bias gradients in one launch, side stream, 48-96 workgroups)", "bound": "mfma",
+                 "launches": gn, "avg_us": round(gms * 1e3 / gn, 1), "achieved": round(g_ach, 1), "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(g_ach / peak, 4), "isolated_frac": round(g_iso / peak, 4), "alg_gflop_per_launch": round(gfl / gn / 1e9, 2),
+                 "alg_bytes_per_launch": round(gby / gn), "traffic": g_traffic,
+                 **({"traffic_note": g_note} if g_traffic is None and g_note.startswith("STALE") else {})}
     if decode or use_csr:
         # the sparse step and the cached decode are HBM-bound.  Algorithmic bytes: decode = 25.7 MB per image
         # (self-KV reads 10.5 + cross-KV 8.0 + logits 7.2) + the weights once per step (18 steps: 110.9 MB dense bf16, or 4 bytes
@@ -431,8 +463,10 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
                       (Md, 1536, 512, 6), (Md, 512, 512, 18), (Md, 2048, 512, 6), (Md, 512, 2048, 6), (Md, 10112, 512, 1)])
             algo = sum(c * (2 * (2 * M * K + 2 * M * N) + (2 * M * K + 2 * M * N + 4 * N * K)) for M, N, K, c in prods) + 3 * nnz_bytes
         gbs = algo / (ms_per_step * 1e-3) / 1e9
+        step_traffic, step_note = pmc_traffic("step", wtag, precision, B)
         roofline = {"bound": "hbm", "kernel": "whole step", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "alg_bytes_per_step": round(algo)}
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": step_traffic, "alg_bytes_per_step": round(algo),
+                    **({"traffic_note": step_note} if step_traffic is None and step_note.startswith("STALE") else {})}
         if decode and precision != "bf16":
             # fp32 parity mode: 6.62 GFLOP per image — ten times the HBM time of its bytes: MFMA-bound.  Its projections run
             # on the bf16 matrix cores as six bf16 partial products per fp32 product (ortk_gemm.hip: gemm_f32x3_kernel; ortk_tuning.f32_split),
@@ -453,6 +487,8 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
             roofline["rollout_kernel"] = stack
     if chain is not None:
         roofline["chain_kernel"] = chain
+    if wgrad is not None:
+        roofline["wgrad_kernel"] = wgrad
     if not decode and workload != "scst":
         # work the step EXECUTES: the valid-position decoder skips the padded caption positions (same loss and gradients), so the
         # decoder's share is scaled by the rows it runs; `padded_equivalent` is the reference's (R x 17)-row layout
@@ -487,6 +523,10 @@ def compact(r):
         out["kernel"] = {x: k[x] for x in ("kernel", "avg_us", "frac", "traffic", "alg_bytes_per_launch")}
     if "chain_kernel" in rf:
         out["chains"] = {x: rf["chain_kernel"][x] for x in ("launches", "avg_us")}
+    if "wgrad_kernel" in rf:
+        out["wgrad"] = {x: rf["wgrad_kernel"][x] for x in ("launches", "avg_us", "frac", "traffic")}
+    if rf.get("traffic") is not None and "traffic" not in out:
+        out["traffic"] = rf["traffic"]
     if "whole_step" in rf:
         out["whole_step_frac"] = rf["whole_step"]["frac"]
     if "mean_sampled_length" in rf:
@@ -523,12 +563,14 @@ def main():
                     help="scst --variant hostreward: EOS logit bias on the x3-scaled random-init generator (5.4: sampled captions of ~13 of 18 "
                          "positions, the length of the XE workload's synthetic captions; the line reports the mean sampled length)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=CPU_THREADS, help="threads of the cpu_baseline leg (default: the fastest of the committed sweep)")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="default run on one GPU: do not add the `workloads` object (BASELINE configs[2], [3], [4] timed in this process)")
     ap.add_argument("--selftest", action="store_true",
                     help="launcher check without a GPU: the ranks form a gloo group, all-reduce their rank ids and rank 0 "
                          "prints one JSON line (tests/test_dist_cpu.py)")
     args = ap.parse_args()
+    globals()["CPU_THREADS"] = max(1, args.cpu_threads)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no HIP

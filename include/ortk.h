@@ -342,6 +342,14 @@ typedef struct ortk_tuning {
     int32_t wgrad_group_wgs;      /* workgroups a grouped launch of the executor is given (row ranges = this / its 256 x 256 tiles, rounded; 80: the
                                      launch shares the chip with the caller's stream instead of filling it, scratch/wgrad_group_ab.py) */
     int32_t wgrad_group_tail;     /* 1 (default): the last group before the caller's stream waits for the side stream gets a full round of workgroups | 0 */
+    int32_t feats_bf16;           /* 1 (default, mixed precision with the side stream): a bf16 copy of the region features per step (att_embed and its weight
+                                     gradient on the bf16-operand kernels; the weight gradient in the backward's last grouped launch) and the chain weights
+                                     packed on a third queue beside att_embed | 0: fp32 features, everything at the head of the forward on the caller's stream */
+    int32_t ln_fuse;              /* bit 0: the executor's backward runs a d_model-wide data gradient and the LayerNorm backward behind it as ONE launch
+                                     (ortk_gemm ln_mode 2 on short row panels).  OFF by default: alone the fused launch ties the two it replaces
+                                     (59.5 vs 62.0 us at 16 640 x 512 x 512), inside the step it needs a free compute unit per workgroup and waits for
+                                     the units the side stream's weight gradients hold: 11.65 vs 10.40 ms per XE step (scratch/wgrad_group_ab.py)
+                                     | bit 1: ln_mode 2 on the 128-row panels of round 3 (measurement) */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

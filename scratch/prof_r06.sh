@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round-6 profile collection (run on the GPU box through gpurun, from the repo root):
+#     gpurun -- "GIT_HEAD=$(git rev-parse HEAD) bash scratch/prof_r06.sh"
+# Summaries land in gpurun_out/r06/ together with r06_manifest.json = {lib_md5, git_head, ...}: the identity of the library every
+# pass ran.  bench.py's pmc_traffic() refuses the PMC passes when that md5 is not the md5 of the library it has loaded.
+# PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r06; mkdir -p $O
+MD5=$(md5sum sparse-image-captioning_amd/libortk.so | cut -d' ' -f1)
+B="python3 bench.py --no-extra-workloads --no-cpu-baseline --steps 3 --warmup 1"
+stats() {   # name, extra args
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_$1 -o t -- $B $2 > $O/$1.log 2>&1
+  cp $O/raw_$1/t_kernel_stats.csv $O/r06_$1_kernel_stats.csv
+}
+pmc() {     # name, counter, then -- extra args
+  local name=$1; shift; local ctr=$1; shift; shift
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/raw_$name -o t -- $B "$@" > $O/$name.log 2>&1
+  python3 scratch/pmc_summary.py $O/raw_$name/t_counter_collection.csv > $O/r06_$name.csv
+}
+stats xe_b256_bf16 ""
+stats decode_stack_b1024_beam5 "--workload decode"
+stats sparse_decode_stack_b1024_beam5 "--workload sparse_decode"
+stats scst_b256_ns5 "--workload scst"
+stats sparse_xe_b256 "--workload sparse_xe"
+stats sparse_xe_kernels_b256 "--workload sparse_xe --variant kernels"
+stats decode_fp32_b1024_beam5 "--workload decode --variant fp32"
+for c in fetch_size write_size; do
+  C=$(echo $c | tr a-z A-Z)
+  pmc xe_b256_pmc_$c $C --
+  pmc decode_stack_pmc_$c $C -- --workload decode
+  pmc sparse_decode_stack_pmc_$c $C -- --workload sparse_decode
+  pmc sparse_decode_988_stack_pmc_$c $C -- --workload sparse_decode --variant 988
+  pmc scst_b256_pmc_$c $C -- --workload scst
+  pmc sparse_xe_b256_pmc_$c $C -- --workload sparse_xe
+  pmc sparse_xe_kernels_b256_pmc_$c $C -- --workload sparse_xe --variant kernels
+done
+rm -rf $O/raw_*
+python3 - <<PY
+import json, time
+json.dump({"lib_md5": "$MD5", "git_head": "${GIT_HEAD:-unknown}", "collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+           "command": "scratch/prof_r06.sh", "bench": "$B",
+           "note": "every r06_*_kernel_stats.csv and r06_*_pmc_*.csv in this directory was produced by this library in this one gpurun call"},
+          open("$O/r06_manifest.json", "w"), indent=1)
+PY
+cp $O/r06_manifest.json profiles/r06_manifest.json; cp $O/r06_*_pmc_*.csv profiles/     # (on the box: the bench line below reads them)
+python3 scratch/cpu_thread_sweep.py > $O/r06_cpu_thread_sweep.txt 2>&1
+python3 bench.py --steps 50 --warmup 10 > $O/r06_default_bench_line.json 2> $O/bench.err
+wc -c $O/r06_default_bench_line.json; tail -2 $O/bench.err
+ls $O | head -60

@@ -102,7 +102,7 @@ class MaskedAdamArgs(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
                 ("side_stream", C.c_int32), ("row_chain", C.c_int32), ("chain_wide", C.c_int32), ("spmm_alias", C.c_int32), ("f32_split", C.c_int32), ("wgrad_wgs", C.c_int32),
-                ("wgrad_group", C.c_int32), ("wgrad_group_splitk", C.c_int32), ("wgrad_group_wgs", C.c_int32), ("wgrad_group_tail", C.c_int32)]
+                ("wgrad_group", C.c_int32), ("wgrad_group_splitk", C.c_int32), ("wgrad_group_wgs", C.c_int32), ("wgrad_group_tail", C.c_int32), ("feats_bf16", C.c_int32), ("ln_fuse", C.c_int32)]
 
 
 DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL, DEC_SPARSE_GATHER = 1, 2, 4, 8, 16, 32, 64      # ortk_decode_opts.exec_flags

@@ -1194,6 +1194,179 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_row512_kernel(ortk_gemm_args
 }
 
 // ------------------------------------------------------------------------------------------------
+// Data-gradient product + LayerNorm backward on SHORT row panels (ln_mode = 2, round 6): (16 MT rows) x 512 columns per workgroup,
+// MT = 2 .. 5 chosen so that the grid is about one workgroup per compute unit (16 640 rows -> 80-row panels, 208 workgroups;
+// 9 216 -> 48-row panels, 192).  The 128-row form above owns whole rows as well, but its 130 workgroups moved the epilogue's
+// 0.6-1.1 MB each through half of the chip's load/store paths and lost to the separate kernels (section 7c of DESIGN.md); here
+// every unit streams its share of x / dres / dx / dz, the LayerNorm input stays in registers between the two passes (the small
+// accumulator tile leaves room), and the weight panel — 512 KB, re-read by every workgroup — comes out of L2 in two 64-column stages
+// (LDS-DMA; the pieces of the next stage issued between this stage's MFMA groups).
+// Replaces, per LayerNorm of the backward: one data-gradient GEMM launch + one ln_bwd launch and the fp32 (rows, 512) product
+// between them (34 MB written and read back at 16 640 rows).  8 waves, wave w = columns 64 w .. 64 w + 63 of all MT row tiles.
+constexpr int LB_BK = 64, LB_N = 512;
+constexpr int LB_IMG_B = LB_N * LB_BK;                          // bf16 elements of a weight stage (64 KB)
+template <int MT> constexpr size_t lb_lds_bytes() { return (size_t)2 * (LB_IMG_B + 16 * MT * LB_BK) * sizeof(__bf16); }
+
+template <int MT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_rowln_bwd_kernel(ortk_gemm_args p) {
+    constexpr int RM = 16 * MT, IMG_A = RM * LB_BK, STAGE = LB_IMG_B + IMG_A;
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = blockIdx.x * RM;
+    const __bf16* Ap = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Bp = reinterpret_cast<const __bf16*>(p.B);
+    const int T = p.K / LB_BK;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Two stages of 64 columns: a [512][64] weight image + a [RM][64] operand image, FULL 128-byte rows (chunk' = chunk ^ ((row >> 1) & 7):
+    // the images of gemm_bf16_dma256_kernel; 32-column stages asked for half cache lines and ran the K loop at 7 B/clk per unit).
+    // Ten 1-KB pieces (8 rows each) per wave and stage: 8 of the weights, 2 of the operand rows (pieces past 2 MT repeat earlier ones —
+    // the same bytes to the same place — so that every wave counts the same vmcnt), issued between the MFMA groups of the stage before.
+    const int prow = lane >> 3;
+    uint32_t offB[8], offA[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int r = (wave * 8 + u) * 8 + prow; offB[u] = (uint32_t)((r * (int)p.ldb + (((lane & 7) ^ swz_mk64(r)) << 3)) * 2); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int r = ((wave * 2 + u) % (2 * MT)) * 8 + prow; offA[u] = (uint32_t)((min(mb + r, p.M - 1) * (int)p.lda + (((lane & 7) ^ swz_mk64(r)) << 3)) * 2); }
+    auto piece = [&](int t, int q) {      // piece q = 0..9 of stage t
+        __bf16* st = smem16 + (size_t)(t & 1) * STAGE;
+        if (q < 8) __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(Bp + t * LB_BK) + offB[q]), (lds_void*)(st + (wave * 8 + q) * 512), 16, 0, 0);
+        else       __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(Ap + t * LB_BK) + offA[q - 8]),
+                                                    (lds_void*)(st + LB_IMG_B + ((wave * 2 + q - 8) % (2 * MT)) * 512), 16, 0, 0);
+    };
+    if (T > 0) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) piece(0, q);
+    }
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool next = t + 1 < T;
+        const __bf16* sB = smem16 + (size_t)(t & 1) * STAGE;
+        const __bf16* sA = sB + LB_IMG_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[MT], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = gfrag64<false>(sB, wave * 64 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = gfrag64<false>(sA, 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (next) {
+                    constexpr int SLOTS = 2 * MT;
+                    const int slot = ks * MT + i;
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) if ((q * SLOTS) / 10 == slot) piece(t + 1, q);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // the ring becomes reduction scratch
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                   // (epilogue addresses from an opaque lane id: not hoisted above the K loop)
+    const int lr = lane_e & 15, lg = lane_e >> 4;
+    float* red0 = reinterpret_cast<float*>(smem16);    // [RM rows][8 column waves]
+    float* red1 = red0 + RM * 8;
+    const int row0 = mb + lr;                          // + 16 i
+    const int col0 = wave * 64 + 4 * lg;               // + 16 j (+ r)
+    // dy = acc.  With xc = x - mean, rr = 1 / (sd + eps), g = dy * a:  dx = rr (g - mean(g)) - rr^2 sum(g xc) xc / (511 sd) + dres;
+    // da += sum_rows dy xc rr, db += sum_rows dy  (ortk_norm.hip: ln_bwd_kernel, the same formulas)
+    float mean[MT], sd[MT], rr[MT], vf[MT], sg[MT], sgx[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int rowc = min(row0 + 16 * i, p.M - 1);
+        mean[i] = p.ln_stats[(int64_t)rowc * 2]; sd[i] = p.ln_stats[(int64_t)rowc * 2 + 1];
+        rr[i] = 1.f / (sd[i] + p.ln_eps);
+        vf[i] = row0 + 16 * i < p.M ? 1.f : 0.f;
+        sg[i] = 0.f; sgx[i] = 0.f;
+    }
+    // pass 1, one column tile at a time: row sums of g = dy a and of g xc, column sums of the parameter gradients (x is read again in
+    // pass 2 — 16 MT more registers per lane would hold it, and spill: the second read comes out of the Infinity Cache)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 xv[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xv[i] = *reinterpret_cast<const f32x4*>(p.ln_x + (int64_t)min(row0 + 16 * i, p.M - 1) * LB_N + col0 + 16 * j);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(p.ln_a + col0 + 16 * j);
+        float pa[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dyv = acc[i][j][r];
+                const float t_ = dyv * (xv[i][r] - mean[i]);
+                pa[r] += t_ * (rr[i] * vf[i]); pb[r] += dyv * vf[i];       // (rows past M only have to stay out of the column sums)
+                const float g = dyv * ga[r];
+                acc[i][j][r] = g; sg[i] += g; sgx[i] += t_ * ga[r];
+            }
+        }
+        // the wave owns its 64 columns: sum over the 16 rows of a lane row by DPP, one atomic per column and workgroup
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pa[r] = row16_sum(pa[r]); pb[r] = row16_sum(pb[r]); }
+        if (lr == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { atomicAdd(p.ln_da + col0 + 16 * j + r, pa[r]); atomicAdd(p.ln_db + col0 + 16 * j + r, pb[r]); }
+        }
+    }
+    // row totals over the 512 columns: the four lane groups by two shuffles, the eight column waves through LDS
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        sg[i] += __shfl_xor(sg[i], 16, 64); sg[i] += __shfl_xor(sg[i], 32, 64);
+        sgx[i] += __shfl_xor(sgx[i], 16, 64); sgx[i] += __shfl_xor(sgx[i], 32, 64);
+        if (lg == 0) { red0[(16 * i + lr) * 8 + wave] = sg[i]; red1[(16 * i + lr) * 8 + wave] = sgx[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(red0 + (16 * i + lr) * 8), q1 = *reinterpret_cast<const f32x4*>(red0 + (16 * i + lr) * 8 + 4);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(red1 + (16 * i + lr) * 8), u1 = *reinterpret_cast<const f32x4*>(red1 + (16 * i + lr) * 8 + 4);
+        sg[i] = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+        sgx[i] = ((u0[0] + u0[1]) + (u0[2] + u0[3])) + ((u1[0] + u1[1]) + (u1[2] + u1[3]));
+    }
+    const float ik = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = row0 + 16 * i, rowc = min(row, p.M - 1);
+        const float mg = sg[i] * (1.f / LB_N);
+        const float coef = rr[i] * rr[i] * sgx[i] / ((float)(LB_N - 1) * sd[i]);
+        f32x4 dr[4], xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[j] = *reinterpret_cast<const f32x4*>(p.ln_x + (int64_t)rowc * LB_N + col0 + 16 * j);
+            const f32x4 t_ = *reinterpret_cast<const f32x4*>((p.ln_dres ? p.ln_dres : p.ln_x) + (int64_t)rowc * LB_N + col0 + 16 * j);
+            dr[j] = p.ln_dres ? t_ : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (row < p.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = rr[i] * (acc[i][j][r] - mg) - coef * (xv[j][r] - mean[i]) + dr[j][r];
+                const int64_t i0 = (int64_t)row * LB_N + col0 + 16 * j;
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + i0) = o;
+                if (p.ln_y) {
+                    bool kp[4] = {true, true, true, true};
+                    if (p.drop_p > 0.f) ortk_keep4(p.drop_seed, p.drop_rows ? (uint64_t)p.drop_rows[row] * LB_N + (uint64_t)(col0 + 16 * j) : (uint64_t)i0, p.drop_p, kp);
+                    st_elem4(p.ln_y, i0, p.ln_y_dtype, make_float4(kp[0] ? o[0] * ik : 0.f, kp[1] ? o[1] * ik : 0.f, kp[2] ? o[2] * ik : 0.f, kp[3] ? o[3] * ik : 0.f));
+                }
+            }
+        }
+    }
+}
+template <int MT> static int launch_rowln_bwd(const ortk_gemm_args& p, hipStream_t s) {
+    if (ortk::lds_attr(reinterpret_cast<const void*>(gemm_bf16_rowln_bwd_kernel<MT>), lb_lds_bytes<MT>())) return ORTK_EINVAL;
+    hipLaunchKernelGGL(gemm_bf16_rowln_bwd_kernel<MT>, dim3((unsigned)ortk_cdiv(p.M, 16 * MT)), dim3(512), lb_lds_bytes<MT>(), s, p);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 64 x 64 tile, 64-column K-steps, forward layout only, for SHORT grids: the decode-time projections (rows = images x
 // beams, a few thousand at most) give the 128 x 128 kernels 48-640 workgroups, so most CUs idle or the last round is
 // nearly empty, and every workgroup walks its K panel as a chain of fetch round trips.  Four times as many workgroups
@@ -1914,6 +2087,29 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             if (p.ln_mode == 1) return ortk_layernorm_fwd(Cf, p.ln_a, p.ln_b, p.ln_y, p.ln_y_dtype, p.ln_stats, p.M, p.N, p.ln_eps, stream);
             return ortk_layernorm_bwd_drop_rows(Cf, p.ln_x, p.ln_a, p.ln_stats, p.ln_dres, Cf, p.ln_da, p.ln_db, p.M, p.N, p.ln_eps,
                                                 p.ln_y, p.ln_y_dtype, p.drop_p, p.drop_seed, p.drop_rows, stream);
+        }
+        if (p.ln_mode == 2 && p.K % LB_BK == 0 && p.lda < (1 << 30) / 2 && p.ldb < (1 << 30) / 2 && (int64_t)p.M * p.lda < (1ll << 30) && !(ortk::tuning().ln_fuse & 2)) {
+            // short row panels, about one workgroup per compute unit
+            const int mt = (int)std::min<int64_t>(5, std::max<int64_t>(2, ortk_cdiv(p.M, 16 * 256)));      // (96-row panels spill)
+            hipStream_t s = ortk_s(stream);
+            ProfRec rec{};
+            if (g_prof_on) {
+                if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return ORTK_EINVAL;
+                rec.key = 4; rec.flops = 2.0 * p.M * p.N * p.K;
+                rec.bytes = (double)p.M * p.K * 2 + (double)p.N * p.K * 2 + (double)p.M * p.N * (4 + 4 + 4 + 2);
+                (void)hipEventRecord(rec.a, s);
+            }
+            int e = 0;
+            switch (mt) {
+                case 2: e = launch_rowln_bwd<2>(p, s); break;
+                case 3: e = launch_rowln_bwd<3>(p, s); break;
+                case 4: e = launch_rowln_bwd<4>(p, s); break;
+                default: e = launch_rowln_bwd<5>(p, s); break;
+            }
+            if (g_prof_on) { (void)hipEventRecord(rec.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof->push_back(rec); }
+            if (e) return e;
+            ORTK_CHECK_LAUNCH();
+            return 0;
         }
         gemm16_fn g = p.ln_mode == 1 ? gemm_bf16_row512_kernel<1> : gemm_bf16_row512_kernel<2>;
         ortk::lds_attr(reinterpret_cast<const void*>(g), RP_LDS_BYTES);

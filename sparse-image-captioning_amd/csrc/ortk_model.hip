@@ -342,6 +342,7 @@ struct TrainWS {
     void* gtp[NGT] = {};
     void* gqkv2 = nullptr;                  // layers alternate between gqkv / gqkv2 and gh / gh2
     void* wg_ws = nullptr; size_t wg_ws_bytes = 0;      // partial tiles + tickets of one grouped launch (launches are ordered by their stream)
+    void* feats16 = nullptr;                // bf16 copy of the region features (mixed precision): operand of att_embed and of its weight gradient
     size_t bytes;
 };
 
@@ -410,6 +411,7 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
         // (at most max(256, tiles) partial tiles per launch: the K ranges are chosen for one round of workgroups; a forced split of 8 at most)
         w.wg_ws_bytes = (size_t)(((tiles * 4 + 255) & ~(int64_t)255) + std::max<int64_t>(256 + tiles, tiles * 8) * 256 * 256 * 4);
         w.wg_ws = b.take_bytes(w.wg_ws_bytes);
+        w.feats16 = b.take_bytes((size_t)Me * c.feat * 2);
     }
     w.bytes = (b.off + 255) & ~(size_t)255;
 }
@@ -427,11 +429,14 @@ static void carve_train(const ortk_config& c, int B, int S, int R, int T, void* 
 // qkv 124 -> 87 us, of the 512 x 512 projections no change.
 struct SideStream {
     hipStream_t s = nullptr;
+    hipStream_t s2 = nullptr;      // a third queue for short independent launches at the head of a forward (the chain weights' packing)
     hipEvent_t ev[64];
     int next = 0;
     bool ok = false;
     bool init() {
+        // (a side stream at the lowest priority the device offers measured the same step: 10.51 ms both ways, round 6)
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return false;
         for (auto& x : ev) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
         return true;
@@ -610,7 +615,10 @@ static int flush_wgrads(const Ctx& c, bool urgent = false) {
     int64_t tiles = 0;
     for (int i = 0; i < c.grp.n; ++i) tiles += ortk_cdiv(c.grp.item[i].Nout, 256) * ortk_cdiv(c.grp.item[i].Kin, 256);
     const int forced = tuning().wgrad_group_splitk, target = tuning().wgrad_group_wgs;
-    c.grp.splitk = forced > 0 ? forced : (urgent && tuning().wgrad_group_tail) ? 0 : (int)std::max<int64_t>(1, (target + tiles / 2) / tiles);
+    // (urgent: one round of workgroups, but never fewer than 64 stages of 32 rows per workgroup — each row range adds its whole tile to the
+    //  arena: nine ranges of 32 stages made the step's last launch 137 us, 50 of them atomics)
+    const int64_t full = std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(1, tiles), c.grp.rows / (64 * 32)));
+    c.grp.splitk = forced > 0 ? forced : (urgent && tuning().wgrad_group_tail) ? (int)full : (int)std::max<int64_t>(1, (target + tiles / 2) / tiles);
     c.grp.flags = 0;
     c.grp.ws = nullptr; c.grp.ws_bytes = 0;
     if (tuning().wgrad_group & 8) {
@@ -689,6 +697,32 @@ static int drop_bwd(const Ctx& c, const float* dx, void* tmp, int64_t n, uint32_
     return 0;
 }
 
+// dX = dLN/dx(dY W) + dres in ONE launch (ortk_gemm ln_mode 2: short row panels, LayerNorm backward in the epilogue), or — sparse plans,
+// fp32 mode, widths other than 512, a sub-block of a packed projection — the data-gradient GEMM into `gy` followed by ln_bwd.
+// (W stored (N_out, K_in) with K_in = d_model; the LayerNorm is the one whose OUTPUT the projection read.)
+static int dgrad_ln_bwd(const Ctx& c, const void* dY, int dydt, int64_t lddy, int64_t woff, int64_t M, int Nout, int Kin, float* gy,
+                        const float* x, float* G, int64_t na, int64_t nb, const float* st, const float* dres, float* dx, void* dz, int next_op,
+                        bool whole_block = true) {
+    const bool fusable = tuning().ln_fuse & 1 && c.prec && c.W16T && whole_block && dydt == ORTK_BF16 && Kin == 512 && Kin == c.cfg->d_model &&
+                         (Nout % 64) == 0 && Ctx::ell_block(c.ell_b, woff, Kin, Nout) < 0 && !c.ell_b;
+    if (!fusable) {
+        TRY(dgrad_gemm(c, dY, dydt, lddy, woff, gy, ORTK_F32, Kin, M, Nout, Kin, nullptr, 0, 0, 1.f, whole_block));
+        return ln_bwd(c, gy, x, G, na, nb, st, dres, dx, M, dz, next_op);
+    }
+    const bool mask = dz && next_op >= 0;        // (mixed precision: the masked copy is also the bf16 conversion)
+    ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
+    a.A = dY; a.a_dtype = ORTK_BF16; a.lda = lddy;
+    a.B = reinterpret_cast<const __bf16*>(c.W16T) + woff; a.b_dtype = ORTK_BF16; a.ldb = Nout;
+    a.C = dx; a.c_dtype = ORTK_F32; a.ldc = Kin; a.M = (int)M; a.N = Kin; a.K = Nout; a.precision = 1;
+    a.ln_mode = 2; a.ln_a = c.P + na; a.ln_stats = const_cast<float*>(st); a.ln_eps = 1e-6f; a.ln_x = x; a.ln_dres = dres;
+    a.ln_da = G + na; a.ln_db = G + nb;
+    a.ln_y = mask ? dz : nullptr; a.ln_y_dtype = c.adt;
+    a.drop_p = c.p_drop(); a.drop_seed = mask ? c.sub((uint32_t)next_op) : 0; a.drop_rows = c.drop_rows;
+    TRY(c.before_write(dx));
+    if (mask) TRY(c.before_write(dz));
+    return ortk_gemm(&a, (ortk_stream)c.s);
+}
+
 static const float DIM_MAT_SENTINEL = -1.f;
 static float g_dim_mat[8] = {DIM_MAT_SENTINEL, 0, 0, 0, 0, 0, 0, 0};
 static const float* dim_mat() {
@@ -737,7 +771,9 @@ static int queue_box_bias(const Ctx& c, const Offsets& o, const float* boxes, fl
 static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, const float* boxes, const float* masks, int B, int S,
                            float* x0, float* logbias, const EncPtrs* bufs, void* mem, int mem_dt, float* st_mem, int qdt = ORTK_F32,
                            const hipEvent_t* box_queued = nullptr, const ChainSet* cs = nullptr, const void* chain_pk = nullptr,
-                           bool keep = true) {       // keep = false (decode): the chains do not store what only a backward would read
+                           bool keep = true,         // keep = false (decode): the chains do not store what only a backward would read
+                           const void* feats16 = nullptr, hipEvent_t feats16_done = nullptr,     // bf16 copy of the features, made on another queue
+                           hipEvent_t pack_done = nullptr) {                                        // the chains' packed weights, likewise
     const ortk_config& cfg = *c.cfg;
     const float* P = c.P;
     const int d = cfg.d_model, ff = cfg.d_ff, H = cfg.n_heads, L = cfg.n_layers, dk = d / H, A = c.adt;
@@ -754,8 +790,15 @@ static int encoder_forward(const Ctx& c, const Offsets& o, const float* feats, c
     } else {
         TRY(queue_box_bias(c, o, boxes, logbias, B, S, &box_done));
     }
-    TRY(fwd_gemm(c, feats, ORTK_F32, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
-                 nullptr, 0, plain ? nullptr : masks));
+    if (feats16) {
+        TRY(c.wait_ev(feats16_done));
+        TRY(fwd_gemm(c, feats16, ORTK_BF16, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
+                     nullptr, 0, plain ? nullptr : masks));
+    } else {
+        TRY(fwd_gemm(c, feats, ORTK_F32, cfg.feat, o.att_w, P + o.att_b, x0, ORTK_F32, d, Me, d, cfg.feat, true, c.p_src(), c.sub(OP_SRC),
+                     nullptr, 0, plain ? nullptr : masks));
+    }
+    TRY(c.wait_ev(pack_done));
     const float* x = x0;
     const AttMode am = att_mode(cfg.share_att_enc);
     // rows-stationary chains (ortk_chain.hip) in place of the LayerNorm / projection launches: bf16 Q|K|V and memory, dense products
@@ -837,7 +880,7 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384, 3, 0, 80, 1};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384, 3, 0, 80, 1, 1, 0};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
@@ -951,7 +994,16 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     // which only the backward reads, is made on the side stream behind it.
     hipEvent_t box_done = nullptr;
     const bool box_early = c.use_side && !cfg->no_box && phase != 2;
+    // mixed precision with the side stream: the region features get a bf16 copy there, ahead of the geometry bias (25 us for 75 MB): the
+    // att_embed product then runs on the LDS-DMA tiles instead of the fp32-operand kernel (89 -> 35 us at the head of the step), and its
+    // weight gradient joins the last grouped launch of the backward (it was a 120-us launch of its own at the very end)
+    hipEvent_t feats16_done = nullptr;
+    const bool f16 = c.use_side && w.feats16 && phase != 2 && (cfg->feat % 64) == 0 && tuning().feats_bf16;
     if (phase != 2) {
+        if (f16) {
+            TRY(ortk_cast_bf16(bt->att_feats, w.feats16, w.Me * cfg->feat, (ortk_stream)c.side->s));
+            TRY(c.side_mark(&feats16_done));
+        }
         if (box_early) TRY(queue_box_bias(c, o, bt->boxes, w.logbias, bt->B, bt->S, &box_done));
         TRY(make_w16(cfg, o, params, w.w16, stream));
         if (c.use_side) {
@@ -994,7 +1046,20 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     // picks the OTHER form of the chain kernel (76-row blocks stream the FFN units in another order) packs again, from the same bf16
     // weight copy, for the layout chain_run() will derive from its own row count (the encoder's units, already consumed, ride along).
     const bool repack2 = phase == 2 && cs.on && chain_wide(w.Md) != chain_wide(Md);
-    if (cs.on && (phase != 2 || repack2)) TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.s));
+    // (with the side streams: on the third queue, beside att_embed — 117 us the first chain used to wait for on the caller's stream;
+    //  the caller's stream and the side stream's decoder prefix wait for it right before their first chain)
+    hipEvent_t pack_done = nullptr;
+    if (cs.on && (phase != 2 || repack2)) {
+        if (c.use_side && phase != 2 && tuning().feats_bf16) {
+            hipEvent_t w16_ready = c.side->take();
+            pack_done = c.side->take();
+            if (hipEventRecord(w16_ready, c.s) != hipSuccess || hipStreamWaitEvent(c.side->s2, w16_ready, 0) != hipSuccess) return ORTK_EINVAL;
+            TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.side->s2));
+            if (hipEventRecord(pack_done, c.side->s2) != hipSuccess) return ORTK_EINVAL;
+        } else {
+            TRY(chain_pack_all(w.w16, w.chain_pk, cs.t, c.s));
+        }
+    }
     EncPtrs ep[MAXLAYERS]; enc_ptrs_from_ws(w, L, ep);
     const AttMode am = att_mode(cfg->share_att_dec);
     const int64_t cw = o.cw, cv = o.cv;
@@ -1040,10 +1105,12 @@ extern "C" int ortk_forward_phase(const ortk_config* cfg, const float* params, c
     const bool prefix_side = c.use_side && phase == 0;       // (split phases: the token side has no encoder to run beside)
     if (prefix_side) {
         TRY(c.fork());                     // the side stream sees the bf16 weight copy
+        if (pack_done && hipStreamWaitEvent(c.side->s, pack_done, 0) != hipSuccess) return ORTK_EINVAL;      // ... and the packed chain weights
     }
     if (phase != 2)
         TRY(encoder_forward(c, o, bt->att_feats, bt->boxes, bt->att_masks, B, S, w.x0, w.logbias, ep, w.mem, A, w.st_mem, w.qdt_enc,
-                            box_early ? &box_done : nullptr, &cs, w.chain_pk));
+                            box_early ? &box_done : nullptr, &cs, w.chain_pk, true, f16 ? w.feats16 : nullptr, feats16_done, pack_done));
+    else TRY(c.wait_ev(pack_done));
     // From here on every operator with a dropout site runs on DECODER rows: on the valid positions it draws what the padded
     // (caption, position) layout draws (a step is the same function of its seed in both layouts; an SCST update on the valid
     // positions reproduces its train-mode rollout's masks).
@@ -1229,6 +1296,8 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     const bool bch_enc = bch_any && tuning().row_chain >= 2, bch = bch_any && tuning().row_chain >= 3;
     if (bch_enc && phase != 2) TRY(chain_pack_all(w.w16t, w.chain_pk_b, bs.t, c.s));
     const bool grp_layers = grouped && (wgm & 1), grp_gen = grouped && (wgm & 2), grp_kv = grouped && (wgm & 4);
+    // the bf16 feature copy of this step's forward (same conditions there) lets att_embed's weight gradient join layer 0's group
+    const bool tail_group = grp_layers && c.use_side && w.feats16 && (cfg->feat % 64) == 0 && tuning().feats_bf16 && !bch_enc;
     auto gq_of = [&](int l) { return (grp_layers && (l & 1)) ? w.gqkv2 : w.gqkv; };
     auto gh_of = [&](int l) { return (grp_layers && (l & 1)) ? w.gh2 : w.gh; };
     const int NCc = ff / 512;
@@ -1349,8 +1418,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Md, d, ff));
         TRY(dgrad_gemm(c, dt, dtt, d, e.w2, ghl, A, ff, Md, d, ff, b.h, A, ff, inv_keep));
         TRY(wgrad_gemm(c, ghl, A, ff, b.y3, A, d, G + e.w1, G + e.b1, Md, ff, d));
-        TRY(dgrad_gemm(c, ghl, A, ff, e.w1, w.gy, ORTK_F32, d, Md, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, Md, gt_new(), dop(l, 3)));
+        TRY(dgrad_ln_bwd(c, ghl, A, ff, e.w1, Md, ff, d, w.gy, b.xm2, G, e.n2a, e.n2b, b.st3, dx, dx2, gt_new(), dop(l, 3)));
         // cross-attention sublayer
         TRY(drop_bwd(c, dx2, gt_cur, Md * d, dop(l, 3), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o2, A, d, G + e.cow, G + e.cob, Md, d, d));
@@ -1369,8 +1437,10 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(c.before_write(gt_cur));
         TRY(ortk_attention_bwd(&a, stream));
         TRY(wgrad_gemm(c, gt_cur, A, d, b.y2, A, d, G + e.cqw, G + e.cqb, Md, d, d));
-        TRY(dgrad_gemm(c, gt_cur, A, d, e.cqw, w.gy, ORTK_F32, d, Md, d, d, nullptr, 0, 0, 1.f, cfg->share_att_dec != 2));
-        TRY(ln_bwd(c, w.gy, b.xm1, G, e.n1a, e.n1b, b.st2, dx2, dx, Md, gt_new(), dop(l, 1)));
+        {
+            const void* dq_ = gt_cur;
+            TRY(dgrad_ln_bwd(c, dq_, A, d, e.cqw, Md, d, d, w.gy, b.xm1, G, e.n1a, e.n1b, b.st2, dx2, dx, gt_new(), dop(l, 1), cfg->share_att_dec != 2));
+        }
         // self-attention sublayer
         TRY(drop_bwd(c, dx, gt_cur, Md * d, dop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o1, A, d, G + e.wo, G + e.bo, Md, d, d));
@@ -1389,8 +1459,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, gql, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Md, amd.n * d, d));
         TRY(flush_wgrads(c, l == 0));        // the layer's six weight gradients: one launch
         c.grp_on = false;
-        TRY(dgrad_gemm(c, gql, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Md, amd.n * d, d));
-        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, Md, gt_new(), l > 0 ? (int)dop(l - 1, 5) : -1));
+        TRY(dgrad_ln_bwd(c, gql, A, 3 * d, e.wqkv, Md, amd.n * d, d, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx, dx2, gt_new(), l > 0 ? (int)dop(l - 1, 5) : -1));
         std::swap(dx, dx2);
     }
     // the embedding gradient (atomics into the 5 M-element table) only feeds the optimizer: beside the K/V projection GEMMs
@@ -1425,6 +1494,7 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
     // kernel for all layers at the very end of the step had the att_embed weight gradient as its only company (the
     // embedding's sin / cos are then evaluated twice: 2 x 0.08 ms of side-stream time against 0.25 ms of exposed tail).
     const bool box_split = c.use_side && !cfg->no_box && L > 2;
+    hipEvent_t box_done_ev = nullptr;
     auto box_grad = [&](int l0, int n) -> int {
         const float* wg[MAXLAYERS]; const float* bg[MAXLAYERS]; float* dwg[MAXLAYERS]; float* dbg[MAXLAYERS];
         for (int l = 0; l < n; ++l) {
@@ -1432,9 +1502,14 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         }
         const float* ds = w.dscore + (int64_t)l0 * B * H * S * S;
         if (c.use_side) {
-            TRY(c.fork());
-            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, ds, dwg, dbg, n, B, S, H, (ortk_stream)c.side->s));
-            return c.side_mark(nullptr);
+            // on the THIRD queue (in order behind the side stream's weight-gradient groups it delayed every later group by its 0.3 ms:
+            // the side stream reached the end of the step 0.25 ms late); joined at the end of the backward
+            hipEvent_t ready = c.side->take();
+            box_done_ev = c.side->take();
+            if (hipEventRecord(ready, c.s) != hipSuccess || hipStreamWaitEvent(c.side->s2, ready, 0) != hipSuccess) return ORTK_EINVAL;
+            TRY(ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, ds, dwg, dbg, n, B, S, H, (ortk_stream)c.side->s2));
+            if (hipEventRecord(box_done_ev, c.side->s2) != hipSuccess) return ORTK_EINVAL;
+            return 0;
         }
         return ortk_box_logbias_bwd(bt->boxes, wg, bg, cfg->box_trig ? dim_mat() : nullptr, ds, dwg, dbg, n, B, S, H, stream);
     };
@@ -1504,10 +1579,11 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(wgrad_gemm(c, dt, dtt, d, b.h, A, ff, G + e.w2, G + e.b2, Me, d, ff));
         TRY(dgrad_gemm(c, dt, dtt, d, e.w2, ghl, A, ff, Me, d, ff, b.h, A, ff, inv_keep));
         TRY(wgrad_gemm(c, ghl, A, ff, b.y2, A, d, G + e.w1, G + e.b1, Me, ff, d));
-        TRY(dgrad_gemm(c, ghl, A, ff, e.w1, w.gy, ORTK_F32, d, Me, ff, d));
-        TRY(ln_bwd(c, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, Me, gt_new(), eop(l, 1)));
+        TRY(dgrad_ln_bwd(c, ghl, A, ff, e.w1, Me, ff, d, w.gy, b.xm, G, e.n1a, e.n1b, b.st2, dx, dx2, gt_new(), eop(l, 1)));
         TRY(drop_bwd(c, dx2, gt_cur, Me * d, eop(l, 1), &dt, &dtt, true));
         TRY(wgrad_gemm(c, dt, dtt, d, b.o, A, d, G + e.wo, G + e.bo, Me, d, d));
+        // (layer 0 with the tail group: the three gradients whose operands exist go now; wqkv's and att_embed's, which the step ends with, form a small last group)
+        if (l == 0 && tail_group) TRY(flush_wgrads(c));
         void* dOe = w.qdt_enc ? w.gdo : (void*)w.gy;
         TRY(dgrad_gemm(c, dt, dtt, d, e.wo, dOe, w.qdt_enc, d, Me, d, d));
         ortk_attn_args a; std::memset(&a, 0, sizeof(a)); a.precision = c.prec;
@@ -1520,24 +1596,33 @@ extern "C" int ortk_backward_phase(const ortk_config* cfg, const float* params, 
         TRY(c.before_write(gql));
         TRY(ortk_attention_bwd(&a, stream));
         if (l == 1 && box_split) TRY(box_grad(1, L - 1));     // layers 1 .. L-1: beside the last two encoder layers
+        if (l == 0 && tail_group && !cfg->no_box) TRY(box_grad(0, box_split ? 1 : L));      // (third queue: done before the step's last launch needs the units)
         TRY(fold(ame, Me, gql));
         TRY(wgrad_gemm(c, gql, A, 3 * d, b.y1, A, d, G + e.wqkv, G + e.bqkv, Me, ame.n * d, d));
-        TRY(flush_wgrads(c, l == 0));        // the layer's four weight gradients: one launch
+        if (l > 0 || !tail_group) TRY(flush_wgrads(c, l == 0));        // the layer's four weight gradients: one launch (layer 0: below)
         c.grp_on = false;
-        TRY(dgrad_gemm(c, gql, A, 3 * d, e.wqkv, w.gy, ORTK_F32, d, Me, ame.n * d, d));
-        TRY(ln_bwd(c, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, Me, gt_new(), l > 0 ? (int)eop(l - 1, 3) : -1));
+        TRY(dgrad_ln_bwd(c, gql, A, 3 * d, e.wqkv, Me, ame.n * d, d, w.gy, xin, G, e.n0a, e.n0b, b.st1, dx2, dx, gt_new(), l > 0 ? (int)eop(l - 1, 3) : -1));
     }
-    // geometry bias weights: layer 0 (with the side stream; else all layers), beside the att_embed gradient
-    if (!cfg->no_box) TRY(box_grad(0, box_split ? 1 : L));
+    // The tail.  With the grouped weight gradients and the bf16 feature copy: layer 0's last weight gradient was held back, att_embed's
+    // joins the one that is still held back (wqkv's), and the two go as ONE launch on the side stream; the geometry-bias gradient of layer 0 went
+    // to the third queue right behind layer 0's attention backward (its workgroups hold the LDS of every unit: beside the last launch they delayed it by their 63 us).  (Before: an urgent 4-gradient launch beside the last LayerNorm backward, which
+    // took 116 instead of 24 us for it, then a 120-us att_embed launch of its own on the caller's stream.)
+    if (!cfg->no_box && !tail_group) TRY(box_grad(0, box_split ? 1 : L));
     // att_embed: x0 = dropout(relu(.) * mask)  ->  d(pre-activation) = dx * [x0 > 0] / (1 - p_src)
     TRY(c.before_write(gt_new()));
     TRY(ortk_gate_apply(dx, w.x0, gt_cur, A, Me * d, c.p_src() > 0.f ? 1.f / (1.f - c.p_src()) : 1.f, stream));
-    {   // the last weight gradient stays on the caller's stream: the side stream is busy with the geometry-bias gradient
+    if (tail_group) {
+        c.grp_on = true;
+        TRY(wgrad_gemm(c, gt_cur, A, d, w.feats16, ORTK_BF16, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
+        TRY(flush_wgrads(c, true));
+        c.grp_on = false;
+    } else {   // the last weight gradient stays on the caller's stream: the side stream is busy with the geometry-bias gradient
         const bool us = c.use_side;
         c.use_side = false;
         TRY(wgrad_gemm(c, gt_cur, A, d, bt->att_feats, ORTK_F32, cfg->feat, G + o.att_w, G + o.att_b, Me, d, cfg->feat));
         c.use_side = us;
     }
+    TRY(c.wait_ev(box_done_ev));
     return c.join();       // every gradient is final in the caller's stream order
 }
 
