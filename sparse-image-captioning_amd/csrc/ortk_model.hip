@@ -474,21 +474,30 @@ struct Ctx {
                                                  // teacher-forced pass (ortk_gemm_args.drop_row_stride / _off); 0: the natural index
     bool use_side = false;                       // weight-gradient GEMMs (and other independent work) on `side`
     SideStream* side = nullptr;                  // the side stream of this call's (device, caller stream)
-    struct Pend { const void* buf; hipEvent_t done; };
+    struct Pend { const void* buf; hipEvent_t done; uint64_t seq; };
     mutable Pend pend[32] = {};                  // buffers a forked, not yet joined wgrad reads
+    // The side stream runs its launches in order: once the caller's stream has waited for launch number k, every buffer read by a
+    // launch <= k is free.  before_write() therefore inserts ONE wait for the newest launch it needs and none for older ones — each
+    // wait is a barrier packet on the caller's queue, ~6 us of idle time even when the event has long fired (12 layers x ~8 of them).
+    mutable uint64_t side_seq = 0, waited_seq = 0;
     // weight gradients collected for ONE grouped launch (ortk_wgrad_group): wgrad_gemm appends while `grp_on`, flush_wgrads launches
     mutable ortk_wgrad_group_args grp = {};
     bool grp_on = false;
     void* wg_ws = nullptr; size_t wg_ws_bytes = 0;
     mutable hipEvent_t last_done = nullptr;
-    void reads(const void* buf, hipEvent_t done) const {
-        for (auto& p : pend) if (p.buf == buf || p.buf == nullptr) { p.buf = buf; p.done = done; last_done = done; return; }
-        pend[0] = Pend{buf, done}; last_done = done;     // table full (never with this path's 5 temporaries): still correct,
-    }                                                    // join_all() below covers whatever fell out
+    uint64_t next_seq() const { return ++side_seq; }     // one per launch (or group of launches behind one event) queued on the side stream
+    void reads(const void* buf, hipEvent_t done, uint64_t seq = 0) const {
+        if (!seq) seq = next_seq();
+        for (auto& p : pend) if (p.buf == buf || p.buf == nullptr) { p.buf = buf; p.done = done; p.seq = seq; last_done = done; return; }
+        pend[0] = Pend{buf, done, seq}; last_done = done;     // table full (never with this path's temporaries): join() covers what fell out
+    }
     int before_write(const void* buf) const {            // the caller's stream is about to overwrite `buf`
         for (auto& p : pend)
             if (p.buf == buf) {
-                if (hipStreamWaitEvent(s, p.done, 0) != hipSuccess) return ORTK_EINVAL;
+                if (p.seq > waited_seq) {
+                    if (hipStreamWaitEvent(s, p.done, 0) != hipSuccess) return ORTK_EINVAL;
+                    waited_seq = p.seq;
+                }
                 p.buf = nullptr;
             }
         return 0;
@@ -511,6 +520,7 @@ struct Ctx {
     Ctx on_side() const { Ctx t = *this; t.s = side->s; t.use_side = false; return t; }
     int join() const {                                   // everything forked so far (the side stream runs in order)
         if (last_done) { if (hipStreamWaitEvent(s, last_done, 0) != hipSuccess) return ORTK_EINVAL; last_done = nullptr; }
+        waited_seq = side_seq;
         for (auto& p : pend) p.buf = nullptr;
         return 0;
     }
@@ -631,7 +641,7 @@ static int flush_wgrads(const Ctx& c, bool urgent = false) {
         if (hipEventRecord(ready, c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, ready, 0) != hipSuccess) return ORTK_EINVAL;
         e = ortk_wgrad_group(&c.grp, (ortk_stream)c.side->s);
         if (!e && hipEventRecord(done, c.side->s) != hipSuccess) e = ORTK_EINVAL;
-        if (!e) for (int i = 0; i < c.grp.n; ++i) c.reads(c.grp.item[i].dY, done);
+        if (!e) { const uint64_t seq = c.next_seq(); for (int i = 0; i < c.grp.n; ++i) c.reads(c.grp.item[i].dY, done, seq); }
     } else {
         e = ortk_wgrad_group(&c.grp, (ortk_stream)c.s);
     }
