@@ -64,7 +64,7 @@ def synth_batch(B, S, F, V, spi, seq_len, seed, device):
                 att_max_len=S, cap_len=cap_len)
 
 
-CPU_THREADS = 32        # main() --cpu-threads; profiles/r06_cpu_thread_sweep.txt is the sweep behind the default
+CPU_THREADS = 16        # main() --cpu-threads; profiles/r06_cpu_thread_sweep.txt is the sweep behind the default
 
 
 def cpu_baseline(workload, cfg_dict, seconds=9.0):
@@ -78,7 +78,7 @@ def cpu_baseline(workload, cfg_dict, seconds=9.0):
     import helpers as H
     from oracle import ort_oracle as O
     # torch's intra-op pool degrades past a few dozen threads on the 256-thread GPU host at these operator sizes (4 images per step):
-    # profiles/r06_cpu_thread_sweep.txt (scratch/cpu_thread_sweep.py: 16 / 32 / 64 / 128 / 256 threads); `cores` reports what was used.
+    # profiles/r06_cpu_thread_sweep.txt (scratch/cpu_thread_sweep.py: 4 .. 256 threads: 16 is the fastest, 96 captions/s against 54 at 32 and 0.05 at 256); `cores` reports what was used.
     cores = min(os.cpu_count() or 1, CPU_THREADS)
     torch.set_num_threads(cores)
     cfg = O.OCfg(**{k: v for k, v in cfg_dict.items() if not k.startswith("prune")})
@@ -399,7 +399,9 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
             for k in (key, key + 1, key + 3, 16, 17, 18):
                 lib.ortk_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl))
                 lib.ortk_prof_collect_bytes(k, C.byref(by))
-                rec[k] = (n.value, ms.value, fl.value, by.value)
+                un = C.c_double()
+                lib.ortk_prof_collect_units(k, C.byref(un))
+                rec[k] = (n.value, ms.value, fl.value, by.value, un.value)
             collected[level] = rec
             lib.ortk_prof_enable(0)
     if rank != 0:
@@ -408,7 +410,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
     # fp32 parity mode: its products run as six bf16 MFMA partial products of three-way split operands unless ortk_tuning.f32_split = 0
     f32_split = precision != "bf16" and L.set_tuning()["f32_split"] != 0
     peak = PEAK_BF16_TFLOPS if precision == "bf16" else round(PEAK_BF16_TFLOPS / 6.0, 1) if f32_split else PEAK_F32_TFLOPS
-    n0, ms0, fl0, by0 = per_key[key]
+    n0, ms0, fl0, by0, _ = per_key[key]
     ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
     ach_iso = iso[key][2] / (iso[key][1] * 1e-3) / 1e12 if iso[key][1] > 0 else 0.0
     wtag = workload + ("_" + variant if variant else "")
@@ -420,7 +422,7 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
             "alg_gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 2), "alg_bytes_per_launch": round(by0 / max(n0, 1))}
     stack = None        # decode: the one-launch-per-position decoder stack (key 16), same HIP-event hook
     if per_key[16][0]:
-        sn, sms, sfl, sby = per_key[16]
+        sn, sms, sfl, sby, _ = per_key[16]
         gbs_k = sby / (sms * 1e-3) / 1e9
         st_traffic, st_note = pmc_traffic("stack" if decode else "rollout", wtag, precision, B)
         stack = {"kernel": ("decoder_stack_kernel<sparse>" if sstream else "decoder_stack_kernel") if decode else "decoder_stack_tp_kernel",
@@ -432,19 +434,21 @@ def run_workload(args, workload, variant, steps, warmup, rank, world, dev, pkg, 
                  **({"traffic_note": st_note} if st_traffic is None and st_note.startswith("STALE") else {})}
     chain = None        # rows-stationary chains of the forward pass (key 17): weights streamed out of L2 per workgroup; HBM-side figure
     if per_key[17][0]:
-        cn, cms, cfl, cby = per_key[17]
+        cn, cms, cfl, cby, _ = per_key[17]
         chain = {"kernel": "row_chain_kernel / row_chain_wide_kernel", "launches": cn, "avg_us": round(cms * 1e3 / cn, 1), "alg_bytes_per_launch": round(cby / cn),
                  "achieved": round(cby / (cms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(cby / (cms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                  "mfma_tflops": round(cfl / (cms * 1e-3) / 1e12, 1)}
     wgrad = None        # grouped weight gradients (key 18): one launch per layer on the side stream, the largest kernel of a training step by time
     if per_key[18][0]:
-        gn, gms, gfl, gby = per_key[18]
+        gn, gms, gfl, gby, gun = per_key[18]
+        held = min(256.0, gun / gn) / 256.0          # average share of the chip's compute units a launch holds
         g_ach = gfl / (gms * 1e-3) / 1e12
         g_iso = iso[18][2] / (iso[18][1] * 1e-3) / 1e12 if iso[18][1] > 0 else 0.0
         g_traffic, g_note = pmc_traffic("wgrad", wtag, precision, B)
         wgrad = {"kernel": "wgrad_group_kernel (a layer's weight + bias gradients in one launch, side stream, 48-96 workgroups)", "bound": "mfma",
                  "launches": gn, "avg_us": round(gms * 1e3 / gn, 1), "achieved": round(g_ach, 1), "peak": peak, "unit": "TFLOP/s",
-                 "frac": round(g_ach / peak, 4), "isolated_frac": round(g_iso / peak, 4), "alg_gflop_per_launch": round(gfl / gn / 1e9, 2),
+                 "frac": round(g_ach / peak, 4), "avg_workgroups": round(gun / gn, 1), "frac_of_held_units": round(g_ach / (peak * held), 4),
+                 "isolated_frac": round(g_iso / peak, 4), "alg_gflop_per_launch": round(gfl / gn / 1e9, 2),
                  "alg_bytes_per_launch": round(gby / gn), "traffic": g_traffic,
                  **({"traffic_note": g_note} if g_traffic is None and g_note.startswith("STALE") else {})}
     if decode or use_csr:
@@ -524,7 +528,7 @@ def compact(r):
     if "chain_kernel" in rf:
         out["chains"] = {x: rf["chain_kernel"][x] for x in ("launches", "avg_us")}
     if "wgrad_kernel" in rf:
-        out["wgrad"] = {x: rf["wgrad_kernel"][x] for x in ("launches", "avg_us", "frac", "traffic")}
+        out["wgrad"] = {x: rf["wgrad_kernel"][x] for x in ("launches", "avg_us", "frac", "frac_of_held_units", "traffic")}
     if rf.get("traffic") is not None and "traffic" not in out:
         out["traffic"] = rf["traffic"]
     if "whole_step" in rf:

@@ -350,6 +350,8 @@ typedef struct ortk_tuning {
                                      (59.5 vs 62.0 us at 16 640 x 512 x 512), inside the step it needs a free compute unit per workgroup and waits for
                                      the units the side stream's weight gradients hold: 11.65 vs 10.40 ms per XE step (scratch/wgrad_group_ab.py)
                                      | bit 1: ln_mode 2 on the 128-row panels of round 3 (measurement) */
+    int32_t samp_epilogue;        /* 1 (default): sampling decodes in mixed precision take their tokens from the generator GEMM's epilogue (Gumbel-max candidates
+                                     + soft-max partials per 64 logits, ortk_gemm_args.tile_samp) and never store the logit rows | 0: logits + sample step */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);
@@ -507,6 +509,15 @@ typedef struct ortk_gemm_args {
      * (ortk_batch.row_pos) draws what the padded (caption, position) layout draws, so a step is the same function of its seed in
      * both layouts and an SCST update on the valid positions reproduces the masks of its train-mode rollout. */
     const int32_t* drop_rows;   /* applied before drop_row_stride / drop_row_off */
+    /* Gumbel-max sampling candidates of the output rows (the generator of a sampling decode step, with tile_stats): per row m and block j of
+     * 64 columns, tile_samp[(m * ceil(N / 64) + j) * 4 + {0, 1, 2}] = {best key, its column (int bits), the logit at that column} where
+     * key(m, v) = C[m, v] * samp_inv_temperature + gumbel(samp_seed, samp_t, hash row of m, v) on sampling rows and C[m, v] on greedy rows
+     * (samp_greedy_stride K > 0: rows with (samp_row_offset + m) % K == 0; the hash row of a sampling row is its index among the sampling
+     * rows — oracle/ort_oracle.py: gumbel_from_hash, caption_model.py:56-111's multinomial draw as a Gumbel arg-max), over the columns below
+     * stat_ncols other than the row's previous token samp_seq[m * samp_L + samp_t - 1] (decoding constraint; NULL: none).  A combine step
+     * (the decode executor's) takes the arg-max over the blocks and the token's log-prob from tile_stats.  samp_no_store: C is not written. */
+    float* tile_samp; const int64_t* samp_seq; uint64_t samp_seed; int64_t samp_row_offset;
+    int32_t samp_L, samp_t, samp_greedy_stride, samp_sample, samp_fast, samp_no_store; float samp_inv_temperature;
 } ortk_gemm_args;
 int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream);
 /* The weight (and bias) gradients of up to ORTK_WGRAD_MAX projections over the SAME `rows` batch rows in one launch (mixed precision):
@@ -544,6 +555,8 @@ int ortk_prof_enable(int32_t on);
 int ortk_prof_collect(int32_t key, int64_t* launches, double* total_ms, double* total_flops);
 /* algorithmic bytes of the same launches: operands once (A: M x K, B: N x K), the output once, residual / gate rows once */
 int ortk_prof_collect_bytes(int32_t key, double* total_bytes);
+/* workgroups started by the launches of `key`, summed (key 18 = ortk_wgrad_group launches: they are sized to hold part of the chip) */
+int ortk_prof_collect_units(int32_t key, double* total_workgroups);
 
 /* LayerNorm of transformer.py:338-341: a*(x-mean)/(std_unbiased+eps)+b.  stats (rows,2) = {mean, std}. */
 int ortk_layernorm_fwd(const float* x, const float* a, const float* b, void* y, int32_t y_dtype, float* stats,

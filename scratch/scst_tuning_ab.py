@@ -1,6 +1,5 @@
-"""A/B of the executor's scheduling switches on the XE step of bench.py (BASELINE configs[1]: 256 images x 5 captions, bf16), same box,
-interleaved: side stream for the weight gradients on / off  x  rows-stationary chains forward only / + encoder backward / + decoder
-backward (ortk_tuning.side_stream, .row_chain)."""
+"""A/B of ortk_tuning switches inside the SCST step of bench.py (BASELINE configs[3]: 256 images, greedy + 5 train-mode rollouts + update),
+one box, interleaved.  argv: field=value,field=value ... (one combination per argument); the first arm is the library's default."""
 import ctypes as C, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,23 +16,25 @@ torch.manual_seed(8888)
 model = pkg.get_model("relation_transformer")(config, precision="bf16").to(dev).train()
 batch = bench.synth_batch(256, 36, 2048, 10001, 5, 18, 1000, dev)
 tr = NativeTrainer(model, noamopt_factor=1.0, noamopt_warmup=20000)
+rw = torch.randn(256 * 5, device=dev)
 base = L.Tuning(); lib.ortk_get_tuning(C.byref(base))
 def set_tuning(**kw):
     t = L.Tuning.from_buffer_copy(base)
     for k, v in kw.items(): setattr(t, k, v)
     assert lib.ortk_set_tuning(C.byref(t)) == 0
-combos = [dict(side_stream=s, row_chain=r) for s in (1, 0) for r in (1, 2, 3)] + [dict(side_stream=1, row_chain=1, chain_wide=0)]
+combos = [dict()] + [{kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.split(",")} for a in sys.argv[1:]]
+def step(): tr.scst_step(batch, lambda seq, greedy: rw, num_samples=5, baseline="greedy")
 res = {i: [] for i in range(len(combos))}
 for i, kw in enumerate(combos):
     set_tuning(**kw)
-    for _ in range(5): tr.xe_step(batch)
-for rep in range(4):
+    for _ in range(3): step()
+for rep in range(3):
     for i, kw in enumerate(combos):
         set_tuning(**kw)
-        for _ in range(2): tr.xe_step(batch)
+        for _ in range(2): step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(20): tr.xe_step(batch)
-        torch.cuda.synchronize(); res[i].append((time.perf_counter() - t0) * 50)
+        for _ in range(12): step()
+        torch.cuda.synchronize(); res[i].append((time.perf_counter() - t0) / 12 * 1e3)
 for i, kw in enumerate(combos):
-    print(kw, [round(x, 3) for x in res[i]])
+    print(kw or "default", [round(x, 3) for x in res[i]], flush=True)
 lib.ortk_set_tuning(C.byref(base))

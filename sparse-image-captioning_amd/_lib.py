@@ -102,7 +102,7 @@ class MaskedAdamArgs(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
                 ("side_stream", C.c_int32), ("row_chain", C.c_int32), ("chain_wide", C.c_int32), ("spmm_alias", C.c_int32), ("f32_split", C.c_int32), ("wgrad_wgs", C.c_int32),
-                ("wgrad_group", C.c_int32), ("wgrad_group_splitk", C.c_int32), ("wgrad_group_wgs", C.c_int32), ("wgrad_group_tail", C.c_int32), ("feats_bf16", C.c_int32), ("ln_fuse", C.c_int32)]
+                ("wgrad_group", C.c_int32), ("wgrad_group_splitk", C.c_int32), ("wgrad_group_wgs", C.c_int32), ("wgrad_group_tail", C.c_int32), ("feats_bf16", C.c_int32), ("ln_fuse", C.c_int32), ("samp_epilogue", C.c_int32)]
 
 
 DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL, DEC_SPARSE_GATHER = 1, 2, 4, 8, 16, 32, 64      # ortk_decode_opts.exec_flags
@@ -128,7 +128,10 @@ class GemmArgs(C.Structure):
                 ("ln_mode", C.c_int32), ("ln_y_dtype", C.c_int32),
                 ("ln_a", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
                 ("ln_x", C.c_void_p), ("ln_dres", C.c_void_p), ("ln_da", C.c_void_p), ("ln_db", C.c_void_p),
-                ("tile_stats", C.c_void_p), ("stat_ncols", C.c_int32), ("drop_rows", C.c_void_p)]
+                ("tile_stats", C.c_void_p), ("stat_ncols", C.c_int32), ("drop_rows", C.c_void_p),
+                ("tile_samp", C.c_void_p), ("samp_seq", C.c_void_p), ("samp_seed", C.c_uint64), ("samp_row_offset", C.c_int64),
+                ("samp_L", C.c_int32), ("samp_t", C.c_int32), ("samp_greedy_stride", C.c_int32), ("samp_sample", C.c_int32),
+                ("samp_fast", C.c_int32), ("samp_no_store", C.c_int32), ("samp_inv_temperature", C.c_float)]
 
 
 class WgradItem(C.Structure):
@@ -197,6 +200,7 @@ SIGNATURES = {
     "ortk_prof_enable": (_I32, [_I32]),
     "ortk_prof_collect": (_I32, [_I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ortk_prof_collect_bytes": (_I32, [_I32, C.POINTER(C.c_double)]),
+    "ortk_prof_collect_units": (_I32, [_I32, C.POINTER(C.c_double)]),
     "ortk_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd_drop": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _I32, _F, C.c_uint32, _P]),

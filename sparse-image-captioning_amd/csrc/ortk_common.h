@@ -108,6 +108,16 @@ __device__ static inline void ortk_keep4_u32(uint32_t seed, uint32_t idx0, uint3
     g ^= g >> 15;
     k[0] = (h & 0xFFFFu) >= thr; k[1] = (h >> 16) >= thr; k[2] = (g & 0xFFFFu) >= thr; k[3] = (g >> 16) >= thr;
 }
+// Gumbel noise of (step t, hash row, token v): identical to oracle/ort_oracle.py: gumbel_from_hash.  FAST (mixed precision): v_log_f32 for
+// the two logarithms — the same uniforms, the noise to ~1 ulp.
+template <bool FAST>
+__device__ __forceinline__ float ortk_gumbel(uint64_t seed, int t, int row, int v) {
+    uint32_t x = (uint32_t)row * 0x9E3779B1u + (uint32_t)v * 0x85EBCA77u + (uint32_t)(t + 1) * 0xC2B2AE3Du + (uint32_t)seed * 0x27D4EB2Fu;
+    const float u = ortk_u01(ortk_mix32(x));
+    return FAST ? -__logf(-__logf(u)) : -logf(-logf(u));
+}
+// total order of (key, index) candidates: larger key first, lower index on a tie
+__device__ __forceinline__ bool ortk_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 __host__ static inline uint32_t ortk_subseed(uint64_t seed, uint32_t op) {
     return ortk_mix32((uint32_t)seed ^ ortk_mix32((uint32_t)(seed >> 32) + 0x632BE5ABu) ^ (op * 0x9E3779B1u + 0x7F4A7C15u));
 }

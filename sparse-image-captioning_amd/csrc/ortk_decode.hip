@@ -463,12 +463,7 @@ __global__ void sample_init_kernel(SampleState st, int bos) {
 // FAST (mixed precision only, with the fast exponential of the soft-max): v_log_f32 for the two logarithms — the same uniforms,
 // the noise to ~1 ulp (the SCST step did not move measurably: 23.2 ms either way)
 template <bool FAST = false>
-__device__ __forceinline__ float gumbel(uint64_t seed, int t, int row, int v) {
-    // identical to oracle/ort_oracle.py: gumbel_from_hash
-    uint32_t x = (uint32_t)row * 0x9E3779B1u + (uint32_t)v * 0x85EBCA77u + (uint32_t)(t + 1) * 0xC2B2AE3Du + (uint32_t)seed * 0x27D4EB2Fu;
-    const float u = ortk_u01(ortk_mix32(x));
-    return FAST ? -__logf(-__logf(u)) : -logf(-logf(u));
-}
+__device__ __forceinline__ float gumbel(uint64_t seed, int t, int row, int v) { return ortk_gumbel<FAST>(seed, t, row, v); }
 
 __global__ __launch_bounds__(256) void sample_step_kernel(SampleState st, const float* __restrict__ logp, int t) {
     __shared__ float red_v[4];
@@ -570,6 +565,46 @@ __global__ __launch_bounds__(256) void sample_step_fused_kernel(SampleState st, 
     }
 }
 
+// The sampling step on the generator's own epilogue output (ortk_gemm_args.tile_samp + tile_stats): per row and block of 64 logits the
+// best Gumbel-max candidate {key, column, logit} and the soft-max partials {max, sum exp}.  One wave per row: arg-max over the blocks
+// (same total order as the row kernels: larger key, lower column on a tie), log-sum-exp from the partials, log-prob of the chosen token,
+// then the bookkeeping of sample_step_fused_kernel.  The logit rows (62 MB per position of the SCST rollout) are neither written nor read.
+template <bool FASTEXP>
+__global__ __launch_bounds__(256) void sample_combine_kernel(SampleState st, const float* __restrict__ gstats, const float* __restrict__ gsamp, int nblk, int t) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= st.rows) return;
+    const float* gs = gstats + (int64_t)row * nblk * 2;
+    const float* gp = gsamp + (int64_t)row * nblk * 4;
+    float m = -INFINITY, mv = -INFINITY, mz = 0.f; int mi = 0x7FFFFFFF;
+    for (int b = lane; b < nblk; b += 64) {
+        m = fmaxf(m, gs[2 * b]);
+        const float x = gp[4 * b]; const int i = __float_as_int(gp[4 * b + 1]);
+        if (ortk_better(x, i, mv, mi)) { mv = x; mi = i; mz = gp[4 * b + 2]; }
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int b = lane; b < nblk; b += 64) { const float sb = gs[2 * b + 1]; if (sb > 0.f) sum += sb * exp_sel<FASTEXP>(gs[2 * b] - m); }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mv, o, 64), oz = __shfl_xor(mz, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (ortk_better(ov, oi, mv, mi)) { mv = ov; mi = oi; mz = oz; }
+    }
+    if (lane == 0) {
+        const float ml = (mz - m) - logf(sum);
+        const bool is_greedy = st.greedy_stride > 0 && row % st.greedy_stride == 0;
+        const int unf = st.unfinished[row];
+        st.it[row] = mi;
+        st.seq[(int64_t)row * st.L + t] = unf ? mi : 0;
+        st.lp[(int64_t)row * st.L + t] = ml;
+        const int now = unf && (mi != st.eos);
+        st.unfinished[row] = now;
+        int32_t* last = st.last_step + (is_greedy ? 1 : 0);
+        if (unf && !now) atomicMax(last, t);
+        if (now && t == st.L - 1) atomicMax(last, t);
+    }
+}
+
 __global__ void sample_finalize_kernel(SampleState st) {
     const int64_t n = (int64_t)st.rows * st.L;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -648,6 +683,14 @@ int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t
         return 0;
     }
     hipLaunchKernelGGL(sample_step_kernel, dim3((unsigned)st.rows), dim3(256), 0, s, st, logp, t);
+    ORTK_CHECK_LAUNCH();
+    return 0;
+}
+int sample_combine(const SampleState& st, const float* gstats, const float* gsamp, int32_t nblk, int32_t t, hipStream_t s, bool fast_exp) {
+    if (st.rows == 0) return 0;
+    const dim3 grid((unsigned)((st.rows + 3) / 4));
+    if (fast_exp) hipLaunchKernelGGL(sample_combine_kernel<true>, grid, dim3(256), 0, s, st, gstats, gsamp, (int)nblk, (int)t);
+    else hipLaunchKernelGGL(sample_combine_kernel<false>, grid, dim3(256), 0, s, st, gstats, gsamp, (int)nblk, (int)t);
     ORTK_CHECK_LAUNCH();
     return 0;
 }

@@ -759,6 +759,47 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
             }
         }
     }
+    if (!BIG && !TA && !TB && p.tile_samp) {
+        // Gumbel-max candidates of this wave's 64 rows x 64 columns (ortk_gemm_args.tile_samp): per row the best key over the block's
+        // columns below stat_ncols other than the row's previous token, in-lane over the lane's 16 values, two shuffles over the four
+        // lane groups (total order: larger key, lower column)
+        const int lr = lane & 15, lg = lane >> 4;
+        const int c0 = nb + wn * 64 + 4 * lg;
+        const int nblk = p.N >> 6, blk = (nb >> 6) + wn;
+        f32x4 bias4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mb + wm * (16 * MI) + 16 * i + lr;
+            const int mc = min(m, p.M - 1);
+            const int gs = p.samp_greedy_stride;
+            const int64_t grow = p.samp_row_offset + mc;
+            const bool is_greedy = gs > 0 && mc % gs == 0;          // (as sample_step: by the row of this call)
+            const bool samp = p.samp_sample && !is_greedy;
+            const int hrow = (int)(gs > 0 ? grow - grow / gs - 1 : grow);
+            const int prev = (p.samp_seq && p.samp_t > 0) ? (int)p.samp_seq[(int64_t)mc * p.samp_L + p.samp_t - 1] : -1;
+            float bv = -INFINITY, bz = 0.f; int bi = 0x7FFFFFFF;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int v = c0 + 16 * j + r;
+                    if (v >= p.stat_ncols || v == prev) continue;
+                    const float z = acc[i][j][r] + bias4[j][r];
+                    float x = z;
+                    if (samp) x = z * p.samp_inv_temperature + (p.samp_fast ? ortk_gumbel<true>(p.samp_seed, p.samp_t, hrow, v) : ortk_gumbel<false>(p.samp_seed, p.samp_t, hrow, v));
+                    if (ortk_better(x, v, bv, bi)) { bv = x; bi = v; bz = z; }
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(bv, o, 64), oz = __shfl_xor(bz, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ortk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; bz = oz; }
+            }
+            if (lg == 0 && m < p.M) *reinterpret_cast<f32x4*>(p.tile_samp + ((int64_t)m * nblk + blk) * 4) = (f32x4){bv, __int_as_float(bi), bz, 0.f};
+        }
+        if (p.samp_no_store) return;
+    }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     if (!BIG && p.accumulate) {
@@ -1962,7 +2003,7 @@ __global__ __launch_bounds__(256, ACC ? 2 : 3) void gemm_f32x3t_kernel(ortk_gemm
 // accumulated per kernel instance (precision, transA, transB).  Disabled by default; the timed region of bench.py
 // never runs with it on.  This is the only process-global state in the library.
 namespace {
-struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; int slot; double per_count; };
+struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; int slot; double per_count; double units; };
 constexpr int PROF_SLOTS = 1 << 16;
 unsigned long long* g_prof_slots = nullptr;      // device counters (ortk::prof_slot)
 int g_prof_slot_next = 0;
@@ -2001,7 +2042,7 @@ bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m)
 void prof_end(const ProfMark& m, hipStream_t s) {
     if (!m.live) return;
     (void)hipEventRecord(m.b, s);
-    ProfRec rec{m.a, m.b, m.key, m.flops, m.bytes, m.slot, m.per_count};
+    ProfRec rec{m.a, m.b, m.key, m.flops, m.bytes, m.slot, m.per_count, m.units};
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof->push_back(rec);
 }
@@ -2037,6 +2078,15 @@ extern "C" int ortk_prof_collect(int32_t key, int64_t* launches, double* total_m
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return ORTK_EINVAL;
         *launches += 1; *total_ms += ms; *total_flops += r.flops;
     }
+    return 0;
+}
+
+// sum over the launches of `key` of the workgroups each one started (recorded by the launchers that size their grids themselves:
+// the grouped weight gradients) — launches / this = the average share of the chip such a launch holds
+extern "C" int ortk_prof_collect_units(int32_t key, double* total_workgroups) {
+    if (!g_prof || !total_workgroups) return ORTK_EINVAL;
+    *total_workgroups = 0;
+    for (auto& r : *g_prof) if (r.key == key) *total_workgroups += r.units;
     return 0;
 }
 
@@ -2151,7 +2201,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         (void)hipEventRecord(rec.a, s);
     }
     if (!p.precision) {
-        if (p.tile_stats) return ORTK_EINVAL;
+        if (p.tile_stats || p.tile_samp) return ORTK_EINVAL;
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         if (key == 0 && ortk::tuning().f32_split && !p.accumulate && p.K > 0 && p.K % 32 == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
             al16(p.A) && al16(p.B)) {
@@ -2213,7 +2263,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
         // runs the bounds-checked epilogue.  (Without this every batch size that is not a multiple of 128 images fell back to
         // the guarded register-staged kernel: 13.4 ms per XE step at 127 images against 9.0 ms at 128.)
         const bool fast4 = fast_nk && key == 4 && !p.accumulate;
-        const bool want_stats = p.tile_stats != nullptr;      // soft-max partials: the 128 x 128 LDS-DMA kernel's epilogue
+        if (p.tile_samp && !p.tile_stats) return ORTK_EINVAL;      // (the combine step needs the partials beside the candidates)
+        const bool want_stats = p.tile_stats != nullptr;      // soft-max partials (+ sampling candidates): the 128 x 128 LDS-DMA kernel's epilogue
         if (want_stats && !(fast4 && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0 && p.K % HBK == 0 && !p.relu &&
                             p.drop_p == 0.f && !p.gate && !p.rowscale && !p.resid && p.stat_ncols > 0 && p.stat_ncols <= p.N))
             return ORTK_EINVAL;

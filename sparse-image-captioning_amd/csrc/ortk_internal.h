@@ -19,7 +19,7 @@ bool ortk_prof_serial();
 constexpr int PROF_KEY_DECSTACK = 16;
 constexpr int PROF_KEY_CHAIN = 17;        // row_chain_kernel launches (ortk_chain.hip)
 constexpr int PROF_KEY_WGRAD_GROUP = 18;  // wgrad_group_kernel launches (ortk_wgrad.hip)
-struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; int slot = -1; double per_count = 0.0; };
+struct ProfMark { hipEvent_t a, b; int key; double flops, bytes; bool live; int slot = -1; double per_count = 0.0; double units = 0.0 /* workgroups of the launch (ortk_prof_collect_units) */; };
 bool prof_begin(int key, double flops, double bytes, hipStream_t s, ProfMark& m);
 void prof_end(const ProfMark& m, hipStream_t s);
 // A device counter a launch's algorithmic bytes depend on (the beam step counts the UNIQUE cache rows of the next decoder pass into it:
@@ -87,6 +87,8 @@ struct SampleState {
 int sample_init(const SampleState& st, int32_t bos, hipStream_t s);
 // fused = true: `logp` holds raw logits (V <= 10 240) and the log-soft-max is taken inside the step
 int sample_step(const SampleState& st, const float* logp, int32_t t, hipStream_t s, bool fused = false, bool fast_exp = false);
+// the same step from the generator GEMM's sampling epilogue (ortk_gemm_args.tile_stats + tile_samp): the logit rows are never materialised
+int sample_combine(const SampleState& st, const float* gstats, const float* gsamp, int32_t nblk, int32_t t, hipStream_t s, bool fast_exp);
 int sample_finalize(const SampleState& st, hipStream_t s);
 
 // One decode position of the whole decoder stack in one launch (ortk_decstack.hip; mixed precision, d_model 512, 8 heads,

@@ -890,7 +890,7 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384, 3, 0, 80, 1, 1, 0};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384, 3, 0, 80, 1, 1, 0, 1};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
@@ -1706,7 +1706,8 @@ struct DecodeWS {
     float *x0, *logbias; void* mem /*A*/; float* st; void* ckv /*ckvdt*/;
     EncPtrs enc;                       // one set of encoder buffers, reused by every layer
     float *xa, *xb; void* y /*A*/; float* qkv; void* o /*A*/; void* q /*ckvdt when xq16*/; void* h /*A*/; float* logits;
-    float* gstats = nullptr;           // soft-max partials of the logit rows (rows, ldv / 64, 2): beam search in mixed precision
+    float* gstats = nullptr;           // soft-max partials of the logit rows (rows, ldv / 64, 2): mixed precision
+    float* gsamp = nullptr;            // Gumbel-max candidates of the logit rows (rows, ldv / 64, 4): sampling decodes, mixed precision
     int ckvdt, xq16;                   // projected memory dtype; 1 = cross-attention through the bf16-operand kernels (bf16 query too)
     void *cache_k[MAXLAYERS], *cache_v[MAXLAYERS]; int kvdt;   // K/V caches + projected memory: bf16 in mixed precision when the
                                                                // decode attention kernels take them (kv16), fp32 otherwise
@@ -1779,7 +1780,8 @@ static void carve_decode(const ortk_config& c, int B, int S, int K, bool beam, v
     w.xa = b.take<float>(rows * d); w.xb = b.take<float>(rows * d); w.y = act(rows * d);
     w.qkv = b.take<float>(rows * 3 * d); w.o = act(rows * d); w.q = b.take<float>(rows * d);      // (fp32-sized; holds bf16 when xq16)
     w.h = act(rows * ff); w.logits = b.take<float>(rows * w.ldv);
-    if (beam && c.precision) w.gstats = b.take<float>(rows * (w.ldv / 64) * 2);
+    if (c.precision) w.gstats = b.take<float>(rows * (w.ldv / 64) * 2);
+    if (!beam && c.precision) w.gsamp = b.take<float>(rows * (w.ldv / 64) * 4);
     for (int l = 0; l < L; ++l) { w.cache_k[l] = b.take_bytes((size_t)(rows * T * d) * kves); w.cache_v[l] = b.take_bytes((size_t)(rows * T * d) * kves); }
     w.it = b.take<int64_t>(rows);
     {
@@ -1880,6 +1882,7 @@ struct StepBufs {
     int kvdt;      // element type of cache_k / cache_v
     int ckvdt = ORTK_F32, xq16 = 0;   // element type of ckv; 1 = bf16 cross-attention query + bf16-operand kernel
     float* gstats = nullptr; int stat_ncols = 0;    // soft-max partials of the logit rows wanted from the generator GEMM
+    float* gsamp = nullptr; const SampleState* samp = nullptr; int samp_t = 0; bool samp_fast = false;     // ... and its sampling candidates (sample_combine)
 };
 // generator logits of a decode step (w.y: the final LayerNorm's output); with w.gstats also their soft-max partials
 static int gen_gemm(const Ctx& c, const Offsets& o, const StepBufs& w, int ydt, int64_t rows) {
@@ -1889,6 +1892,12 @@ static int gen_gemm(const Ctx& c, const Offsets& o, const StepBufs& w, int ydt, 
     a.A = w.y; a.a_dtype = ydt; a.lda = d; a.B = c.W(o.gen_w); a.b_dtype = c.wdt(); a.ldb = d; a.C = w.logits; a.c_dtype = ORTK_F32; a.ldc = w.ldv;
     a.M = (int)rows; a.N = (int)w.ldv; a.K = d; a.bias = c.P + o.gen_b; a.precision = c.prec;
     a.tile_stats = w.gstats; a.stat_ncols = w.stat_ncols;
+    if (w.gsamp && w.samp) {
+        const SampleState& ss = *w.samp;
+        a.tile_samp = w.gsamp; a.samp_seq = ss.decoding_constraint ? ss.seq : nullptr; a.samp_seed = ss.seed; a.samp_row_offset = ss.row_offset;
+        a.samp_L = ss.L; a.samp_t = w.samp_t; a.samp_greedy_stride = ss.greedy_stride; a.samp_sample = ss.sample; a.samp_fast = w.samp_fast;
+        a.samp_no_store = 1; a.samp_inv_temperature = 1.f / ss.temperature;
+    }
     return ortk_gemm(&a, (ortk_stream)c.s);
 }
 static int decoder_step(const Ctx& c, const Offsets& o, const StepBufs& w, int64_t rows, int groups, int per_group, int /*row_mult*/,
@@ -2113,6 +2122,11 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         ss.row_offset = op->sample_row_offset;
         TRY(sample_init(ss, cfg->bos_id, s));
     }
+    // Sampling decodes in mixed precision on the dense generator: the generator GEMM's epilogue emits the Gumbel-max candidates and the
+    // soft-max partials of every 64-logit block and a combine step picks the token — the (rows, V) fp32 logits are never stored
+    // (the conditions are the statistics epilogue's: ortk_gemm; tuning().samp_epilogue = 0 keeps the logit rows and sample_step)
+    const bool samp_epi = !beam && w.gsamp && w.gstats && tuning().samp_epilogue && !op->sparse && !c.ell_f && A == ORTK_BF16 && d % 64 == 0 && w.ldv % 128 == 0 &&
+                          w.ldv / 64 <= 256 && op->temperature > 0.f;
     int uniq_slot = 0;          // (profiling only) counter of the unique cache rows the NEXT pass references, filled by this pass's beam step
     TRY(c.wait_ev(sstream_done));
     for (int t = 0; t < T; ++t) {
@@ -2124,6 +2138,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         StepBufs sb{w.it, w.xa, w.xb, w.y, w.qkv, w.o, w.q, w.h, w.logits, w.st, w.ldv, w.ckv, att_masks};
         sb.kvdt = w.kvdt; sb.ckvdt = w.ckvdt; sb.xq16 = w.xq16;
         if (beam && bs.gstats) { sb.gstats = w.gstats; sb.stat_ncols = V; }
+        if (samp_epi) { sb.gstats = w.gstats; sb.stat_ncols = V; sb.gsamp = w.gsamp; sb.samp = &ss; sb.samp_t = t; sb.samp_fast = cfg->precision == 1; }
         for (int l = 0; l < L; ++l) { sb.cache_k[l] = w.cache_k[l]; sb.cache_v[l] = w.cache_v[l]; }
         const SplitBufs spb{w.tp, w.tp_wpk, w.tp_xbuf, w.tp_flag, stack_tp_groups(rows_full), w.status};
         if (stack) TRY(decoder_stack_step(c, o, sb, w.wpk, sstream ? &w.ss : nullptr, w.progress, op->exec_flags, rows, per_img, S, T, t, beam ? w.kvidx[t & 1] : nullptr, &spb,
@@ -2135,6 +2150,7 @@ extern "C" int ortk_decode(const ortk_config* cfg, const float* params, const fl
         const bool fast_exp = cfg->precision == 1;                     // (the fp32 parity mode keeps libm's expf)
         if (beam && stack && ortk_prof_active()) { int ix = -1; bs.uniq = prof_slot(&ix); uniq_slot = ix + 1; }
         if (beam) TRY(beam_step(bs, w.logits, t, s, true, scale, fast_exp));     // log-soft-max fused into the candidate scan
+        else if (samp_epi) TRY(sample_combine(ss, w.gstats, w.gsamp, (int32_t)(w.ldv / 64), t, s, fast_exp));      // the generator's epilogue has the candidates
         else if (V <= 256 * 40) TRY(sample_step(ss, w.logits, t, s, true, fast_exp));     // log-soft-max fused (scale is 1 on this branch)
         else {
             TRY(ortk_log_softmax(w.logits, rows, V, w.ldv, scale, stream));

@@ -408,6 +408,7 @@ extern "C" int ortk_wgrad_group(const ortk_wgrad_group_args* a, ortk_stream stre
     if (ortk::lds_attr(reinterpret_cast<const void*>(wgrad_group_kernel), W_LDS_BYTES)) return ORTK_EINVAL;
     ortk::ProfMark pm;
     ortk::prof_begin(ortk::PROF_KEY_WGRAD_GROUP, flops, bytes, s, pm);
+    pm.units = (double)tiles * sk;
     hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)(tiles * sk)), dim3(512), W_LDS_BYTES, s, p);
     ortk::prof_end(pm, s);
     ORTK_CHECK_LAUNCH();

@@ -1184,6 +1184,53 @@ def test_gemm_tile_softmax_partials(L, M, V):
     torch.testing.assert_close(lse2, lse, rtol=1e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("M,V,K_greedy,temp,constraint", [(300, 1000, 0, 1.0, 0), (258, 10001, 6, 1.0, 1), (129, 5000, 3, 0.7, 1)])
+def test_gemm_gumbel_max_candidates(L, M, V, K_greedy, temp, constraint):
+    """ortk_gemm_args.tile_samp: per row and block of 64 logits the Gumbel-max candidate {key, column, logit} the sampling decode
+    combines instead of reading the logit rows (caption_model.py:56-111's multinomial draw as an arg-max over logit / T + Gumbel noise;
+    the noise is oracle/ort_oracle.py: gumbel_from_hash).  Against the same launch's own fp32 logits: every block's candidate IS the
+    arg-max of key(m, v) over the block's admissible columns (exact: same floats, same total order), greedy rows take the plain
+    logits, the previous token is excluded, and the arg-max over the blocks equals the row's arg-max."""
+    N, Kd, t, seed, off = ((V + 127) // 128) * 128, 512, 3, 77, 1000
+    A = rnd(M, Kd, seed=60).bfloat16()
+    W = torch.zeros(N, Kd); W[:V] = rnd(V, Kd, seed=61, scale=Kd ** -0.5) * 3
+    bias = torch.zeros(N); bias[:V] = rnd(V, seed=62)
+    nblk, T = N // 64, 8
+    seqs = torch.randint(0, V, (M, T), generator=torch.Generator().manual_seed(5))
+    stats = torch.full((M, nblk, 2), float("nan"), device="cuda"); cand = torch.full((M, nblk, 4), float("nan"), device="cuda")
+    kw = dict(samp_seq=dev(seqs)) if constraint else {}
+    c = gemm(L, dev(A), dev(W.bfloat16()), M, N, Kd, 0, 0, 1, a_dtype=1, b_dtype=1, bias=dev(bias), tile_stats=stats, stat_ncols=V, tile_samp=cand,
+             samp_seed=seed, samp_row_offset=off, samp_L=T, samp_t=t, samp_greedy_stride=K_greedy, samp_sample=1, samp_fast=0,
+             samp_inv_temperature=1.0 / temp, **kw)
+    torch.cuda.synchronize()
+    z = c.cpu()[:, :V]
+    rows = torch.arange(M)
+    greedy = (rows % K_greedy == 0) if K_greedy else torch.zeros(M, dtype=torch.bool)
+    grow = rows + off
+    hrow = (grow - grow // K_greedy - 1) if K_greedy else grow
+    g = torch.stack([O.gumbel_from_hash(seed, t, 1, V, int(h))[0] for h in hrow])
+    key = torch.where(greedy[:, None], z, z * torch.tensor(1.0 / temp, dtype=torch.float32) + g)
+    if constraint:
+        key[rows, seqs[:, t - 1]] = float("-inf")
+    keyp = torch.full((M, N), float("-inf")); keyp[:, :V] = key
+    kb = keyp.view(M, nblk, 64)
+    ref_key, ref_idx = kb.max(2)
+    ref_idx = ref_idx + 64 * torch.arange(nblk)[None, :]
+    got = cand.cpu()
+    gi = got[..., 1].contiguous().view(torch.int32)
+    live = ~ref_key.isinf()
+    # the Gumbel noise comes from libm logf on the device against torch.log on the host: keys agree to 1e-6, ties aside the columns agree
+    assert (got[..., 0][live] - ref_key[live]).abs().max().item() < 2e-5
+    agree = (gi[live] == ref_idx[live].int()).float().mean().item()
+    assert agree > 0.999, agree
+    same = live & (gi == ref_idx.int())
+    assert torch.equal(got[..., 2][same], z[rows[:, None].expand(-1, nblk)[same], ref_idx[same]])
+    # the arg-max over the blocks is the row's arg-max
+    best_blk = got[..., 0].argmax(1)
+    tok = gi[rows, best_blk]
+    assert (tok.long() == key.argmax(1)).float().mean().item() > 0.99
+
+
 # ------------------------------------------------------------------------------------------------ rows-stationary chains (round 4)
 def _keep_mask(L, seed, n, p):
     """keep / (1 - p) per element of a dropout site, as the kernels draw it (counter hash, element index = row * N + col)."""
