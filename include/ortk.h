@@ -349,9 +349,13 @@ typedef struct ortk_tuning {
                                      (ortk_gemm ln_mode 2 on short row panels).  OFF by default: alone the fused launch ties the two it replaces
                                      (59.5 vs 62.0 us at 16 640 x 512 x 512), inside the step it needs a free compute unit per workgroup and waits for
                                      the units the side stream's weight gradients hold: 11.65 vs 10.40 ms per XE step (scratch/wgrad_group_ab.py)
-                                     | bit 1: ln_mode 2 on the 128-row panels of round 3 (measurement) */
+                                     | bit 1: ln_mode 2 on the 128-row panels of round 3 (measurement) | bit 2: the LayerNorm backward of width 512 with four
+                                     instead of eight consecutive columns per lane (measurement) */
     int32_t samp_epilogue;        /* 1 (default): sampling decodes in mixed precision take their tokens from the generator GEMM's epilogue (Gumbel-max candidates
                                      + soft-max partials per 64 logits, ortk_gemm_args.tile_samp) and never store the logit rows | 0: logits + sample step */
+    int32_t gemm_epilogue;        /* 0 (default): the forward-layout LDS-DMA GEMM kernels run the lean epilogue (options the launcher has verified compiled
+                                     out, dropout / gate as kernel instances; bf16 results of the 256 x 256 tile stored 16 bytes per lane) | 1: the general
+                                     epilogue of rounds 2-5 everywhere (measurement: profiles/r06_gemm_epilogue.txt) */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);
@@ -575,6 +579,10 @@ int ortk_layernorm_bwd_drop(const float* dy, const float* x, const float* a, con
 int ortk_layernorm_bwd_drop_rows(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
                                  float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
                                  float drop_p, uint32_t drop_seed, const int32_t* drop_rows, ortk_stream stream);
+/* the same with the output gradient dy in fp32 or bf16 (dy_dtype; bf16: d = 512 and 16-byte aligned rows only) */
+int ortk_layernorm_bwd_dt(const void* dy, int32_t dy_dtype, const float* x, const float* a, const float* stats, const float* dres,
+                          float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
+                          float drop_p, uint32_t drop_seed, const int32_t* drop_rows, ortk_stream stream);
 
 /* Geometry bias of BoxMultiHeadedAttention (relation_transformer.py:196-256,177-183,286):
  * out[l,b,h,i,j] = log(max(relu(WG[l,h].e_ij + bG[l,h]), 1e-6)).  wg[l]/bg[l] are per-layer device pointers

@@ -102,7 +102,7 @@ class MaskedAdamArgs(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("gemm_impl", C.c_int32), ("gemm_t64", C.c_int32), ("attn_impl", C.c_int32), ("attn16_min_lq", C.c_int32),
                 ("side_stream", C.c_int32), ("row_chain", C.c_int32), ("chain_wide", C.c_int32), ("spmm_alias", C.c_int32), ("f32_split", C.c_int32), ("wgrad_wgs", C.c_int32),
-                ("wgrad_group", C.c_int32), ("wgrad_group_splitk", C.c_int32), ("wgrad_group_wgs", C.c_int32), ("wgrad_group_tail", C.c_int32), ("feats_bf16", C.c_int32), ("ln_fuse", C.c_int32), ("samp_epilogue", C.c_int32)]
+                ("wgrad_group", C.c_int32), ("wgrad_group_splitk", C.c_int32), ("wgrad_group_wgs", C.c_int32), ("wgrad_group_tail", C.c_int32), ("feats_bf16", C.c_int32), ("ln_fuse", C.c_int32), ("samp_epilogue", C.c_int32), ("gemm_epilogue", C.c_int32)]
 
 
 DEC_UNFUSED, DEC_STACK, DEC_SPARSE_STREAM, DEC_STACK_RB20, DEC_STACK_SPLIT, DEC_SPLIT_SMALL, DEC_SPARSE_GATHER = 1, 2, 4, 8, 16, 32, 64      # ortk_decode_opts.exec_flags
@@ -205,6 +205,7 @@ SIGNATURES = {
     "ortk_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "ortk_layernorm_bwd_drop": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _I32, _F, C.c_uint32, _P]),
     "ortk_layernorm_bwd_drop_rows": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _I32, _F, C.c_uint32, _P, _P]),
+    "ortk_layernorm_bwd_dt": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _I32, _F, C.c_uint32, _P, _P]),
     "ortk_box_logbias_fwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, _I32, _I32, _I32, _I32, _P]),
     "ortk_box_logbias_bwd": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), _P, C.POINTER(_P), C.POINTER(_P),
                                    _I32, _I32, _I32, _I32, _P]),

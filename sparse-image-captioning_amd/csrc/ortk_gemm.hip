@@ -74,8 +74,13 @@ __device__ __forceinline__ float4 ldrow4(const float* __restrict__ p, int n0, in
 // Bias is loaded once per j; residual / gate rows are fetched as float4 for all four j of a row BEFORE any of that
 // row's stores (independent loads in flight together instead of 16 load->store chains per thread).
 // (MS / NS: row / column distance between neighbouring accumulators: 16 / 16 for the 16x16 MFMA grid, 32 / 8 for the 32x32 one)
-template <bool FAST, int MI = 4, int NJ = 4, int MS = 16, int NS = 16>
+// PAIR: accumulator j holds the columns ncol0 + 32 (j >> 1) + 4 (j & 1) + 0..3 instead (gemm_bf16_dma256_kernel's permuted B image:
+// ncol0 = 8 x lane group), so that j = 2 J, 2 J + 1 are 8 consecutive columns: one 16-byte store of a bf16 result instead of two
+// 8-byte ones (the epilogue is store-ISSUE bound: scratch/micro/store_width.hip, 16 640 x 2 048 bf16 20.8 -> 12.7 us).
+template <bool FAST, int MI = 4, int NJ = 4, int MS = 16, int NS = 16, bool PAIR = false>
 __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0, f32x4 (&acc)[MI][NJ]) {
+    static_assert(!PAIR || (NJ % 2 == 0), "paired columns");
+    auto colof = [&](int j) { return PAIR ? ncol0 + 32 * (j >> 1) + 4 * (j & 1) : ncol0 + NS * j; };
     const bool first = e.first_split;
     // FAST: the launcher has verified full tiles and vector alignment of every pointer -> no bounds / alignment tests
     const bool vec_b = FAST || (e.bias && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0));
@@ -88,7 +93,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
     float4 bias4[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int n0 = ncol0 + NS * j;
+        const int n0 = colof(j);
         bias4[j] = (e.bias && first && n0 < EN) ? ldrow4(e.bias + n0, n0, EN, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -98,9 +103,10 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
         const float rs = e.rowscale ? e.rowscale[m] : 1.f;
         const uint64_t dm = (e.drop_p > 0.f && e.drop_rows) ? (uint64_t)e.drop_rows[m] : (uint64_t)m;
         float4 res[NJ], gat[NJ];
+        bf16x4 held = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n0 = ncol0 + NS * j;
+            const int n0 = colof(j);
             res[j] = (e.resid && first && n0 < EN) ? ldrow4(e.resid + (int64_t)m * e.ldr + n0, n0, EN, vec_r) : make_float4(0.f, 0.f, 0.f, 0.f);
             gat[j] = make_float4(1.f, 1.f, 1.f, 1.f);
             if (e.gate && n0 < EN) {
@@ -114,7 +120,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n0 = ncol0 + NS * j;
+            const int n0 = colof(j);
             if (n0 >= EN) continue;
             const float bb[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
             const float rr[4] = {res[j].x, res[j].y, res[j].z, res[j].w};
@@ -137,6 +143,11 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n0 + r < EN) atomicAdd(c + r, v[r]);
+            } else if (PAIR && c16 && vec_c && ((e.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) && n0 + 7 < EN + (j & 1) * 4) {
+                // both halves of the 8 columns are whole: the even accumulator's half waits in `held`, the odd one stores all 16 bytes
+                const bf16x4 h4 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                if ((j & 1) == 0) held = h4;
+                else *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(e.C) + ci - 4) = (bf16x8){held[0], held[1], held[2], held[3], h4[0], h4[1], h4[2], h4[3]};
             } else if (vec_c && n0 + 3 < EN) {
                 st_elem4(e.C, ci, e.c_dt, make_float4(v[0], v[1], v[2], v[3]));   // 16-B (fp32) or 8-B (bf16) store
             } else {
@@ -145,6 +156,75 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
                     if (n0 + r < EN) st_elem(e.C, ci + r, e.c_dt, v[r]);
             }
             (void)c16;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The forward-layout LDS-DMA kernels' epilogue, LEAN: what the launcher has verified is compiled out (full column tiles, vector
+// alignment, no split-K accumulation, no row scale) and dropout / gate are template switches, so that a workgroup's epilogue is a
+// few hundred instructions.  The general epilogue_tile above, inlined for 8 row blocks x 4 column blocks x {checked, unchecked} with
+// every option a run-time test, made gemm_bf16_dma256_kernel 31 000 instructions (~190 KB of code against a 64-KB instruction
+// cache): with the loads and MFMAs switched off, a 16 640 x 2 048 launch took 33 us where its stores alone take 16
+// (scratch/micro/store_like_gemm.hip; profiles/r06_gemm_epilogue.txt).
+// acc[i][j]: rows mrow0 + 16 i; columns ncol0 + 16 j + 0..3, or with PAIR ncol0 + 32 (j >> 1) + 4 (j & 1) + 0..3 (ncol0 = 8 x lane
+// group: blocks 2 J, 2 J + 1 are 8 consecutive columns -> one 16-byte store of a bf16 result).  Same arithmetic, in the same order,
+// as epilogue_tile: (acc + bias) -> relu -> dropout -> gate -> + residual.
+template <int MI, bool PAIR, bool DROP, bool GATE>
+__device__ __forceinline__ void epilogue_lean(const ortk_gemm_args& p, int mrow0, int ncol0, f32x4 (&acc)[MI][4]) {
+    auto colof = [&](int j) { return PAIR ? ncol0 + 32 * (j >> 1) + 4 * (j & 1) : ncol0 + 16 * j; };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colof(j)) : zero4;
+    const bool c16 = p.c_dtype == ORTK_BF16, g16 = p.gate_dtype == ORTK_BF16;
+    const bool pair_ok = PAIR && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+    const float inv_keep = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint64_t drs = p.drop_row_stride > 0 ? (uint64_t)p.drop_row_stride : 1ull;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mrow0 + 16 * i;
+        if (m >= p.M) continue;                    // (a partial last row tile: ragged M)
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = p.resid ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + colof(j)) : zero4;
+        const uint64_t dbase = DROP ? ((p.drop_rows ? (uint64_t)p.drop_rows[m] : (uint64_t)m) * drs + (uint64_t)p.drop_row_off) * (uint64_t)p.N : 0ull;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 x = acc[i][j] + bias4[j];
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+            }
+            if (DROP) {
+                bool kp[4];
+                ortk_keep4(p.drop_seed, dbase + (uint64_t)colof(j), p.drop_p, kp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * inv_keep : 0.f;
+            }
+            if (GATE) {
+                const float4 g = ld_elem4(p.gate, (int64_t)m * p.ldg + colof(j), g16 ? ORTK_BF16 : ORTK_F32);
+                const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = gg[r] > 0.f ? x[r] * p.gate_scale : 0.f;
+            }
+            v[j] = x + v[j];
+        }
+        if (c16) {
+            __bf16* c = reinterpret_cast<__bf16*>(p.C) + (int64_t)m * p.ldc;
+            if (pair_ok) {
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+                    *reinterpret_cast<bf16x8*>(c + colof(2 * J)) = (bf16x8){(__bf16)v[2 * J][0], (__bf16)v[2 * J][1], (__bf16)v[2 * J][2], (__bf16)v[2 * J][3],
+                                                                            (__bf16)v[2 * J + 1][0], (__bf16)v[2 * J + 1][1], (__bf16)v[2 * J + 1][2], (__bf16)v[2 * J + 1][3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4*>(c + colof(j)) = (bf16x4){(__bf16)v[j][0], (__bf16)v[j][1], (__bf16)v[j][2], (__bf16)v[j][3]};
+            }
+        } else {
+            float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(c + colof(j)) = v[j];
         }
     }
 }
@@ -282,6 +362,9 @@ constexpr int PITCH_MK = BK16;
 constexpr int PITCH_KM = 128;
 constexpr int IMG_ELEMS = 128 * BK16;                             // 16 KB per operand image
 __device__ __forceinline__ int swz_mk64(int row) { return (row >> 1) & 7; }
+// the [n][k] image whose fragments take rows 8 a + 4 p + b (a, b = 0..3, p fixed) instead of 16 consecutive ones
+// (gemm_bf16_dma256_kernel's column permutation): bit 1 of the row and bits 3-4 give the 8 distinct slots of such a group
+__device__ __forceinline__ int swz_mk64p(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 __device__ __forceinline__ int swz_km(int k) { return 2 * ((k & 3) | ((k >> 1) & 4)); }
 // element offset of (row, col) inside a swizzled image
 template <bool T> __device__ __forceinline__ int img_off(int row, int col) {
@@ -586,13 +669,17 @@ constexpr int G_IMG = 128 * GBK;                       // bf16 elements per oper
 constexpr size_t GLDS_RING_BYTES = (size_t)GNS * 2 * G_IMG * sizeof(__bf16);   // 64 KB
 
 __device__ __forceinline__ int swz_mk(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0,2,3,1} packed as 0b01111000
+// 64-byte rows read as 8 a + 4 p + b (a, b = 0..3: the permuted column order of the lean epilogue's 16-byte bf16 stores): b picks the
+// quarter of the 256 bytes, a the chunk
+__device__ __forceinline__ int swz_mkp(int row) { return (row >> 3) & 3; }
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
 // issue this wave's share (2 wave-instructions) of one operand tile of TM rows / columns (128: 8 instructions over
 // 4 waves; 256: 16 instructions over 8 waves)
 // rmax: last valid row of an [m][k] operand (a partial last row tile re-reads it; its results are dropped by the epilogue)
-template <bool T, int TM>
+// (PERM: the [n][k] image of the permuted column order, see swz_mkp)
+template <bool T, int TM, bool PERM = false>
 __device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane,
                                           int rmax = 0x7FFFFFFF) {
 #pragma unroll
@@ -600,7 +687,7 @@ __device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, int64
         const int inst = wave * 2 + u;
         const __bf16* g;
         if (!T) {
-            const int r = inst * 16 + (lane >> 2), c = (lane & 3) ^ swz_mk(r);
+            const int r = inst * 16 + (lane >> 2), c = (lane & 3) ^ (PERM ? swz_mkp(r) : swz_mk(r));
             g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
         } else {
             constexpr int CPR = TM / 8;                       // 16-byte chunks per k-row
@@ -609,6 +696,13 @@ __device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, int64
         }
         __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
     }
+}
+
+// fragment of MFMA block j (0..3) of a wave's 64 permuted columns (gfrag64p's order on the 32-column image)
+__device__ __forceinline__ bf16x8 gfragp(const __bf16* img, int n0, int j, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const int row = n0 + 32 * (j >> 1) + 8 * (lr >> 2) + 4 * (j & 1) + (lr & 3);
+    return *reinterpret_cast<const bf16x8*>(img + row * GBK + ((lg ^ swz_mkp(row)) << 3));
 }
 
 template <bool T, int TM>
@@ -632,8 +726,13 @@ __device__ __forceinline__ bf16x8 gfrag(const __bf16* img, int m0, int lane) {
 //              L2 -> CU fetch rate (~13 B/clk/CU sustained), not MFMA issue.
 // NS = ring depth (4, or 8 for grids of at most one workgroup per CU: with 7 tiles in flight almost the whole K = 512
 // panel of a decode-sized GEMM is requested up front and the K loop stops being a chain of fetch latencies).
-template <bool TA, bool TB, bool BIG, int NS>
+// EPI (128 x 128 forward layout without split-K accumulation or row scale; the launcher chooses): -1 = the general epilogue; 0..3 = the
+// lean one (epilogue_lean: bit 0 dropout, bit 1 gate) on the permuted column order; 4 = soft-max partials / sampling candidates, then
+// the lean store.
+template <bool TA, bool TB, bool BIG, int NS, int EPI = -1>
 __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm_bf16_glds_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    static_assert(EPI < 0 || (!TA && !TB && !BIG), "lean epilogues: the 128 x 128 forward layout");
+    constexpr bool PERM = EPI >= 0 && EPI < 4;      // (the statistics' column blocks keep the natural order)
     constexpr int TM = BIG ? 256 : 128;             // tile rows = tile columns
     constexpr int MI = BIG ? 8 : 4;                 // 16-row fragments per wave
     constexpr int IMG = TM * GBK;                   // elements per operand image
@@ -665,7 +764,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
     auto issue = [&](int t) {
         __bf16* st = smem16 + (size_t)(t & (NS - 1)) * 2 * IMG;
         glds_tile<TA, TM>(Ap, p.lda, mb, k_begin + t * GBK, st, wave, lane, TA ? 0x7FFFFFFF : p.M - 1);
-        glds_tile<TB, TM>(Bp, p.ldb, nb, k_begin + t * GBK, st + IMG, wave, lane);
+        glds_tile<TB, TM, PERM>(Bp, p.ldb, nb, k_begin + t * GBK, st + IMG, wave, lane);
     };
     for (int t = 0; t < NS - 1 && t < T; ++t) issue(t);
     for (int t = 0; t < T; ++t) {
@@ -688,7 +787,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
         const __bf16* sB = sA + IMG;
         bf16x8 a[MI], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = gfrag<TB, TM>(sB, wn * 64 + 16 * j, lane);
+        for (int j = 0; j < 4; ++j) b[j] = PERM ? gfragp(sB, wn * 64, j, lane) : gfrag<TB, TM>(sB, wn * 64 + 16 * j, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[i] = gfrag<TA, TM>(sA, wm * (16 * MI) + 16 * i, lane);
         if (TA && do_cs) {
@@ -705,7 +804,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
 #pragma unroll
         for (int i = 0; i < MI; ++i) atomicAdd(p.colsum + mb + wm * (16 * MI) + 16 * i + lane, acc_cs[i][0]);
     }
-    if (!BIG && !TA && !TB && p.tile_stats) {
+    if ((EPI < 0 || EPI == 4) && !BIG && !TA && !TB && p.tile_stats) {
         // soft-max partials of this wave's 64 rows x 64 columns (bias included, columns past stat_ncols left out): in-lane over
         // the lane's 16 values of a row, two shuffles over the four lane groups
         const int lr = lane & 15, lg = lane >> 4;
@@ -759,7 +858,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
             }
         }
     }
-    if (!BIG && !TA && !TB && p.tile_samp) {
+    if ((EPI < 0 || EPI == 4) && !BIG && !TA && !TB && p.tile_samp) {
         // Gumbel-max candidates of this wave's 64 rows x 64 columns (ortk_gemm_args.tile_samp): per row the best key over the block's
         // columns below stat_ncols other than the row's previous token, in-lane over the lane's 16 values, two shuffles over the four
         // lane groups (total order: larger key, lower column)
@@ -800,6 +899,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
         }
         if (p.samp_no_store) return;
     }
+    if constexpr (EPI >= 0) {
+        epilogue_lean<4, PERM, (EPI & 1) != 0 && EPI < 4, (EPI & 2) != 0 && EPI < 4>(p, mb + wm * 64 + (lane & 15), nb + wn * 64 + (PERM ? 8 : 4) * (lane >> 4),
+                                                                                   *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]));
+        return;
+    }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     if (!BIG && p.accumulate) {
@@ -830,7 +934,7 @@ constexpr size_t GLDS_LDS_BYTES_BIG = (size_t)GNS * 2 * 256 * GBK * sizeof(__bf1
 // the 16 lanes of every ds_read_b128 service group then hit 16 distinct 16-byte slots.
 constexpr int HBK = 64;
 
-template <bool T>
+template <bool T, bool PERM = false>
 __device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane,
                                             int rmax = 0x7FFFFFFF) {
 #pragma unroll
@@ -838,7 +942,7 @@ __device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int
         const int inst = wave * 4 + u;                         // 32 wave-instructions of 1 KB per 256 x 64 operand tile
         const __bf16* g;
         if (!T) {
-            const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
+            const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ (PERM ? swz_mk64p(r) : swz_mk64(r));
             g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
         } else {
             const int f = inst * 64 + lane, kr = f >> 5, c = (f & 31) ^ swz_km(kr);     // 32 chunks per 512-byte k-row
@@ -849,19 +953,27 @@ __device__ __forceinline__ void glds_tile64(const __bf16* __restrict__ base, int
 }
 
 // one 1-KB piece (wave-instruction) of a 256 x 64 operand tile: piece index u = 0..3 of this wave
-template <bool T>
+template <bool T, bool PERM = false>
 __device__ __forceinline__ void glds_piece64(const __bf16* __restrict__ base, int64_t ld, int tile0, int k0, __bf16* img, int wave, int lane, int u,
                                              int rmax = 0x7FFFFFFF) {
     const int inst = wave * 4 + u;
     const __bf16* g;
     if (!T) {
-        const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ swz_mk64(r);
+        const int r = inst * 8 + (lane >> 3), c = (lane & 7) ^ (PERM ? swz_mk64p(r) : swz_mk64(r));
         g = base + (int64_t)min(tile0 + r, rmax) * ld + k0 + c * 8;
     } else {
         const int f = inst * 64 + lane, kr = f >> 5, c = (f & 31) ^ swz_km(kr);
         g = base + (int64_t)(k0 + kr) * ld + tile0 + c * 8;
     }
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(img + inst * 512), 16, 0, 0);
+}
+
+// the fragment of MFMA block j (0..3) of a wave's 64 permuted columns: MFMA row 4 g + r of block j is column
+// 32 (j >> 1) + 8 g + 4 (j & 1) + r, so that a lane's accumulators of blocks 2 J, 2 J + 1 are 8 CONSECUTIVE columns
+__device__ __forceinline__ bf16x8 gfrag64p(const __bf16* img, int n0, int j, int ks, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const int row = n0 + 32 * (j >> 1) + 8 * (lr >> 2) + 4 * (j & 1) + (lr & 3);
+    return *reinterpret_cast<const bf16x8*>(img + row * HBK + (((ks * 4 + lg) ^ swz_mk64p(row)) << 3));
 }
 
 template <bool T>
@@ -878,7 +990,9 @@ __device__ __forceinline__ bf16x8 gfrag64(const __bf16* img, int m0, int ks, int
     }
 }
 
-template <bool TA, bool TB>
+// EPI: -1 = the general epilogue (every option a run-time test); 0..3 = the lean one, bit 0 dropout, bit 1 gate (forward layout, no
+// split-K accumulation, no row scale: the launcher chooses)
+template <bool TA, bool TB, int EPI = -1>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
     constexpr int IMG = 256 * HBK;                  // elements per operand image (32 KB)
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
@@ -901,7 +1015,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
     auto issue = [&](int t) {
         __bf16* st = smem16 + (size_t)(t & 1) * 2 * IMG;
         glds_tile64<TA>(Ap, p.lda, mb, k_begin + t * HBK, st, wave, lane, TA ? 0x7FFFFFFF : p.M - 1);
-        glds_tile64<TB>(Bp, p.ldb, nb, k_begin + t * HBK, st + IMG, wave, lane);
+        glds_tile64<TB, !TB>(Bp, p.ldb, nb, k_begin + t * HBK, st + IMG, wave, lane);
     };
     if (T > 0) issue(0);
     for (int t = 0; t < T; ++t) {
@@ -920,7 +1034,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[8], b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = gfrag64<TB>(sB, wn * 64 + 16 * j, ks, lane);
+            for (int j = 0; j < 4; ++j) b[j] = TB ? gfrag64<TB>(sB, wn * 64 + 16 * j, ks, lane) : gfrag64p(sB, wn * 64, j, ks, lane);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = gfrag64<TA>(sA, wm * 128 + 16 * i, ks, lane);
 #pragma unroll
@@ -928,7 +1042,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
                 if (next && (i & 1) == 0) {
                     const int u = ks * 4 + (i >> 1);               // 0..7: pieces 0-3 of A, then 0-3 of B
                     if (u < 4) glds_piece64<TA>(Ap, p.lda, mb, nk0, nst, wave, lane, u, TA ? 0x7FFFFFFF : p.M - 1);
-                    else       glds_piece64<TB>(Bp, p.ldb, nb, nk0, nst + IMG, wave, lane, u - 4);
+                    else       glds_piece64<TB, !TB>(Bp, p.ldb, nb, nk0, nst + IMG, wave, lane, u - 4);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -936,18 +1050,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
             }
         }
     }
+    if constexpr (EPI >= 0) {
+        epilogue_lean<8, !TB, (EPI & 1) != 0, (EPI & 2) != 0>(p, mb + wm * 128 + (lane & 15), nb + wn * 64 + (TB ? 4 : 8) * (lane >> 4), acc);
+        return;
+    }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
+    // (forward-layout B: the permuted column order, a lane's accumulators pair up into 8 consecutive columns)
+    const int ncol0 = nb + wn * 64 + (TB ? 4 : 8) * (lane >> 4);
     if (mb + 256 <= p.M) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
-            epilogue_tile<true>(e, mb + wm * 128 + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
-                                *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+            epilogue_tile<true, 4, 4, 16, 16, !TB>(e, mb + wm * 128 + 64 * hh + (lane & 15), ncol0, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
     } else {              // partial last row tile (ragged M)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
-            epilogue_tile<false>(e, mb + wm * 128 + 64 * hh + (lane & 15), nb + wn * 64 + 4 * (lane >> 4),
-                                 *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+            epilogue_tile<false, 4, 4, 16, 16, !TB>(e, mb + wm * 128 + 64 * hh + (lane & 15), ncol0, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
     }
 }
 constexpr size_t DMA256_LDS_BYTES = (size_t)2 * 2 * 256 * HBK * sizeof(__bf16);   // 128 KB
@@ -2313,12 +2431,30 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             if (big)       gf = key == 4 ? gemm_bf16_glds_kernel<false, false, true, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, true, 4> : gemm_bf16_glds_kernel<true, true, true, 4>;
             else if (deep) gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 8> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 8> : gemm_bf16_glds_kernel<true, true, false, 8>;
             else           gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 4> : gemm_bf16_glds_kernel<true, true, false, 4>;
+            const bool lean = key == 4 && !p.accumulate && !p.rowscale && !ortk::tuning().gemm_epilogue;
+            if (lean && !big && !deep) {
+                if (want_stats) gf = gemm_bf16_glds_kernel<false, false, false, 4, 4>;
+                else switch ((p.drop_p > 0.f ? 1 : 0) | (p.gate ? 2 : 0)) {
+                    case 0:  gf = gemm_bf16_glds_kernel<false, false, false, 4, 0>; break;
+                    case 1:  gf = gemm_bf16_glds_kernel<false, false, false, 4, 1>; break;
+                    case 2:  gf = gemm_bf16_glds_kernel<false, false, false, 4, 2>; break;
+                    default: gf = gemm_bf16_glds_kernel<false, false, false, 4, 3>; break;
+                }
+            }
             const size_t lds = big ? GLDS_LDS_BYTES_BIG : deep ? 2 * GLDS_RING_BYTES : GLDS_LDS_BYTES;
             ortk::lds_attr(reinterpret_cast<const void*>(gf), lds);
             if (big && impl != 6 && p.K % HBK == 0) {
                 // 64-column stages (full cache lines); impl 6 = the 32-column 4-stage ring for comparison
                 gemm16_fn g2 = key == 4 ? gemm_bf16_dma256_kernel<false, false> : key == 5 ? gemm_bf16_dma256_kernel<false, true>
                                                                                               : gemm_bf16_dma256_kernel<true, true>;
+                if (lean) {
+                    switch ((p.drop_p > 0.f ? 1 : 0) | (p.gate ? 2 : 0)) {
+                        case 0:  g2 = gemm_bf16_dma256_kernel<false, false, 0>; break;
+                        case 1:  g2 = gemm_bf16_dma256_kernel<false, false, 1>; break;
+                        case 2:  g2 = gemm_bf16_dma256_kernel<false, false, 2>; break;
+                        default: g2 = gemm_bf16_dma256_kernel<false, false, 3>; break;
+                    }
+                }
                 ortk::lds_attr(reinterpret_cast<const void*>(g2), DMA256_LDS_BYTES);
                 hipLaunchKernelGGL(g2, dim3((unsigned)big_blocks), dim3(512), DMA256_LDS_BYTES, s, p, (int)ortk_cdiv(p.M, 256), p.N / 256, kchunk);
             }

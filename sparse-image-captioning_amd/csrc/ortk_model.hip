@@ -890,7 +890,7 @@ extern "C" int ortk_version(void) { return ORTK_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ tuning switches
 namespace ortk {
-static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384, 3, 0, 80, 1, 1, 0, 1};
+static ortk_tuning g_tuning = {0, 640, 0, 33, 1, 1, 1, 1, 1, 384, 3, 0, 80, 1, 1, 0, 1, 0};
 const ortk_tuning& tuning() { return g_tuning; }
 }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }

@@ -4,7 +4,7 @@
 // (statically indexed, so nothing spills to scratch): lane l owns columns {4l..4l+3} + 256*it (vector form)
 // or l + 64*it (scalar form for d % 4 != 0 or unaligned rows).
 #include <cstdlib>
-#include "ortk_common.h"
+#include "ortk_internal.h"
 
 namespace {
 
@@ -189,6 +189,102 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// d = 512 (the model width), vector-aligned rows: lane l owns the EIGHT consecutive columns 8 l .. 8 l + 7, so that the masked bf16 copy
+// dz leaves as one 16-byte store per lane (the form above stores bf16x4 = 8 bytes: half the rate per byte, MI355X_MICROARCH.md) and a
+// bf16 dy (DYT = __bf16: the data-gradient GEMM's output stored as bf16) arrives as one 16-byte load.  Same arithmetic, same pipeline.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_n;
+template <typename DYT>
+__global__ __launch_bounds__(256) void ln_bwd512_kernel(const DYT* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ a,
+                                                        const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
+                                                        float* __restrict__ da, float* __restrict__ db, int64_t rows, float eps, int rows_per_block,
+                                                        void* __restrict__ dz, int dz_dt, float drop_p, uint32_t drop_seed,
+                                                        const int32_t* __restrict__ drop_rows) {
+    constexpr int d = 512;
+    extern __shared__ float red[];  // [4 waves][2][d] partial da / db
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c0 = 8 * lane;
+    float pa[8], pb[8], av[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
+    { const f32x4 t0 = *reinterpret_cast<const f32x4*>(a + c0), t1 = *reinterpret_cast<const f32x4*>(a + c0 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = t0[i]; av[4 + i] = t1[i]; } }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    f32x4 xn[2], rn[2]; f32x4 gn32[2]; u32x4_n gn16;
+    float mean_n = 0.f, sd_n = 1.f;
+    auto fetch = [&](int64_t row) {
+        xn[0] = *reinterpret_cast<const f32x4*>(x + row * d + c0); xn[1] = *reinterpret_cast<const f32x4*>(x + row * d + c0 + 4);
+        if (sizeof(DYT) == 4) {
+            gn32[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + row * d + c0);
+            gn32[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + row * d + c0 + 4);
+        } else {
+            gn16 = *reinterpret_cast<const u32x4_n*>(reinterpret_cast<const __bf16*>(dy) + row * d + c0);
+        }
+        if (dres) { rn[0] = *reinterpret_cast<const f32x4*>(dres + row * d + c0); rn[1] = *reinterpret_cast<const f32x4*>(dres + row * d + c0 + 4); }
+        mean_n = stats[row * 2]; sd_n = stats[row * 2 + 1];
+    };
+    if (r0 + wave < rows && wave < rows_per_block) fetch(r0 + wave);
+    for (int rr = wave; rr < rows_per_block; rr += 4) {
+        const int64_t row = r0 + rr;
+        if (row >= rows) break;
+        float xv[8], gv[8], rv[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xv[i] = xn[0][i]; xv[4 + i] = xn[1][i];
+            rv[i] = dres ? rn[0][i] : 0.f; rv[4 + i] = dres ? rn[1][i] : 0.f;
+            if (sizeof(DYT) == 4) { gv[i] = gn32[0][i]; gv[4 + i] = gn32[1][i]; }
+            else { gv[2 * i] = __uint_as_float(gn16[i] << 16); gv[2 * i + 1] = __uint_as_float(gn16[i] & 0xFFFF0000u); }
+        }
+        const float mean = mean_n, sd = sd_n;
+        if (rr + 4 < rows_per_block && row + 4 < rows) fetch(row + 4);
+        const float r = 1.f / (sd + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xc = xv[i] - mean, dyv = gv[i];
+            pa[i] += dyv * xc * r; pb[i] += dyv;
+            const float g = dyv * av[i];
+            xv[i] = xc; gv[i] = g; sg += g; sgx += g * xc;
+        }
+        sg = wave_sum(sg); sgx = wave_sum(sgx);
+        const float mg = sg / (float)d;
+        const float coef = r * r * sgx / ((float)(d - 1) * sd);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = r * (gv[i] - mg) - coef * xv[i] + rv[i];
+        float* dxr = dx + row * d + c0;
+        *reinterpret_cast<f32x4*>(dxr) = (f32x4){o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(dxr + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+        if (dz) {
+            const uint64_t krow = drop_rows ? (uint64_t)drop_rows[row] : (uint64_t)row;
+            const float ik = 1.f / (1.f - drop_p);
+            float z[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bool kp[4] = {true, true, true, true};
+                if (drop_p > 0.f) ortk_keep4(drop_seed, krow * (uint64_t)d + (uint64_t)(c0 + 4 * h), drop_p, kp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[4 * h + q] = kp[q] ? o[4 * h + q] * ik : 0.f;
+            }
+            const int64_t i0 = row * d + c0;
+            if (dz_dt == ORTK_BF16) {
+                const bf16x8 pk = {(__bf16)z[0], (__bf16)z[1], (__bf16)z[2], (__bf16)z[3], (__bf16)z[4], (__bf16)z[5], (__bf16)z[6], (__bf16)z[7]};
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dz) + i0) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dz) + i0) = (f32x4){z[0], z[1], z[2], z[3]};
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dz) + i0 + 4) = (f32x4){z[4], z[5], z[6], z[7]};
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[wave * 2 * d + c0 + i] = pa[i]; red[wave * 2 * d + d + c0 + i] = pb[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        const float v = (red[c] + red[2 * d + c]) + (red[4 * d + c] + red[6 * d + c]);
+        atomicAdd(c < d ? &da[c] : &db[c - d], v);
+    }
+}
+
 inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -216,6 +312,14 @@ extern "C" int ortk_layernorm_bwd_drop(const float* dy, const float* x, const fl
 extern "C" int ortk_layernorm_bwd_drop_rows(const float* dy, const float* x, const float* a, const float* stats, const float* dres,
                                             float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
                                             float drop_p, uint32_t drop_seed, const int32_t* drop_rows, ortk_stream stream) {
+    return ortk_layernorm_bwd_dt(dy, ORTK_F32, x, a, stats, dres, dx, da, db, rows, d, eps, dz, dz_dtype, drop_p, drop_seed, drop_rows, stream);
+}
+
+extern "C" int ortk_layernorm_bwd_dt(const void* dy_, int32_t dy_dtype, const float* x, const float* a, const float* stats, const float* dres,
+                                     float* dx, float* da, float* db, int64_t rows, int32_t d, float eps, void* dz, int32_t dz_dtype,
+                                     float drop_p, uint32_t drop_seed, const int32_t* drop_rows, ortk_stream stream) {
+    const float* dy = reinterpret_cast<const float*>(dy_);
+    if (dy_dtype != ORTK_F32 && dy_dtype != ORTK_BF16) return ORTK_EINVAL;
     if (!dy || !x || !a || !stats || !dx || !da || !db || d < 2 || d > 2048 || rows < 0) return ORTK_EINVAL;
     if (dz && ((dz_dtype != ORTK_F32 && dz_dtype != ORTK_BF16) || drop_p < 0.f || drop_p >= 1.f)) return ORTK_EINVAL;
     if (rows == 0) return 0;
@@ -225,6 +329,13 @@ extern "C" int ortk_layernorm_bwd_drop_rows(const float* dy, const float* x, con
     dim3 grid((unsigned)ortk_cdiv(rows, rpb)), block(256);
     const size_t shm = 8 * (size_t)d * sizeof(float);
     const bool vec = d % 4 == 0 && al16(dy) && al16(x) && al16(a) && al16(dres) && al16(dx) && (dz == nullptr || (reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+    if (d == 512 && vec && (dy_dtype == ORTK_BF16 || !(ortk::tuning().ln_fuse & 4))) {       // the model width: eight consecutive columns per lane (16-byte bf16 accesses; ln_fuse & 4: the four-column form, measurement)
+        if (dy_dtype == ORTK_BF16) hipLaunchKernelGGL(ln_bwd512_kernel<__bf16>, grid, block, shm, ortk_s(stream), reinterpret_cast<const __bf16*>(dy_), x, a, stats, dres, dx, da, db, rows, eps, rpb, dz, (int)dz_dtype, drop_p, drop_seed, drop_rows);
+        else hipLaunchKernelGGL(ln_bwd512_kernel<float>, grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, eps, rpb, dz, (int)dz_dtype, drop_p, drop_seed, drop_rows);
+        ORTK_CHECK_LAUNCH();
+        return 0;
+    }
+    if (dy_dtype != ORTK_F32) return ORTK_EINVAL;        // (bf16 output gradients: d = 512 only)
 #define LN_B(V, N) hipLaunchKernelGGL((ln_bwd_kernel<V, N>), grid, block, shm, ortk_s(stream), dy, x, a, stats, dres, dx, da, db, rows, d, eps, rpb, dz, (int)dz_dtype, drop_p, drop_seed, drop_rows)
     if (d <= 512) { if (vec) LN_B(true, 8); else LN_B(false, 8); }
     else          { if (vec) LN_B(true, 32); else LN_B(false, 32); }

@@ -1090,6 +1090,44 @@ def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
         torch.testing.assert_close(csum.cpu(), 2 + At16.float().cpu().sum(0), rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(16640, 512, 128), (4500, 2560, 192), (21590, 512, 64),      # 256 x 256 tiles (whole, ragged last row tile)
+                                   (1000, 512, 512), (9216, 1536, 64), (37, 2048, 128)])           # 128 x 128 tiles
+def test_gemm_lean_epilogue_equals_general(L, M, N, K):
+    """The lean epilogue of the forward-layout LDS-DMA kernels (options compiled out, dropout / gate as kernel instances, permuted column
+    order with 16-byte bf16 stores; ortk_tuning.gemm_epilogue = 0) gives BIT-identical results to the general epilogue it replaces
+    (gemm_epilogue = 1: same arithmetic in the same order), for every option the executor's forward-layout products use — bias, ReLU,
+    residual, dropout (with a row map, stride and offset), gate in both element types, both result types — and both agree with torch."""
+    A16, B16 = dev(rnd(M, K, seed=21).bfloat16()), dev(rnd(N, K, seed=22).bfloat16())
+    bias, resid, gate = dev(rnd(N, seed=23)), dev(rnd(M, N, seed=24)), rnd(M, N, seed=25)
+    g = torch.Generator().manual_seed(5)
+    rows = dev(torch.randperm(M, generator=g).int())
+    combos = [dict(), dict(bias=bias, relu=1, c_dtype=1), dict(bias=bias, resid=resid), dict(resid=resid, c_dtype=1, relu=1),
+              dict(bias=bias, relu=1, drop_p=0.1, drop_seed=77, c_dtype=1), dict(drop_p=0.3, drop_seed=5, drop_rows=rows, drop_row_stride=3, drop_row_off=1, resid=resid),
+              dict(gate=dev(gate), gate_scale=1.25), dict(gate=dev(gate.bfloat16()), gate_dtype=1, gate_scale=1.0 / 0.9, c_dtype=1, bias=bias),
+              dict(gate=dev(gate), gate_scale=2.0, drop_p=0.2, drop_seed=9, resid=resid, bias=bias, relu=1)]
+    ref0 = (A16.float() @ B16.float().t())
+    try:
+        for kw in combos:
+            out = []
+            for general in (0, 1):
+                L.set_tuning(gemm_epilogue=general)
+                Cx = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if kw.get("c_dtype") else torch.float32)
+                out.append(gemm(L, A16, B16, M, N, K, 0, 0, 1, a_dtype=1, b_dtype=1, C=Cx, **kw).clone())
+            assert torch.equal(out[0], out[1]), sorted(kw)
+            if "drop_p" not in kw:
+                ref = ref0 + (bias if "bias" in kw else 0)
+                if kw.get("relu"): ref = ref.clamp_min(0)
+                if "gate" in kw: ref = torch.where(dev(gate) > 0, ref * kw["gate_scale"], torch.zeros_like(ref))
+                if "resid" in kw: ref = ref + resid
+                err = (out[0].float() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+                assert err < (1e-2 if kw.get("c_dtype") else 1e-4), (sorted(kw), err)
+            else:
+                keep = (out[0].float() != (resid if "resid" in kw else 0)).float().mean().item()
+                if "gate" not in kw and not kw.get("relu"): assert abs(keep - (1 - kw["drop_p"])) < 0.02, keep
+    finally:
+        L.set_tuning(gemm_epilogue=0)
+
+
 def _ln_gemm_inputs(M, K, seed):
     A = rnd(M, K, seed=seed).bfloat16()
     W = rnd(512, K, seed=seed + 1, scale=K ** -0.5).bfloat16()

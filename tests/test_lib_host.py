@@ -48,6 +48,15 @@ def test_every_header_under_include_is_fully_exported():
             assert hasattr(lib, n), f"{n} declared in {os.path.basename(h)} but not exported by libortk.so"
 
 
+def test_graft_entry_build_runs_and_checks_the_abi_version():
+    """__graft_entry__.build() is the driver's "does it build" check: it must pass on the CPU box, and against the bindings' own
+    ABI version (it once held a literal that an ORTK_VERSION bump left behind)."""
+    import __graft_entry__ as G
+    import sparse_image_captioning_amd as P
+    G.build()
+    assert P._lib.lib().ortk_version() == P._lib.ABI_VERSION
+
+
 def test_struct_sizes_match_header():
     """sizeof() of the ctypes mirrors == what the C compiler lays out (checked by compiling a tiny C program)."""
     import subprocess, tempfile
