@@ -172,6 +172,7 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
 // as epilogue_tile: (acc + bias) -> relu -> dropout -> gate -> + residual.
 template <int MI, bool PAIR, bool DROP, bool GATE>
 __device__ __forceinline__ void epilogue_lean(const ortk_gemm_args& p, int mrow0, int ncol0, f32x4 (&acc)[MI][4]) {
+    static_assert(MI % 4 == 0, "row blocks in groups of four or two");
     auto colof = [&](int j) { return PAIR ? ncol0 + 32 * (j >> 1) + 4 * (j & 1) : ncol0 + 16 * j; };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 bias4[4];
@@ -181,50 +182,81 @@ __device__ __forceinline__ void epilogue_lean(const ortk_gemm_args& p, int mrow0
     const bool pair_ok = PAIR && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
     const float inv_keep = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
     const uint64_t drs = p.drop_row_stride > 0 ? (uint64_t)p.drop_row_stride : 1ull;
+    // G row blocks at a time: ALL their residual / gate loads are issued first (rows past a ragged M clamped: no control flow between
+    // the loads, one round trip per group instead of one per row block — the epilogue has no other workgroup to hide behind), then the
+    // arithmetic and the stores, the stores alone under the row test.
+    constexpr int G = GATE ? 2 : 4;                  // (row blocks per group: what fits the registers beside the accumulators)
+    const uint32_t thr = DROP ? ortk_keep_thr(p.drop_p) : 0u;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = mrow0 + 16 * i;
-        if (m >= p.M) continue;                    // (a partial last row tile: ragged M)
-        f32x4 v[4];
+    for (int h = 0; h < MI / G; ++h) {
+        f32x4 res[G][4];
+        float4 gat[G][4];
+        if (p.resid) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.resid ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + colof(j)) : zero4;
-        const uint64_t dbase = DROP ? ((p.drop_rows ? (uint64_t)p.drop_rows[m] : (uint64_t)m) * drs + (uint64_t)p.drop_row_off) * (uint64_t)p.N : 0ull;
+            for (int i = 0; i < G; ++i) {
+                const int64_t mc = min(mrow0 + 16 * (G * h + i), p.M - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 x = acc[i][j] + bias4[j];
-            if (p.relu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
-            }
-            if (DROP) {
-                bool kp[4];
-                ortk_keep4(p.drop_seed, dbase + (uint64_t)colof(j), p.drop_p, kp);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * inv_keep : 0.f;
-            }
-            if (GATE) {
-                const float4 g = ld_elem4(p.gate, (int64_t)m * p.ldg + colof(j), g16 ? ORTK_BF16 : ORTK_F32);
-                const float gg[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = gg[r] > 0.f ? x[r] * p.gate_scale : 0.f;
-            }
-            v[j] = x + v[j];
-        }
-        if (c16) {
-            __bf16* c = reinterpret_cast<__bf16*>(p.C) + (int64_t)m * p.ldc;
-            if (pair_ok) {
-#pragma unroll
-                for (int J = 0; J < 2; ++J)
-                    *reinterpret_cast<bf16x8*>(c + colof(2 * J)) = (bf16x8){(__bf16)v[2 * J][0], (__bf16)v[2 * J][1], (__bf16)v[2 * J][2], (__bf16)v[2 * J][3],
-                                                                            (__bf16)v[2 * J + 1][0], (__bf16)v[2 * J + 1][1], (__bf16)v[2 * J + 1][2], (__bf16)v[2 * J + 1][3]};
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4*>(c + colof(j)) = (bf16x4){(__bf16)v[j][0], (__bf16)v[j][1], (__bf16)v[j][2], (__bf16)v[j][3]};
+                for (int j = 0; j < 4; ++j) res[i][j] = *reinterpret_cast<const f32x4*>(p.resid + mc * p.ldr + colof(j));
             }
         } else {
-            float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(c + colof(j)) = v[j];
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) res[i][j] = zero4;
+        }
+        if (GATE) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int64_t mc = min(mrow0 + 16 * (G * h + i), p.M - 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gat[i][j] = ld_elem4(p.gate, mc * p.ldg + colof(j), g16 ? ORTK_BF16 : ORTK_F32);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int m = mrow0 + 16 * (G * h + i);
+            const int mc = min(m, p.M - 1);
+            const uint64_t dbase = DROP ? ((p.drop_rows ? (uint64_t)p.drop_rows[mc] : (uint64_t)mc) * drs + (uint64_t)p.drop_row_off) * (uint64_t)p.N : 0ull;
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 x = acc[G * h + i][j] + bias4[j];
+                if (p.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+                }
+                if (DROP) {
+                    // (ortk_keep4's aligned form: N and the column are multiples of 4 here)
+                    const uint2 kb = ortk_keep_bits(p.drop_seed, (dbase + (uint64_t)colof(j)) >> 2);
+                    const bool kp[4] = {(kb.x & 0xFFFFu) >= thr, (kb.x >> 16) >= thr, (kb.y & 0xFFFFu) >= thr, (kb.y >> 16) >= thr};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * inv_keep : 0.f;
+                }
+                if (GATE) {
+                    const float gg[4] = {gat[i][j].x, gat[i][j].y, gat[i][j].z, gat[i][j].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = gg[r] > 0.f ? x[r] * p.gate_scale : 0.f;
+                }
+                v[j] = x + res[i][j];
+            }
+            if (m < p.M) {                              // (a partial last row tile: ragged M)
+                if (c16) {
+                    __bf16* c = reinterpret_cast<__bf16*>(p.C) + (int64_t)m * p.ldc;
+                    if (pair_ok) {
+#pragma unroll
+                        for (int J = 0; J < 2; ++J)
+                            *reinterpret_cast<bf16x8*>(c + colof(2 * J)) = (bf16x8){(__bf16)v[2 * J][0], (__bf16)v[2 * J][1], (__bf16)v[2 * J][2], (__bf16)v[2 * J][3],
+                                                                                    (__bf16)v[2 * J + 1][0], (__bf16)v[2 * J + 1][1], (__bf16)v[2 * J + 1][2], (__bf16)v[2 * J + 1][3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4*>(c + colof(j)) = (bf16x4){(__bf16)v[j][0], (__bf16)v[j][1], (__bf16)v[j][2], (__bf16)v[j][3]};
+                    }
+                } else {
+                    float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(c + colof(j)) = v[j];
+                }
+            }
         }
     }
 }
@@ -726,9 +758,54 @@ __device__ __forceinline__ bf16x8 gfrag(const __bf16* img, int m0, int lane) {
 //              L2 -> CU fetch rate (~13 B/clk/CU sustained), not MFMA issue.
 // NS = ring depth (4, or 8 for grids of at most one workgroup per CU: with 7 tiles in flight almost the whole K = 512
 // panel of a decode-sized GEMM is requested up front and the K loop stops being a chain of fetch latencies).
+// Gumbel-max candidates of a wave's (16 MI) rows x 64 columns at (m0, n0) (ortk_gemm_args.tile_samp), FAST: the draw function
+template <bool FAST, int MI>
+__device__ __forceinline__ void samp_candidates(const ortk_gemm_args& p, int m0, int n0, int lane, f32x4 (&acc)[MI][4]) {
+    // Gumbel-max candidates of this wave's 64 rows x 64 columns (ortk_gemm_args.tile_samp): per row the best key over the block's
+    // columns below stat_ncols other than the row's previous token, in-lane over the lane's 16 values, two shuffles over the four
+    // lane groups (total order: larger key, lower column)
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = n0 + 4 * lg;
+    const int nblk = p.N >> 6, blk = n0 >> 6;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + 16 * i + lr;
+        const int mc = min(m, p.M - 1);
+        const int gs = p.samp_greedy_stride;
+        const int64_t grow = p.samp_row_offset + mc;
+        const bool is_greedy = gs > 0 && mc % gs == 0;          // (as sample_step: by the row of this call)
+        const bool samp = p.samp_sample && !is_greedy;
+        const int hrow = (int)(gs > 0 ? grow - grow / gs - 1 : grow);
+        const int prev = (p.samp_seq && p.samp_t > 0) ? (int)p.samp_seq[(int64_t)mc * p.samp_L + p.samp_t - 1] : -1;
+        float bv = -INFINITY, bz = 0.f; int bi = 0x7FFFFFFF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (branch-free: a column past the vocabulary or the row's previous token competes as (-inf, no column) and never wins)
+                const int v = c0 + 16 * j + r;
+                const bool ok = v < p.stat_ncols && v != prev;
+                const float z = acc[i][j][r] + bias4[j][r];
+                const float xs = z * p.samp_inv_temperature + ortk_gumbel<FAST>(p.samp_seed, p.samp_t, hrow, v);
+                const float x = ok ? (samp ? xs : z) : -INFINITY;
+                const int vv = ok ? v : 0x7FFFFFFF;
+                if (ortk_better(x, vv, bv, bi)) { bv = x; bi = vv; bz = z; }
+            }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64), oz = __shfl_xor(bz, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ortk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; bz = oz; }
+        }
+        if (lg == 0 && m < p.M) *reinterpret_cast<f32x4*>(p.tile_samp + ((int64_t)m * nblk + blk) * 4) = (f32x4){bv, __int_as_float(bi), bz, 0.f};
+    }
+}
+
 // EPI (128 x 128 forward layout without split-K accumulation or row scale; the launcher chooses): -1 = the general epilogue; 0..3 = the
-// lean one (epilogue_lean: bit 0 dropout, bit 1 gate) on the permuted column order; 4 = soft-max partials / sampling candidates, then
-// the lean store.
+// lean one (epilogue_lean: bit 0 dropout, bit 1 gate) on the permuted column order; 4 = soft-max partials, 5 = partials + sampling
+// candidates, then the lean store.
 template <bool TA, bool TB, bool BIG, int NS, int EPI = -1>
 __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm_bf16_glds_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
     static_assert(EPI < 0 || (!TA && !TB && !BIG), "lean epilogues: the 128 x 128 forward layout");
@@ -804,7 +881,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
 #pragma unroll
         for (int i = 0; i < MI; ++i) atomicAdd(p.colsum + mb + wm * (16 * MI) + 16 * i + lane, acc_cs[i][0]);
     }
-    if ((EPI < 0 || EPI == 4) && !BIG && !TA && !TB && p.tile_stats) {
+    if ((EPI < 0 || EPI >= 4) && !BIG && !TA && !TB && p.tile_stats) {
         // soft-max partials of this wave's 64 rows x 64 columns (bias included, columns past stat_ncols left out): in-lane over
         // the lane's 16 values of a row, two shuffles over the four lane groups
         const int lr = lane & 15, lg = lane >> 4;
@@ -858,45 +935,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
             }
         }
     }
-    if ((EPI < 0 || EPI == 4) && !BIG && !TA && !TB && p.tile_samp) {
-        // Gumbel-max candidates of this wave's 64 rows x 64 columns (ortk_gemm_args.tile_samp): per row the best key over the block's
-        // columns below stat_ncols other than the row's previous token, in-lane over the lane's 16 values, two shuffles over the four
-        // lane groups (total order: larger key, lower column)
-        const int lr = lane & 15, lg = lane >> 4;
-        const int c0 = nb + wn * 64 + 4 * lg;
-        const int nblk = p.N >> 6, blk = (nb >> 6) + wn;
-        f32x4 bias4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = mb + wm * (16 * MI) + 16 * i + lr;
-            const int mc = min(m, p.M - 1);
-            const int gs = p.samp_greedy_stride;
-            const int64_t grow = p.samp_row_offset + mc;
-            const bool is_greedy = gs > 0 && mc % gs == 0;          // (as sample_step: by the row of this call)
-            const bool samp = p.samp_sample && !is_greedy;
-            const int hrow = (int)(gs > 0 ? grow - grow / gs - 1 : grow);
-            const int prev = (p.samp_seq && p.samp_t > 0) ? (int)p.samp_seq[(int64_t)mc * p.samp_L + p.samp_t - 1] : -1;
-            float bv = -INFINITY, bz = 0.f; int bi = 0x7FFFFFFF;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int v = c0 + 16 * j + r;
-                    if (v >= p.stat_ncols || v == prev) continue;
-                    const float z = acc[i][j][r] + bias4[j][r];
-                    float x = z;
-                    if (samp) x = z * p.samp_inv_temperature + (p.samp_fast ? ortk_gumbel<true>(p.samp_seed, p.samp_t, hrow, v) : ortk_gumbel<false>(p.samp_seed, p.samp_t, hrow, v));
-                    if (ortk_better(x, v, bv, bi)) { bv = x; bi = v; bz = z; }
-                }
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const float ov = __shfl_xor(bv, o, 64), oz = __shfl_xor(bz, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                if (ortk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; bz = oz; }
-            }
-            if (lg == 0 && m < p.M) *reinterpret_cast<f32x4*>(p.tile_samp + ((int64_t)m * nblk + blk) * 4) = (f32x4){bv, __int_as_float(bi), bz, 0.f};
-        }
+    if ((EPI < 0 || EPI == 5) && !BIG && !TA && !TB && p.tile_samp) {
+        // (one instance per draw function, chosen once: the per-element choice doubled the straight-line code of the block)
+        if (p.samp_fast) samp_candidates<true, MI>(p, mb + wm * (16 * MI), nb + wn * 64, lane, *reinterpret_cast<f32x4(*)[MI][4]>(&acc[0]));
+        else             samp_candidates<false, MI>(p, mb + wm * (16 * MI), nb + wn * 64, lane, *reinterpret_cast<f32x4(*)[MI][4]>(&acc[0]));
         if (p.samp_no_store) return;
     }
     if constexpr (EPI >= 0) {
@@ -2433,7 +2475,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             else           gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 4> : gemm_bf16_glds_kernel<true, true, false, 4>;
             const bool lean = key == 4 && !p.accumulate && !p.rowscale && !ortk::tuning().gemm_epilogue;
             if (lean && !big && !deep) {
-                if (want_stats) gf = gemm_bf16_glds_kernel<false, false, false, 4, 4>;
+                if (want_stats) gf = p.tile_samp ? gemm_bf16_glds_kernel<false, false, false, 4, 5> : gemm_bf16_glds_kernel<false, false, false, 4, 4>;
                 else switch ((p.drop_p > 0.f ? 1 : 0) | (p.gate ? 2 : 0)) {
                     case 0:  gf = gemm_bf16_glds_kernel<false, false, false, 4, 0>; break;
                     case 1:  gf = gemm_bf16_glds_kernel<false, false, false, 4, 1>; break;
