@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round-6 profile collection (run on the GPU box through gpurun, from the repo root):
-#     gpurun -- "GIT_HEAD=$(git rev-parse HEAD) bash scratch/prof_r06.sh"
+#     gpurun -- "GIT_HEAD=$(git rev-parse HEAD) bash scratch/prof_r06.sh stats|pmc|final"
+# three calls (the whole set does not fit one call's time limit): `stats` = kernel-trace summaries of every workload, `pmc` = the HBM
+# counter passes, `final` = host-thread sweep of the CPU baseline + the default bench line (run it after the pmc call's CSVs have been
+# copied into profiles/: bench.py reads them for roofline.traffic).
 # Summaries land in gpurun_out/r06/ together with r06_manifest.json = {lib_md5, git_head, ...}: the identity of the library every
 # pass ran.  bench.py's pmc_traffic() refuses the PMC passes when that md5 is not the md5 of the library it has loaded.
 # PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
@@ -17,6 +20,8 @@ pmc() {     # name, counter, then -- extra args
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/raw_$name -o t -- $B "$@" > $O/$name.log 2>&1
   python3 scratch/pmc_summary.py $O/raw_$name/t_counter_collection.csv > $O/r06_$name.csv
 }
+PART=${1:-stats}
+if [ "$PART" = stats ]; then
 stats xe_b256_bf16 ""
 stats decode_stack_b1024_beam5 "--workload decode"
 stats sparse_decode_stack_b1024_beam5 "--workload sparse_decode"
@@ -24,6 +29,8 @@ stats scst_b256_ns5 "--workload scst"
 stats sparse_xe_b256 "--workload sparse_xe"
 stats sparse_xe_kernels_b256 "--workload sparse_xe --variant kernels"
 stats decode_fp32_b1024_beam5 "--workload decode --variant fp32"
+fi
+if [ "$PART" = pmc ]; then
 for c in fetch_size write_size; do
   C=$(echo $c | tr a-z A-Z)
   pmc xe_b256_pmc_$c $C --
@@ -34,16 +41,18 @@ for c in fetch_size write_size; do
   pmc sparse_xe_b256_pmc_$c $C -- --workload sparse_xe
   pmc sparse_xe_kernels_b256_pmc_$c $C -- --workload sparse_xe --variant kernels
 done
+fi
 rm -rf $O/raw_*
 python3 - <<PY
 import json, time
 json.dump({"lib_md5": "$MD5", "git_head": "${GIT_HEAD:-unknown}", "collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-           "command": "scratch/prof_r06.sh", "bench": "$B",
-           "note": "every r06_*_kernel_stats.csv and r06_*_pmc_*.csv in this directory was produced by this library in this one gpurun call"},
-          open("$O/r06_manifest.json", "w"), indent=1)
+           "command": "scratch/prof_r06.sh $PART", "bench": "$B",
+           "note": "every r06_*_kernel_stats.csv and r06_*_pmc_*.csv of round 6 was produced by the library with this md5 (three gpurun calls: stats, pmc, final)"},
+          open("$O/r06_manifest_$PART.json", "w"), indent=1)
 PY
-cp $O/r06_manifest.json profiles/r06_manifest.json; cp $O/r06_*_pmc_*.csv profiles/     # (on the box: the bench line below reads them)
+if [ "$PART" = final ]; then
 python3 scratch/cpu_thread_sweep.py > $O/r06_cpu_thread_sweep.txt 2>&1
 python3 bench.py --steps 50 --warmup 10 > $O/r06_default_bench_line.json 2> $O/bench.err
 wc -c $O/r06_default_bench_line.json; tail -2 $O/bench.err
-ls $O | head -60
+fi
+echo "lib md5 $MD5"; ls $O | head -80

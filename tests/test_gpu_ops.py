@@ -251,6 +251,37 @@ def test_layernorm_fwd_bwd(L, rows, d):
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("rows,d", [(16640, 512), (333, 512), (100, 256)])
+def test_layernorm_bwd_element_types_and_forms(L, rows, d):
+    """ortk_layernorm_bwd_dt on a bf16 output gradient == the fp32 entry on the same (bf16-rounded) values; the eight-column form of
+    width 512 == the four-column form (ortk_tuning.ln_fuse bit 2) up to the order of the row sums; both with the residual gradient, the
+    dropout-masked bf16 copy and the parameter gradients of the executor's call."""
+    lib = L.lib()
+    x, dy, a, b, dres = dev(rnd(rows, d, seed=1)), rnd(rows, d, seed=2), dev(rnd(d, seed=3)), dev(rnd(d, seed=4)), dev(rnd(rows, d, seed=5))
+    dy16 = dev(dy.bfloat16()); dy32 = dy16.float()
+    y = torch.empty(rows, d, device="cuda"); st = torch.empty(rows, 2, device="cuda")
+    L.check(lib.ortk_layernorm_fwd(L.ptr(x), L.ptr(a), L.ptr(b), L.ptr(y), 0, L.ptr(st), rows, d, 1e-6, L.stream_ptr()), "fwd")
+    out = {}
+    try:
+        for key, g, dt, fuse in (("f32", dy32, 0, 0), ("bf16", dy16, 1, 0), ("four", dy32, 0, 4)):
+            L.set_tuning(ln_fuse=fuse)
+            dx = torch.full((rows, d), float("nan"), device="cuda"); dz = torch.zeros(rows, d, device="cuda", dtype=torch.bfloat16)
+            da, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+            L.check(lib.ortk_layernorm_bwd_dt(L.ptr(g), dt, L.ptr(x), L.ptr(a), L.ptr(st), L.ptr(dres), L.ptr(dx), L.ptr(da), L.ptr(db), rows, d, 1e-6,
+                                              L.ptr(dz), 1, 0.1, 7, None, L.stream_ptr()), "bwd")
+            torch.cuda.synchronize()
+            out[key] = (dx, dz, da, db)
+    finally:
+        L.set_tuning(ln_fuse=0)
+    sc = out["f32"][0].abs().max().item()
+    for key in ("bf16", "four"):
+        assert (out[key][0] - out["f32"][0]).abs().max().item() <= 4e-6 * sc, key
+        assert ((out[key][1].float() != 0) == (out["f32"][1].float() != 0)).all(), key                # the same dropout mask
+        assert (out[key][1].float() - out["f32"][1].float()).abs().max().item() <= 2 ** -7 * sc, key      # (bf16 copies: one rounding apart at most)
+        for u in (2, 3):
+            torch.testing.assert_close(out[key][u], out["f32"][u], rtol=1e-4, atol=1e-3 * rows ** 0.5)
+
+
 @pytest.mark.parametrize("rows,d,p,dt", [(300, 512, 0.1, 1), (77, 512, 0.0, 1), (33, 100, 0.25, 0), (64, 2048, 0.1, 1)])
 def test_layernorm_bwd_with_fused_dropout_output(L, rows, d, p, dt):
     """ortk_layernorm_bwd_drop == ortk_layernorm_bwd followed by ortk_dropout_apply on its dx (bitwise)."""
