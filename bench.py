@@ -143,9 +143,11 @@ STACK_SPARSE = "ortk::decoder_stack_kernel<true, 20, false>(ortk::StackArgs)"
 STACK_GATHER = "ortk::decoder_stack_kernel<true, 20, true>(ortk::StackArgs)"
 ROLLOUT = "ortk::decoder_stack_tp_kernel<8, true>(ortk::StackArgs)"
 WGRAD = "wgrad_group_kernel(WgArgs)"
-GEMM_FWD = ("gemm_bf16_dma256_kernel<false, false>(ortk_gemm_args, int, int, int)",
-            "gemm_bf16_glds_kernel<false, false, false, 4>(ortk_gemm_args, int, int, int)",
-            "gemm_bf16_dma64_kernel<3>(ortk_gemm_args, int, int, int)", "gemm_bf16_dma64_kernel<8>(ortk_gemm_args, int, int, int)")
+# (round 6: the epilogue is a template argument — 0..3 lean with dropout / gate instances, 4 / 5 soft-max partials (+ sampling
+#  candidates), -1 the general one; the first name is the family's dominant instance and must be in the passes)
+GEMM_FWD = tuple(f"gemm_bf16_dma256_kernel<false, false, {e}>(ortk_gemm_args, int, int, int)" for e in (0, 1, 2, 3, -1)) + \
+           tuple(f"gemm_bf16_glds_kernel<false, false, false, 4, {e}>(ortk_gemm_args, int, int, int)" for e in (0, 1, 2, 3, 4, 5, -1)) + \
+           ("gemm_bf16_dma64_kernel<3>(ortk_gemm_args, int, int, int)", "gemm_bf16_dma64_kernel<8>(ortk_gemm_args, int, int, int)")
 
 
 def lib_md5():

@@ -267,14 +267,20 @@ def test_layernorm_bwd_element_types_and_forms(L, rows, d):
             L.set_tuning(ln_fuse=fuse)
             dx = torch.full((rows, d), float("nan"), device="cuda"); dz = torch.zeros(rows, d, device="cuda", dtype=torch.bfloat16)
             da, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
-            L.check(lib.ortk_layernorm_bwd_dt(L.ptr(g), dt, L.ptr(x), L.ptr(a), L.ptr(st), L.ptr(dres), L.ptr(dx), L.ptr(da), L.ptr(db), rows, d, 1e-6,
-                                              L.ptr(dz), 1, 0.1, 7, None, L.stream_ptr()), "bwd")
+            rc = lib.ortk_layernorm_bwd_dt(L.ptr(g), dt, L.ptr(x), L.ptr(a), L.ptr(st), L.ptr(dres), L.ptr(dx), L.ptr(da), L.ptr(db), rows, d, 1e-6,
+                                           L.ptr(dz), 1, 0.1, 7, None, L.stream_ptr())
+            if dt == 1 and d != 512:          # bf16 output gradients: the model width only (include/ortk.h) — refused, not mis-read
+                assert rc == -1
+                continue
+            L.check(rc, "bwd")
             torch.cuda.synchronize()
             out[key] = (dx, dz, da, db)
     finally:
         L.set_tuning(ln_fuse=0)
     sc = out["f32"][0].abs().max().item()
     for key in ("bf16", "four"):
+        if key not in out:
+            continue
         assert (out[key][0] - out["f32"][0]).abs().max().item() <= 4e-6 * sc, key
         assert ((out[key][1].float() != 0) == (out["f32"][1].float() != 0)).all(), key                # the same dropout mask
         assert (out[key][1].float() - out["f32"][1].float()).abs().max().item() <= 2 ** -7 * sc, key      # (bf16 copies: one rounding apart at most)
