@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-6 profile collection (run on the GPU box through gpurun, from the repo root):
-#     gpurun -- "GIT_HEAD=$(git rev-parse HEAD) bash scratch/prof_r06.sh stats|pmc|final"
-# three calls (the whole set does not fit one call's time limit): `stats` = kernel-trace summaries of every workload, `pmc` = the HBM
-# counter passes, `final` = host-thread sweep of the CPU baseline + the default bench line (run it after the pmc call's CSVs have been
+#     gpurun -- "GIT_HEAD=$(git rev-parse HEAD) bash scratch/prof_r06.sh stats|pmc|final|sweep"
+# four calls (the whole set does not fit one call's time limit): `stats` = kernel-trace summaries of every workload, `pmc` = the HBM
+# counter passes, `sweep` = host-thread sweep of the CPU baseline (40 min: the 256-thread setting), `final` = the default bench line + the A/B texts (run it after the pmc call's CSVs have been
 # copied into profiles/: bench.py reads them for roofline.traffic).
 # Summaries land in gpurun_out/r06/ together with r06_manifest.json = {lib_md5, git_head, ...}: the identity of the library every
 # pass ran.  bench.py's pmc_traffic() refuses the PMC passes when that md5 is not the md5 of the library it has loaded.
@@ -50,8 +50,12 @@ json.dump({"lib_md5": "$MD5", "git_head": "${GIT_HEAD:-unknown}", "collected_utc
            "note": "every r06_*_kernel_stats.csv and r06_*_pmc_*.csv of round 6 was produced by the library with this md5 (three gpurun calls: stats, pmc, final)"},
           open("$O/r06_manifest_$PART.json", "w"), indent=1)
 PY
-if [ "$PART" = final ]; then
+if [ "$PART" = sweep ]; then     # (its own call: the 128- and 256-thread settings run for minutes per step)
 python3 scratch/cpu_thread_sweep.py > $O/r06_cpu_thread_sweep.txt 2>&1
+fi
+if [ "$PART" = final ]; then
+python3 bench.py --steps 50 --warmup 10 > $O/r06_default_bench_line.json 2> $O/bench.err
+wc -c $O/r06_default_bench_line.json; tail -2 $O/bench.err
 # the round's A/B and kernel-alone figures cited from DESIGN.md / the sources, from this library
 python3 scratch/wgrad_group_ab.py > $O/r06_wgrad_group_ab.txt 2>&1
 python3 scratch/wgrad_group_ab.py gemm_epilogue=1 gemm_epilogue=0 wgrad_group_wgs=64 wgrad_group_wgs=96 ln_fuse=1 gemm_impl=2 gemm_impl=3 > $O/r06_xe_step_switches_ab.txt 2>&1
@@ -62,7 +66,5 @@ python3 scratch/ln_bench.py > $O/r06_ln_bwd.txt 2>&1
 python3 scratch/gemm_ln_bench.py > $O/r06_gemm_ln_fused.txt 2>&1
 ./scratch/micro/store_like_gemm > $O/r06_store_pattern.txt 2>&1
 python3 scratch/scst_tuning_ab.py samp_epilogue=0 samp_epilogue=1 gemm_epilogue=1 > $O/r06_scst_switches_ab.txt 2>&1
-python3 bench.py --steps 50 --warmup 10 > $O/r06_default_bench_line.json 2> $O/bench.err
-wc -c $O/r06_default_bench_line.json; tail -2 $O/bench.err
 fi
 echo "lib md5 $MD5"; ls $O | head -80

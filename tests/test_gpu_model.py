@@ -42,6 +42,12 @@ def g1(golden):
     return golden("g1_tiny_dense")
 
 
+def test_graft_entry_smoke_runs(P):
+    """__graft_entry__.smoke(): the driver's one small forward / backward + decode on cuda:0, checked against the oracle inside."""
+    import __graft_entry__ as G
+    G.smoke()
+
+
 def test_encoder_and_logp_vs_reference_golden(P, g1):
     m, b = _model(P, "relation_transformer", C.TINY_CFG, H.g1_state()), _cuda(H.g1_batch())
     close(m.encode(b["att_feats"], b["boxes"], b["att_masks"]), g1["memory"], 5e-5)
