@@ -350,7 +350,9 @@ typedef struct ortk_tuning {
                                      (59.5 vs 62.0 us at 16 640 x 512 x 512), inside the step it needs a free compute unit per workgroup and waits for
                                      the units the side stream's weight gradients hold: 11.65 vs 10.40 ms per XE step (scratch/wgrad_group_ab.py)
                                      | bit 1: ln_mode 2 on the 128-row panels of round 3 (measurement) | bit 2: the LayerNorm backward of width 512 with four
-                                     instead of eight consecutive columns per lane (measurement) */
+                                     instead of eight consecutive columns per lane (measurement) | bit 3: the executor keeps the LayerNorm output gradients
+                                     (data gradient -> ortk_layernorm_bwd_dt) in fp32 in mixed precision too; default: bf16 there, as every other gradient
+                                     that is a GEMM operand in that mode */
     int32_t samp_epilogue;        /* 1 (default): sampling decodes in mixed precision take their tokens from the generator GEMM's epilogue (Gumbel-max candidates
                                      + soft-max partials per 64 logits, ortk_gemm_args.tile_samp) and never store the logit rows | 0: logits + sample step */
     int32_t gemm_epilogue;        /* 0 (default): the forward-layout LDS-DMA GEMM kernels run the lean epilogue (options the launcher has verified compiled

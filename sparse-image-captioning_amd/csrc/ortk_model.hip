@@ -688,12 +688,12 @@ static int ln_fwd(const Ctx& c, const float* x, int64_t a, int64_t b, void* y, i
 }
 // next_op >= 0: also emit, into `dz`, the dropout-masked / bf16 copy of dx that the NEXT drop_bwd(dx, dz, ., next_op) would
 // produce (that call then finds its work done, see drop_bwd)
-static int ln_bwd(const Ctx& c, const float* dy, const float* x, float* G, int64_t a, int64_t b, const float* st,
-                  const float* dres, float* dx, int64_t rows, void* dz = nullptr, int next_op = -1) {
+static int ln_bwd(const Ctx& c, const void* dy, const float* x, float* G, int64_t a, int64_t b, const float* st,
+                  const float* dres, float* dx, int64_t rows, void* dz = nullptr, int next_op = -1, int dy_dt = ORTK_F32) {
     const bool fuse = dz && next_op >= 0 && (c.p_drop() > 0.f || c.adt == ORTK_BF16);
     if (fuse) TRY(c.before_write(dz));
-    return ortk_layernorm_bwd_drop_rows(dy, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, fuse ? dz : nullptr,
-                                        c.adt, c.p_drop(), fuse ? c.sub((uint32_t)next_op) : 0, c.drop_rows, (ortk_stream)c.s);
+    return ortk_layernorm_bwd_dt(dy, dy_dt, x, c.P + a, st, dres, dx, G + a, G + b, rows, c.cfg->d_model, 1e-6f, fuse ? dz : nullptr,
+                                 c.adt, c.p_drop(), fuse ? c.sub((uint32_t)next_op) : 0, c.drop_rows, (ortk_stream)c.s);
 }
 // gradient through a residual-branch dropout: the buffer (and its dtype) holding dx * keep/(1-p).
 // Mixed precision always goes through `tmp` (it also performs the fp32 -> bf16 conversion of the GEMM operand).
@@ -716,8 +716,11 @@ static int dgrad_ln_bwd(const Ctx& c, const void* dY, int dydt, int64_t lddy, in
     const bool fusable = tuning().ln_fuse & 1 && c.prec && c.W16T && whole_block && dydt == ORTK_BF16 && Kin == 512 && Kin == c.cfg->d_model &&
                          (Nout % 64) == 0 && Ctx::ell_block(c.ell_b, woff, Kin, Nout) < 0 && !c.ell_b;
     if (!fusable) {
-        TRY(dgrad_gemm(c, dY, dydt, lddy, woff, gy, ORTK_F32, Kin, M, Nout, Kin, nullptr, 0, 0, 1.f, whole_block));
-        return ln_bwd(c, gy, x, G, na, nb, st, dres, dx, M, dz, next_op);
+        // Mixed precision on the dense kernels: the LayerNorm's output gradient lives as bf16 between the two launches, like every other
+        // gradient that is a GEMM operand there (half the bytes out of the GEMM's epilogue and into ln_bwd; tuning().ln_fuse & 8 keeps fp32)
+        const int gdt = (c.prec && c.adt == ORTK_BF16 && c.W16T && whole_block && !c.ell_b && Kin == 512 && Kin == c.cfg->d_model && !(tuning().ln_fuse & 8)) ? ORTK_BF16 : ORTK_F32;
+        TRY(dgrad_gemm(c, dY, dydt, lddy, woff, gy, gdt, Kin, M, Nout, Kin, nullptr, 0, 0, 1.f, whole_block));
+        return ln_bwd(c, gy, x, G, na, nb, st, dres, dx, M, dz, next_op, gdt);
     }
     const bool mask = dz && next_op >= 0;        // (mixed precision: the masked copy is also the bf16 conversion)
     ortk_gemm_args a; std::memset(&a, 0, sizeof(a));
