@@ -58,13 +58,14 @@ python3 bench.py --steps 50 --warmup 10 > $O/r06_default_bench_line.json 2> $O/b
 wc -c $O/r06_default_bench_line.json; tail -2 $O/bench.err
 # the round's A/B and kernel-alone figures cited from DESIGN.md / the sources, from this library
 python3 scratch/wgrad_group_ab.py > $O/r06_wgrad_group_ab.txt 2>&1
-python3 scratch/wgrad_group_ab.py gemm_epilogue=1 gemm_epilogue=0 wgrad_group_wgs=64 wgrad_group_wgs=96 ln_fuse=1 gemm_impl=2 gemm_impl=3 > $O/r06_xe_step_switches_ab.txt 2>&1
+python3 scratch/wgrad_group_ab.py gemm_epilogue=1 gemm_epilogue=0 ln_fuse=8 ln_fuse=0 wgrad_group_wgs=64 wgrad_group_wgs=96 ln_fuse=1 gemm_impl=2 gemm_impl=3 > $O/r06_xe_step_switches_ab.txt 2>&1
 python3 scratch/wgrad_group_bench.py 0 > $O/r06_wgrad_group.txt 2>&1
 python3 scratch/box_bwd_bench.py > $O/r06_box_bwd.txt 2>&1
 python3 scratch/gemm_fixed_cost.py > $O/r06_gemm_fixed_cost.txt 2>&1
 python3 scratch/ln_bench.py > $O/r06_ln_bwd.txt 2>&1
 python3 scratch/gemm_ln_bench.py > $O/r06_gemm_ln_fused.txt 2>&1
 ./scratch/micro/store_like_gemm > $O/r06_store_pattern.txt 2>&1
-python3 scratch/scst_tuning_ab.py samp_epilogue=0 samp_epilogue=1 gemm_epilogue=1 > $O/r06_scst_switches_ab.txt 2>&1
+python3 scratch/scst_tuning_ab.py samp_epilogue=0 samp_epilogue=1 gemm_epilogue=1 ln_fuse=8 > $O/r06_scst_switches_ab.txt 2>&1
+python3 scratch/gy_bf16_grad_error.py > $O/r06_ln_gradient_bf16.txt 2>&1
 fi
 echo "lib md5 $MD5"; ls $O | head -80
