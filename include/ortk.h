@@ -356,8 +356,9 @@ typedef struct ortk_tuning {
     int32_t samp_epilogue;        /* 1 (default): sampling decodes in mixed precision take their tokens from the generator GEMM's epilogue (Gumbel-max candidates
                                      + soft-max partials per 64 logits, ortk_gemm_args.tile_samp) and never store the logit rows | 0: logits + sample step */
     int32_t gemm_epilogue;        /* 0 (default): the forward-layout LDS-DMA GEMM kernels run the lean epilogue (options the launcher has verified compiled
-                                     out, dropout / gate as kernel instances; bf16 results of the 256 x 256 tile stored 16 bytes per lane) | 1: the general
-                                     epilogue of rounds 2-5 everywhere (measurement: profiles/r06_gemm_epilogue.txt) */
+                                     out, dropout / gate as kernel instances; bf16 results of the 256 x 256 tile stored 16 bytes per lane) | bit 0: the general
+                                     epilogue of rounds 2-5 everywhere (measurement: profiles/r06_gemm_epilogue.txt) | bit 1: a column count of 256 n + 128
+                                     (the padded vocabulary) is NOT split into a 256 x 256-tile launch + a 128-column remainder (measurement) */
 } ortk_tuning;
 void ortk_get_tuning(ortk_tuning* out);
 int ortk_set_tuning(const ortk_tuning* t);

@@ -758,6 +758,63 @@ __device__ __forceinline__ bf16x8 gfrag(const __bf16* img, int m0, int lane) {
 //              L2 -> CU fetch rate (~13 B/clk/CU sustained), not MFMA issue.
 // NS = ring depth (4, or 8 for grids of at most one workgroup per CU: with 7 tiles in flight almost the whole K = 512
 // panel of a decode-sized GEMM is requested up front and the K loop stops being a chain of fetch latencies).
+// Soft-max partials {max, sum exp(. - max)} of a wave's (16 MI) rows x 64 columns at (m0, n0) (ortk_gemm_args.tile_stats; natural column order)
+template <int MI>
+__device__ __forceinline__ void stats_partials(const ortk_gemm_args& p, int m0, int n0, int lane, f32x4 (&acc)[MI][4]) {
+    // soft-max partials of this wave's 64 rows x 64 columns (bias included, columns past stat_ncols left out): in-lane over
+    // the lane's 16 values of a row, two shuffles over the four lane groups
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = n0 + 4 * lg;
+    const int nblk = p.N >> 6, blk = n0 >> 6;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (a block that lies below stat_ncols as a whole — every block but the vocabulary's last — takes the form without the
+    //  per-element bounds tests: the epilogue is vector-ALU time the CU's other workgroup cannot use for its MFMAs)
+    const bool whole = n0 + 64 <= p.stat_ncols;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + 16 * i + lr;
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] + bias4[j][r];
+        float mx = -INFINITY, sm = 0.f;
+        if (whole) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, v[j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm += __expf(v[j][r] - mx);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 16 * j + r < p.stat_ncols) mx = fmaxf(mx, v[j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 16 * j + r < p.stat_ncols) sm += __expf(v[j][r] - mx);
+        }
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if (lg == 0 && m < p.M) {
+            float* q = p.tile_stats + ((int64_t)m * nblk + blk) * 2;
+            q[0] = mx; q[1] = sm;
+        }
+    }
+}
+
 // Gumbel-max candidates of a wave's (16 MI) rows x 64 columns at (m0, n0) (ortk_gemm_args.tile_samp), FAST: the draw function
 template <bool FAST, int MI>
 __device__ __forceinline__ void samp_candidates(const ortk_gemm_args& p, int m0, int n0, int lane, f32x4 (&acc)[MI][4]) {
@@ -817,7 +874,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = BIG ? wave >> 2 : wave >> 1, wn = BIG ? wave & 3 : wave & 1;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = bid % tilesN, rest = bid / tilesN, mt = rest % tilesM, ks_ = rest / tilesM;
+    // (tilesN >> 16: first column tile of this launch — the launcher's remainder launch behind a 256 x 256-tile launch over the
+    //  columns below the last multiple of 256)
+    const int nt0 = tilesN >> 16;
+    tilesN &= 0xFFFF;
+    const int nt = bid % tilesN + nt0, rest = bid / tilesN, mt = rest % tilesM, ks_ = rest / tilesM;
     const int mb = mt * TM, nb = nt * TM;
     const int k_begin = ks_ * kchunk;
     const int k_end = min(p.K, k_begin + kchunk);
@@ -881,60 +942,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, (BIG || NS > 4) ? 1 : 2) void gemm
 #pragma unroll
         for (int i = 0; i < MI; ++i) atomicAdd(p.colsum + mb + wm * (16 * MI) + 16 * i + lane, acc_cs[i][0]);
     }
-    if ((EPI < 0 || EPI >= 4) && !BIG && !TA && !TB && p.tile_stats) {
-        // soft-max partials of this wave's 64 rows x 64 columns (bias included, columns past stat_ncols left out): in-lane over
-        // the lane's 16 values of a row, two shuffles over the four lane groups
-        const int lr = lane & 15, lg = lane >> 4;
-        const int c0 = nb + wn * 64 + 4 * lg;
-        const int nblk = p.N >> 6, blk = (nb >> 6) + wn;
-        f32x4 bias4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        // (a block that lies below stat_ncols as a whole — every block but the vocabulary's last — takes the form without the
-        //  per-element bounds tests: the epilogue is vector-ALU time the CU's other workgroup cannot use for its MFMAs)
-        const bool whole = nb + wn * 64 + 64 <= p.stat_ncols;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = mb + wm * (16 * MI) + 16 * i + lr;
-            float v[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] + bias4[j][r];
-            float mx = -INFINITY, sm = 0.f;
-            if (whole) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, v[j][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sm += __expf(v[j][r] - mx);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (c0 + 16 * j + r < p.stat_ncols) mx = fmaxf(mx, v[j][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (c0 + 16 * j + r < p.stat_ncols) sm += __expf(v[j][r] - mx);
-            }
-            sm += __shfl_xor(sm, 16, 64);
-            sm += __shfl_xor(sm, 32, 64);
-            if (lg == 0 && m < p.M) {
-                float* q = p.tile_stats + ((int64_t)m * nblk + blk) * 2;
-                q[0] = mx; q[1] = sm;
-            }
-        }
-    }
+    if ((EPI < 0 || EPI >= 4) && !BIG && !TA && !TB && p.tile_stats)
+        stats_partials<MI>(p, mb + wm * (16 * MI), nb + wn * 64, lane, *reinterpret_cast<f32x4(*)[MI][4]>(&acc[0]));
     if ((EPI < 0 || EPI == 5) && !BIG && !TA && !TB && p.tile_samp) {
         // (one instance per draw function, chosen once: the per-element choice doubled the straight-line code of the block)
         if (p.samp_fast) samp_candidates<true, MI>(p, mb + wm * (16 * MI), nb + wn * 64, lane, *reinterpret_cast<f32x4(*)[MI][4]>(&acc[0]));
@@ -1036,6 +1045,8 @@ __device__ __forceinline__ bf16x8 gfrag64(const __bf16* img, int m0, int ks, int
 // split-K accumulation, no row scale: the launcher chooses)
 template <bool TA, bool TB, int EPI = -1>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args p, int tilesM, int tilesN, int kchunk) {
+    constexpr bool PERM = !TB && EPI < 4;            // (EPI 4: soft-max partials per natural 64-column block, then the lean store — measured slower
+                                                     //  than the 128 x 128 kernel on the decode-time generator, not dispatched)
     constexpr int IMG = 256 * HBK;                  // elements per operand image (32 KB)
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1057,7 +1068,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
     auto issue = [&](int t) {
         __bf16* st = smem16 + (size_t)(t & 1) * 2 * IMG;
         glds_tile64<TA>(Ap, p.lda, mb, k_begin + t * HBK, st, wave, lane, TA ? 0x7FFFFFFF : p.M - 1);
-        glds_tile64<TB, !TB>(Bp, p.ldb, nb, k_begin + t * HBK, st + IMG, wave, lane);
+        glds_tile64<TB, PERM>(Bp, p.ldb, nb, k_begin + t * HBK, st + IMG, wave, lane);
     };
     if (T > 0) issue(0);
     for (int t = 0; t < T; ++t) {
@@ -1076,7 +1087,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[8], b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = TB ? gfrag64<TB>(sB, wn * 64 + 16 * j, ks, lane) : gfrag64p(sB, wn * 64, j, ks, lane);
+            for (int j = 0; j < 4; ++j) b[j] = PERM ? gfrag64p(sB, wn * 64, j, ks, lane) : gfrag64<TB>(sB, wn * 64 + 16 * j, ks, lane);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = gfrag64<TA>(sA, wm * 128 + 16 * i, ks, lane);
 #pragma unroll
@@ -1084,7 +1095,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
                 if (next && (i & 1) == 0) {
                     const int u = ks * 4 + (i >> 1);               // 0..7: pieces 0-3 of A, then 0-3 of B
                     if (u < 4) glds_piece64<TA>(Ap, p.lda, mb, nk0, nst, wave, lane, u, TA ? 0x7FFFFFFF : p.M - 1);
-                    else       glds_piece64<TB, !TB>(Bp, p.ldb, nb, nk0, nst + IMG, wave, lane, u - 4);
+                    else       glds_piece64<TB, PERM>(Bp, p.ldb, nb, nk0, nst + IMG, wave, lane, u - 4);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1093,21 +1104,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(ortk_gemm_args
         }
     }
     if constexpr (EPI >= 0) {
-        epilogue_lean<8, !TB, (EPI & 1) != 0, (EPI & 2) != 0>(p, mb + wm * 128 + (lane & 15), nb + wn * 64 + (TB ? 4 : 8) * (lane >> 4), acc);
+        if (EPI == 4 && p.tile_stats) stats_partials<8>(p, mb + wm * 128, nb + wn * 64, lane, acc);
+        epilogue_lean<8, PERM, (EPI & 1) != 0 && EPI < 4, (EPI & 2) != 0 && EPI < 4>(p, mb + wm * 128 + (lane & 15), nb + wn * 64 + (PERM ? 8 : 4) * (lane >> 4), acc);
         return;
     }
     Epi e{p.C, p.ldc, p.c_dtype, p.bias, p.rowscale, p.resid, p.ldr, p.gate, p.ldg, p.gate_dtype, p.gate_scale,
           p.relu, p.drop_p, p.drop_seed, p.accumulate, ks_ == 0, p.M, p.N, p.drop_row_stride > 0 ? p.drop_row_stride : 1, p.drop_row_off, p.drop_rows};
     // (forward-layout B: the permuted column order, a lane's accumulators pair up into 8 consecutive columns)
-    const int ncol0 = nb + wn * 64 + (TB ? 4 : 8) * (lane >> 4);
+    const int ncol0 = nb + wn * 64 + (PERM ? 8 : 4) * (lane >> 4);
     if (mb + 256 <= p.M) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
-            epilogue_tile<true, 4, 4, 16, 16, !TB>(e, mb + wm * 128 + 64 * hh + (lane & 15), ncol0, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+            epilogue_tile<true, 4, 4, 16, 16, PERM>(e, mb + wm * 128 + 64 * hh + (lane & 15), ncol0, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
     } else {              // partial last row tile (ragged M)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
-            epilogue_tile<false, 4, 4, 16, 16, !TB>(e, mb + wm * 128 + 64 * hh + (lane & 15), ncol0, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
+            epilogue_tile<false, 4, 4, 16, 16, PERM>(e, mb + wm * 128 + 64 * hh + (lane & 15), ncol0, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * hh]));
     }
 }
 constexpr size_t DMA256_LDS_BYTES = (size_t)2 * 2 * 256 * HBK * sizeof(__bf16);   // 128 KB
@@ -2465,7 +2477,17 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             // the other half of the chip to the weight-gradient GEMM of the side stream (XE step 12.47 -> 12.10 ms; 40 % and
             // 30 % measure the same)
             const bool fills = big_blocks * 10 >= rounds * 256 * 5;
-            const bool big = !p.accumulate && !want_stats && (p.M % 256 == 0 || fast4) && p.N % 256 == 0 && impl != 2 && (impl == 3 || fills);
+            const bool lean = key == 4 && !p.accumulate && !p.rowscale && !(ortk::tuning().gemm_epilogue & 1);
+            // Round 6: a column count of 256 n + 128 (the padded vocabulary: 10 112 = 39 x 256 + 128) runs its first 256 n columns on the
+            // 256 x 256 tiles and the last 128 as a second launch of the 128 x 128 kernel on the same stream: the training-time generator
+            // (16 640 / 21 760 rows; XE step 10.03 -> 10.00 ms, SCST step 23.06 -> 22.94).  NOT the launches that carry soft-max
+            // partials: the decode-time generator (5 120 rows) is slower that way — 18.00 vs 17.65 ms per 1 024-image decode,
+            // scratch/decode_tuning_ab.py — as it was in round 5 (the statistics epilogue has nothing to overlap with at one workgroup per
+            // unit), so launches with statistics never take the big tile.
+            // (ortk_tuning.gemm_epilogue & 2: never split.)
+            const bool nsplit = lean && !want_stats && !(ortk::tuning().gemm_epilogue & 2) && p.N % 256 == 128 && p.N > 256 && p.K % HBK == 0;
+            const bool big = !p.accumulate && !want_stats && (p.M % 256 == 0 || fast4) &&
+                             (p.N % 256 == 0 || nsplit) && impl != 2 && (impl == 3 || fills);
             // 8-deep ring for grids of at most one workgroup per CU (decode-time projections): measured SLOWER in the
             // 1024-image decode (36.9 vs 35.8 ms) -> experiment only (ORTK_GEMM_IMPL=5)
             const bool deep = !big && (int64_t)tilesM * tilesN * splitk <= 256 && impl == 5;
@@ -2473,8 +2495,9 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             if (big)       gf = key == 4 ? gemm_bf16_glds_kernel<false, false, true, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, true, 4> : gemm_bf16_glds_kernel<true, true, true, 4>;
             else if (deep) gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 8> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 8> : gemm_bf16_glds_kernel<true, true, false, 8>;
             else           gf = key == 4 ? gemm_bf16_glds_kernel<false, false, false, 4> : key == 5 ? gemm_bf16_glds_kernel<false, true, false, 4> : gemm_bf16_glds_kernel<true, true, false, 4>;
-            const bool lean = key == 4 && !p.accumulate && !p.rowscale && !ortk::tuning().gemm_epilogue;
-            if (lean && !big && !deep) {
+            // (the remainder launch of a split takes the small kernel's lean instance too)
+            if (big && nsplit) gf = gemm_bf16_glds_kernel<false, false, false, 4>;
+            if (lean && (!big || nsplit) && !deep) {
                 if (want_stats) gf = p.tile_samp ? gemm_bf16_glds_kernel<false, false, false, 4, 5> : gemm_bf16_glds_kernel<false, false, false, 4, 4>;
                 else switch ((p.drop_p > 0.f ? 1 : 0) | (p.gate ? 2 : 0)) {
                     case 0:  gf = gemm_bf16_glds_kernel<false, false, false, 4, 0>; break;
@@ -2483,7 +2506,7 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
                     default: gf = gemm_bf16_glds_kernel<false, false, false, 4, 3>; break;
                 }
             }
-            const size_t lds = big ? GLDS_LDS_BYTES_BIG : deep ? 2 * GLDS_RING_BYTES : GLDS_LDS_BYTES;
+            const size_t lds = (big && !nsplit) ? GLDS_LDS_BYTES_BIG : deep ? 2 * GLDS_RING_BYTES : GLDS_LDS_BYTES;
             ortk::lds_attr(reinterpret_cast<const void*>(gf), lds);
             if (big && impl != 6 && p.K % HBK == 0) {
                 // 64-column stages (full cache lines); impl 6 = the 32-column 4-stage ring for comparison
@@ -2499,6 +2522,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
                 }
                 ortk::lds_attr(reinterpret_cast<const void*>(g2), DMA256_LDS_BYTES);
                 hipLaunchKernelGGL(g2, dim3((unsigned)big_blocks), dim3(512), DMA256_LDS_BYTES, s, p, (int)ortk_cdiv(p.M, 256), p.N / 256, kchunk);
+                if (nsplit)      // the last 128 columns: one column tile of the 128 x 128 kernel, starting at tile (N / 128 - 1)
+                    hipLaunchKernelGGL(gf, dim3((unsigned)tilesM), block, lds, s, p, tilesM, 1 | ((tilesN - 1) << 16), kchunk);
             }
             else if (big) hipLaunchKernelGGL(gf, dim3((unsigned)big_blocks), dim3(512), lds, s, p, (int)ortk_cdiv(p.M, 256), p.N / 256, kchunk);
             else          hipLaunchKernelGGL(gf, grid, block, lds, s, p, tilesM, tilesN, kchunk);

@@ -1128,7 +1128,8 @@ def test_gemm_full_tile_bf16_pipeline(L, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(16640, 512, 128), (4500, 2560, 192), (21590, 512, 64),      # 256 x 256 tiles (whole, ragged last row tile)
-                                   (1000, 512, 512), (9216, 1536, 64), (37, 2048, 128)])           # 128 x 128 tiles
+                                   (1000, 512, 512), (9216, 1536, 64), (37, 2048, 128),            # 128 x 128 tiles
+                                   (16640, 640, 128), (16500, 896, 64)])                           # 256 n + 128 columns: big tiles + a 128-column remainder launch
 def test_gemm_lean_epilogue_equals_general(L, M, N, K):
     """The lean epilogue of the forward-layout LDS-DMA kernels (options compiled out, dropout / gate as kernel instances, permuted column
     order with 16-byte bf16 stores; ortk_tuning.gemm_epilogue = 0) gives BIT-identical results to the general epilogue it replaces
