@@ -2465,7 +2465,8 @@ extern "C" int ortk_gemm(const ortk_gemm_args* a, ortk_stream stream) {
             ORTK_CHECK_LAUNCH();
             return 0;
         }
-        if ((fast || fast4) && (impl != 1 || want_stats) && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0) {
+        if (want_stats && tilesN > 0xFFFF) return ORTK_EINVAL;       // (the 128 x 128 kernel's column-tile argument is 16 bits wide: 8.3 M columns)
+        if ((fast || fast4) && (impl != 1 || want_stats) && dma_layout && p.a_dtype == ORTK_BF16 && p.b_dtype == ORTK_BF16 && kchunk % GBK == 0 && tilesN <= 0xFFFF) {
             // 256 x 256 tiles when they still give enough workgroups (and no split-K accumulation, which needs the
             // staged 128 x 128 epilogue); impl 2 = small tiles only, impl 3 = big tiles whenever legal
             const int64_t big_blocks = (int64_t)ortk_cdiv(p.M, 256) * (p.N / 256);

@@ -899,7 +899,8 @@ const ortk_tuning& tuning() { return g_tuning; }
 extern "C" void ortk_get_tuning(ortk_tuning* out) { if (out) *out = ortk::g_tuning; }
 extern "C" int ortk_set_tuning(const ortk_tuning* t) {
     if (!t || t->gemm_impl < 0 || t->gemm_impl > 3 || t->attn_impl < 0 || t->attn_impl > 4 || t->attn16_min_lq < 1 || t->f32_split < 0 || t->f32_split > 7 || t->wgrad_wgs < 1 ||
-        t->wgrad_group < 0 || t->wgrad_group > 15 || t->wgrad_group_splitk < 0 || t->wgrad_group_splitk > 8 || t->wgrad_group_wgs < 1 || t->wgrad_group_tail < 0 || t->wgrad_group_tail > 1) return ORTK_EINVAL;
+        t->wgrad_group < 0 || t->wgrad_group > 15 || t->wgrad_group_splitk < 0 || t->wgrad_group_splitk > 8 || t->wgrad_group_wgs < 1 || t->wgrad_group_tail < 0 || t->wgrad_group_tail > 1 ||
+        t->feats_bf16 < 0 || t->feats_bf16 > 1 || t->ln_fuse < 0 || t->ln_fuse > 15 || t->samp_epilogue < 0 || t->samp_epilogue > 1 || t->gemm_epilogue < 0 || t->gemm_epilogue > 3) return ORTK_EINVAL;
     ortk::g_tuning = *t;
     return 0;
 }
