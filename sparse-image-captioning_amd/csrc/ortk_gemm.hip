@@ -18,6 +18,7 @@
 // (n fastest): they share the A panel in that XCD's L2 instead of fetching it 8 times.
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "ortk_internal.h"
 
@@ -170,52 +171,73 @@ __device__ __forceinline__ void epilogue_tile(const Epi& e, int mrow0, int ncol0
 // acc[i][j]: rows mrow0 + 16 i; columns ncol0 + 16 j + 0..3, or with PAIR ncol0 + 32 (j >> 1) + 4 (j & 1) + 0..3 (ncol0 = 8 x lane
 // group: blocks 2 J, 2 J + 1 are 8 consecutive columns -> one 16-byte store of a bf16 result).  Same arithmetic, in the same order,
 // as epilogue_tile: (acc + bias) -> relu -> dropout -> gate -> + residual.
-template <int MI, bool PAIR, bool DROP, bool GATE>
-__device__ __forceinline__ void epilogue_lean(const ortk_gemm_args& p, int mrow0, int ncol0, f32x4 (&acc)[MI][4]) {
+template <int MI, bool PAIR, bool DROP, bool GATE, bool G16, bool GWIDE>
+__device__ __forceinline__ void epilogue_lean_impl(const ortk_gemm_args& p, int mrow0, int ncol0, f32x4 (&acc)[MI][4]) {
     static_assert(MI % 4 == 0, "row blocks in groups of four or two");
     auto colof = [&](int j) { return PAIR ? ncol0 + 32 * (j >> 1) + 4 * (j & 1) : ncol0 + 16 * j; };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 bias4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colof(j)) : zero4;
-    const bool c16 = p.c_dtype == ORTK_BF16, g16 = p.gate_dtype == ORTK_BF16;
+    const bool c16 = p.c_dtype == ORTK_BF16;
     const bool pair_ok = PAIR && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
     const float inv_keep = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
     const uint64_t drs = p.drop_row_stride > 0 ? (uint64_t)p.drop_row_stride : 1ull;
     // G row blocks at a time: ALL their residual / gate loads are issued first (rows past a ragged M clamped: no control flow between
     // the loads, one round trip per group instead of one per row block — the epilogue has no other workgroup to hide behind), then the
     // arithmetic and the stores, the stores alone under the row test.
-    constexpr int G = GATE ? 2 : 4;                  // (row blocks per group: what fits the registers beside the accumulators)
+    // (row blocks per group: what fits the registers beside the accumulators — a bf16 gate is kept as loaded, 2 registers per 4 columns)
+    constexpr int G = (GATE && !G16) ? 2 : 4;
     const uint32_t thr = DROP ? ortk_keep_thr(p.drop_p) : 0u;
 #pragma unroll
     for (int h = 0; h < MI / G; ++h) {
-        f32x4 res[G][4];
-        float4 gat[G][4];
-        if (p.resid) {
+        // (with a gate the residual rows — never both in the executor — are fetched per row block instead: registers)
+        constexpr int GR = GATE ? 1 : G;
+        f32x4 res[GR][4];
+        typename std::conditional<G16, bf16x4, f32x4>::type gat[G][4];
+        if constexpr (!GATE) {
+            if (p.resid) {
 #pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const int64_t mc = min(mrow0 + 16 * (G * h + i), p.M - 1);
+                for (int i = 0; i < G; ++i) {
+                    const int64_t mc = min(mrow0 + 16 * (G * h + i), p.M - 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) res[i][j] = *reinterpret_cast<const f32x4*>(p.resid + mc * p.ldr + colof(j));
+                    for (int j = 0; j < 4; ++j) res[i][j] = *reinterpret_cast<const f32x4*>(p.resid + mc * p.ldr + colof(j));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) res[i][j] = zero4;
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) res[i][j] = zero4;
         }
         if (GATE) {
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int64_t mc = min(mrow0 + 16 * (G * h + i), p.M - 1);
+                if constexpr (G16 && PAIR && GWIDE) {          // 8 consecutive columns of a bf16 gate: one 16-byte load
+                    const __bf16* gp = reinterpret_cast<const __bf16*>(p.gate) + mc * p.ldg;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gat[i][j] = ld_elem4(p.gate, mc * p.ldg + colof(j), g16 ? ORTK_BF16 : ORTK_F32);
+                    for (int J = 0; J < 2; ++J) {
+                        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gp + colof(2 * J));
+                        gat[i][2 * J] = (bf16x4){g8[0], g8[1], g8[2], g8[3]}; gat[i][2 * J + 1] = (bf16x4){g8[4], g8[5], g8[6], g8[7]};
+                    }
+                } else if constexpr (G16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gat[i][j] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.gate) + mc * p.ldg + colof(j));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gat[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.gate) + mc * p.ldg + colof(j));
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int m = mrow0 + 16 * (G * h + i);
             const int mc = min(m, p.M - 1);
+            if constexpr (GATE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) res[0][j] = p.resid ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)mc * p.ldr + colof(j)) : zero4;
+            }
             const uint64_t dbase = DROP ? ((p.drop_rows ? (uint64_t)p.drop_rows[mc] : (uint64_t)mc) * drs + (uint64_t)p.drop_row_off) * (uint64_t)p.N : 0ull;
             f32x4 v[4];
 #pragma unroll
@@ -233,11 +255,11 @@ __device__ __forceinline__ void epilogue_lean(const ortk_gemm_args& p, int mrow0
                     for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * inv_keep : 0.f;
                 }
                 if (GATE) {
-                    const float gg[4] = {gat[i][j].x, gat[i][j].y, gat[i][j].z, gat[i][j].w};
+                    const float gg[4] = {(float)gat[i][j][0], (float)gat[i][j][1], (float)gat[i][j][2], (float)gat[i][j][3]};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[r] = gg[r] > 0.f ? x[r] * p.gate_scale : 0.f;
                 }
-                v[j] = x + res[i][j];
+                v[j] = x + res[GATE ? 0 : i][j];
             }
             if (m < p.M) {                              // (a partial last row tile: ragged M)
                 if (c16) {
@@ -259,6 +281,18 @@ __device__ __forceinline__ void epilogue_lean(const ortk_gemm_args& p, int mrow0
             }
         }
     }
+}
+
+template <int MI, bool PAIR, bool DROP, bool GATE>
+__device__ __forceinline__ void epilogue_lean(const ortk_gemm_args& p, int mrow0, int ncol0, f32x4 (&acc)[MI][4]) {
+    // (the gate's element type picks the instance once: a bf16 gate — the executor's — takes 16-byte loads of 8 columns with PAIR and
+    //  four row blocks per group; 16-byte alignment of its rows is the launcher's fast_nk test + ldg % 8, else the 8-byte form)
+    if constexpr (GATE) {
+        if (p.gate_dtype == ORTK_BF16) {
+            if (PAIR && (p.ldg & 7) == 0 && (reinterpret_cast<uintptr_t>(p.gate) & 15) == 0) epilogue_lean_impl<MI, PAIR, DROP, true, true, true>(p, mrow0, ncol0, acc);
+            else epilogue_lean_impl<MI, PAIR, DROP, true, true, false>(p, mrow0, ncol0, acc);
+        } else epilogue_lean_impl<MI, PAIR, DROP, true, false, false>(p, mrow0, ncol0, acc);
+    } else epilogue_lean_impl<MI, PAIR, DROP, false, false, false>(p, mrow0, ncol0, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 MFMA
